@@ -1,0 +1,69 @@
+"""ctypes binding of libctdet_hip.so (the C ABI in include/ctdet_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised (the reference raises RuntimeError from TORCH_CHECK/AT_ERROR the same way,
+detectron2/layers/csrc/deformable/deform_conv.h:282-311).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libctdet_hip.so")
+
+F16, F32, U8 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP = 0, 1, 2
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "B", "H", "W", "Cin", "in_stride", "Cout", "Ho", "Wo", "out_stride",
+        "R", "S", "stride", "pad", "dil", "Kpad", "Cout_pad",
+        "compute_dtype", "out_dtype", "act", "res_stride")] + [("clamp_lo", C.c_float), ("clamp_hi", C.c_float)]
+
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+# name -> (restype, argtypes); must list every symbol declared in include/ctdet_hip.h
+SIGNATURES = {
+    "ctdet_last_error": (C.c_char_p, []),
+    "ctdet_abi_version": (_i32, []),
+    "ctdet_conv_cout_tile": (_i32, [_i32]),
+    "ctdet_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ctdet_dcnv2_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ctdet_preprocess": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _vp]),
+    "ctdet_maxpool2x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_dwconvT_add": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_decode_workspace_bytes": (_sz, [_i32]),
+    "ctdet_decode": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ctdet_decode_status": (_i32, [_vp, _i32, _vp]),
+    "ctdet_gaussian_targets": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ctdet_gaussian_radius": (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    "ctdet_focal_loss_workspace_bytes": (_sz, [_i64]),
+    "ctdet_focal_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "ctdet_reg_l1_loss": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _vp]),
+    "ctdet_sgd_momentum": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _i32, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library once; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C detectron2-centernet_amd/csrc`). There is no CPU fallback for the HIP path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().ctdet_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,192 @@
+// C-ABI entry points of libctdet_hip.so (see include/ctdet_hip.h for the contract and the reference
+// interfaces each function replaces).  No torch types, no allocation, no synchronisation (except the
+// explicit diagnostic helper ctdet_decode_status).
+#include "common.h"
+#include "../../include/ctdet_hip.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+void ctdet_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// launchers from the kernel files
+int launch_preprocess(const void*, int, void*, int, int, int, int, int, int, long, const float*, const float*, int,
+                      hipStream_t);
+int launch_maxpool2x2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
+int launch_dwconvT_add(const void*, const float*, const void*, void*, int, int, int, int, int, int, int, int, int,
+                       hipStream_t);
+size_t decode_workspace_bytes(int B);
+int launch_decode(const DecArgs&, hipStream_t);
+int launch_gaussian_radius(const int*, int, double*, int*, hipStream_t);
+int launch_gaussian_targets(const float*, const int64_t*, const int*, int, int, int, int, int, float*, float*, float*,
+                            int64_t*, uint8_t*, hipStream_t);
+size_t focal_workspace_bytes(long numel);
+int launch_focal_loss(const float*, const float*, const float*, int, int, int, int, float, void*, float*, float*, float*,
+                      hipStream_t);
+int launch_reg_l1(const float*, int, const uint8_t*, const int64_t*, const float*, int, int, int, float, float*, float*,
+                  int, hipStream_t);
+int launch_sgd(float*, const float*, float*, long, const float*, float, float, int, hipStream_t);
+
+static int fill_args(const ctdet_conv_desc* d, ConvArgs& a) {
+  CTDET_CHECK(d != nullptr, "conv: null descriptor");
+  CTDET_CHECK(d->B >= 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: bad shape B=%d H=%d W=%d Cin=%d Cout=%d",
+              d->B, d->H, d->W, d->Cin, d->Cout);
+  CTDET_CHECK(d->R > 0 && d->S > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0, "conv: bad kernel geometry");
+  const int ho = (d->H + 2 * d->pad - (d->dil * (d->R - 1) + 1)) / d->stride + 1;
+  const int wo = (d->W + 2 * d->pad - (d->dil * (d->S - 1) + 1)) / d->stride + 1;
+  CTDET_CHECK(ho == d->Ho && wo == d->Wo, "conv: output size %dx%d does not match geometry (expected %dx%d)", d->Ho,
+              d->Wo, ho, wo);
+  CTDET_CHECK(d->in_stride >= d->Cin && d->out_stride >= d->Cout, "conv: pixel strides smaller than channel counts");
+  memset(&a, 0, sizeof(a));
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_stride = d->in_stride;
+  a.Cout = d->Cout; a.Ho = d->Ho; a.Wo = d->Wo; a.out_stride = d->out_stride; a.res_stride = d->res_stride;
+  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+  a.K = d->R * d->S * d->Cin; a.Kpad = d->Kpad; a.Cout_pad = d->Cout_pad;
+  a.M = d->B * d->Ho * d->Wo;
+  a.act = d->act; a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi;
+  CTDET_CHECK((long)d->B * d->Ho * d->Wo < (1L << 31), "conv: too many output pixels");
+  return 0;
+}
+
+extern "C" {
+
+const char* ctdet_last_error(void) { return g_err; }
+int32_t ctdet_abi_version(void) { return 1; }
+int32_t ctdet_conv_cout_tile(int32_t cout) {
+  if (cout <= 16) return 16;
+  if (cout <= 32) return 32;
+  if (cout <= 64) return 64;
+  if (cout % 128 == 0) return 128;
+  if (cout % 64 == 0) return 64;
+  return 32;
+}
+
+int32_t ctdet_conv2d_fwd(const ctdet_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                         const float* bias, const void* residual, void* y, void* stream) {
+  ConvArgs a;
+  int rc = fill_args(d, a);
+  if (rc) return rc;
+  if (a.M == 0) return 0;
+  CTDET_CHECK(x && w_packed && y, "conv: null pointer");
+  a.x = x; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
+  if (d->compute_dtype == CTDET_DT_F16) return launch_conv_f16(a, d->out_dtype, false, (hipStream_t)stream);
+  if (d->compute_dtype == CTDET_DT_F32) {
+    CTDET_CHECK(d->out_dtype == CTDET_DT_F32, "conv(f32): output must be f32");
+    return launch_conv_f32(a, false, (hipStream_t)stream);
+  }
+  CTDET_CHECK(false, "conv: bad compute dtype %d", d->compute_dtype);
+}
+
+int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* offset_mask, int32_t om_stride,
+                        const void* w_packed, const float* scale, const float* bias, void* y, void* stream) {
+  ConvArgs a;
+  int rc = fill_args(d, a);
+  if (rc) return rc;
+  if (a.M == 0) return 0;
+  CTDET_CHECK(x && w_packed && y && offset_mask, "dcnv2: null pointer");
+  CTDET_CHECK(om_stride >= 3 * d->R * d->S, "dcnv2: om_stride=%d < 3*R*S", om_stride);
+  a.x = x; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = nullptr; a.y = y;
+  a.om = offset_mask; a.om_stride = om_stride;
+  if (d->compute_dtype == CTDET_DT_F16) return launch_conv_f16(a, d->out_dtype, true, (hipStream_t)stream);
+  if (d->compute_dtype == CTDET_DT_F32) {
+    CTDET_CHECK(d->out_dtype == CTDET_DT_F32, "dcnv2(f32): output must be f32");
+    return launch_conv_f32(a, true, (hipStream_t)stream);
+  }
+  CTDET_CHECK(false, "dcnv2: bad compute dtype %d", d->compute_dtype);
+}
+
+int32_t ctdet_preprocess(const void* img, int32_t img_dtype, void* out, int32_t out_dtype, int32_t B, int32_t H,
+                         int32_t W, int32_t Hp, int32_t Wp, int64_t img_batch_stride, const float* mean3,
+                         const float* std3, int32_t out_stride, void* stream) {
+  CTDET_CHECK(img && out && mean3 && std3, "preprocess: null pointer");
+  return launch_preprocess(img, img_dtype, out, out_dtype, B, H, W, Hp, Wp, (long)img_batch_stride, mean3, std3,
+                           out_stride, (hipStream_t)stream);
+}
+
+int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
+                         int32_t in_stride, int32_t out_stride, void* stream) {
+  CTDET_CHECK(x && y, "maxpool2x2: null pointer");
+  return launch_maxpool2x2(x, y, dtype, B, H, W, C, in_stride, out_stride, (hipStream_t)stream);
+}
+
+int32_t ctdet_dwconvT_add(const void* x, const float* w, const void* skip, void* y, int32_t dtype, int32_t B,
+                          int32_t H, int32_t W, int32_t C, int32_t f, int32_t in_stride, int32_t skip_stride,
+                          int32_t out_stride, void* stream) {
+  CTDET_CHECK(x && w && y, "dwconvT: null pointer");
+  return launch_dwconvT_add(x, w, skip, y, dtype, B, H, W, C, f, in_stride, skip_stride, out_stride,
+                            (hipStream_t)stream);
+}
+
+size_t ctdet_decode_workspace_bytes(int32_t B) { return decode_workspace_bytes(B); }
+
+int32_t ctdet_decode(const float* heat, const float* wh, int32_t wh_stride, const float* reg, int32_t reg_stride,
+                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t K, float down_ratio, void* workspace,
+                     float* boxes, float* scores, int32_t* classes, int32_t* inds, void* stream) {
+  CTDET_CHECK(heat && wh && workspace && boxes && scores && classes, "decode: null pointer");
+  DecArgs a;
+  a.heat = heat; a.wh = wh; a.reg = reg; a.wh_stride = wh_stride; a.reg_stride = reg_stride;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.K = K; a.down_ratio = down_ratio;
+  a.ws = (uint32_t*)workspace; a.boxes = boxes; a.scores = scores; a.classes = classes; a.inds = inds;
+  return launch_decode(a, (hipStream_t)stream);
+}
+
+int32_t ctdet_decode_status(const void* workspace, int32_t B, void* stream) {
+  const size_t per = decode_workspace_bytes(1);
+  for (int b = 0; b < B; ++b) {
+    uint32_t st[16];
+    hipError_t e = hipMemcpyAsync(st, (const char*)workspace + per * b, sizeof(st), hipMemcpyDeviceToHost,
+                                  (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    CTDET_CHECK(e == hipSuccess, "decode_status: copy failed: %s", hipGetErrorString(e));
+    if (st[7]) {
+      ctdet_set_error("decode: image %d overflowed the candidate buffer (degenerate heatmap)", b);
+      return -75;
+    }
+  }
+  return 0;
+}
+
+int32_t ctdet_gaussian_targets(const float* boxes, const int64_t* classes, const int32_t* counts, int32_t B,
+                               int32_t Nmax, int32_t H, int32_t W, int32_t C, float* hm, float* wh, float* reg,
+                               int64_t* ind, uint8_t* reg_mask, void* stream) {
+  CTDET_CHECK(boxes && classes && counts && hm && wh && reg && ind && reg_mask, "gaussian_targets: null pointer");
+  CTDET_CHECK(Nmax >= 1, "gaussian_targets: Nmax must be >= 1");
+  return launch_gaussian_targets(boxes, classes, counts, B, Nmax, H, W, C, hm, wh, reg, ind, reg_mask,
+                                 (hipStream_t)stream);
+}
+
+int32_t ctdet_gaussian_radius(const int32_t* hw_pairs, int32_t n, double* out_radius, int32_t* out_int, void* stream) {
+  CTDET_CHECK(hw_pairs, "gaussian_radius: null pointer");
+  return launch_gaussian_radius(hw_pairs, n, out_radius, out_int, (hipStream_t)stream);
+}
+
+size_t ctdet_focal_loss_workspace_bytes(int64_t numel) { return focal_workspace_bytes((long)numel); }
+
+int32_t ctdet_focal_loss(const float* logits, const float* gt, const float* alpha, int32_t B, int32_t H, int32_t W,
+                         int32_t C, float grad_scale, void* workspace, float* loss, float* stats, float* grad,
+                         void* stream) {
+  CTDET_CHECK(logits && gt && alpha && workspace && loss && stats, "focal_loss: null pointer");
+  return launch_focal_loss(logits, gt, alpha, B, H, W, C, grad_scale, workspace, loss, stats, grad, (hipStream_t)stream);
+}
+
+int32_t ctdet_reg_l1_loss(const float* pred, int32_t pred_stride, const uint8_t* mask, const int64_t* ind,
+                          const float* target, int32_t B, int32_t N, int32_t HW, float grad_scale, float* loss,
+                          float* grad, int32_t grad_stride, void* stream) {
+  CTDET_CHECK(pred && mask && ind && target && loss, "reg_l1_loss: null pointer");
+  return launch_reg_l1(pred, pred_stride, mask, ind, target, B, N, HW, grad_scale, loss, grad, grad_stride,
+                       (hipStream_t)stream);
+}
+
+int32_t ctdet_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, const float* lr_dev,
+                           float momentum, float weight_decay, int32_t first_step, void* stream) {
+  CTDET_CHECK(param && grad && momentum_buf && lr_dev, "sgd: null pointer");
+  return launch_sgd(param, grad, momentum_buf, (long)n, lr_dev, momentum, weight_decay, first_step, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// Shared declarations for the CenterNet hot-path HIP kernels (gfx950 / CDNA4 only).
+// Data layout everywhere on the device: activations are NHWC ("pixel rows": one
+// pixel = `stride` contiguous channel elements), weights are KRSC packed to
+// [Cout_pad][Kpad] (f16 MFMA path) or [Kpad][Cout_pad] (f32 exact path).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// error plumbing (thread-local message, returned through ctdet_last_error()).
+void ctdet_set_error(const char* fmt, ...);
+#define CTDET_CHECK(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      ctdet_set_error(__VA_ARGS__);       \
+      return -22; /* -EINVAL */           \
+    }                                     \
+  } while (0)
+#define CTDET_LAUNCH_CHECK()                                          \
+  do {                                                                \
+    hipError_t e_ = hipGetLastError();                                \
+    if (e_ != hipSuccess) {                                           \
+      ctdet_set_error("kernel launch failed: %s (%s:%d)",            \
+                      hipGetErrorString(e_), __FILE__, __LINE__);     \
+      return -5; /* -EIO */                                           \
+    }                                                                 \
+  } while (0)
+
+enum { CTDET_F16 = 0, CTDET_F32 = 1, CTDET_U8 = 2 };
+enum { CTDET_ACT_NONE = 0, CTDET_ACT_RELU = 1, CTDET_ACT_SIGMOID_CLAMP = 2 };
+
+// Kernel-side argument block for every conv-shaped contraction on the path
+// (plain conv, DCNv2 main contraction, offset/mask conv, head convs).
+struct ConvArgs {
+  const void* x;        // [B,H,W,in_stride] input pixels (channel slice starts at x)
+  const void* w;        // packed weights
+  const float* scale;   // per-cout multiplier (folded BN gamma/sqrt(var+eps)) or null
+  const float* bias;    // per-cout bias (folded BN beta - mean*scale, or conv bias) or null
+  const void* res;      // residual added before activation, same dtype as y, or null
+  void* y;              // [B,Ho,Wo,out_stride]
+  const float* om;      // DCNv2 only: [M, om_stride] f32; ch 0..17 offsets (2k=dh,2k+1=dw), 18..26 mask logits
+  int om_stride;
+  int B, H, W, Cin, in_stride;
+  int Cout, Ho, Wo, out_stride, res_stride;
+  int R, S, stride, pad, dil;
+  int K, Kpad, Cout_pad;
+  int M;                // B*Ho*Wo
+  int act;
+  float clamp_lo, clamp_hi;
+};
+
+// argument block of the batched decode (decode.hip)
+struct DecArgs {
+  const float* heat; const float* wh; const float* reg;
+  int wh_stride, reg_stride;
+  int B, H, W, C, K;
+  float down_ratio;
+  uint32_t* ws;
+  float* boxes; float* scores; int* classes; int* inds;
+};
+
+__device__ __forceinline__ float ctdet_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float ctdet_sigmoid_exact(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// launchers implemented in the .hip files (return 0 or negative errno)
+int launch_conv_f16(const ConvArgs& a, int out_dtype, bool deform, hipStream_t s);
+int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s);

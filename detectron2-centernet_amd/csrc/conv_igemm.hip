@@ -1,0 +1,380 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4), NHWC activations, KRSC weights.
+//
+// One kernel template covers every conv-shaped contraction of the CenterNet/DLA-34 path:
+//   * plain KxK / 1x1 convolutions (stride 1/2)         -- reference: torch.nn.Conv2d in
+//     detectron2/modeling/backbone/dla.py:48-55,79-81,132-133,213-214,253-255 and
+//     detectron2/modeling/meta_arch/centernet.py:115-121
+//   * DCNv2 main contraction (DEFORM=true): the A operand is produced by 4-corner bilinear
+//     sampling x mask instead of a shifted load          -- reference arithmetic:
+//     detectron2/layers/csrc/deformable/deform_conv_cuda_kernel.cu:666-699 (bilinear),
+//     :786-868 (im2col), deform_conv_cuda.cu:874-927 (GEMM + bias).  No `columns` buffer ever
+//     reaches HBM and there is no per-image loop: the batch is part of the GEMM M dimension.
+//
+// GEMM view:  D[cout][pixel] = sum_k W[cout][k] * A[pixel][k],  k = (r*S + s)*Cin + c.
+// MFMA: v_mfma_f32_16x16x32_f16, weights as the A operand, pixels as the B operand, so every
+// lane ends up with 4*TC *contiguous* output channels of one pixel (vector NHWC stores).
+// LDS tiles are [row][32 k] f16 (64-byte rows) with a 16-byte-slot XOR swizzle that makes the
+// ds_read_b128 fragment reads bank-conflict free (see swz()).  Global->LDS staging goes through
+// registers (the loader must zero-fill padding and, for DCNv2, blend four corners), double
+// buffered, one barrier per 32-deep K step.
+#include "common.h"
+
+// slot permutation for 64-byte LDS rows read as 16-row fragments by ds_read_b128:
+// rows r and r+4 share banks, so the 4 rows {r, r+4, r+8, r+12} get distinct slot XORs.
+__device__ __forceinline__ int swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+struct DcnSample {
+  int off[4];    // element offsets of the 4 corner pixels (already * in_stride), -1 = contributes 0
+  float wt[4];   // bilinear weights
+  float mask;    // sigmoid(mask logit)
+};
+
+// Sampling geometry of one (pixel, tap); follows deform_conv_cuda_kernel.cu:836-861 and :666-699.
+__device__ __forceinline__ void dcn_setup(const ConvArgs& a, bool row_ok, int pix_base, int hb, int wb,
+                                          int tr, int ts, const float* omrow, DcnSample& sp) {
+  sp.off[0] = sp.off[1] = sp.off[2] = sp.off[3] = -1;
+  sp.wt[0] = sp.wt[1] = sp.wt[2] = sp.wt[3] = 0.f;
+  sp.mask = 0.f;
+  if (!row_ok || tr >= a.R) return;
+  const int tap = tr * a.S + ts;
+  const float oh = omrow[2 * tap], ow = omrow[2 * tap + 1];
+  sp.mask = ctdet_sigmoid_exact(omrow[2 * a.R * a.S + tap]);
+  const float h_im = (float)(hb + tr * a.dil) + oh;
+  const float w_im = (float)(wb + ts * a.dil) + ow;
+  if (!(h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W)) return;
+  const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+  const float hh = 1.f - lh, hw = 1.f - lw;
+  sp.wt[0] = hh * hw; sp.wt[1] = hh * lw; sp.wt[2] = lh * hw; sp.wt[3] = lh * lw;
+  if (h_low >= 0 && w_low >= 0) sp.off[0] = (pix_base + h_low * a.W + w_low) * a.in_stride;
+  if (h_low >= 0 && w_high <= a.W - 1) sp.off[1] = (pix_base + h_low * a.W + w_high) * a.in_stride;
+  if (h_high <= a.H - 1 && w_low >= 0) sp.off[2] = (pix_base + h_high * a.W + w_low) * a.in_stride;
+  if (h_high <= a.H - 1 && w_high <= a.W - 1) sp.off[3] = (pix_base + h_high * a.W + w_high) * a.in_stride;
+}
+
+template <typename TOut>
+__device__ __forceinline__ void epilogue_store4(const ConvArgs& a, int m, int c, f32x4 v) {
+  // c is a multiple of 4; Cout is a multiple of 4 (host guarantees), so a group is all-in or all-out
+  if (c >= a.Cout) return;
+  if (a.scale) { const f32x4 s = *(const f32x4*)(a.scale + c); v = v * s; }
+  if (a.bias) { const f32x4 b = *(const f32x4*)(a.bias + c); v = v + b; }
+  if (a.res) {
+    const TOut* rp = (const TOut*)a.res + (long)m * a.res_stride + c;
+    if constexpr (sizeof(TOut) == 2) {
+      const f16x4 r = *(const f16x4*)rp;
+      v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+    } else {
+      v = v + *(const f32x4*)rp;
+    }
+  }
+  if (a.act == CTDET_ACT_RELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+  } else if (a.act == CTDET_ACT_SIGMOID_CLAMP) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(ctdet_sigmoid_exact(v[j]), a.clamp_lo), a.clamp_hi);
+  }
+  TOut* yp = (TOut*)a.y + (long)m * a.out_stride + c;
+  if constexpr (sizeof(TOut) == 2) {
+    f16x4 o; o[0] = (f16)v[0]; o[1] = (f16)v[1]; o[2] = (f16)v[2]; o[3] = (f16)v[3];
+    *(f16x4*)yp = o;
+  } else {
+    *(f32x4*)yp = v;
+  }
+}
+
+template <int BP, int BC, int WP, int WC_, bool DEFORM, typename TOut>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
+  constexpr int TP = BP / WP / 16;   // 16-pixel MFMA tiles per wave
+  constexpr int TC = BC / WC_ / 16;  // 16-cout MFMA tiles per wave
+  constexpr int A_LD = BP / 64;      // pixel rows staged per thread per K step
+  constexpr int B_LD = (BC >= 64) ? BC / 64 : 1;
+  constexpr int STAGE = (BP + BC) * 64;
+  static_assert(WP * WC_ == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wp = wave / WC_, wc = wave % WC_;
+  const int m0 = blockIdx.x * BP, n0 = blockIdx.y * BC;
+  const f16* __restrict__ x = (const f16*)a.x;
+  const f16* __restrict__ w = (const f16*)a.w;
+
+  // ---- loader coordinates: thread stages LDS rows lrow+64*i, 16-byte slot `slot` ----
+  const int lrow = tid >> 2, slot = tid & 3;
+  const int g = slot ^ swz(lrow);  // k-group (8 channels) this thread fetches every step
+  int a_pix[A_LD], a_hb[A_LD], a_wb[A_LD];
+  bool a_ok[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = m0 + lrow + 64 * i;
+    a_ok[i] = m < a.M;
+    const int mm = a_ok[i] ? m : 0;
+    const int wo = mm % a.Wo, t = mm / a.Wo;
+    const int ho = t % a.Ho, b = t / a.Ho;
+    a_pix[i] = b * a.H * a.W;
+    a_hb[i] = a_ok[i] ? ho * a.stride - a.pad : -(1 << 28);
+    a_wb[i] = wo * a.stride - a.pad;
+  }
+  // weight rows: LDS row L (tile-major inside a wave's cout block) <- packed cout row `cl`
+  long b_off[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int L = lrow + 64 * j;
+    const int Lw = L % (16 * TC), wv = L / (16 * TC);
+    const int tt = Lw >> 4, r = Lw & 15;
+    const int cl = wv * 16 * TC + 4 * TC * (r >> 2) + 4 * tt + (r & 3);
+    b_off[j] = (long)(n0 + cl) * a.Kpad + g * 8;
+  }
+  const bool b_ld = lrow < BC;
+
+  // k-state of this thread's k-group: (tr, ts, c0)
+  int c0, tr, ts;
+  {
+    const int kc = g * 8, tap = kc / a.Cin;
+    c0 = kc - tap * a.Cin;
+    tr = tap / a.S;
+    ts = tap - tr * a.S;
+  }
+
+  DcnSample sp[DEFORM ? A_LD : 1];
+  auto setup_samples = [&]() {
+    if constexpr (DEFORM) {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        const int m = m0 + lrow + 64 * i;
+        dcn_setup(a, a_ok[i], a_pix[i], a_hb[i], a_wb[i], tr, ts, a.om + (long)(a_ok[i] ? m : 0) * a.om_stride,
+                  sp[i]);
+      }
+    }
+  };
+  setup_samples();
+
+  f16x8 areg[DEFORM ? 1 : A_LD];
+  f16x8 creg[DEFORM ? A_LD : 1][4];
+  f16x8 breg[B_LD];
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  auto issue_loads = [&](int kt) {
+    if constexpr (!DEFORM) {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        const int hi = a_hb[i] + tr * a.dil, wi = a_wb[i] + ts * a.dil;
+        const bool ok = (tr < a.R) && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+        areg[i] = ok ? *(const f16x8*)(x + (long)(a_pix[i] + hi * a.W + wi) * a.in_stride + c0) : zero8;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          creg[i][q] = sp[i].off[q] >= 0 ? *(const f16x8*)(x + (long)sp[i].off[q] + c0) : zero8;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) breg[j] = b_ld ? *(const f16x8*)(w + b_off[j] + kt * 32) : zero8;
+  };
+
+  auto store_stage = [&](int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      f16x8 v;
+      if constexpr (!DEFORM) {
+        v = areg[i];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float s = sp[i].wt[0] * (float)creg[i][0][e] + sp[i].wt[1] * (float)creg[i][1][e] +
+                          sp[i].wt[2] * (float)creg[i][2][e] + sp[i].wt[3] * (float)creg[i][3][e];
+          v[e] = (f16)(s * sp[i].mask);
+        }
+      }
+      *(f16x8*)(base + (lrow + 64 * i) * 64 + slot * 16) = v;
+    }
+    if (b_ld) {
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j) *(f16x8*)(base + BP * 64 + (lrow + 64 * j) * 64 + slot * 16) = breg[j];
+    }
+  };
+
+  auto advance_k = [&]() {
+    c0 += 32;
+    bool moved = false;
+    while (c0 >= a.Cin) {
+      c0 -= a.Cin;
+      if (++ts == a.S) { ts = 0; ++tr; }
+      moved = true;
+    }
+    return moved;
+  };
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15;
+  const int frag_off = fr * 64 + (((lane >> 4) ^ swz(fr)) << 4);
+  const int nk = a.Kpad / 32;
+
+  issue_loads(0);
+  store_stage(0);
+  __syncthreads();
+
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      // the blend in store_stage() below must still see the samples the in-flight corners belong to,
+      // so for DEFORM the k-state advances after the blend of the *previous* prefetch (done: it was
+      // stored before the barrier), i.e. here.
+      const bool moved = advance_k();
+      if (DEFORM && moved) setup_samples();
+      issue_loads(kt + 1);
+    }
+    const char* base = smem + buf * STAGE;
+    f16x8 wf[TC];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(base + BP * 64 + (wc * 16 * TC + 16 * c) * 64 + frag_off);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const f16x8 pf = *(const f16x8*)(base + (wp * 16 * TP + 16 * p) * 64 + frag_off);
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf, acc[p][c], 0, 0, 0);
+    }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue: lane holds couts [cb, cb+4*TC) of pixel m for every pixel tile ----
+  const int q = lane >> 4;
+  const int cb = n0 + wc * 16 * TC + 4 * TC * q;
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int m = m0 + wp * 16 * TP + 16 * p + fr;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cb + 4 * c, acc[p][c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact-f32 direct form (parity mode): one thread per (pixel, cout), f32 FMA chain in k order.
+// Weights packed [Kpad][Cout_pad] f32.  Used to pin the algorithm against the oracle at 1e-5;
+// the f16 MFMA kernels above are the throughput path.
+// ------------------------------------------------------------------------------------------
+template <bool DEFORM>
+__global__ void __launch_bounds__(256) conv_direct_f32_kernel(const ConvArgs a) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int CP = (a.Cout + 3) & ~3;
+  if (idx >= (long)a.M * CP) return;
+  const int n = (int)(idx % CP);
+  const int m = (int)(idx / CP);
+  if (n >= a.Cout) return;
+  const float* __restrict__ x = (const float*)a.x;
+  const float* __restrict__ w = (const float*)a.w;
+  const int wo = m % a.Wo, t = m / a.Wo;
+  const int ho = t % a.Ho, b = t / a.Ho;
+  const int pix_base = b * a.H * a.W;
+  const int hb = ho * a.stride - a.pad, wb = wo * a.stride - a.pad;
+  float acc = 0.f;
+  for (int tr = 0; tr < a.R; ++tr)
+    for (int ts = 0; ts < a.S; ++ts) {
+      const float* wk = w + (long)((tr * a.S + ts) * a.Cin) * a.Cout_pad + n;
+      if constexpr (!DEFORM) {
+        const int hi = hb + tr * a.dil, wi = wb + ts * a.dil;
+        if (hi < 0 || hi >= a.H || wi < 0 || wi >= a.W) continue;
+        const float* xp = x + (long)(pix_base + hi * a.W + wi) * a.in_stride;
+        for (int c = 0; c < a.Cin; ++c) acc = fmaf(xp[c], wk[(long)c * a.Cout_pad], acc);
+      } else {
+        DcnSample sp;
+        dcn_setup(a, true, pix_base, hb, wb, tr, ts, a.om + (long)m * a.om_stride, sp);
+        for (int c = 0; c < a.Cin; ++c) {
+          const float v1 = sp.off[0] >= 0 ? x[(long)sp.off[0] + c] : 0.f;
+          const float v2 = sp.off[1] >= 0 ? x[(long)sp.off[1] + c] : 0.f;
+          const float v3 = sp.off[2] >= 0 ? x[(long)sp.off[2] + c] : 0.f;
+          const float v4 = sp.off[3] >= 0 ? x[(long)sp.off[3] + c] : 0.f;
+          const float val = sp.wt[0] * v1 + sp.wt[1] * v2 + sp.wt[2] * v3 + sp.wt[3] * v4;
+          acc = fmaf(val * sp.mask, wk[(long)c * a.Cout_pad], acc);
+        }
+      }
+    }
+  float v = acc;
+  if (a.scale) v *= a.scale[n];
+  if (a.bias) v += a.bias[n];
+  if (a.res) v += ((const float*)a.res)[(long)m * a.res_stride + n];
+  if (a.act == CTDET_ACT_RELU) v = fmaxf(v, 0.f);
+  else if (a.act == CTDET_ACT_SIGMOID_CLAMP) v = fminf(fmaxf(ctdet_sigmoid_exact(v), a.clamp_lo), a.clamp_hi);
+  ((float*)a.y)[(long)m * a.out_stride + n] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline int pick_bc(int cout) {
+  if (cout <= 16) return 16;
+  if (cout <= 32) return 32;
+  if (cout <= 64) return 64;
+  if (cout % 128 == 0) return 128;
+  if (cout % 64 == 0) return 64;
+  return 32;
+}
+
+template <int BP, int BC, int WP, int WC_, bool DEFORM, typename TOut>
+static int launch_cfg(const ConvArgs& a, hipStream_t s) {
+  dim3 grid((a.M + BP - 1) / BP, a.Cout_pad / BC);
+  hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC_, DEFORM, TOut>), grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename TOut>
+static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
+  const int bc = pick_bc(a.Cout);
+  CTDET_CHECK(a.Cout_pad % bc == 0 && a.Cout_pad >= a.Cout, "conv: Cout_pad=%d does not match tile %d (Cout=%d)",
+              a.Cout_pad, bc, a.Cout);
+  if (deform) {
+    CTDET_CHECK(a.Cin % 32 == 0, "dcnv2: Cin=%d must be a multiple of 32", a.Cin);
+    if (bc == 128) return launch_cfg<128, 128, 2, 2, true, TOut>(a, s);
+    if (bc == 64) return launch_cfg<128, 64, 2, 2, true, TOut>(a, s);
+    if (bc == 32) return launch_cfg<128, 32, 4, 1, true, TOut>(a, s);
+    CTDET_CHECK(false, "dcnv2: unsupported Cout=%d", a.Cout);
+  }
+  // enough pixel tiles to fill 256 CUs with the big tile? otherwise use the 128-pixel variants
+  const long tiles256 = ((long)a.M + 255) / 256 * (a.Cout_pad / bc);
+  const bool big = tiles256 >= 512;
+  switch (bc) {
+    case 16: return launch_cfg<256, 16, 4, 1, false, TOut>(a, s);
+    case 32: return big ? launch_cfg<256, 32, 4, 1, false, TOut>(a, s) : launch_cfg<128, 32, 4, 1, false, TOut>(a, s);
+    case 64: return big ? launch_cfg<256, 64, 4, 1, false, TOut>(a, s) : launch_cfg<128, 64, 2, 2, false, TOut>(a, s);
+    case 128: return big ? launch_cfg<256, 128, 2, 2, false, TOut>(a, s) : launch_cfg<128, 128, 2, 2, false, TOut>(a, s);
+  }
+  CTDET_CHECK(false, "conv: no tile for Cout=%d", a.Cout);
+}
+
+int launch_conv_f16(const ConvArgs& a, int out_dtype, bool deform, hipStream_t s) {
+  CTDET_CHECK(a.Cin % 8 == 0 && a.in_stride % 8 == 0, "conv(f16): Cin=%d / in_stride=%d must be multiples of 8", a.Cin,
+              a.in_stride);
+  CTDET_CHECK(a.Cout % 4 == 0 && a.out_stride % 4 == 0, "conv(f16): Cout=%d / out_stride=%d must be multiples of 4",
+              a.Cout, a.out_stride);
+  CTDET_CHECK(a.Kpad % 32 == 0 && a.Kpad >= a.K, "conv(f16): Kpad=%d invalid for K=%d", a.Kpad, a.K);
+  CTDET_CHECK((long)a.B * a.H * a.W * a.in_stride < (1L << 31), "conv: input too large for 32-bit element offsets");
+  if (out_dtype == CTDET_F16) return launch_conv_f16_t<f16>(a, deform, s);
+  if (out_dtype == CTDET_F32) return launch_conv_f16_t<float>(a, deform, s);
+  CTDET_CHECK(false, "conv: bad out dtype %d", out_dtype);
+}
+
+int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s) {
+  CTDET_CHECK((long)a.B * a.H * a.W * a.in_stride < (1L << 31), "conv: input too large for 32-bit element offsets");
+  const int CP = (a.Cout + 3) & ~3;
+  const long total = (long)a.M * CP;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (deform)
+    hipLaunchKernelGGL((conv_direct_f32_kernel<true>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_direct_f32_kernel<false>), grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,267 @@
+// Batched CenterNet decode: 3x3 max-pool peak test + exact top-K + box assembly.
+// Reference: detectron2/modeling/meta_arch/centernet.py:399-405 (_nms, `hmax == heat` exact equality,
+// plateaus all kept), :408-424 (_topk: per-class top-K then top-K of C*K == global top-K),
+// :426-458 (ctdet_decode).  The reference handles batch==1 only and loops over images in Python
+// (:224-233); here the whole batch is one set of launches with no host round trip.
+//
+// Layout: heat is f32 NHWC [B,H,W,C] (the layout the head conv writes).  Ordering contract
+// ("canonical order"): score descending, ties by the reference's flat NCHW index
+// canon = c*H*W + y*W + x ascending.  torch.topk's own tie order is unspecified, so ties are
+// where a difference is permitted; fixtures are tie-free or assert the canonical rule.
+//
+// Selection = MSD radix select on the 88-bit key (score bits, ~canon): level 0 uses 4096 fine bins
+// over the sigmoid range [2^-15, 2), further levels (only run for degenerate inputs, they early-exit
+// otherwise) split the remaining 56 bits 14 at a time.  Then the <= K-1 certain + <= CAP uncertain
+// candidates are sorted by one workgroup per image.
+// HBM traffic: heat is read twice (histogram pass, collect pass); 3x3 neighbours come from L1/L2.
+#include "common.h"
+
+#define DEC_CAP 2048            // max uncertain candidates carried to the final sort
+#define DEC_NCAND 4096          // sort width (>= K-1 + DEC_CAP)
+#define DEC_HIST 16384          // bins per level >= 1 (level 0 uses 4096)
+#define DEC_LEVELS 5
+// per-image workspace (uint32 words): [0..31] state, [32..32+DEC_HIST) histogram, then candidates (u64)
+#define DEC_ST_WORDS 32
+#define DEC_WS_WORDS (DEC_ST_WORDS + DEC_HIST + 2 * DEC_NCAND)
+enum { ST_RESOLVED = 0, ST_NABOVE = 1, ST_LEVEL = 2, ST_P0 = 3, ST_PR_LO = 4, ST_PR_HI = 5, ST_NCAND = 6,
+       ST_OVERFLOW = 7, ST_TAKEALL = 8 };
+
+__device__ __forceinline__ int dec_d0(uint32_t bits) {
+  const int d = ((int)bits - 0x38000000) >> 15;
+  return d < 0 ? 0 : (d > 4095 ? 4095 : d);
+}
+__device__ __forceinline__ uint64_t dec_r56(uint32_t bits, uint32_t canon) {
+  return ((uint64_t)bits << 24) | (uint64_t)(0xFFFFFFu - canon);
+}
+
+// visits every positive peak of image b handled by this block: f(bits, canon)
+template <typename F>
+__device__ __forceinline__ void for_each_peak(const DecArgs& a, int b, F f) {
+  const int CV = a.C >> 2;
+  const long nvec = (long)a.H * a.W * CV;
+  const float* hb = a.heat + (long)b * a.H * a.W * a.C;
+  const int HW = a.H * a.W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const int p = (int)(i / CV);
+    const int x = p % a.W, y = p / a.W;
+    const float* ctr = hb + (long)p * a.C + cv * 4;
+    const f32x4 v = *(const f32x4*)ctr;
+    f32x4 mx = v;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = y + dy;
+      if (yy < 0 || yy >= a.H) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int xx = x + dx;
+        if ((dy == 0 && dx == 0) || xx < 0 || xx >= a.W) continue;
+        const f32x4 n = *(const f32x4*)(ctr + (long)(dy * a.W + dx) * a.C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx[e] = n[e] > mx[e] ? n[e] : mx[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (v[e] == mx[e] && v[e] > 0.f) f(__float_as_uint(v[e]), (uint32_t)((cv * 4 + e) * HW + p));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) dec_init_kernel(DecArgs a) {
+  uint32_t* ws = a.ws + (long)blockIdx.x * DEC_WS_WORDS;
+  for (int i = threadIdx.x; i < DEC_ST_WORDS + DEC_HIST; i += 256) ws[i] = 0;
+}
+
+__global__ void __launch_bounds__(256) dec_hist_kernel(DecArgs a, int level) {
+  extern __shared__ uint32_t lh[];
+  const int b = blockIdx.y;
+  uint32_t* ws = a.ws + (long)b * DEC_WS_WORDS;
+  if (ws[ST_RESOLVED]) return;
+  const int nb = level == 0 ? 4096 : DEC_HIST;
+  for (int i = threadIdx.x; i < nb; i += 256) lh[i] = 0;
+  __syncthreads();
+  const uint32_t p0 = ws[ST_P0];
+  const uint64_t pr = ((uint64_t)ws[ST_PR_HI] << 32) | ws[ST_PR_LO];
+  for_each_peak(a, b, [&](uint32_t bits, uint32_t canon) {
+    if (level == 0) {
+      atomicAdd(&lh[dec_d0(bits)], 1u);
+    } else {
+      if ((uint32_t)dec_d0(bits) != p0) return;
+      const uint64_t r = dec_r56(bits, canon);
+      if (level > 1 && (r >> (56 - 14 * (level - 1))) != pr) return;
+      atomicAdd(&lh[(uint32_t)(r >> (56 - 14 * level)) & 0x3FFFu], 1u);
+    }
+  });
+  __syncthreads();
+  uint32_t* gh = ws + DEC_ST_WORDS;
+  for (int i = threadIdx.x; i < nb; i += 256)
+    if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
+// one workgroup per image: find the digit holding the K-th largest key at this level
+__global__ void __launch_bounds__(1024) dec_scan_kernel(DecArgs a, int level) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t sh_T, sh_above;
+  const int b = blockIdx.x;
+  uint32_t* ws = a.ws + (long)b * DEC_WS_WORDS;
+  if (ws[ST_RESOLVED]) return;
+  uint32_t* gh = ws + DEC_ST_WORDS;
+  const int nb = level == 0 ? 4096 : DEC_HIST;
+  const int per = nb / 1024;  // 4 or 16 bins per thread, thread t owns bins [t*per, (t+1)*per)
+  const int t = threadIdx.x;
+  uint32_t loc[16];
+  uint32_t s = 0;
+  for (int j = 0; j < per; ++j) { loc[j] = gh[t * per + j]; s += loc[j]; }
+  part[t] = s;
+  __syncthreads();
+  // inclusive suffix sum over threads (sum of bins owned by threads >= t)
+  for (int off = 1; off < 1024; off <<= 1) {
+    const uint32_t add = (t + off < 1024) ? part[t + off] : 0;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  const uint32_t need = (uint32_t)a.K - ws[ST_NABOVE];
+  const uint32_t total = part[0];
+  if (t == 0) { sh_T = 0xFFFFFFFFu; sh_above = 0; }
+  __syncthreads();
+  if (total >= need) {
+    const uint32_t above_me = (t + 1 < 1024) ? part[t + 1] : 0;  // keys in bins of higher threads
+    if (above_me < need && part[t] >= need) {
+      uint32_t cum = above_me;
+      for (int j = per - 1; j >= 0; --j) {
+        if (cum + loc[j] >= need) { sh_T = t * per + j; sh_above = cum; break; }
+        cum += loc[j];
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = 0; j < per; ++j) gh[t * per + j] = 0;  // ready for the next level
+  if (t == 0) {
+    if (total < need) {
+      // fewer positive peaks than K (only possible at level 0): take them all
+      ws[ST_TAKEALL] = 1;
+      ws[ST_RESOLVED] = 1;
+      ws[ST_LEVEL] = 0;
+    } else {
+      const uint32_t T = sh_T;
+      ws[ST_NABOVE] += sh_above;
+      ws[ST_LEVEL] = level;
+      if (level == 0) ws[ST_P0] = T;
+      else {
+        const uint64_t pr = (((uint64_t)ws[ST_PR_HI] << 32) | ws[ST_PR_LO]);
+        const uint64_t npr = (level == 1 ? 0ull : (pr << 14)) | T;
+        ws[ST_PR_LO] = (uint32_t)npr;
+        ws[ST_PR_HI] = (uint32_t)(npr >> 32);
+      }
+    }
+  }
+  __syncthreads();
+  // the owner of bin T decides whether the uncertain bin fits the final sort
+  if (total >= need && sh_T != 0xFFFFFFFFu && (int)(sh_T / per) == t) {
+    const uint32_t cnt = loc[sh_T % per];
+    if (cnt <= DEC_CAP || level == DEC_LEVELS - 1) {
+      ws[ST_RESOLVED] = 1;
+      if (cnt > DEC_CAP) ws[ST_OVERFLOW] = 1;  // cannot happen: last level keys are unique
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) dec_collect_kernel(DecArgs a) {
+  const int b = blockIdx.y;
+  uint32_t* ws = a.ws + (long)b * DEC_WS_WORDS;
+  const int level = (int)ws[ST_LEVEL];
+  const uint32_t p0 = ws[ST_P0];
+  const uint64_t pr = ((uint64_t)ws[ST_PR_HI] << 32) | ws[ST_PR_LO];
+  const bool takeall = ws[ST_TAKEALL] != 0;
+  uint64_t* cand = (uint64_t*)(ws + DEC_ST_WORDS + DEC_HIST);
+  for_each_peak(a, b, [&](uint32_t bits, uint32_t canon) {
+    if (!takeall) {
+      const uint32_t d0 = (uint32_t)dec_d0(bits);
+      if (d0 < p0) return;
+      if (d0 == p0 && level > 0) {
+        const uint64_t r = dec_r56(bits, canon) >> (56 - 14 * level);
+        if (r < pr) return;
+      }
+    }
+    const uint32_t slot = atomicAdd(&ws[ST_NCAND], 1u);
+    if (slot < DEC_NCAND) cand[slot] = ((uint64_t)bits << 32) | (uint64_t)(0xFFFFFFFFu - canon);
+    else ws[ST_OVERFLOW] = 1;
+  });
+}
+
+// one workgroup per image: bitonic sort (descending) of the candidates, emit top K
+__global__ void __launch_bounds__(1024) dec_final_kernel(DecArgs a) {
+  __shared__ uint64_t keys[DEC_NCAND];
+  const int b = blockIdx.x;
+  uint32_t* ws = a.ws + (long)b * DEC_WS_WORDS;
+  const uint64_t* cand = (const uint64_t*)(ws + DEC_ST_WORDS + DEC_HIST);
+  uint32_t n = ws[ST_NCAND];
+  if (n > DEC_NCAND) n = DEC_NCAND;
+  const int t = threadIdx.x;
+  for (int i = t; i < DEC_NCAND; i += 1024) keys[i] = (uint32_t)i < n ? cand[i] : 0ull;
+  __syncthreads();
+  for (int k = 2; k <= DEC_NCAND; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < DEC_NCAND; i += 1024) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint64_t x = keys[i], y = keys[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int HW = a.H * a.W;
+  for (int k = t; k < a.K; k += 1024) {
+    const uint64_t key = keys[k];
+    float score = 0.f; int cls = 0, ind = 0;
+    if ((uint32_t)k < n) {
+      score = __uint_as_float((uint32_t)(key >> 32));
+      const uint32_t canon = 0xFFFFFFFFu - (uint32_t)key;
+      cls = (int)(canon / HW);
+      ind = (int)(canon % HW);
+    }
+    const int x = ind % a.W, y = ind / a.W;
+    const long pix = (long)b * HW + ind;
+    float xs = (float)x, ys = (float)y;
+    if (a.reg) { xs = xs + a.reg[pix * a.reg_stride]; ys = ys + a.reg[pix * a.reg_stride + 1]; }
+    else { xs += 0.5f; ys += 0.5f; }
+    const float w = a.wh[pix * a.wh_stride], h = a.wh[pix * a.wh_stride + 1];
+    const long o = (long)b * a.K + k;
+    a.boxes[o * 4 + 0] = (xs - w / 2) * a.down_ratio;
+    a.boxes[o * 4 + 1] = (ys - h / 2) * a.down_ratio;
+    a.boxes[o * 4 + 2] = (xs + w / 2) * a.down_ratio;
+    a.boxes[o * 4 + 3] = (ys + h / 2) * a.down_ratio;
+    a.scores[o] = score;
+    a.classes[o] = cls;
+    if (a.inds) a.inds[o] = ind;
+  }
+}
+
+size_t decode_workspace_bytes(int B) { return (size_t)B * DEC_WS_WORDS * sizeof(uint32_t); }
+
+int launch_decode(const DecArgs& a, hipStream_t s) {
+  CTDET_CHECK(a.C % 4 == 0, "decode: C=%d must be a multiple of 4", a.C);
+  CTDET_CHECK(a.K >= 1 && a.K <= 1024 && a.K - 1 + DEC_CAP <= DEC_NCAND, "decode: K=%d out of range", a.K);
+  CTDET_CHECK((long)a.C * a.H * a.W < (1L << 24), "decode: C*H*W too large for the 24-bit index field");
+  CTDET_CHECK(((uintptr_t)a.heat & 15) == 0, "decode: heat must be 16-byte aligned");
+  if (a.B == 0) return 0;
+  const long nvec = (long)a.H * a.W * (a.C / 4);
+  int chunks = (int)((nvec + 256 * 16 - 1) / (256 * 16));
+  if (chunks < 1) chunks = 1;
+  if (chunks > 256) chunks = 256;
+  hipLaunchKernelGGL(dec_init_kernel, dim3(a.B), dim3(256), 0, s, a);
+  for (int level = 0; level < DEC_LEVELS; ++level) {
+    const size_t lds = (level == 0 ? 4096 : DEC_HIST) * sizeof(uint32_t);
+    hipLaunchKernelGGL(dec_hist_kernel, dim3(chunks, a.B), dim3(256), lds, s, a, level);
+    hipLaunchKernelGGL(dec_scan_kernel, dim3(a.B), dim3(1024), 0, s, a, level);
+  }
+  hipLaunchKernelGGL(dec_collect_kernel, dim3(chunks, a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(dec_final_kernel, dim3(a.B), dim3(1024), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}

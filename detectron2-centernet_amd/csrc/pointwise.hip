@@ -1,0 +1,176 @@
+// HBM-bound helper kernels of the DLA-34 forward path (NHWC, 16-byte vector accesses).
+//   preprocess   : CenterNet.preprocess_image  (detectron2/modeling/meta_arch/centernet.py:173-185)
+//                  x/255, (x-mean)/std, zero pad to size_divisibility, CHW -> NHWC(8 ch, 3 used)
+//   maxpool2x2   : Tree.downsample = nn.MaxPool2d(stride)   (detectron2/modeling/backbone/dla.py:128-129,139)
+//   dwconvT_add  : IDAUp `up_i` depthwise ConvTranspose2d(k=2f, s=f, p=f/2, groups=C) fused with the
+//                  `layers[i] + layers[i-1]` that feeds `node_i`  (dla.py:162-177)
+#include "common.h"
+
+template <typename TIn, typename TOut>
+__global__ void __launch_bounds__(256) preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict__ out, int B,
+                                                         int H, int W, int Hp, int Wp, long img_batch_stride,
+                                                         float m0, float m1, float m2, float s0, float s1, float s2,
+                                                         int out_stride) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * Hp * Wp;
+  if (idx >= total) return;
+  const int wx = (int)(idx % Wp);
+  const long t = idx / Wp;
+  const int hy = (int)(t % Hp);
+  const int b = (int)(t / Hp);
+  float v[3] = {0.f, 0.f, 0.f};
+  if (hy < H && wx < W) {
+    const TIn* p = img + (long)b * img_batch_stride + (long)hy * W + wx;
+    const long plane = (long)H * W;
+    // same operation order as the reference: (x / 255 - mean) / std, fp32
+    v[0] = ((float)p[0] / 255.f - m0) / s0;
+    v[1] = ((float)p[plane] / 255.f - m1) / s1;
+    v[2] = ((float)p[2 * plane] / 255.f - m2) / s2;
+  }
+  TOut* o = out + idx * out_stride;
+  if constexpr (sizeof(TOut) == 2) {
+    f16x8 r = {(f16)v[0], (f16)v[1], (f16)v[2], 0, 0, 0, 0, 0};
+    *(f16x8*)o = r;
+  } else {
+    *(f32x4*)o = (f32x4){v[0], v[1], v[2], 0.f};
+    *(f32x4*)(o + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// generic channel-vector helpers: VEC elements per thread (8 f16 = 16 B, 4 f32 = 16 B)
+template <typename T> struct Vec;
+template <> struct Vec<f16> { typedef f16x8 type; static constexpr int N = 8; };
+template <> struct Vec<float> { typedef f32x4 type; static constexpr int N = 4; };
+
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool2x2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W,
+                                                         int C, int in_stride, int out_stride) {
+  using V = typename Vec<T>::type;
+  constexpr int N = Vec<T>::N;
+  const int Ho = H / 2, Wo = W / 2, CV = C / N;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * Ho * Wo * CV) return;
+  const int cv = (int)(idx % CV);
+  long t = idx / CV;
+  const int wo = (int)(t % Wo); t /= Wo;
+  const int ho = (int)(t % Ho);
+  const int b = (int)(t / Ho);
+  const T* p = x + ((long)(b * H + 2 * ho) * W + 2 * wo) * in_stride + cv * N;
+  const V v00 = *(const V*)p, v01 = *(const V*)(p + in_stride);
+  const V v10 = *(const V*)(p + (long)W * in_stride), v11 = *(const V*)(p + (long)(W + 1) * in_stride);
+  V r;
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    const float a0 = (float)v00[e] > (float)v01[e] ? (float)v00[e] : (float)v01[e];
+    const float a1 = (float)v10[e] > (float)v11[e] ? (float)v10[e] : (float)v11[e];
+    r[e] = (T)(a0 > a1 ? a0 : a1);
+  }
+  *(V*)(y + ((long)(b * Ho + ho) * Wo + wo) * out_stride + cv * N) = r;
+}
+
+// y[b,oy,ox,c] = skip[b,oy,ox,c] + sum_{ky,kx} x[b,iy,ix,c] * w[c,ky,kx],  oy = iy*f - f/2 + ky, k = 2f:
+// exactly two input rows/cols contribute per output row/col.  w is f32 [C][k][k] (PyTorch
+// ConvTranspose2d weight [C,1,k,k]).
+template <typename T>
+__global__ void __launch_bounds__(256) dwconvT_add_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                          const T* __restrict__ skip, T* __restrict__ y, int B, int H,
+                                                          int W, int C, int f, int in_stride, int skip_stride,
+                                                          int out_stride) {
+  using V = typename Vec<T>::type;
+  constexpr int N = Vec<T>::N;
+  const int Ho = H * f, Wo = W * f, CV = C / N, k = 2 * f, p = f / 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * Ho * Wo * CV) return;
+  const int cv = (int)(idx % CV);
+  long t = idx / CV;
+  const int ox = (int)(t % Wo); t /= Wo;
+  const int oy = (int)(t % Ho);
+  const int b = (int)(t / Ho);
+  const int iy1 = (oy + p) / f, ky1 = (oy + p) - f * iy1;  // ky1 in [0,f)
+  const int ix1 = (ox + p) / f, kx1 = (ox + p) - f * ix1;
+  float acc[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    const int iy = iy1 - dy, ky = ky1 + dy * f;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int ix = ix1 - dx, kx = kx1 + dx * f;
+      if (ix < 0 || ix >= W) continue;
+      const V xv = *(const V*)(x + ((long)(b * H + iy) * W + ix) * in_stride + cv * N);
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[e] = fmaf((float)xv[e], w[((cv * N + e) * k + ky) * k + kx], acc[e]);
+    }
+  }
+  const long opix = (long)(b * Ho + oy) * Wo + ox;
+  V r;
+  if (skip) {
+    const V sv = *(const V*)(skip + opix * skip_stride + cv * N);
+#pragma unroll
+    for (int e = 0; e < N; ++e) r[e] = (T)(acc[e] + (float)sv[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < N; ++e) r[e] = (T)acc[e];
+  }
+  *(V*)(y + opix * out_stride + cv * N) = r;
+}
+
+static inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
+
+int launch_preprocess(const void* img, int img_dtype, void* out, int out_dtype, int B, int H, int W, int Hp, int Wp,
+                      long img_batch_stride, const float* mean, const float* stdv, int out_stride, hipStream_t s) {
+  CTDET_CHECK(out_stride >= 8 && out_stride % 8 == 0, "preprocess: out_stride=%d must be a multiple of 8", out_stride);
+  CTDET_CHECK(Hp >= H && Wp >= W, "preprocess: padded size smaller than image");
+  const long total = (long)B * Hp * Wp;
+  if (total == 0) return 0;
+#define PP(TI, TO)                                                                                               \
+  hipLaunchKernelGGL((preprocess_kernel<TI, TO>), dim3(nblk(total)), dim3(256), 0, s, (const TI*)img, (TO*)out, \
+                     B, H, W, Hp, Wp, img_batch_stride, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], out_stride)
+  if (img_dtype == CTDET_U8 && out_dtype == CTDET_F16) PP(uint8_t, f16);
+  else if (img_dtype == CTDET_U8 && out_dtype == CTDET_F32) PP(uint8_t, float);
+  else if (img_dtype == CTDET_F32 && out_dtype == CTDET_F16) PP(float, f16);
+  else if (img_dtype == CTDET_F32 && out_dtype == CTDET_F32) PP(float, float);
+  else CTDET_CHECK(false, "preprocess: unsupported dtypes in=%d out=%d", img_dtype, out_dtype);
+#undef PP
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_maxpool2x2(const void* x, void* y, int dtype, int B, int H, int W, int C, int in_stride, int out_stride,
+                      hipStream_t s) {
+  CTDET_CHECK(H % 2 == 0 && W % 2 == 0, "maxpool2x2: odd spatial size %dx%d", H, W);
+  const int N = dtype == CTDET_F16 ? 8 : 4;
+  CTDET_CHECK(C % N == 0 && in_stride % N == 0 && out_stride % N == 0, "maxpool2x2: channels must be multiples of %d", N);
+  const long total = (long)B * (H / 2) * (W / 2) * (C / N);
+  if (total == 0) return 0;
+  if (dtype == CTDET_F16)
+    hipLaunchKernelGGL((maxpool2x2_kernel<f16>), dim3(nblk(total)), dim3(256), 0, s, (const f16*)x, (f16*)y, B, H, W, C,
+                       in_stride, out_stride);
+  else if (dtype == CTDET_F32)
+    hipLaunchKernelGGL((maxpool2x2_kernel<float>), dim3(nblk(total)), dim3(256), 0, s, (const float*)x, (float*)y, B, H,
+                       W, C, in_stride, out_stride);
+  else CTDET_CHECK(false, "maxpool2x2: bad dtype %d", dtype);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_dwconvT_add(const void* x, const float* w, const void* skip, void* y, int dtype, int B, int H, int W, int C,
+                       int f, int in_stride, int skip_stride, int out_stride, hipStream_t s) {
+  const int N = dtype == CTDET_F16 ? 8 : 4;
+  CTDET_CHECK(f >= 1 && (f == 1 || f % 2 == 0), "dwconvT: up factor %d unsupported", f);
+  CTDET_CHECK(C % N == 0 && in_stride % N == 0 && out_stride % N == 0 && (!skip || skip_stride % N == 0),
+              "dwconvT: channels must be multiples of %d", N);
+  const long total = (long)B * H * f * W * f * (C / N);
+  if (total == 0) return 0;
+  if (dtype == CTDET_F16)
+    hipLaunchKernelGGL((dwconvT_add_kernel<f16>), dim3(nblk(total)), dim3(256), 0, s, (const f16*)x, w, (const f16*)skip,
+                       (f16*)y, B, H, W, C, f, in_stride, skip_stride, out_stride);
+  else if (dtype == CTDET_F32)
+    hipLaunchKernelGGL((dwconvT_add_kernel<float>), dim3(nblk(total)), dim3(256), 0, s, (const float*)x, w,
+                       (const float*)skip, (float*)y, B, H, W, C, f, in_stride, skip_stride, out_stride);
+  else CTDET_CHECK(false, "dwconvT: bad dtype %d", dtype);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,309 @@
+"""Host-side wrappers over the C ABI: torch tensors are used only as device-memory handles
+(data_ptr + shape); every computation below happens in libctdet_hip.so on the current HIP stream.
+
+Activation convention: NHWC tensors ``[B, H, W, C]`` that may be channel-slices of a wider NHWC
+buffer (that is how Root's ``torch.cat`` (reference dla.py:88) is made free: producers write straight
+into their slice of the concat buffer).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, F16, F32, U8, ConvDesc
+
+_TORCH_DT = {F16: torch.float16, F32: torch.float32}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            # same contract as the reference's native op (deform_conv.py:203-204): no CPU implementation
+            raise NotImplementedError("the CenterNet HIP path has no CPU implementation; tensors must be on a ROCm device")
+
+
+def _nhwc_stride(t):
+    """pixel stride (elements) of an NHWC tensor or channel-slice view; validates the layout."""
+    assert t.dim() == 4, f"expected NHWC 4-D tensor, got {tuple(t.shape)}"
+    B, H, W, Cc = t.shape
+    s = t.stride()
+    ps = s[2] if W > 1 else (s[1] if H > 1 else (s[0] if B > 1 else Cc))
+    if Cc > 1:
+        assert s[3] == 1, "channel dim must be contiguous"
+    assert ps >= Cc
+    if W > 1 and H > 1:
+        assert s[1] == W * ps, "rows must be dense"
+    if B > 1 and H > 1:
+        assert s[0] == H * W * ps, "images must be dense"
+    return ps
+
+
+def dt_of(t):
+    if t.dtype == torch.float16:
+        return F16
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.uint8:
+        return U8
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class PackedConv:
+    """Weights of one conv-shaped contraction, packed for the kernels, plus its folded epilogue.
+
+    weight: [Cout, Cin, R, S] (PyTorch OIHW, the reference's parameter layout).
+    scale/bias: per-output-channel f32 epilogue (folded BatchNorm and/or conv bias) or None.
+    compute: F16 (MFMA) or F32 (exact).
+    """
+
+    def __init__(self, weight, scale=None, bias=None, stride=1, pad=0, dil=1, compute=F16, cin_pad=None):
+        _require_cuda(weight)
+        Cout, Cin, R, S = weight.shape
+        self.Cout, self.R, self.S = Cout, R, S
+        self.Cin = cin_pad if cin_pad is not None else Cin
+        assert self.Cin >= Cin
+        self.stride, self.pad, self.dil, self.compute = stride, pad, dil, compute
+        self.Cout_eff = round_up(Cout, 4)
+        K = R * S * self.Cin
+        self.K = K
+        w = weight.detach().to(torch.float32).permute(0, 2, 3, 1)  # [Cout,R,S,Cin]
+        if self.Cin != Cin:
+            w = torch.nn.functional.pad(w, (0, self.Cin - Cin))
+        w = w.reshape(Cout, K)
+        dev = weight.device
+        if compute == F16:
+            if self.Cin % 8:
+                raise ValueError(f"f16 path needs Cin % 8 == 0 (got {self.Cin}); pass cin_pad")
+            tile = _lib.lib().ctdet_conv_cout_tile(self.Cout_eff)
+            self.Kpad = round_up(K, 32)
+            self.Cout_pad = round_up(self.Cout_eff, tile)
+            wp = torch.zeros(self.Cout_pad, self.Kpad, dtype=torch.float16, device=dev)
+            wp[:Cout, :K] = w.to(torch.float16)
+        else:
+            self.Kpad = K
+            self.Cout_pad = self.Cout_eff
+            wp = torch.zeros(self.Kpad, self.Cout_pad, dtype=torch.float32, device=dev)
+            wp[:K, :Cout] = w.t()
+        self.w = wp.contiguous()
+
+        def _pad(v, fill):
+            if v is None:
+                return None
+            o = torch.full((self.Cout_eff,), fill, dtype=torch.float32, device=dev)
+            o[:Cout] = v.detach().to(torch.float32)
+            return o
+
+        self.scale = _pad(scale, 1.0)
+        self.bias = _pad(bias, 0.0)
+
+    def out_hw(self, H, W):
+        Ho = (H + 2 * self.pad - (self.dil * (self.R - 1) + 1)) // self.stride + 1
+        Wo = (W + 2 * self.pad - (self.dil * (self.S - 1) + 1)) // self.stride + 1
+        return Ho, Wo
+
+    def desc(self, x, out, act, residual, clamp=(0.0, 1.0)):
+        B, H, W, Cx = x.shape
+        assert Cx == self.Cin, f"conv expects {self.Cin} input channels, got {Cx}"
+        Ho, Wo = self.out_hw(H, W)
+        assert tuple(out.shape[:3]) == (B, Ho, Wo) and out.shape[3] >= self.Cout_eff, (out.shape, (B, Ho, Wo, self.Cout_eff))
+        d = ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.in_stride = B, H, W, self.Cin, _nhwc_stride(x)
+        d.Cout, d.Ho, d.Wo, d.out_stride = self.Cout_eff, Ho, Wo, _nhwc_stride(out)
+        d.R, d.S, d.stride, d.pad, d.dil = self.R, self.S, self.stride, self.pad, self.dil
+        d.Kpad, d.Cout_pad = self.Kpad, self.Cout_pad
+        d.compute_dtype, d.out_dtype, d.act = self.compute, dt_of(out), act
+        d.res_stride = _nhwc_stride(residual) if residual is not None else 0
+        d.clamp_lo, d.clamp_hi = clamp
+        return d
+
+
+def _alloc_out(x, p, out, out_dtype):
+    B, H, W, _ = x.shape
+    Ho, Wo = p.out_hw(H, W)
+    if out is None:
+        dt = out_dtype if out_dtype is not None else (torch.float16 if p.compute == F16 else torch.float32)
+        out = torch.empty(B, Ho, Wo, p.Cout_eff, dtype=dt, device=x.device)
+    return out
+
+
+def conv2d(x, p, out=None, act=ACT_NONE, residual=None, out_dtype=None, clamp=(0.0, 1.0)):
+    """y = act(conv(x) * scale + bias + residual); x NHWC. Returns the NHWC output buffer."""
+    _require_cuda(x, residual, out)
+    assert dt_of(x) == p.compute, "input dtype must match the packed compute dtype"
+    out = _alloc_out(x, p, out, out_dtype)
+    if residual is not None:
+        assert residual.dtype == out.dtype and residual.shape[:3] == out.shape[:3]
+    d = p.desc(x, out, act, residual, clamp)
+    rc = _lib.lib().ctdet_conv2d_fwd(C.byref(d), _ptr(x), _ptr(p.w), _ptr(p.scale), _ptr(p.bias), _ptr(residual),
+                                     _ptr(out), _stream())
+    _lib.check(rc, "ctdet_conv2d_fwd")
+    return out
+
+
+def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None):
+    """Modulated deformable conv: offset_mask is the raw f32 NHWC output of conv_offset_mask (>= 27 ch)."""
+    _require_cuda(x, offset_mask, out)
+    assert dt_of(x) == p.compute and offset_mask.dtype == torch.float32
+    out = _alloc_out(x, p, out, out_dtype)
+    assert tuple(offset_mask.shape[:3]) == tuple(out.shape[:3])
+    d = p.desc(x, out, act, None)
+    rc = _lib.lib().ctdet_dcnv2_fwd(C.byref(d), _ptr(x), _ptr(offset_mask), _nhwc_stride(offset_mask), _ptr(p.w),
+                                    _ptr(p.scale), _ptr(p.bias), _ptr(out), _stream())
+    _lib.check(rc, "ctdet_dcnv2_fwd")
+    return out
+
+
+def preprocess(images, mean, std, Hp, Wp, out_dtype=torch.float16, out=None):
+    """images: [B,3,H,W] uint8/float32 CHW on device -> normalised NHWC [B,Hp,Wp,8] (3 channels used)."""
+    _require_cuda(images)
+    B, Cc, H, W = images.shape
+    assert Cc == 3 and images.stride(3) == 1 and images.stride(2) == W and images.stride(1) == H * W
+    if out is None:
+        out = torch.empty(B, Hp, Wp, 8, dtype=out_dtype, device=images.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    rc = _lib.lib().ctdet_preprocess(_ptr(images), dt_of(images), _ptr(out), dt_of(out), B, H, W, Hp, Wp,
+                                     images.stride(0), m, s, _nhwc_stride(out), _stream())
+    _lib.check(rc, "ctdet_preprocess")
+    return out
+
+
+def maxpool2x2(x, out=None):
+    _require_cuda(x, out)
+    B, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty(B, H // 2, W // 2, Cc, dtype=x.dtype, device=x.device)
+    rc = _lib.lib().ctdet_maxpool2x2(_ptr(x), _ptr(out), dt_of(x), B, H, W, Cc, _nhwc_stride(x), _nhwc_stride(out),
+                                     _stream())
+    _lib.check(rc, "ctdet_maxpool2x2")
+    return out
+
+
+def dwconvT_add(x, weight, f, skip=None, out=None):
+    """ConvTranspose2d(C,C,2f,stride=f,padding=f//2,groups=C)(x) + skip; weight f32 [C,1,2f,2f] or [C,2f,2f]."""
+    _require_cuda(x, weight, skip, out)
+    B, H, W, Cc = x.shape
+    w = weight.detach().reshape(Cc, 2 * f, 2 * f).to(torch.float32).contiguous()
+    if out is None:
+        out = torch.empty(B, H * f, W * f, Cc, dtype=x.dtype, device=x.device)
+    rc = _lib.lib().ctdet_dwconvT_add(_ptr(x), _ptr(w), _ptr(skip), _ptr(out), dt_of(x), B, H, W, Cc, f,
+                                      _nhwc_stride(x), _nhwc_stride(skip) if skip is not None else 0,
+                                      _nhwc_stride(out), _stream())
+    _lib.check(rc, "ctdet_dwconvT_add")
+    return out
+
+
+class DecodeWorkspace:
+    def __init__(self, B, device):
+        n = _lib.lib().ctdet_decode_workspace_bytes(B)
+        self.B = B
+        self.buf = torch.empty(n // 4, dtype=torch.int32, device=device)
+
+
+def decode(heat, wh, reg, K, down_ratio, workspace=None, check_status=False):
+    """Batched ctdet_decode. heat f32 NHWC [B,H,W,C]; wh/reg f32 NHWC (2 channels, may be slices).
+    Returns boxes [B,K,4], scores [B,K], classes [B,K] (int32), inds [B,K] (int32)."""
+    _require_cuda(heat, wh, reg)
+    assert heat.dtype == torch.float32 and heat.is_contiguous()
+    B, H, W, Cc = heat.shape
+    if workspace is None or workspace.B < B:
+        workspace = DecodeWorkspace(B, heat.device)
+    dev = heat.device
+    boxes = torch.empty(B, K, 4, dtype=torch.float32, device=dev)
+    scores = torch.empty(B, K, dtype=torch.float32, device=dev)
+    classes = torch.empty(B, K, dtype=torch.int32, device=dev)
+    inds = torch.empty(B, K, dtype=torch.int32, device=dev)
+    rc = _lib.lib().ctdet_decode(_ptr(heat), _ptr(wh), _nhwc_stride(wh), _ptr(reg),
+                                 _nhwc_stride(reg) if reg is not None else 0, B, H, W, Cc, K, float(down_ratio),
+                                 _ptr(workspace.buf), _ptr(boxes), _ptr(scores), _ptr(classes), _ptr(inds), _stream())
+    _lib.check(rc, "ctdet_decode")
+    if check_status:
+        _lib.check(_lib.lib().ctdet_decode_status(_ptr(workspace.buf), B, _stream()), "ctdet_decode_status")
+    return boxes, scores, classes, inds
+
+
+def gaussian_targets(boxes, classes, counts, H, W, num_classes, hm=None):
+    """Batched gen_heatmap. boxes f32 [B,Nmax,4], classes i64 [B,Nmax], counts i32 [B].
+    Returns dict(hm [B,H,W,C] NHWC f32, wh [B,128,2], reg [B,128,2], ind [B,128] i64, reg_mask [B,128] u8)."""
+    _require_cuda(boxes, classes, counts)
+    B, Nmax, _ = boxes.shape
+    dev = boxes.device
+    assert boxes.dtype == torch.float32 and classes.dtype == torch.int64 and counts.dtype == torch.int32
+    boxes, classes = boxes.contiguous(), classes.contiguous()
+    if hm is None:
+        hm = torch.empty(B, H, W, num_classes, dtype=torch.float32, device=dev)
+    wh = torch.empty(B, 128, 2, dtype=torch.float32, device=dev)
+    reg = torch.empty(B, 128, 2, dtype=torch.float32, device=dev)
+    ind = torch.empty(B, 128, dtype=torch.int64, device=dev)
+    reg_mask = torch.empty(B, 128, dtype=torch.uint8, device=dev)
+    rc = _lib.lib().ctdet_gaussian_targets(_ptr(boxes), _ptr(classes), _ptr(counts), B, Nmax, H, W, num_classes,
+                                           _ptr(hm), _ptr(wh), _ptr(reg), _ptr(ind), _ptr(reg_mask), _stream())
+    _lib.check(rc, "ctdet_gaussian_targets")
+    return {"hm": hm, "wh": wh, "reg": reg, "ind": ind, "reg_mask": reg_mask}
+
+
+def gaussian_radius(hw_pairs):
+    """hw_pairs i32 [n,2] (h, w) on device -> (radius f64 [n], int radius i32 [n])."""
+    _require_cuda(hw_pairs)
+    n = hw_pairs.shape[0]
+    r = torch.empty(n, dtype=torch.float64, device=hw_pairs.device)
+    ri = torch.empty(n, dtype=torch.int32, device=hw_pairs.device)
+    rc = _lib.lib().ctdet_gaussian_radius(_ptr(hw_pairs.contiguous()), n, _ptr(r), _ptr(ri), _stream())
+    _lib.check(rc, "ctdet_gaussian_radius")
+    return r, ri
+
+
+def focal_loss(logits, gt, alpha, want_grad=True, grad_scale=1.0):
+    """_neg_loss on sigmoid+clamp of logits. logits/gt f32 NHWC [B,H,W,C]; alpha f32 [C].
+    Returns (loss [1], stats [4] = pos, neg, num_pos, 1/num_pos, grad or None)."""
+    _require_cuda(logits, gt, alpha)
+    assert logits.is_contiguous() and gt.is_contiguous() and logits.shape == gt.shape
+    B, H, W, Cc = logits.shape
+    dev = logits.device
+    ws = torch.empty(_lib.lib().ctdet_focal_loss_workspace_bytes(logits.numel()) // 4, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    stats = torch.empty(4, dtype=torch.float32, device=dev)
+    grad = torch.empty_like(logits) if want_grad else None
+    rc = _lib.lib().ctdet_focal_loss(_ptr(logits), _ptr(gt), _ptr(alpha), B, H, W, Cc, float(grad_scale), _ptr(ws),
+                                     _ptr(loss), _ptr(stats), _ptr(grad), _stream())
+    _lib.check(rc, "ctdet_focal_loss")
+    return loss, stats, grad
+
+
+def reg_l1_loss(pred, mask, ind, target, want_grad=True, grad_scale=1.0, grad=None):
+    """RegL1Loss. pred f32 NHWC [B,H,W,2] (may be a channel slice); mask u8 [B,N]; ind i64 [B,N]; target [B,N,2]."""
+    _require_cuda(pred, mask, ind, target)
+    B, H, W, _ = pred.shape
+    N = mask.shape[1]
+    dev = pred.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    if want_grad and grad is None:
+        grad = torch.zeros(B, H, W, 2, dtype=torch.float32, device=dev)
+    rc = _lib.lib().ctdet_reg_l1_loss(_ptr(pred), _nhwc_stride(pred), _ptr(mask.contiguous()), _ptr(ind.contiguous()),
+                                      _ptr(target.contiguous()), B, N, H * W, float(grad_scale), _ptr(loss),
+                                      _ptr(grad) if want_grad else C.c_void_p(0),
+                                      _nhwc_stride(grad) if want_grad else 0, _stream())
+    _lib.check(rc, "ctdet_reg_l1_loss")
+    return loss, grad
+
+
+def sgd_momentum_(param, grad, buf, lr_dev, momentum, weight_decay, first_step):
+    """In-place fused SGD step on flat f32 tensors; lr_dev is a 1-element device tensor."""
+    _require_cuda(param, grad, buf, lr_dev)
+    assert param.is_contiguous() and grad.is_contiguous() and buf.is_contiguous()
+    rc = _lib.lib().ctdet_sgd_momentum(_ptr(param), _ptr(grad), _ptr(buf), param.numel(), _ptr(lr_dev),
+                                       float(momentum), float(weight_decay), int(bool(first_step)), _stream())
+    _lib.check(rc, "ctdet_sgd_momentum")

@@ -1,0 +1,125 @@
+/* ctdet_hip.h -- C ABI of the MI355X-native CenterNet hot path (libctdet_hip.so).
+ *
+ * Drop-in boundary: these entry points are what the reference's own native binding for this path
+ * would bind.  In the reference the binding is the pybind11 module `detectron2._C`
+ * (detectron2/layers/csrc/vision.cpp:70-117) whose functions take at::Tensor; here every function
+ * takes plain device pointers + explicit shapes + a hipStream_t (as void*), the caller owns all
+ * buffers (no hidden allocation, workspace sizes are queried), and every function returns 0 or a
+ * negative errno-style code with the message available from ctdet_last_error().
+ *
+ * Device layout: activations NHWC ("pixel rows" of `*_stride` elements), f16 (throughput mode) or
+ * f32 (exact mode); conv weights pre-packed with ctdet-side layout (see ctdet_conv_desc).
+ * All launches go to the stream passed in; nothing synchronises; all functions are graph-capturable.
+ */
+#ifndef CTDET_HIP_H
+#define CTDET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum ctdet_dtype { CTDET_DT_F16 = 0, CTDET_DT_F32 = 1, CTDET_DT_U8 = 2 };
+enum ctdet_act { CTDET_AC_NONE = 0, CTDET_AC_RELU = 1, CTDET_AC_SIGMOID_CLAMP = 2 };
+
+/* Geometry of one conv-shaped contraction.
+ * compute_dtype F16: x is f16 NHWC, weights f16 packed [Cout_pad][Kpad], k = (r*S+s)*Cin + c,
+ *   Kpad = roundup(R*S*Cin, 32), Cout_pad = roundup(Cout, tile) with tile = ctdet_conv_cout_tile(Cout);
+ *   MFMA f16 x f16 -> f32 accumulate; y is out_dtype (f16 or f32).
+ * compute_dtype F32: x, y f32, weights f32 packed [Kpad][Cout_pad] (any Kpad >= K, Cout_pad >= Cout);
+ *   exact f32 FMA chain (parity mode). */
+typedef struct ctdet_conv_desc {
+  int32_t B, H, W, Cin, in_stride;
+  int32_t Cout, Ho, Wo, out_stride;
+  int32_t R, S, stride, pad, dil;
+  int32_t Kpad, Cout_pad;
+  int32_t compute_dtype, out_dtype;
+  int32_t act;          /* ctdet_act, applied after scale/bias/residual */
+  int32_t res_stride;   /* pixel stride of the residual tensor (same dtype as y) */
+  float clamp_lo, clamp_hi; /* for CTDET_AC_SIGMOID_CLAMP */
+} ctdet_conv_desc;
+
+const char* ctdet_last_error(void);
+int32_t ctdet_abi_version(void);
+int32_t ctdet_conv_cout_tile(int32_t cout);
+
+/* y = act(conv(x, w) * scale + bias + residual).  Replaces torch.nn.Conv2d (+BatchNorm2d eval +ReLU
+ * +residual add) at detectron2/modeling/backbone/dla.py:59-73,86-94,212-220,249-259 and the head convs at
+ * detectron2/modeling/meta_arch/centernet.py:115-121.  scale/bias/residual may be NULL. */
+int32_t ctdet_conv2d_fwd(const ctdet_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                         const float* bias, const void* residual, void* y, void* stream);
+
+/* Modulated deformable conv v2 forward, batched and fused (sampling -> MFMA, no columns buffer).
+ * Replaces _C.modulated_deform_conv_forward (detectron2/layers/csrc/vision.cpp:85-88,
+ * deform_conv_cuda.cu:804-927, deform_conv.py:214-234).  offset_mask is the raw f32 output of the
+ * 27-channel conv_offset_mask conv, [B*Ho*Wo, om_stride]: ch 2k = dh, 2k+1 = dw of tap k, ch 18+k = mask
+ * logit (sigmoid applied here).  scale/bias fold the conv bias and the following BatchNorm. */
+int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* offset_mask, int32_t om_stride,
+                        const void* w_packed, const float* scale, const float* bias, void* y, void* stream);
+
+/* CenterNet.preprocess_image (centernet.py:173-185) + ImageList.from_tensors padding
+ * (detectron2/structures/image_list.py:58-130): img is [B,3,H,W] (u8 or f32, CHW, batch stride given in
+ * elements), out is NHWC [B,Hp,Wp,out_stride] with channels 0..2 = (x/255 - mean)/std, the rest 0. */
+int32_t ctdet_preprocess(const void* img, int32_t img_dtype, void* out, int32_t out_dtype, int32_t B, int32_t H,
+                         int32_t W, int32_t Hp, int32_t Wp, int64_t img_batch_stride, const float* mean3,
+                         const float* std3, int32_t out_stride, void* stream);
+
+/* nn.MaxPool2d(2, stride=2) on NHWC (dla.py:128-129). */
+int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
+                         int32_t in_stride, int32_t out_stride, void* stream);
+
+/* y = ConvTranspose2d(C, C, 2f, stride=f, padding=f/2, groups=C, bias=False)(x) + skip  (dla.py:162-177).
+ * w is f32 [C][2f][2f]; skip may be NULL. */
+int32_t ctdet_dwconvT_add(const void* x, const float* w, const void* skip, void* y, int32_t dtype, int32_t B,
+                          int32_t H, int32_t W, int32_t C, int32_t f, int32_t in_stride, int32_t skip_stride,
+                          int32_t out_stride, void* stream);
+
+/* Batched ctdet_decode (centernet.py:399-458): heat f32 NHWC [B,H,W,C] (already sigmoid+clamp), wh/reg f32
+ * with pixel strides; outputs boxes [B,K,4] f32, scores [B,K] f32, classes [B,K] i32, inds [B,K] i32
+ * (spatial index y*W+x; may be NULL).  Order: score desc, ties by c*H*W+y*W+x asc.  reg may be NULL. */
+size_t ctdet_decode_workspace_bytes(int32_t B);
+int32_t ctdet_decode(const float* heat, const float* wh, int32_t wh_stride, const float* reg, int32_t reg_stride,
+                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t K, float down_ratio, void* workspace,
+                     float* boxes, float* scores, int32_t* classes, int32_t* inds, void* stream);
+/* reads back the per-image status words of the last decode on this workspace (device->host copy + sync):
+ * returns 0 if every image decoded exactly, -75 (EOVERFLOW) if a degenerate input overflowed the
+ * candidate buffer.  Test/diagnostic helper, not on the hot path. */
+int32_t ctdet_decode_status(const void* workspace, int32_t B, void* stream);
+
+/* gen_heatmap + gaussian_radius + draw_umich_gaussian, batched on device
+ * (detectron2/data/detection_utils.py:600-705).  boxes f32 [B,Nmax,4] XYXY input pixels, classes i64
+ * [B,Nmax], counts i32 [B].  hm f32 NHWC [B,H,W,C] is zeroed here.  wh/reg f32 [B,128,2], ind i64 [B,128],
+ * reg_mask u8 [B,128]. */
+int32_t ctdet_gaussian_targets(const float* boxes, const int64_t* classes, const int32_t* counts, int32_t B,
+                               int32_t Nmax, int32_t H, int32_t W, int32_t C, float* hm, float* wh, float* reg,
+                               int64_t* ind, uint8_t* reg_mask, void* stream);
+/* gaussian_radius((h, w)) for a grid of integer sizes (test hook for detection_utils.py:654-680):
+ * out_radius f64 [n], out_int i32 [n] = max(0, (int)radius). */
+int32_t ctdet_gaussian_radius(const int32_t* hw_pairs, int32_t n, double* out_radius, int32_t* out_int, void* stream);
+
+/* FocalLoss/_neg_loss forward + gradient wrt the logits, fused (centernet.py:204,323-369).
+ * logits, gt: f32 NHWC [B,H,W,C]; alpha f32 [C].  partial: f32 workspace [3*nblocks] from
+ * ctdet_focal_loss_workspace_bytes.  Outputs: loss f32[1]; stats f32[3] = {pos_loss, neg_loss, num_pos};
+ * grad f32 NHWC (d loss / d logits, times grad_scale), may be NULL for forward only. */
+size_t ctdet_focal_loss_workspace_bytes(int64_t numel);
+int32_t ctdet_focal_loss(const float* logits, const float* gt, const float* alpha, int32_t B, int32_t H, int32_t W,
+                         int32_t C, float grad_scale, void* workspace, float* loss, float* stats, float* grad,
+                         void* stream);
+
+/* RegL1Loss forward + gradient (centernet.py:372-397): pred f32 NHWC [B,H,W,pred_stride] (2 channels used
+ * starting at pred), mask u8 [B,N], ind i64 [B,N], target f32 [B,N,2]; loss f32[1];
+ * grad (same layout/stride as pred, 2 channels, must be pre-zeroed by the caller) may be NULL. */
+int32_t ctdet_reg_l1_loss(const float* pred, int32_t pred_stride, const uint8_t* mask, const int64_t* ind,
+                          const float* target, int32_t B, int32_t N, int32_t HW, float grad_scale, float* loss,
+                          float* grad, int32_t grad_stride, void* stream);
+
+/* torch.optim.SGD step with momentum/weight decay (detectron2/solver/build.py:93-137):
+ * g' = g + wd*p; buf = mom*buf + g'; p -= lr*buf   (first step: buf = g'). lr is read from device memory
+ * so the captured graph stays valid across the WarmupMultiStepLR schedule. */
+int32_t ctdet_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, const float* lr_dev,
+                           float momentum, float weight_decay, int32_t first_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

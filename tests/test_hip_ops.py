@@ -1,0 +1,347 @@
+"""GPU parity tests of every HIP kernel, called through the C ABI, against the CPU oracle.
+
+Tolerances: index / class / mask outputs bit-exact; f32 kernels 1e-4 relative to the oracle's f32 result
+(different summation order only); f16-MFMA kernels are fed f16-representable inputs so the only differences
+are f32 accumulation order and the final f16 rounding (2e-3 relative).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ctdet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import detectron2_centernet_amd.ops as ops
+
+    return ops
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def h16(t):  # round to f16-representable f32
+    return t.half().float()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, residual, relu
+    (2, 20, 24, 16, 16, 3, 1, 1, False, True),
+    (2, 20, 24, 16, 32, 3, 2, 1, False, True),
+    (1, 18, 22, 32, 64, 3, 2, 1, False, True),
+    (2, 16, 16, 64, 64, 3, 1, 1, True, True),
+    (1, 12, 20, 128, 128, 3, 1, 1, True, True),
+    (1, 8, 8, 256, 256, 3, 1, 1, False, False),
+    (3, 9, 7, 448, 128, 1, 1, 0, False, True),
+    (1, 16, 16, 64, 768, 3, 1, 1, False, True),
+    (1, 16, 16, 256, 80, 1, 1, 0, False, False),
+    (1, 10, 10, 64, 27, 3, 1, 1, False, False),
+    (5, 40, 40, 64, 64, 3, 1, 1, False, True),   # > 512 tiles -> 256-pixel tile variant
+    (4, 64, 64, 128, 128, 3, 1, 1, True, True),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+def test_conv2d(ops, dev, case, mode):
+    B, H, W, Cin, Cout, k, s, p, use_res, relu = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = h16(torch.randn(B, Cin, H, W, generator=g))
+    w = h16(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, None, s, p) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    res = None
+    if use_res:
+        res = h16(torch.randn(ref.shape, generator=g))
+        ref = ref + res
+    if relu:
+        ref = ref.relu()
+    comp = ops.F16 if mode == "f16" else ops.F32
+    tdt = torch.float16 if mode == "f16" else torch.float32
+    pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=s, pad=p, compute=comp)
+    res_d = None
+    if res is not None:
+        res_d = torch.zeros(ref.shape[0], ref.shape[2], ref.shape[3], pc.Cout_eff, dtype=tdt)
+        res_d[..., :Cout] = nhwc(res).to(tdt)
+        res_d = res_d.to(dev)
+    y = ops.conv2d(nhwc(x).to(tdt).to(dev), pc, act=ops.ACT_RELU if relu else ops.ACT_NONE, residual=res_d)
+    got = nchw(y[..., :Cout].float().cpu())
+    tol = 3e-3 if mode == "f16" else 1e-4
+    err = (got - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), f"max err {err}"
+
+
+def test_conv_f16_f32_output_and_slices(ops, dev):
+    """f32 output from the f16 MFMA kernel, reading a channel slice and writing into a slice of a wider buffer."""
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 12, 12
+    xw = h16(torch.randn(B, H, W, 96, generator=g))
+    w = h16(torch.randn(32, 64, 1, 1, generator=g) / 8)
+    pc = ops.PackedConv(w.to(dev), None, None, compute=ops.F16)
+    big = torch.zeros(B, H, W, 64, dtype=torch.float32, device=dev)
+    ops.conv2d(xw.half().to(dev)[..., 32:96], pc, out=big[..., 16:48])
+    ref = nhwc(F.conv2d(nchw(xw[..., 32:96]), w))
+    assert (big[..., 16:48].cpu() - ref).abs().max() < 2e-3
+    assert big[..., :16].abs().max() == 0 and big[..., 48:].abs().max() == 0
+
+
+def test_stem_7x7(ops, dev):
+    g = torch.Generator().manual_seed(4)
+    x = h16(torch.randn(2, 3, 32, 40, generator=g))
+    w = h16(torch.randn(16, 3, 7, 7, generator=g) / 12)
+    ref = F.conv2d(x, w, None, 1, 3).relu()
+    x8 = torch.zeros(2, 32, 40, 8)
+    x8[..., :3] = nhwc(x)
+    for comp, tdt, tol in ((ops.F16, torch.float16, 3e-3), (ops.F32, torch.float32, 1e-4)):
+        pc = ops.PackedConv(w.to(dev), None, None, stride=1, pad=3, compute=comp, cin_pad=8)
+        y = ops.conv2d(x8.to(tdt).to(dev), pc, act=ops.ACT_RELU)
+        assert (nchw(y.float().cpu()) - ref).abs().max() < tol * ref.abs().max()
+
+
+DCN_CASES = [(2, 12, 14, 64, 64, 2.0), (1, 9, 9, 128, 64, 0.0), (2, 8, 10, 128, 128, 4.0), (1, 6, 6, 256, 256, 1.0),
+             (1, 7, 5, 512, 256, 8.0)]
+
+
+@pytest.mark.parametrize("case", DCN_CASES)
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+def test_dcnv2(ops, dev, case, mode):
+    B, H, W, Cin, Cout, off_std = case
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = h16(torch.randn(B, Cin, H, W, generator=g))
+    w = h16(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    om = torch.randn(B, 27, H, W, generator=g)
+    om[:, :18] *= off_std
+    # put a few samples exactly on integer / border coordinates
+    om[:, 0, 0, 0] = -0.0
+    om[:, 1, 0, 0] = -1.0
+    om[:, 2, -1, -1] = 1.0
+    bias = torch.randn(Cout, generator=g)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    ref = O.dcnv2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, None, 1, 1, 1)
+    ref = (ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)).relu()
+    comp = ops.F16 if mode == "f16" else ops.F32
+    tdt = torch.float16 if mode == "f16" else torch.float32
+    pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=1, pad=1, compute=comp)
+    om_d = torch.zeros(B, H, W, 32)
+    om_d[..., :27] = nhwc(om)
+    y = ops.dcnv2(nhwc(x).to(tdt).to(dev), om_d.to(dev), pc, act=ops.ACT_RELU)
+    got = nchw(y[..., :Cout].float().cpu())
+    # f16 mode additionally rounds the sampled*mask operand to f16 before the MFMA
+    tol = 6e-3 if mode == "f16" else 2e-4
+    err = (got - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), f"max err {err}"
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.float32])
+def test_maxpool_and_dwconvT(ops, dev, tdt):
+    g = torch.Generator().manual_seed(7)
+    x = h16(torch.randn(2, 64, 12, 16, generator=g))
+    y = ops.maxpool2x2(nhwc(x).to(tdt).to(dev))
+    assert torch.equal(nchw(y.float().cpu()), F.max_pool2d(x, 2, 2))
+    for f in (2, 4):
+        w = torch.rand(64, 1, 2 * f, 2 * f, generator=g)
+        skip = h16(torch.randn(2, 64, 12 * f, 16 * f, generator=g))
+        ref = F.conv_transpose2d(x, w, None, stride=f, padding=f // 2, groups=64) + skip
+        out = ops.dwconvT_add(nhwc(x).to(tdt).to(dev), w.to(dev), f, skip=nhwc(skip).to(tdt).to(dev))
+        tol = 2e-3 if tdt == torch.float16 else 1e-5
+        assert (nchw(out.float().cpu()) - ref).abs().max() < tol * ref.abs().max()
+
+
+def test_preprocess(ops, dev):
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (3, 3, 50, 70), generator=g, dtype=torch.uint8)
+    mean, std = [0.408, 0.447, 0.470], [0.289, 0.274, 0.278]
+    ref, _ = O.preprocess([i for i in img], mean, std, 32)
+    out = ops.preprocess(img.to(dev), mean, std, 64, 96, out_dtype=torch.float32)
+    assert torch.allclose(nchw(out[..., :3].cpu()), ref, atol=2e-6, rtol=1e-6)
+    assert out[..., 3:].abs().max() == 0
+    out16 = ops.preprocess(img.float().to(dev), mean, std, 64, 96, out_dtype=torch.float16)
+    assert (nchw(out16[..., :3].float().cpu()) - ref).abs().max() < 2e-3
+
+
+def _rand_heat(B, C, H, W, seed, lo=1e-4, hi=1 - 1e-4):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(B, C, H, W, generator=g) * 1.5 - 2.19
+    return torch.clamp(torch.sigmoid(logits), lo, hi)
+
+
+@pytest.mark.parametrize("shape", [(1, 80, 128, 128), (3, 80, 32, 48), (2, 4, 16, 16), (2, 8, 128, 128)])
+def test_decode_matches_oracle(ops, dev, shape):
+    B, C, H, W = shape
+    heat = _rand_heat(B, C, H, W, seed=sum(shape))
+    g = torch.Generator().manual_seed(1)
+    wh = torch.rand(B, 2, H, W, generator=g) * 20
+    reg = torch.rand(B, 2, H, W, generator=g)
+    K = 100
+    rb, rs, rc, ri = O.ctdet_decode(heat, wh, reg, down_ratio=4, K=K)
+    whreg = torch.cat([nhwc(wh), nhwc(reg)], dim=3).to(dev)
+    b, s, c, i = ops.decode(nhwc(heat).to(dev), whreg[..., 0:2], whreg[..., 2:4], K, 4.0, check_status=True)
+    assert torch.equal(s.cpu(), rs), "scores differ"
+    assert torch.equal(c.cpu(), rc), "classes differ"
+    assert torch.equal(i.cpu().long(), ri), "peak indices differ"
+    assert torch.allclose(b.cpu(), rb, atol=1e-4, rtol=1e-6)
+
+
+def test_decode_plateau_and_sparse(ops, dev):
+    """plateaus: `hmax == heat` keeps every plateau cell; ties resolve by flat NCHW index ascending.
+    sparse: fewer than K positive peaks -> remaining slots have score 0."""
+    B, C, H, W = 1, 4, 16, 16
+    heat = torch.full((B, C, H, W), 0.01)
+    heat[0, 1, 4:6, 4:6] = 0.9      # 2x2 plateau: all four kept
+    heat[0, 2, 10, 10] = 0.95
+    wh = torch.ones(B, 2, H, W)
+    reg = torch.zeros(B, 2, H, W)
+    rb, rs, rc, ri = O.ctdet_decode(heat, wh, reg, down_ratio=4, K=20)
+    whreg = torch.cat([nhwc(wh), nhwc(reg)], dim=3).to(dev)
+    b, s, c, i = ops.decode(nhwc(heat).to(dev), whreg[..., 0:2], whreg[..., 2:4], 20, 4.0, check_status=True)
+    assert torch.equal(s.cpu(), rs) and torch.equal(c.cpu(), rc) and torch.equal(i.cpu().long(), ri)
+    assert s[0, 0].item() == pytest.approx(0.95) and (s[0, 1:5].cpu() == 0.9).all()
+    # sparse
+    heat2 = torch.zeros(B, C, H, W)
+    heat2[0, 0, 3, 3] = 0.5
+    heat2[0, 3, 8, 9] = 0.7
+    b, s, c, i = ops.decode(nhwc(heat2).to(dev), whreg[..., 0:2], whreg[..., 2:4], 20, 4.0, check_status=True)
+    assert s[0, :2].tolist() == pytest.approx([0.7, 0.5]) and (s[0, 2:] == 0).all()
+    assert c[0, :2].tolist() == [3, 0] and i[0, :2].tolist() == [8 * W + 9, 3 * W + 3]
+
+
+def test_decode_big_tie_block(ops, dev):
+    """a constant heatmap (every cell a peak, all equal) needs the deep radix levels: top-K = first K flat indices."""
+    B, C, H, W = 2, 8, 32, 32
+    heat = torch.full((B, C, H, W), 0.25)
+    wh = torch.ones(B, 2, H, W)
+    whreg = torch.cat([nhwc(wh), nhwc(torch.zeros(B, 2, H, W))], dim=3).to(dev)
+    b, s, c, i = ops.decode(nhwc(heat).to(dev), whreg[..., 0:2], whreg[..., 2:4], 100, 4.0, check_status=True)
+    assert (s == 0.25).all() and (c == 0).all()
+    assert i[0].tolist() == list(range(100)) and i[1].tolist() == list(range(100))
+
+
+def test_gaussian_radius_grid(ops, dev):
+    hw = torch.stack(torch.meshgrid(torch.arange(1, 129), torch.arange(1, 129), indexing="ij"), -1).reshape(-1, 2)
+    r, ri = ops.gaussian_radius(hw.int().to(dev))
+    ref = np.array([O.gaussian_radius((int(h), int(w))) for h, w in hw.tolist()])
+    assert np.array_equal(r.cpu().numpy(), ref), "f64 radius not bit-identical"
+    assert np.array_equal(ri.cpu().numpy(), np.maximum(0, ref.astype(np.int64)).astype(np.int32))
+
+
+def _rand_instances(B, n_max, size, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    boxes = torch.zeros(B, n_max, 4)
+    classes = torch.zeros(B, n_max, dtype=torch.int64)
+    counts = torch.randint(1, n_max + 1, (B,), generator=g).int()
+    for b in range(B):
+        n = counts[b].item()
+        wh = torch.rand(n, 2, generator=g) * 248 + 8
+        ctr = torch.rand(n, 2, generator=g) * (size - wh) + wh / 2
+        boxes[b, :n] = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+        classes[b, :n] = torch.randint(0, C, (n,), generator=g)
+    return boxes, classes, counts
+
+
+def test_gaussian_targets(ops, dev):
+    B, C, size = 4, 80, 512
+    boxes, classes, counts = _rand_instances(B, 32, size, C, seed=5)
+    # edge cases: zero-area box, box touching the border, duplicate centre/class, class at the last index
+    boxes[0, 0] = torch.tensor([10.0, 10.0, 10.0, 50.0])
+    boxes[0, 1] = torch.tensor([0.0, 0.0, 37.0, 23.0])
+    boxes[0, 2] = torch.tensor([400.0, 380.0, 511.9, 511.9])
+    boxes[0, 3] = boxes[0, 2]
+    classes[0, 3] = classes[0, 2]
+    classes[0, 1] = C - 1
+    counts[0] = max(counts[0].item(), 4)
+    out = ops.gaussian_targets(boxes.to(dev), classes.to(dev), counts.to(dev), size // 4, size // 4, C)
+    for b in range(B):
+        n = counts[b].item()
+        ref = O.gen_heatmap(boxes[b, :n], classes[b, :n], size // 4, size // 4, C)
+        hm = nchw(out["hm"][b:b + 1].cpu())[0].numpy()
+        assert np.array_equal(out["ind"][b].cpu().numpy(), ref["ind"])
+        assert np.array_equal(out["reg_mask"][b].cpu().numpy(), ref["reg_mask"])
+        assert np.array_equal(out["wh"][b].cpu().numpy(), ref["wh"])
+        assert np.array_equal(out["reg"][b].cpu().numpy(), ref["reg"])
+        assert np.array_equal(hm == 1.0, ref["hm"] == 1.0)
+        assert np.array_equal(hm > 0, ref["hm"] > 0)
+        assert np.abs(hm - ref["hm"]).max() <= 1e-6
+
+
+def test_gaussian_targets_more_than_128(ops, dev):
+    B, C = 1, 8
+    g = torch.Generator().manual_seed(9)
+    n = 150
+    ctr = torch.rand(n, 2, generator=g) * 400 + 50
+    boxes = torch.cat([ctr - 12, ctr + 12], 1).view(1, n, 4)
+    classes = torch.randint(0, C, (1, n), generator=g)
+    out = ops.gaussian_targets(boxes.to(dev), classes.to(dev), torch.tensor([n], dtype=torch.int32, device=dev), 128, 128, C)
+    ref = O.gen_heatmap(boxes[0], classes[0], 128, 128, C)
+    assert np.array_equal(out["ind"][0].cpu().numpy(), ref["ind"])
+    assert np.abs(nchw(out["hm"].cpu())[0].numpy() - ref["hm"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("alpha", [[1.0], [0.25]])
+@pytest.mark.parametrize("with_pos", [True, False])
+def test_focal_loss(ops, dev, alpha, with_pos):
+    B, C, H, W = 2, 8, 32, 32
+    g = torch.Generator().manual_seed(21)
+    logits = (torch.randn(B, C, H, W, generator=g) * 3 - 2).requires_grad_(True)
+    logits.data[0, 0, 0, 0] = 12.0   # sigmoid above the clamp: zero gradient there
+    logits.data[0, 0, 0, 1] = -12.0
+    gt = torch.rand(B, C, H, W, generator=g) ** 4
+    if with_pos:
+        gt.view(-1)[torch.randint(0, gt.numel(), (30,), generator=g)] = 1.0
+        gt[0, 0, 0, 0] = 1.0
+    ref = O.focal_loss_from_logits(logits, gt, alpha)
+    ref.backward()
+    a = torch.tensor(alpha * C if len(alpha) == 1 else alpha, dtype=torch.float32)
+    loss, stats, grad = ops.focal_loss(nhwc(logits.detach()).to(dev), nhwc(gt).to(dev), a.to(dev))
+    assert loss.item() == pytest.approx(ref.item(), rel=1e-5, abs=1e-6)
+    assert stats[2].item() == float((gt == 1).sum())
+    gref = logits.grad
+    assert (nchw(grad.cpu()) - gref).abs().max() <= 1e-5 * max(1.0, gref.abs().max().item())
+
+
+def test_reg_l1_loss(ops, dev):
+    B, H, W, N = 3, 16, 16, 128
+    g = torch.Generator().manual_seed(31)
+    out = torch.randn(B, 2, H, W, generator=g, requires_grad=True)
+    mask = (torch.rand(B, N, generator=g) < 0.2).to(torch.uint8)
+    ind = torch.randint(0, H * W, (B, N), generator=g)
+    ind[0, 1] = ind[0, 0]
+    mask[0, 0] = mask[0, 1] = 1     # duplicate index: gradients accumulate
+    tgt = torch.randn(B, N, 2, generator=g)
+    ref = O.reg_l1_loss(out, mask, ind, tgt)
+    ref.backward()
+    loss, grad = ops.reg_l1_loss(nhwc(out.detach()).to(dev), mask.to(dev), ind.to(dev), tgt.to(dev))
+    assert loss.item() == pytest.approx(ref.item(), rel=1e-5)
+    assert (nchw(grad.cpu()) - out.grad).abs().max() < 1e-6
+    # all-masked-out: loss 0 / 1e-4
+    loss0, _ = ops.reg_l1_loss(nhwc(out.detach()).to(dev), torch.zeros_like(mask).to(dev), ind.to(dev), tgt.to(dev))
+    assert loss0.item() == 0.0
+
+
+def test_sgd_matches_torch(ops, dev):
+    g = torch.Generator().manual_seed(41)
+    p = torch.randn(10007, generator=g)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    pd, buf = p.to(dev), torch.zeros(10007, device=dev)
+    lr = torch.tensor([0.01], device=dev)
+    for step in range(3):
+        gr = torch.randn(10007, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        ops.sgd_momentum_(pd, gr.to(dev), buf, lr, 0.9, 1e-4, first_step=(step == 0))
+    assert torch.allclose(pd.cpu(), pr.detach(), atol=1e-6, rtol=1e-6)
+
+
+def test_cpu_tensors_are_rejected(ops):
+    with pytest.raises(NotImplementedError):
+        ops.maxpool2x2(torch.zeros(1, 4, 4, 8))
