@@ -23,6 +23,8 @@ int launch_dwconvT_add(const void*, const float*, const void*, void*, int, int, 
                        hipStream_t);
 size_t decode_workspace_bytes(int B);
 int launch_decode(const DecArgs&, hipStream_t);
+int launch_postprocess(const float*, const float*, const int*, int, int, int, float, const float*, float*, float*, int*,
+                       int*, hipStream_t);
 int launch_gaussian_radius(const int*, int, double*, int*, hipStream_t);
 int launch_gaussian_targets(const float*, const int64_t*, const int*, int, int, int, int, int, float*, float*, float*,
                             int64_t*, uint8_t*, hipStream_t);
@@ -83,8 +85,43 @@ int32_t ctdet_conv2d_fwd(const ctdet_conv_desc* d, const void* x, const void* w_
   CTDET_CHECK(false, "conv: bad compute dtype %d", d->compute_dtype);
 }
 
+int32_t ctdet_conv1x1_cat_fwd(const ctdet_conv_desc* d, const void* const* xs, const int32_t* cins,
+                              const int32_t* strides, int32_t nsrc, const void* w_packed, const float* scale,
+                              const float* bias, const void* residual, void* y, void* stream) {
+  ConvArgs a;
+  int rc = fill_args(d, a);
+  if (rc) return rc;
+  if (a.M == 0) return 0;
+  CTDET_CHECK(xs && cins && strides && w_packed && y, "conv1x1_cat: null pointer");
+  CTDET_CHECK(nsrc >= 1 && nsrc <= 4, "conv1x1_cat: nsrc=%d must be 1..4", nsrc);
+  CTDET_CHECK(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0, "conv1x1_cat: only 1x1 stride-1 convs");
+  const int align = d->compute_dtype == CTDET_DT_F16 ? 8 : 1;
+  int cum = 0;
+  for (int j = 0; j < 4; ++j) {
+    if (j < nsrc) {
+      CTDET_CHECK(xs[j] && cins[j] > 0 && cins[j] % align == 0 && strides[j] >= cins[j] && strides[j] % align == 0,
+                  "conv1x1_cat: bad source %d (cin=%d stride=%d)", j, cins[j], strides[j]);
+      cum += cins[j];
+      a.xs[j] = xs[j]; a.xs_stride[j] = strides[j];
+    } else {
+      a.xs[j] = xs[nsrc - 1]; a.xs_stride[j] = strides[nsrc - 1];
+    }
+    a.xs_cend[j] = cum;
+  }
+  CTDET_CHECK(cum == d->Cin, "conv1x1_cat: sources sum to %d channels, descriptor says %d", cum, d->Cin);
+  a.nsrc = nsrc < 2 ? 2 : nsrc;  // always take the multi-source path (a single source is sources {0, 0-length})
+  if (nsrc == 1) { a.nsrc = 1; a.in_stride = strides[0]; }
+  a.x = xs[0]; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
+  if (d->compute_dtype == CTDET_DT_F16) return launch_conv_f16(a, d->out_dtype, false, (hipStream_t)stream);
+  if (d->compute_dtype == CTDET_DT_F32) {
+    CTDET_CHECK(d->out_dtype == CTDET_DT_F32, "conv1x1_cat(f32): output must be f32");
+    return launch_conv_f32(a, false, (hipStream_t)stream);
+  }
+  CTDET_CHECK(false, "conv1x1_cat: bad compute dtype %d", d->compute_dtype);
+}
+
 int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* offset_mask, int32_t om_stride,
-                        const void* w_packed, const float* scale, const float* bias, void* y, void* stream) {
+                        int32_t mask_is_prob, const void* w_packed, const float* scale, const float* bias, void* y, void* stream) {
   ConvArgs a;
   int rc = fill_args(d, a);
   if (rc) return rc;
@@ -92,7 +129,7 @@ int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* of
   CTDET_CHECK(x && w_packed && y && offset_mask, "dcnv2: null pointer");
   CTDET_CHECK(om_stride >= 3 * d->R * d->S, "dcnv2: om_stride=%d < 3*R*S", om_stride);
   a.x = x; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = nullptr; a.y = y;
-  a.om = offset_mask; a.om_stride = om_stride;
+  a.om = offset_mask; a.om_stride = om_stride; a.mask_is_prob = mask_is_prob;
   if (d->compute_dtype == CTDET_DT_F16) return launch_conv_f16(a, d->out_dtype, true, (hipStream_t)stream);
   if (d->compute_dtype == CTDET_DT_F32) {
     CTDET_CHECK(d->out_dtype == CTDET_DT_F32, "dcnv2(f32): output must be f32");
@@ -134,6 +171,15 @@ int32_t ctdet_decode(const float* heat, const float* wh, int32_t wh_stride, cons
   a.B = B; a.H = H; a.W = W; a.C = C; a.K = K; a.down_ratio = down_ratio;
   a.ws = (uint32_t*)workspace; a.boxes = boxes; a.scores = scores; a.classes = classes; a.inds = inds;
   return launch_decode(a, (hipStream_t)stream);
+}
+
+int32_t ctdet_postprocess(const float* boxes, const float* scores, const int32_t* classes, int32_t B, int32_t K,
+                          int32_t max_det, float score_thresh, const float* img_params, float* out_boxes,
+                          float* out_scores, int32_t* out_classes, int32_t* counts, void* stream) {
+  CTDET_CHECK(boxes && scores && classes && img_params && out_boxes && out_scores && out_classes && counts,
+              "postprocess: null pointer");
+  return launch_postprocess(boxes, scores, classes, B, K, max_det, score_thresh, img_params, out_boxes, out_scores,
+                            out_classes, counts, (hipStream_t)stream);
 }
 
 int32_t ctdet_decode_status(const void* workspace, int32_t B, void* stream) {

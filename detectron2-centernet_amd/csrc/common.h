@@ -42,8 +42,15 @@ struct ConvArgs {
   const float* bias;    // per-cout bias (folded BN beta - mean*scale, or conv bias) or null
   const void* res;      // residual added before activation, same dtype as y, or null
   void* y;              // [B,Ho,Wo,out_stride]
+  // Root (dla.py:86-94) = 1x1 conv over torch.cat(children): instead of materialising the concat the
+  // kernel reads K segments from up to 4 source tensors (nsrc > 1; 1x1, stride 1, pad 0 only).
+  const void* xs[4];
+  int xs_stride[4];
+  int xs_cend[4];       // cumulative channel ends of the sources
+  int nsrc;
   const float* om;      // DCNv2 only: [M, om_stride] f32; ch 0..17 offsets (2k=dh,2k+1=dw), 18..26 mask logits
   int om_stride;
+  int mask_is_prob;     // DCNv2: 0 = mask channels are logits (sigmoid here), 1 = already probabilities
   int B, H, W, Cin, in_stride;
   int Cout, Ho, Wo, out_stride, res_stride;
   int R, S, stride, pad, dil;

@@ -38,7 +38,8 @@ __device__ __forceinline__ void dcn_setup(const ConvArgs& a, bool row_ok, int pi
   if (!row_ok || tr >= a.R) return;
   const int tap = tr * a.S + ts;
   const float oh = omrow[2 * tap], ow = omrow[2 * tap + 1];
-  sp.mask = ctdet_sigmoid_exact(omrow[2 * a.R * a.S + tap]);
+  const float mraw = omrow[2 * a.R * a.S + tap];
+  sp.mask = a.mask_is_prob ? mraw : ctdet_sigmoid_exact(mraw);
   const float h_im = (float)(hb + tr * a.dil) + oh;
   const float w_im = (float)(wb + ts * a.dil) + ow;
   if (!(h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W)) return;
@@ -157,6 +158,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 
   auto issue_loads = [&](int kt) {
     if constexpr (!DEFORM) {
+      if (a.nsrc > 1) {
+        // concat-free Root: pick the source tensor holding channel kk of the virtual concat
+        const int kk = kt * 32 + g * 8;
+        const f16* src = (const f16*)a.xs[0];
+        int st = a.xs_stride[0], cb0 = 0;
+        if (kk >= a.xs_cend[0]) { src = (const f16*)a.xs[1]; st = a.xs_stride[1]; cb0 = a.xs_cend[0]; }
+        if (a.nsrc > 2 && kk >= a.xs_cend[1]) { src = (const f16*)a.xs[2]; st = a.xs_stride[2]; cb0 = a.xs_cend[1]; }
+        if (a.nsrc > 3 && kk >= a.xs_cend[2]) { src = (const f16*)a.xs[3]; st = a.xs_stride[3]; cb0 = a.xs_cend[2]; }
+        const bool kin = kk < a.Cin;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+          const long pix = a_pix[i] + a_hb[i] * a.W + a_wb[i];
+          areg[i] = (kin && a_ok[i]) ? *(const f16x8*)(src + pix * st + (kk - cb0)) : zero8;
+        }
+      } else
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         const int hi = a_hb[i] + tr * a.dil, wi = a_wb[i] + ts * a.dil;
@@ -226,9 +242,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) {
-      // the blend in store_stage() below must still see the samples the in-flight corners belong to,
-      // so for DEFORM the k-state advances after the blend of the *previous* prefetch (done: it was
-      // stored before the barrier), i.e. here.
+      // advance the k-state (and, for DEFORM, the sampling geometry) to step kt+1 before prefetching it;
+      // the blend in store_stage() below then uses the same geometry the in-flight corner loads used.
       const bool moved = advance_k();
       if (DEFORM && moved) setup_samples();
       issue_loads(kt + 1);
@@ -286,6 +301,14 @@ __global__ void __launch_bounds__(256) conv_direct_f32_kernel(const ConvArgs a) 
       if constexpr (!DEFORM) {
         const int hi = hb + tr * a.dil, wi = wb + ts * a.dil;
         if (hi < 0 || hi >= a.H || wi < 0 || wi >= a.W) continue;
+        if (a.nsrc > 1) {
+          int c = 0;
+          for (int j = 0; j < a.nsrc; ++j) {
+            const float* xp = (const float*)a.xs[j] + (long)m * a.xs_stride[j] - c;
+            for (; c < a.xs_cend[j]; ++c) acc = fmaf(xp[c], wk[(long)c * a.Cout_pad], acc);
+          }
+          continue;
+        }
         const float* xp = x + (long)(pix_base + hi * a.W + wi) * a.in_stride;
         for (int c = 0; c < a.Cin; ++c) acc = fmaf(xp[c], wk[(long)c * a.Cout_pad], acc);
       } else {

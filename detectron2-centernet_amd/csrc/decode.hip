@@ -242,6 +242,57 @@ __global__ void __launch_bounds__(1024) dec_final_kernel(DecArgs a) {
   }
 }
 
+// inference_single_image (centernet.py:251-261: slice to max detections, score > threshold) followed by
+// detector_postprocess (detectron2/modeling/postprocessing.py:11-72: scale, clip, drop empty boxes), for the
+// whole batch: one wave per image, order-preserving compaction.  img_params[b] = {scale_x, scale_y, out_w, out_h}.
+__global__ void __launch_bounds__(64) dec_postprocess_kernel(const float* __restrict__ boxes,
+                                                            const float* __restrict__ scores,
+                                                            const int* __restrict__ classes, int K, int max_det,
+                                                            float thresh, const float* __restrict__ img_params,
+                                                            float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                            int* __restrict__ out_classes, int* __restrict__ counts) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float sx = img_params[b * 4 + 0], sy = img_params[b * 4 + 1];
+  const float ow = img_params[b * 4 + 2], oh = img_params[b * 4 + 3];
+  int base = 0;
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    const int k = k0 + lane;
+    bool keep = false;
+    float x1 = 0, y1 = 0, x2 = 0, y2 = 0, sc = 0;
+    int cl = 0;
+    if (k < K && k < max_det) {
+      const long o = (long)b * K + k;
+      sc = scores[o];
+      cl = classes[o];
+      x1 = fminf(fmaxf(boxes[o * 4 + 0] * sx, 0.f), ow);
+      y1 = fminf(fmaxf(boxes[o * 4 + 1] * sy, 0.f), oh);
+      x2 = fminf(fmaxf(boxes[o * 4 + 2] * sx, 0.f), ow);
+      y2 = fminf(fmaxf(boxes[o * 4 + 3] * sy, 0.f), oh);
+      keep = sc > thresh && (x2 - x1) > 0.f && (y2 - y1) > 0.f;
+    }
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      const long o = (long)b * K + pos;
+      out_boxes[o * 4 + 0] = x1; out_boxes[o * 4 + 1] = y1; out_boxes[o * 4 + 2] = x2; out_boxes[o * 4 + 3] = y2;
+      out_scores[o] = sc;
+      out_classes[o] = cl;
+    }
+    base += __popcll(m);
+  }
+  if (lane == 0) counts[b] = base;
+}
+
+int launch_postprocess(const float* boxes, const float* scores, const int* classes, int B, int K, int max_det,
+                       float thresh, const float* img_params, float* out_boxes, float* out_scores, int* out_classes,
+                       int* counts, hipStream_t s) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(dec_postprocess_kernel, dim3(B), dim3(64), 0, s, boxes, scores, classes, K, max_det, thresh,
+                     img_params, out_boxes, out_scores, out_classes, counts);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
 size_t decode_workspace_bytes(int B) { return (size_t)B * DEC_WS_WORDS * sizeof(uint32_t); }
 
 int launch_decode(const DecArgs& a, hipStream_t s) {

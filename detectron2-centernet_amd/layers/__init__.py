@@ -1,0 +1,5 @@
+from .shape_spec import ShapeSpec
+from .deform_conv import DCN, DeformConvV2, ModulatedDeformConv, modulated_deform_conv
+from . import hipnn
+
+__all__ = ["ShapeSpec", "DCN", "DeformConvV2", "ModulatedDeformConv", "modulated_deform_conv", "hipnn"]

@@ -1,0 +1,265 @@
+"""DLA-34 with DCNv2 up-sampling (IDAUp / DLAUp), executed by the HIP kernels.
+
+Structure, parameter names and initialisers follow detectron2/modeling/backbone/dla.py
+(`DLABasicBlock` :45-73, `Root` :76-94, `Tree` :97-150, `IDAUp` :152-177, `DLAUp` :180-203, `DLA` :206-279,
+`DLA34` :283-315, `build_dla34_backbone` :318-321, `fill_up_weights` :33-42), so a reference state dict loads
+key-for-key.  The torch.nn layer objects are parameter containers only: `hip_forward` runs NHWC HIP kernels --
+conv+BN(+residual)+ReLU are one kernel each, Root's `torch.cat` is never materialised (multi-source 1x1 conv),
+the depthwise ConvTranspose is fused with the following `layers[i] + layers[i-1]`.
+
+Differences by necessity: the reference constructor downloads ImageNet weights (dla.py:297-298, 269-279);
+this build never touches the network -- `pretrained` is a local file path or empty.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from ... import ops
+from ...layers import DeformConvV2, ShapeSpec, hipnn
+from ...ops import ACT_NONE, ACT_RELU, F16, F32
+from .backbone import Backbone
+from .build import BACKBONE_REGISTRY
+
+BN_MOMENTUM = 0.1
+
+
+def fill_up_weights(up):
+    """bilinear-interpolation initialiser of the depthwise up-convolution (dla.py:33-42)."""
+    w = up.weight.data
+    f = math.ceil(w.size(2) / 2)
+    c = (2 * f - 1 - f % 2) / (2.0 * f)
+    for i in range(w.size(2)):
+        for j in range(w.size(3)):
+            w[0, 0, i, j] = (1 - math.fabs(i / f - c)) * (1 - math.fabs(j / f - c))
+    for ch in range(1, w.size(0)):
+        w[ch, 0, :, :] = w[0, 0, :, :]
+
+
+class DLABasicBlock(nn.Module):
+    def __init__(self, inplanes, planes, stride=1, dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=dilation, bias=False,
+                               dilation=dilation)
+        self.bn1 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=dilation, bias=False,
+                               dilation=dilation)
+        self.bn2 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.stride = stride
+
+    def hip_forward(self, x, ctx, residual=None):
+        if residual is None:
+            residual = x
+        out = hipnn.conv_module(x, self.conv1, self.bn1, ACT_RELU, ctx=ctx)
+        return hipnn.conv_module(out, self.conv2, self.bn2, ACT_RELU, residual=residual, ctx=ctx)
+
+
+class Root(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, residual):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, 1, stride=1, bias=False, padding=(kernel_size - 1) // 2)
+        self.bn = nn.BatchNorm2d(out_channels, momentum=BN_MOMENTUM)
+        self.relu = nn.ReLU(inplace=True)
+        self.residual = residual
+
+    def hip_forward(self, xs, ctx):
+        p = hipnn.packed(self.conv, "conv", ctx.compute, self.conv.weight, self.bn, None, 1, 0, 1)
+        return ops.conv1x1_cat(list(xs), p, act=ACT_RELU, residual=xs[0] if self.residual else None)
+
+
+class Tree(nn.Module):
+    def __init__(self, levels, block, in_channels, out_channels, stride=1, level_root=False, root_dim=0,
+                 root_kernel_size=1, dilation=1, root_residual=False):
+        super().__init__()
+        if root_dim == 0:
+            root_dim = 2 * out_channels
+        if level_root:
+            root_dim += in_channels
+        if levels == 1:
+            self.tree1 = block(in_channels, out_channels, stride, dilation=dilation)
+            self.tree2 = block(out_channels, out_channels, 1, dilation=dilation)
+        else:
+            self.tree1 = Tree(levels - 1, block, in_channels, out_channels, stride, root_dim=0,
+                              root_kernel_size=root_kernel_size, dilation=dilation, root_residual=root_residual)
+            self.tree2 = Tree(levels - 1, block, out_channels, out_channels, root_dim=root_dim + out_channels,
+                              root_kernel_size=root_kernel_size, dilation=dilation, root_residual=root_residual)
+        if levels == 1:
+            self.root = Root(root_dim, out_channels, root_kernel_size, root_residual)
+        self.level_root = level_root
+        self.root_dim = root_dim
+        self.downsample = None
+        self.project = None
+        self.levels = levels
+        if stride > 1:
+            assert stride == 2, "HIP max-pool kernel is 2x2/2 (the only one DLA-34 uses)"
+            self.downsample = nn.MaxPool2d(stride, stride=stride)
+        if in_channels != out_channels:
+            self.project = nn.Sequential(
+                nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, bias=False),
+                nn.BatchNorm2d(out_channels, momentum=BN_MOMENTUM))
+
+    def hip_forward(self, x, ctx, residual=None, children=None):
+        children = [] if children is None else children
+        bottom = ops.maxpool2x2(x) if self.downsample else x
+        residual = hipnn.conv_module(bottom, self.project[0], self.project[1], ACT_NONE, ctx=ctx) if self.project \
+            else bottom
+        if self.level_root:
+            children.append(bottom)
+        if self.levels == 1:
+            x1 = self.tree1.hip_forward(x, ctx, residual)
+            x2 = self.tree2.hip_forward(x1, ctx)
+            return self.root.hip_forward([x2, x1] + children, ctx)
+        x1 = self.tree1.hip_forward(x, ctx, residual)
+        children.append(x1)
+        return self.tree2.hip_forward(x1, ctx, children=children)
+
+
+class IDAUp(nn.Module):
+    def __init__(self, o, channels, up_f):
+        super().__init__()
+        for i in range(1, len(channels)):
+            c = channels[i]
+            f = int(up_f[i])
+            proj = DeformConvV2(c, o)
+            node = DeformConvV2(o, o)
+            up = nn.ConvTranspose2d(o, o, f * 2, stride=f, padding=f // 2, output_padding=0, groups=o, bias=False)
+            fill_up_weights(up)
+            setattr(self, "proj_" + str(i), proj)
+            setattr(self, "up_" + str(i), up)
+            setattr(self, "node_" + str(i), node)
+
+    def hip_forward(self, layers, startp, endp, ctx):
+        for i in range(startp + 1, endp):
+            up = getattr(self, "up_" + str(i - startp))
+            proj = getattr(self, "proj_" + str(i - startp))
+            node = getattr(self, "node_" + str(i - startp))
+            # layers[i] = up(proj(layers[i])); layers[i] = node(layers[i] + layers[i-1])   (dla.py:175-177)
+            t = proj.hip_forward(layers[i], ctx)
+            t = ops.dwconvT_add(t, up.weight, up.stride[0], skip=layers[i - 1])
+            layers[i] = node.hip_forward(t, ctx)
+
+
+class DLAUp(nn.Module):
+    def __init__(self, startp, channels, scales, in_channels=None):
+        super().__init__()
+        self.startp = startp
+        if in_channels is None:
+            in_channels = channels
+        self.channels = channels
+        channels = list(channels)
+        in_channels = list(in_channels)
+        scales = np.array(scales, dtype=int)
+        for i in range(len(channels) - 1):
+            j = -i - 2
+            setattr(self, "ida_{}".format(i), IDAUp(channels[j], in_channels[j:], scales[j:] // scales[j]))
+            scales[j + 1:] = scales[j]
+            in_channels[j + 1:] = [channels[j] for _ in channels[j + 1:]]
+
+    def hip_forward(self, layers, ctx):
+        layers = list(layers)
+        out = [layers[-1]]
+        for i in range(len(layers) - self.startp - 1):
+            ida = getattr(self, "ida_{}".format(i))
+            ida.hip_forward(layers, len(layers) - i - 2, len(layers), ctx)
+            out.insert(0, layers[-1])
+        return out
+
+
+class DLA(Backbone):
+    def __init__(self, levels, channels, num_classes=1000, block=DLABasicBlock, residual_root=False):
+        super().__init__()
+        self.channels = channels
+        self.num_classes = num_classes
+        self.base_layer = nn.Sequential(
+            nn.Conv2d(3, channels[0], kernel_size=7, stride=1, padding=3, bias=False),
+            nn.BatchNorm2d(channels[0], momentum=BN_MOMENTUM), nn.ReLU(inplace=True))
+        self.level0 = self._make_conv_level(channels[0], channels[0], levels[0])
+        self.level1 = self._make_conv_level(channels[0], channels[1], levels[1], stride=2)
+        self.level2 = Tree(levels[2], block, channels[1], channels[2], 2, level_root=False, root_residual=residual_root)
+        self.level3 = Tree(levels[3], block, channels[2], channels[3], 2, level_root=True, root_residual=residual_root)
+        self.level4 = Tree(levels[4], block, channels[3], channels[4], 2, level_root=True, root_residual=residual_root)
+        self.level5 = Tree(levels[5], block, channels[4], channels[5], 2, level_root=True, root_residual=residual_root)
+
+    def _make_conv_level(self, inplanes, planes, convs, stride=1, dilation=1):
+        modules = []
+        for i in range(convs):
+            modules.extend([
+                nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride if i == 0 else 1, padding=dilation, bias=False,
+                          dilation=dilation),
+                nn.BatchNorm2d(planes, momentum=BN_MOMENTUM), nn.ReLU(inplace=True)])
+            inplanes = planes
+        return nn.Sequential(*modules)
+
+    @staticmethod
+    def _conv_level_forward(seq, x, ctx, cin_pad=None):
+        mods = list(seq)
+        for i in range(0, len(mods), 3):
+            x = hipnn.conv_module(x, mods[i], mods[i + 1], ACT_RELU, ctx=ctx, cin_pad=cin_pad if i == 0 else None)
+        return x
+
+    def hip_forward(self, x, ctx):
+        """x: NHWC [B,H,W,8] (3 image channels + zero padding) -> the six level outputs (NHWC)."""
+        y = []
+        x = self._conv_level_forward(self.base_layer, x, ctx, cin_pad=x.shape[3])
+        for i in range(6):
+            lvl = getattr(self, "level{}".format(i))
+            x = self._conv_level_forward(lvl, x, ctx) if i < 2 else lvl.hip_forward(x, ctx)
+            y.append(x)
+        return y
+
+    def forward(self, x):
+        ctx = hipnn.Ctx(F16 if x.dtype == torch.float16 else F32)
+        return [hipnn.to_nchw_view(t) for t in self.hip_forward(hipnn.to_nhwc(x, ctx, pad_to=8), ctx)]
+
+    def load_pretrained_model(self, path):
+        """local-file replacement of dla.py:269-279 (the reference fetches a URL here)."""
+        weights = torch.load(path, map_location="cpu")
+        weights = {k: v for k, v in weights.items() if not k.startswith("fc.")}
+        self.load_state_dict(weights, strict=True)
+
+
+class DLA34(Backbone):
+    def __init__(self, cfg, pretrained=""):
+        super().__init__()
+        self.down_ratio = cfg.MODEL.CENTERNET.DOWN_RATIO
+        self.num_classes = cfg.MODEL.CENTERNET.NUM_CLASSES
+        self.last_level = cfg.MODEL.CENTERNET.LAST_LEVEL
+        self.levels = list(cfg.MODEL.CENTERNET.LEVELS)
+        self.channels = list(cfg.MODEL.CENTERNET.CHANNELS)
+        self.size_div = cfg.MODEL.CENTERNET.SIZE_DIVISIBILITY
+        assert self.down_ratio in [2, 4, 8, 16]
+        self.first_level = int(np.log2(self.down_ratio))
+        out_channel = self.channels[self.first_level]
+        self.base = DLA(self.levels, self.channels, block=DLABasicBlock)
+        if pretrained:
+            self.base.load_pretrained_model(pretrained)
+        scales = [2 ** i for i in range(len(self.channels[self.first_level:]))]
+        self.dla_up = DLAUp(self.first_level, self.channels[self.first_level:], scales)
+        self.ida_up = IDAUp(out_channel, self.channels[self.first_level:self.last_level],
+                            [2 ** i for i in range(self.last_level - self.first_level)])
+
+    @property
+    def size_divisibility(self):
+        return self.size_div
+
+    def hip_forward(self, x, ctx):
+        """x: NHWC [B,H,W,8] normalised image -> list of NHWC maps; the last one is the [B,H/4,W/4,64] head input."""
+        x = self.base.hip_forward(x, ctx)
+        x = self.dla_up.hip_forward(x, ctx)
+        # the reference clones these maps (dla.py:311-313) because IDAUp mutates in place; buffers here are
+        # never written twice, so no copy is needed
+        y = [x[i] for i in range(self.last_level - self.first_level)]
+        self.ida_up.hip_forward(y, 0, len(y), ctx)
+        return y
+
+    def forward(self, x):
+        """logical NCHW image batch in, list of logical NCHW maps out (like dla.py:308-315)."""
+        ctx = hipnn.Ctx(F16 if x.dtype == torch.float16 else F32)
+        return [hipnn.to_nchw_view(t) for t in self.hip_forward(hipnn.to_nhwc(x, ctx, pad_to=8), ctx)]
+
+
+@BACKBONE_REGISTRY.register()
+def build_dla34_backbone(cfg, input_shape: ShapeSpec):
+    return DLA34(cfg, pretrained=cfg.MODEL.CENTERNET.get("PRETRAINED_BACKBONE", ""))

@@ -1,0 +1,377 @@
+"""CenterNet meta-architecture on the HIP kernels.
+
+Mirrors detectron2/modeling/meta_arch/centernet.py: `CenterNet` (:35-321; constructor reads the same cfg keys
+:42-55, heads built from `cfg.MODEL.CENTERNET.TASK` :111-134 with hm bias -2.19), `forward` (:140-171),
+`preprocess_image` (:173-189), `losses` (:191-212), `inference` / `inference_single_image` (:214-266) and
+`ctdet_decode` (:426-458).
+
+What is different by design (MI355X-first, same results):
+  * the whole eval forward -- preprocess, DLA-34, heads, sigmoid+clamp, peak-NMS, top-K, box assembly,
+    thresholding and detector_postprocess -- is one HIP graph replay per batch; the reference loops over
+    images in Python with ~25 tiny launches each (:224-233) and only decodes batch == 1 (:450-456);
+  * the three head 3x3 convs share their input and run as one 64->768 conv; sigmoid+clamp is the hm conv's
+    epilogue;
+  * gaussian targets are splatted on the device for the whole batch (the reference does it in numpy on the
+    host inside forward, :188).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from ... import ops
+from ...data.catalog import DatasetCatalog, MetadataCatalog
+from ...layers import hipnn
+from ...ops import ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, F16, F32
+from ...structures import Boxes, ImageList, Instances
+from ..backbone import build_backbone
+from .build import META_ARCH_REGISTRY
+
+__all__ = ["CenterNet", "ctdet_decode"]
+
+
+def fill_fc_weights(layers):
+    for m in layers.modules():
+        if isinstance(m, nn.Conv2d) and m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+
+def ctdet_decode(heat, wh, reg=None, down_ratio=1, cat_spec_wh=False, K=100):
+    """Reference signature (centernet.py:426): logical-NCHW `heat` [B,C,H,W] (after sigmoid+clamp), `wh`, `reg`
+    [B,2,H,W].  Unlike the reference this accepts any batch size; for B == 1 it returns the reference's shapes
+    (bboxes [K,4], scores [K], clses [K] int32), otherwise a leading batch dimension is kept."""
+    if cat_spec_wh:
+        raise NotImplementedError("cat_spec_wh is not used by any CenterNet config of the reference")
+    if not heat.is_cuda:
+        raise NotImplementedError("ctdet_decode runs on the HIP device only")
+    h = heat.permute(0, 2, 3, 1).float().contiguous()
+    w = wh.permute(0, 2, 3, 1).float().contiguous()
+    r = reg.permute(0, 2, 3, 1).float().contiguous() if reg is not None else None
+    boxes, scores, classes, _ = ops.decode(h, w, r, K, down_ratio)
+    if heat.shape[0] == 1:
+        return boxes[0], scores[0], classes[0]
+    return boxes, scores, classes
+
+
+class _EvalEngine:
+    """Static-shape inference engine: buffers + a captured HIP graph of the whole eval forward."""
+
+    def __init__(self, model, B, H, W, Hp, Wp, img_dtype, use_graph=True):
+        self.model, self.key = model, (B, H, W, Hp, Wp, img_dtype)
+        dev = model.device
+        self.images = torch.zeros(B, 3, H, W, dtype=img_dtype, device=dev)
+        self.img_params = torch.zeros(B, 4, dtype=torch.float32, device=dev)
+        self.graph = None
+        self.Hp, self.Wp = Hp, Wp
+        self._run()                      # warm-up: packs weights, sizes the allocator
+        torch.cuda.synchronize()
+        if use_graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._run()
+            self.graph = g
+
+    def _run(self):
+        m = self.model
+        x = ops.preprocess(self.images, m._mean_host, m._std_host, self.Hp, self.Wp, out_dtype=m._ctx.dtype)
+        self.out = m._network_outputs(x, apply_sigmoid=True)
+        hm, wh, reg = self.out
+        self.dec = ops.decode(hm, wh, reg, m.topk_candidates, m.backbone.down_ratio)
+        boxes, scores, classes, _ = self.dec
+        max_det = min(m.max_detections_per_image, m.topk_candidates)
+        self.final = ops.postprocess(boxes, scores, classes, max_det, m.score_threshold, self.img_params)
+
+    def __call__(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._run()
+        return self.final
+
+
+@META_ARCH_REGISTRY.register()
+class CenterNet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        # fmt: off
+        head_conv                     = cfg.MODEL.CENTERNET.HEAD_CONV
+        final_kernel                  = cfg.MODEL.CENTERNET.FINAL_KERNEL
+        backbone_type                 = cfg.MODEL.BACKBONE.NAME
+        self.heads                    = dict(cfg.MODEL.CENTERNET.TASK)
+        self.hm_weight                = cfg.MODEL.CENTERNET.HM_WEIGHT
+        self.wh_weight                = cfg.MODEL.CENTERNET.WH_WEIGHT
+        self.off_weight               = cfg.MODEL.CENTERNET.OFF_WEIGHT
+        self.focal_loss_alpha         = list(cfg.MODEL.CENTERNET.FOCAL_LOSS_ALPHA)
+        self.score_threshold          = cfg.MODEL.CENTERNET.SCORE_THRESH_TEST
+        self.topk_candidates          = cfg.MODEL.CENTERNET.TOPK_CANDIDATES_TEST
+        self.max_detections_per_image = cfg.TEST.DETECTIONS_PER_IMAGE
+        precision                     = cfg.MODEL.CENTERNET.get("HIP_PRECISION", "f16")
+        # fmt: on
+        assert precision in ("f16", "f32"), precision
+        self._ctx = hipnn.Ctx(F16 if precision == "f16" else F32)
+
+        given_dataset = cfg.DATASETS.TRAIN[0]
+        DatasetCatalog.get(given_dataset)
+        self.meta = MetadataCatalog.get(given_dataset)
+        self.num_classes = len(self.meta.thing_classes)  # class count comes from the dataset metadata (:62)
+        self.heads["HM"] = self.num_classes
+        self.register_buffer("pixel_mean", torch.Tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1))
+        self.register_buffer("pixel_std", torch.Tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1))
+        self._mean_host = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
+        self._std_host = [float(v) for v in cfg.MODEL.PIXEL_STD]
+
+        self.backbone_type = backbone_type.split("_")[1]
+        self.backbone = build_backbone(cfg)
+        if self.backbone_type != "dla34":
+            raise NotImplementedError(
+                f"backbone '{backbone_type}': only the DLA-34 path is built in this round (SURVEY.md 8(a) a21 is next)")
+        self.size_divisibility = self.backbone.size_divisibility
+        cin = self.backbone.channels[self.backbone.first_level]
+        self.head_conv = head_conv
+        for head in self.heads:
+            classes = self.heads[head]
+            if head_conv > 0:
+                fc = nn.Sequential(
+                    nn.Conv2d(cin, head_conv, kernel_size=3, padding=1, bias=True),
+                    nn.ReLU(inplace=True),
+                    nn.Conv2d(head_conv, classes, kernel_size=final_kernel, stride=1, padding=final_kernel // 2,
+                              bias=True))
+                if "hm" in head.lower():
+                    fc[-1].bias.data.fill_(-2.19)
+                else:
+                    fill_fc_weights(fc)
+            else:
+                fc = nn.Conv2d(cin, classes, kernel_size=final_kernel, stride=1, padding=final_kernel // 2, bias=True)
+                if "hm" in head.lower():
+                    fc.bias.data.fill_(-2.19)
+                else:
+                    fill_fc_weights(fc)
+            self.__setattr__(head.lower(), fc)
+        self._engines = {}
+        self.use_hip_graph = True
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    # ------------------------------------------------------------------ network (NHWC, HIP kernels)
+    def _head_outputs(self, y, apply_sigmoid):
+        """y NHWC [B,h,w,64] -> dict head -> f32 NHWC buffer (channels padded to a multiple of 4)."""
+        ctx = self._ctx
+        names = [h.lower() for h in self.heads]
+        out = {}
+        if self.head_conv > 0:
+            convs = [getattr(self, n)[0] for n in names]
+            # the first convs of all heads share their input: one conv with concatenated output channels
+            w = torch.cat([c.weight for c in convs], 0)
+            b = torch.cat([c.bias for c in convs], 0)
+            p = self._packed_cat("heads3x3", w, b, convs, 1)
+            hid = ops.conv2d(y, p, act=ACT_RELU)
+            c0 = 0
+            for n in names:
+                fc = getattr(self, n)
+                hs = hid[..., c0:c0 + self.head_conv]
+                c0 += self.head_conv
+                act = ACT_SIGMOID_CLAMP if (apply_sigmoid and n == "hm") else ACT_NONE
+                out[n] = hipnn.conv_module(hs, fc[2], None, act, ctx=ctx, out_dtype=torch.float32,
+                                           clamp=(1e-4, 1 - 1e-4))
+        else:
+            for n in names:
+                act = ACT_SIGMOID_CLAMP if (apply_sigmoid and n == "hm") else ACT_NONE
+                out[n] = hipnn.conv_module(y, getattr(self, n), None, act, ctx=ctx, out_dtype=torch.float32,
+                                           clamp=(1e-4, 1 - 1e-4))
+        return out
+
+    def _packed_cat(self, key, w, b, convs, pad):
+        cache = self.__dict__.setdefault("_ctdet_packed", {})
+        ver = tuple((c.weight.data_ptr(), c.weight._version, c.bias._version) for c in convs)
+        hit = cache.get((key, self._ctx.compute))
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        p = ops.PackedConv(w, None, b, stride=1, pad=pad, compute=self._ctx.compute)
+        cache[(key, self._ctx.compute)] = (ver, p)
+        return p
+
+    def _network_outputs(self, x_nhwc, apply_sigmoid):
+        y = self.backbone.hip_forward(x_nhwc, self._ctx)[-1]
+        z = self._head_outputs(y, apply_sigmoid)
+        hm = z["hm"]
+        assert hm.shape[3] == self.num_classes or hm.shape[3] == ops.round_up(self.num_classes, 4)
+        return hm[..., :self.num_classes] if hm.shape[3] != self.num_classes else hm, z["wh"][..., :2], z["reg"][..., :2]
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, batched_inputs):
+        if self.training:
+            return self._forward_train(batched_inputs)
+        return self._forward_eval(batched_inputs)
+
+    def _forward_eval(self, batched_inputs):
+        dev = self.device
+        if dev.type != "cuda":
+            raise NotImplementedError("the CenterNet HIP path has no CPU implementation (MODEL.DEVICE must be cuda)")
+        imgs = [x["image"] for x in batched_inputs]
+        sizes = [tuple(im.shape[-2:]) for im in imgs]
+        B = len(imgs)
+        same = all(s == sizes[0] for s in sizes) and all(im.dtype == imgs[0].dtype for im in imgs)
+        Hp, Wp = ImageList.padded_size(sizes, self.size_divisibility)
+        if not same:
+            return self._forward_eval_ragged(batched_inputs, imgs, sizes, Hp, Wp)
+        H, W = sizes[0]
+        img_dtype = torch.uint8 if imgs[0].dtype == torch.uint8 else torch.float32
+        key = (B, H, W, Hp, Wp, img_dtype)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = self._engines[key] = _EvalEngine(self, B, H, W, Hp, Wp, img_dtype, self.use_hip_graph)
+        for b, im in enumerate(imgs):
+            eng.images[b].copy_(im if im.dtype == img_dtype else im.to(img_dtype), non_blocking=True)
+        return self._finish_eval(eng, batched_inputs, sizes)
+
+    def infer_batch_tensor(self, images, out_sizes=None):
+        """Fast path for an already-batched device tensor [B,3,H,W] (uint8 or float32, 0..255): one copy + one
+        graph replay.  Returns the same list of {"instances": Instances} as forward()."""
+        B, _, H, W = images.shape
+        Hp, Wp = ImageList.padded_size([(H, W)], self.size_divisibility)
+        img_dtype = torch.uint8 if images.dtype == torch.uint8 else torch.float32
+        key = (B, H, W, Hp, Wp, img_dtype)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = self._engines[key] = _EvalEngine(self, B, H, W, Hp, Wp, img_dtype, self.use_hip_graph)
+        eng.images.copy_(images, non_blocking=True)
+        inputs = [{} if out_sizes is None else {"height": out_sizes[b][0], "width": out_sizes[b][1]} for b in range(B)]
+        return self._finish_eval(eng, inputs, [(H, W)] * B)
+
+    def _finish_eval(self, eng, batched_inputs, sizes):
+        B = len(sizes)
+        params = torch.empty(B, 4, dtype=torch.float32)
+        out_sizes = []
+        for b, (inp, size) in enumerate(zip(batched_inputs, sizes)):
+            oh, ow = inp.get("height", size[0]), inp.get("width", size[1])
+            out_sizes.append((oh, ow))
+            params[b, 0], params[b, 1], params[b, 2], params[b, 3] = ow / size[1], oh / size[0], ow, oh
+        eng.img_params.copy_(params, non_blocking=True)
+        boxes, scores, classes, counts = eng()
+        counts = counts.tolist()  # the only host<->device synchronisation of the eval step
+        boxes, scores, classes = boxes.clone(), scores.clone(), classes.clone()
+        results = []
+        for b in range(B):
+            n = counts[b]
+            r = Instances(out_sizes[b])
+            r.pred_boxes = Boxes(boxes[b, :n])
+            r.scores = scores[b, :n]
+            r.pred_classes = classes[b, :n]
+            results.append({"instances": r})
+        return results
+
+    def _forward_eval_ragged(self, batched_inputs, imgs, sizes, Hp, Wp):
+        """images of different sizes: per-image preprocess launches into the zero-padded batch, eager launches."""
+        dev, B = self.device, len(imgs)
+        x = torch.zeros(B, Hp, Wp, 8, dtype=self._ctx.dtype, device=dev)
+        for b, im in enumerate(imgs):
+            im = im.to(dev)
+            im = im if im.dtype == torch.uint8 else im.float()
+            ops.preprocess(im.unsqueeze(0).contiguous(), self._mean_host, self._std_host, Hp, Wp, out=x[b:b + 1],
+                           partial=True)
+        hm, wh, reg = self._network_outputs(x, apply_sigmoid=True)
+        boxes, scores, classes, _ = ops.decode(hm, wh, reg, self.topk_candidates, self.backbone.down_ratio)
+        params = torch.empty(B, 4, dtype=torch.float32)
+        out_sizes = []
+        for b, (inp, size) in enumerate(zip(batched_inputs, sizes)):
+            oh, ow = inp.get("height", size[0]), inp.get("width", size[1])
+            out_sizes.append((oh, ow))
+            params[b, 0], params[b, 1], params[b, 2], params[b, 3] = ow / size[1], oh / size[0], ow, oh
+        max_det = min(self.max_detections_per_image, self.topk_candidates)
+        boxes, scores, classes, counts = ops.postprocess(boxes, scores, classes, max_det, self.score_threshold,
+                                                         params.to(dev))
+        counts = counts.tolist()
+        results = []
+        for b in range(B):
+            r = Instances(out_sizes[b])
+            r.pred_boxes = Boxes(boxes[b, :counts[b]])
+            r.scores = scores[b, :counts[b]]
+            r.pred_classes = classes[b, :counts[b]]
+            results.append({"instances": r})
+        return results
+
+    def preprocess_image(self, batched_inputs):
+        """centernet.py:173-189.  Returns (ImageList of the normalised, padded batch as a logical-NCHW view of the
+        NHWC device buffer, list of per-image target dicts when training)."""
+        dev = self.device
+        imgs = [x["image"].to(dev) for x in batched_inputs]
+        sizes = [tuple(im.shape[-2:]) for im in imgs]
+        Hp, Wp = ImageList.padded_size(sizes, self.size_divisibility)
+        x = torch.zeros(len(imgs), Hp, Wp, 8, dtype=self._ctx.dtype, device=dev)
+        for b, im in enumerate(imgs):
+            im = im if im.dtype == torch.uint8 else im.float()
+            ops.preprocess(im.unsqueeze(0).contiguous(), self._mean_host, self._std_host, Hp, Wp, out=x[b:b + 1],
+                           partial=True)
+        images = ImageList(x[..., :3].permute(0, 3, 1, 2), sizes)
+        images.nhwc = x
+        if not self.training:
+            return images, []
+        targets = self.generate_targets([x["instances"] for x in batched_inputs], Hp // self.backbone.down_ratio,
+                                        Wp // self.backbone.down_ratio)
+        return images, targets
+
+    def generate_targets(self, instances, out_h, out_w):
+        """batched device version of gen_heatmap (detection_utils.py:600-651) over a list of Instances."""
+        dev = self.device
+        B = len(instances)
+        nmax = max(1, max(len(i) for i in instances))
+        boxes = torch.zeros(B, nmax, 4, dtype=torch.float32)
+        classes = torch.zeros(B, nmax, dtype=torch.int64)
+        counts = torch.zeros(B, dtype=torch.int32)
+        for b, inst in enumerate(instances):
+            n = len(inst)
+            counts[b] = n
+            if n:
+                boxes[b, :n] = inst.gt_boxes.tensor.detach().float().cpu()
+                classes[b, :n] = inst.gt_classes.detach().cpu()
+        return ops.gaussian_targets(boxes.to(dev), classes.to(dev), counts.to(dev), out_h, out_w, self.num_classes)
+
+    def _alpha_tensor(self):
+        a = list(self.focal_loss_alpha)
+        C = self.num_classes
+        if len(a) == 1:
+            a = a * C
+        elif len(a) != C:
+            a = a + [1] * (C - len(a))
+        return torch.tensor(a, dtype=torch.float32, device=self.device)
+
+    def losses(self, outputs, targets):
+        """centernet.py:191-212 on device tensors: outputs = (hm logits, wh, reg) NHWC f32; targets from
+        generate_targets.  Returns the weighted loss dict (forward values)."""
+        hm, wh, reg = outputs
+        hm_loss, _, _ = ops.focal_loss(hm.contiguous(), targets["hm"], self._alpha_tensor(), want_grad=False)
+        wh_loss, _ = ops.reg_l1_loss(wh, targets["reg_mask"], targets["ind"], targets["wh"], want_grad=False)
+        off_loss, _ = ops.reg_l1_loss(reg, targets["reg_mask"], targets["ind"], targets["reg"], want_grad=False)
+        return {"hm_loss": hm_loss[0] * self.hm_weight, "wh_loss": wh_loss[0] * self.wh_weight,
+                "off_loss": off_loss[0] * self.off_weight}
+
+    def _forward_train(self, batched_inputs):
+        from ...engine.train_step import centernet_train_forward
+        return centernet_train_forward(self, batched_inputs)
+
+    def inference(self, outputs, image_sizes):
+        """centernet.py:214-234: outputs dict of logical-NCHW hm (after sigmoid+clamp) / wh / reg."""
+        hm = outputs["hm"].permute(0, 2, 3, 1).float().contiguous()
+        wh = outputs["wh"].permute(0, 2, 3, 1).float().contiguous()
+        reg = outputs["reg"].permute(0, 2, 3, 1).float().contiguous()
+        boxes, scores, classes, _ = ops.decode(hm, wh, reg, self.topk_candidates, self.backbone.down_ratio)
+        B = hm.shape[0]
+        params = torch.tensor([[1.0, 1.0, float(s[1]), float(s[0])] for s in image_sizes], dtype=torch.float32)
+        params[:, 2:] = 1e30  # no clipping here: detector_postprocess does it (:169)
+        max_det = min(self.max_detections_per_image, self.topk_candidates)
+        boxes, scores, classes, counts = ops.postprocess(boxes, scores, classes, max_det, self.score_threshold,
+                                                         params.to(hm.device))
+        counts = counts.tolist()
+        results = []
+        for b in range(B):
+            r = Instances(tuple(image_sizes[b]))
+            r.pred_boxes = Boxes(boxes[b, :counts[b]])
+            r.scores = scores[b, :counts[b]]
+            r.pred_classes = classes[b, :counts[b]]
+            results.append(r)
+        return results
+
+    def inference_single_image(self, output, image_size):
+        """centernet.py:236-266 (batch of one)."""
+        return self.inference(output, [image_size])[0]

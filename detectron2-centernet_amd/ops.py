@@ -15,6 +15,40 @@ from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, F16, F32, U8, ConvDesc
 
 _TORCH_DT = {F16: torch.float16, F32: torch.float32}
 
+# bench.py's roofline leg: when PROFILE_ON, every conv-shaped launch is bracketed by HIP events on the
+# launch stream and (kernel instantiation, algorithmic FLOPs, start, end) is appended to PROFILE.
+PROFILE_ON = False
+PROFILE = []
+
+
+def _kernel_name(p, M, deform, out_dt):
+    """mirrors the tile selection of launch_conv_f16_t() in csrc/conv_igemm.hip"""
+    if p.compute != F16:
+        return "conv_direct_f32<dcn>" if deform else "conv_direct_f32<conv>"
+    bc = _lib.lib().ctdet_conv_cout_tile(p.Cout_eff)
+    if deform:
+        bp = 128
+    else:
+        big = ((M + 255) // 256) * (p.Cout_pad // bc) >= 512
+        bp = 256 if (big or bc == 16) else 128
+    return f"conv_igemm<{bp}x{bc},{'dcn' if deform else 'conv'},{'f16' if out_dt == F16 else 'f32'}>"
+
+
+class _Prof:
+    def __init__(self, p, M, deform, out_dt):
+        self.on = PROFILE_ON
+        if self.on:
+            self.name = _kernel_name(p, M, deform, out_dt)
+            self.flops = 2.0 * M * p.Cout * p.R * p.S * p.Cin_real
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def done(self):
+        if self.on:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE.append((self.name, self.flops, self.e0, e1))
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -74,6 +108,7 @@ class PackedConv:
         Cout, Cin, R, S = weight.shape
         self.Cout, self.R, self.S = Cout, R, S
         self.Cin = cin_pad if cin_pad is not None else Cin
+        self.Cin_real = Cin
         assert self.Cin >= Cin
         self.stride, self.pad, self.dil, self.compute = stride, pad, dil, compute
         self.Cout_eff = round_up(Cout, 4)
@@ -147,27 +182,67 @@ def conv2d(x, p, out=None, act=ACT_NONE, residual=None, out_dtype=None, clamp=(0
     if residual is not None:
         assert residual.dtype == out.dtype and residual.shape[:3] == out.shape[:3]
     d = p.desc(x, out, act, residual, clamp)
+    prof = _Prof(p, d.B * d.Ho * d.Wo, False, d.out_dtype)
     rc = _lib.lib().ctdet_conv2d_fwd(C.byref(d), _ptr(x), _ptr(p.w), _ptr(p.scale), _ptr(p.bias), _ptr(residual),
                                      _ptr(out), _stream())
     _lib.check(rc, "ctdet_conv2d_fwd")
+    prof.done()
     return out
 
 
-def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None):
-    """Modulated deformable conv: offset_mask is the raw f32 NHWC output of conv_offset_mask (>= 27 ch)."""
+def conv1x1_cat(xs, p, out=None, act=ACT_NONE, residual=None, out_dtype=None):
+    """1x1 conv over the channel-concatenation of the NHWC tensors `xs` (<= 4) without building the concat."""
+    _require_cuda(*xs)
+    assert 1 <= len(xs) <= 4 and p.R == 1 and p.S == 1 and p.stride == 1 and p.pad == 0
+    B, H, W, _ = xs[0].shape
+    for t in xs:
+        assert tuple(t.shape[:3]) == (B, H, W) and dt_of(t) == p.compute
+    cins = [t.shape[3] for t in xs]
+    assert sum(cins) == p.Cin, (cins, p.Cin)
+    if out is None:
+        dt = out_dtype if out_dtype is not None else (torch.float16 if p.compute == F16 else torch.float32)
+        out = torch.empty(B, H, W, p.Cout_eff, dtype=dt, device=xs[0].device)
+    d = ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.in_stride = B, H, W, p.Cin, p.Cin
+    d.Cout, d.Ho, d.Wo, d.out_stride = p.Cout_eff, H, W, _nhwc_stride(out)
+    d.R = d.S = d.stride = d.dil = 1
+    d.pad = 0
+    d.Kpad, d.Cout_pad = p.Kpad, p.Cout_pad
+    d.compute_dtype, d.out_dtype, d.act = p.compute, dt_of(out), act
+    d.res_stride = _nhwc_stride(residual) if residual is not None else 0
+    d.clamp_lo, d.clamp_hi = 0.0, 1.0
+    n = len(xs)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
+    cin_a = (C.c_int32 * n)(*cins)
+    str_a = (C.c_int32 * n)(*[_nhwc_stride(t) for t in xs])
+    prof = _Prof(p, B * H * W, False, d.out_dtype)
+    rc = _lib.lib().ctdet_conv1x1_cat_fwd(C.byref(d), ptrs, cin_a, str_a, n, _ptr(p.w), _ptr(p.scale), _ptr(p.bias),
+                                          _ptr(residual), _ptr(out), _stream())
+    _lib.check(rc, "ctdet_conv1x1_cat_fwd")
+    prof.done()
+    return out
+
+
+def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_prob=False):
+    """Modulated deformable conv: offset_mask is the raw f32 NHWC output of conv_offset_mask (>= 27 ch);
+    with mask_is_prob the 9 mask channels already went through sigmoid."""
     _require_cuda(x, offset_mask, out)
     assert dt_of(x) == p.compute and offset_mask.dtype == torch.float32
     out = _alloc_out(x, p, out, out_dtype)
     assert tuple(offset_mask.shape[:3]) == tuple(out.shape[:3])
     d = p.desc(x, out, act, None)
-    rc = _lib.lib().ctdet_dcnv2_fwd(C.byref(d), _ptr(x), _ptr(offset_mask), _nhwc_stride(offset_mask), _ptr(p.w),
+    prof = _Prof(p, d.B * d.Ho * d.Wo, True, d.out_dtype)
+    rc = _lib.lib().ctdet_dcnv2_fwd(C.byref(d), _ptr(x), _ptr(offset_mask), _nhwc_stride(offset_mask), int(mask_is_prob),
+                                    _ptr(p.w),
                                     _ptr(p.scale), _ptr(p.bias), _ptr(out), _stream())
     _lib.check(rc, "ctdet_dcnv2_fwd")
+    prof.done()
     return out
 
 
-def preprocess(images, mean, std, Hp, Wp, out_dtype=torch.float16, out=None):
-    """images: [B,3,H,W] uint8/float32 CHW on device -> normalised NHWC [B,Hp,Wp,8] (3 channels used)."""
+def preprocess(images, mean, std, Hp, Wp, out_dtype=torch.float16, out=None, partial=False):
+    """images: [B,3,H,W] uint8/float32 CHW on device -> normalised NHWC [B,Hp,Wp,8] (3 channels used).
+    `out` may be a batch-slice of a larger padded buffer (ragged batches: one call per image)."""
     _require_cuda(images)
     B, Cc, H, W = images.shape
     assert Cc == 3 and images.stride(3) == 1 and images.stride(2) == W and images.stride(1) == H * W
@@ -233,6 +308,19 @@ def decode(heat, wh, reg, K, down_ratio, workspace=None, check_status=False):
     if check_status:
         _lib.check(_lib.lib().ctdet_decode_status(_ptr(workspace.buf), B, _stream()), "ctdet_decode_status")
     return boxes, scores, classes, inds
+
+
+def postprocess(boxes, scores, classes, max_det, score_thresh, img_params):
+    """Batched threshold + rescale + clip + drop-empty, order preserving. img_params f32 [B,4] on device
+    = (scale_x, scale_y, out_w, out_h).  Returns compacted (boxes, scores, classes, counts[B] i32)."""
+    _require_cuda(boxes, scores, classes, img_params)
+    B, K = scores.shape
+    ob, os_, oc = torch.empty_like(boxes), torch.empty_like(scores), torch.empty_like(classes)
+    counts = torch.empty(B, dtype=torch.int32, device=boxes.device)
+    rc = _lib.lib().ctdet_postprocess(_ptr(boxes), _ptr(scores), _ptr(classes), B, K, int(max_det), float(score_thresh),
+                                      _ptr(img_params), _ptr(ob), _ptr(os_), _ptr(oc), _ptr(counts), _stream())
+    _lib.check(rc, "ctdet_postprocess")
+    return ob, os_, oc, counts
 
 
 def gaussian_targets(boxes, classes, counts, H, W, num_classes, hm=None):

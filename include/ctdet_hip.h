@@ -49,13 +49,21 @@ int32_t ctdet_conv_cout_tile(int32_t cout);
 int32_t ctdet_conv2d_fwd(const ctdet_conv_desc* d, const void* x, const void* w_packed, const float* scale,
                          const float* bias, const void* residual, void* y, void* stream);
 
+/* Root of the DLA tree (dla.py:86-94): 1x1 conv over torch.cat(xs, dim=channels) without materialising the
+ * concat.  xs[j] are NHWC tensors of identical B,H,W with cins[j] channels and pixel stride strides[j]
+ * (nsrc <= 4); d->Cin = sum(cins), d->in_stride is ignored. */
+int32_t ctdet_conv1x1_cat_fwd(const ctdet_conv_desc* d, const void* const* xs, const int32_t* cins,
+                              const int32_t* strides, int32_t nsrc, const void* w_packed, const float* scale,
+                              const float* bias, const void* residual, void* y, void* stream);
+
 /* Modulated deformable conv v2 forward, batched and fused (sampling -> MFMA, no columns buffer).
  * Replaces _C.modulated_deform_conv_forward (detectron2/layers/csrc/vision.cpp:85-88,
  * deform_conv_cuda.cu:804-927, deform_conv.py:214-234).  offset_mask is the raw f32 output of the
  * 27-channel conv_offset_mask conv, [B*Ho*Wo, om_stride]: ch 2k = dh, 2k+1 = dw of tap k, ch 18+k = mask
- * logit (sigmoid applied here).  scale/bias fold the conv bias and the following BatchNorm. */
+ * logit (sigmoid applied here) or, with mask_is_prob != 0, the already-sigmoided mask the reference's
+ * functional API passes.  scale/bias fold the conv bias and the following BatchNorm. */
 int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* offset_mask, int32_t om_stride,
-                        const void* w_packed, const float* scale, const float* bias, void* y, void* stream);
+                        int32_t mask_is_prob, const void* w_packed, const float* scale, const float* bias, void* y, void* stream);
 
 /* CenterNet.preprocess_image (centernet.py:173-185) + ImageList.from_tensors padding
  * (detectron2/structures/image_list.py:58-130): img is [B,3,H,W] (u8 or f32, CHW, batch stride given in
@@ -81,6 +89,13 @@ size_t ctdet_decode_workspace_bytes(int32_t B);
 int32_t ctdet_decode(const float* heat, const float* wh, int32_t wh_stride, const float* reg, int32_t reg_stride,
                      int32_t B, int32_t H, int32_t W, int32_t C, int32_t K, float down_ratio, void* workspace,
                      float* boxes, float* scores, int32_t* classes, int32_t* inds, void* stream);
+/* CenterNet.inference_single_image (centernet.py:251-261) + detector_postprocess
+ * (detectron2/modeling/postprocessing.py:11-72, structures/boxes.py:184-213,271-278) for a whole batch:
+ * keep k < max_det with score > score_thresh, scale boxes by (scale_x, scale_y), clip to (out_w, out_h), drop
+ * empty boxes, compact in order.  img_params f32 [B,4] = {scale_x, scale_y, out_w, out_h}; counts i32 [B]. */
+int32_t ctdet_postprocess(const float* boxes, const float* scores, const int32_t* classes, int32_t B, int32_t K,
+                          int32_t max_det, float score_thresh, const float* img_params, float* out_boxes,
+                          float* out_scores, int32_t* out_classes, int32_t* counts, void* stream);
 /* reads back the per-image status words of the last decode on this workspace (device->host copy + sync):
  * returns 0 if every image decoded exactly, -75 (EOVERFLOW) if a degenerate input overflowed the
  * candidate buffer.  Test/diagnostic helper, not on the hot path. */
@@ -99,7 +114,7 @@ int32_t ctdet_gaussian_radius(const int32_t* hw_pairs, int32_t n, double* out_ra
 
 /* FocalLoss/_neg_loss forward + gradient wrt the logits, fused (centernet.py:204,323-369).
  * logits, gt: f32 NHWC [B,H,W,C]; alpha f32 [C].  partial: f32 workspace [3*nblocks] from
- * ctdet_focal_loss_workspace_bytes.  Outputs: loss f32[1]; stats f32[3] = {pos_loss, neg_loss, num_pos};
+ * ctdet_focal_loss_workspace_bytes.  Outputs: loss f32[1]; stats f32[4] = {pos_loss, neg_loss, num_pos, 1/num_pos (1 if 0)};
  * grad f32 NHWC (d loss / d logits, times grad_scale), may be NULL for forward only. */
 size_t ctdet_focal_loss_workspace_bytes(int64_t numel);
 int32_t ctdet_focal_loss(const float* logits, const float* gt, const float* alpha, int32_t B, int32_t H, int32_t W,
