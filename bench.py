@@ -115,27 +115,25 @@ def cpu_baseline(model, cfg, size, n_images=2, reps=3):
 
 
 def roofline_pass(model, images, passes=2):
-    """instrumented eager passes: HIP events around every conv-shaped launch; returns per-kernel aggregates."""
+    """instrumented eager passes (no graph): every conv-shaped launch is issued ops.PROFILE_REP times back to
+    back between one HIP event pair on the launch stream; returns per-kernel-instantiation aggregates."""
     from detectron2_centernet_amd import ops
+    from detectron2_centernet_amd.modeling.meta_arch.centernet import _EvalEngine
 
+    B, _, H, W = images.shape
+    eng = _EvalEngine(model, B, H, W, H, W, images.dtype, use_graph=False)
+    eng.images.copy_(images)
     agg = {}
-    for p in range(passes + 1):
+    for p in range(passes):
         ops.PROFILE.clear()
         ops.PROFILE_ON = True
         with torch.no_grad():
-            model.use_hip_graph = False
-            eng_saved = model._engines
-            model._engines = {}
-            model.infer_batch_tensor(images)
-            model._engines = eng_saved
-            model.use_hip_graph = True
+            eng()
         ops.PROFILE_ON = False
         torch.cuda.synchronize()
-        if p == 0:
-            continue  # first pass warms the eager path
         for name, flops, e0, e1 in ops.PROFILE:
             a = agg.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0})
-            a["ms"] += e0.elapsed_time(e1)
+            a["ms"] += e0.elapsed_time(e1) / ops.PROFILE_REP
             a["flops"] += flops
             a["launches"] += 1
     for a in agg.values():

@@ -276,6 +276,176 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// LDS-DMA variant for plain convolutions (everything except the DCNv2 sampler): tiles go HBM/L2 -> LDS
+// with global_load_lds_dwordx4 (no staging registers, no ds_write), 3-stage LDS ring, loads two K steps
+// ahead kept in flight across the barrier with a counted s_waitcnt vmcnt (never 0 in the main loop),
+// one raw s_barrier per K step.  Padding / K-tail / rows beyond M read a 16-byte zero page instead of
+// being zero-filled in registers.  The LDS image is the same swizzled [row][32 k] layout as above: the
+// DMA writes lane-linear (wave base + lane*16), so the swizzle lives in which k-group a lane *fetches*.
+// ------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void dma16(const void* g, char* lds_wave_base) {
+  asm volatile("" : "+v"(g));  // materialise the selected address: exactly one DMA instruction per call
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BP, int BC, int WP, int WC_, typename TOut>
+__global__ void __launch_bounds__(256) conv_igemm_dma_kernel(const ConvArgs a) {
+  constexpr int TP = BP / WP / 16;
+  constexpr int TC = BC / WC_ / 16;
+  constexpr int A_LD = BP / 64;
+  constexpr int BCL = BC < 64 ? 64 : BC;  // weight rows staged (>= 64 so every wave issues the same DMA count)
+  constexpr int B_LD = BCL / 64;
+  constexpr int NLOAD = A_LD + B_LD;
+  constexpr int STAGE = (BP + BCL) * 64;
+  constexpr int NST = 3;
+  static_assert(WP * WC_ == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave / WC_, wc = wave % WC_;
+  const int m0 = blockIdx.x * BP, n0 = blockIdx.y * BC;
+  const f16* __restrict__ x = (const f16*)a.x;
+  const f16* __restrict__ w = (const f16*)a.w;
+  // the zero page pointer is made opaque (lives in a VGPR pair) so that `cond ? real : zero` compiles to a
+  // v_cndmask and ONE global_load_lds per staged row; if the compiler sees a uniform address on one side it
+  // emits two exec-masked DMAs instead, which would break the counted vmcnt below.
+  const f16* zero = (const f16*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+
+  const int lrow = tid >> 2, slot = tid & 3;
+  const int g = slot ^ swz(lrow);
+  // per staged pixel row: element offset of tap (0,0) and a bit mask of the taps that fall inside the image
+  long rowoff[A_LD];
+  unsigned long long tapmask[A_LD];
+  long rowm[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = m0 + lrow + 64 * i;
+    const bool ok = m < a.M;
+    const int mm = ok ? m : 0;
+    const int wo = mm % a.Wo, t = mm / a.Wo;
+    const int ho = t % a.Ho, b = t / a.Ho;
+    const int hb = ho * a.stride - a.pad, wb = wo * a.stride - a.pad;
+    rowoff[i] = ((long)b * a.H * a.W + (long)hb * a.W + wb) * a.in_stride;
+    rowm[i] = ok ? (long)m : -1;
+    unsigned long long mk = 0;
+    if (ok)
+      for (int r = 0; r < a.R; ++r)
+        for (int s2 = 0; s2 < a.S; ++s2) {
+          const int hi = hb + r * a.dil, wi = wb + s2 * a.dil;
+          if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) mk |= 1ull << (r * a.S + s2);
+        }
+    tapmask[i] = mk;
+  }
+  long b_off[B_LD];
+  bool b_ok[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int L = lrow + 64 * j;
+    const int Lw = L % (16 * TC), wv = L / (16 * TC);
+    const int tt = Lw >> 4, r = Lw & 15;
+    const int cl = wv * 16 * TC + 4 * TC * (r >> 2) + 4 * tt + (r & 3);
+    b_ok[j] = L < BC;
+    b_off[j] = (long)(n0 + (b_ok[j] ? cl : 0)) * a.Kpad + g * 8;
+  }
+
+  int c0, tr, ts;
+  {
+    const int kc = g * 8, tap = kc / a.Cin;
+    c0 = kc - tap * a.Cin;
+    tr = tap / a.S;
+    ts = tap - tr * a.S;
+  }
+  auto advance_k = [&]() {
+    c0 += 32;
+    while (c0 >= a.Cin) {
+      c0 -= a.Cin;
+      if (++ts == a.S) { ts = 0; ++tr; }
+    }
+  };
+
+  auto issue = [&](int kt, int stage) {
+    char* sb = smem + stage * STAGE + wave * 1024;
+    if (a.nsrc > 1) {
+      const int kk = kt * 32 + g * 8;
+      const f16* src = (const f16*)a.xs[0];
+      int st = a.xs_stride[0], cb0 = 0;
+      if (kk >= a.xs_cend[0]) { src = (const f16*)a.xs[1]; st = a.xs_stride[1]; cb0 = a.xs_cend[0]; }
+      if (a.nsrc > 2 && kk >= a.xs_cend[1]) { src = (const f16*)a.xs[2]; st = a.xs_stride[2]; cb0 = a.xs_cend[1]; }
+      if (a.nsrc > 3 && kk >= a.xs_cend[2]) { src = (const f16*)a.xs[3]; st = a.xs_stride[3]; cb0 = a.xs_cend[2]; }
+      const bool kin = kk < a.Cin;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i)
+        dma16((kin && rowm[i] >= 0) ? src + rowm[i] * st + (kk - cb0) : zero, sb + i * 4096);
+    } else {
+      const int tap = tr * a.S + ts;
+      const bool kin = tr < a.R;
+      const long delta = (long)((tr * a.dil) * a.W + ts * a.dil) * a.in_stride + c0;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i)
+        dma16((kin && ((tapmask[i] >> tap) & 1ull)) ? x + rowoff[i] + delta : zero, sb + i * 4096);
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) dma16(b_ok[j] ? w + b_off[j] + kt * 32 : zero, sb + BP * 64 + j * 4096);
+  };
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15;
+  const int frag_off = fr * 64 + (((lane >> 4) ^ swz(fr)) << 4);
+  const int nk = a.Kpad / 32;
+
+  // prologue: two tiles in flight
+  issue(0, 0);
+  advance_k();
+  if (nk > 1) { issue(1, 1); advance_k(); }
+
+  int st_c = 0, st_l = 2;  // stage being computed / stage the next prefetch goes to
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once at most one younger tile's DMAs are still outstanding
+    if (kt + 1 < nk) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the stage about to be refilled are done
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) { issue(kt + 2, st_l); advance_k(); }
+    const char* base = smem + st_c * STAGE;
+    f16x8 wf[TC];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(base + BP * 64 + (wc * 16 * TC + 16 * c) * 64 + frag_off);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const f16x8 pf = *(const f16x8*)(base + (wp * 16 * TP + 16 * p) * 64 + frag_off);
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf, acc[p][c], 0, 0, 0);
+    }
+    st_c = st_c == NST - 1 ? 0 : st_c + 1;
+    st_l = st_l == NST - 1 ? 0 : st_l + 1;
+  }
+
+  const int q = lane >> 4;
+  const int cb = n0 + wc * 16 * TC + 4 * TC * q;
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int m = m0 + wp * 16 * TP + 16 * p + fr;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cb + 4 * c, acc[p][c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Exact-f32 direct form (parity mode): one thread per (pixel, cout), f32 FMA chain in k order.
 // Weights packed [Kpad][Cout_pad] f32.  Used to pin the algorithm against the oracle at 1e-5;
 // the f16 MFMA kernels above are the throughput path.
@@ -353,6 +523,14 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   return 0;
 }
 
+template <int BP, int BC, int WP, int WC_, typename TOut>
+static int launch_dma(const ConvArgs& a, hipStream_t s) {
+  dim3 grid((a.M + BP - 1) / BP, a.Cout_pad / BC);
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<BP, BC, WP, WC_, TOut>), grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename TOut>
 static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   const int bc = pick_bc(a.Cout);
@@ -368,11 +546,12 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   // enough pixel tiles to fill 256 CUs with the big tile? otherwise use the 128-pixel variants
   const long tiles256 = ((long)a.M + 255) / 256 * (a.Cout_pad / bc);
   const bool big = tiles256 >= 512;
+  CTDET_CHECK(a.R * a.S <= 64, "conv: at most 64 taps (R*S=%d)", a.R * a.S);
   switch (bc) {
-    case 16: return launch_cfg<256, 16, 4, 1, false, TOut>(a, s);
-    case 32: return big ? launch_cfg<256, 32, 4, 1, false, TOut>(a, s) : launch_cfg<128, 32, 4, 1, false, TOut>(a, s);
-    case 64: return big ? launch_cfg<256, 64, 4, 1, false, TOut>(a, s) : launch_cfg<128, 64, 2, 2, false, TOut>(a, s);
-    case 128: return big ? launch_cfg<256, 128, 2, 2, false, TOut>(a, s) : launch_cfg<128, 128, 2, 2, false, TOut>(a, s);
+    case 16: return launch_dma<256, 16, 4, 1, TOut>(a, s);
+    case 32: return big ? launch_dma<256, 32, 4, 1, TOut>(a, s) : launch_dma<128, 32, 4, 1, TOut>(a, s);
+    case 64: return big ? launch_dma<256, 64, 4, 1, TOut>(a, s) : launch_dma<128, 64, 2, 2, TOut>(a, s);
+    case 128: return big ? launch_dma<256, 128, 2, 2, TOut>(a, s) : launch_dma<128, 128, 2, 2, TOut>(a, s);
   }
   CTDET_CHECK(false, "conv: no tile for Cout=%d", a.Cout);
 }

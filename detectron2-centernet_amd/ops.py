@@ -19,6 +19,7 @@ _TORCH_DT = {F16: torch.float16, F32: torch.float32}
 # launch stream and (kernel instantiation, algorithmic FLOPs, start, end) is appended to PROFILE.
 PROFILE_ON = False
 PROFILE = []
+PROFILE_REP = 5   # each profiled launch is issued this many times back to back between one event pair
 
 
 def _kernel_name(p, M, deform, out_dt):
@@ -42,6 +43,9 @@ class _Prof:
             self.flops = 2.0 * M * p.Cout * p.R * p.S * p.Cin_real
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
+
+    def reps(self):
+        return PROFILE_REP if self.on else 1
 
     def done(self):
         if self.on:
@@ -183,8 +187,9 @@ def conv2d(x, p, out=None, act=ACT_NONE, residual=None, out_dtype=None, clamp=(0
         assert residual.dtype == out.dtype and residual.shape[:3] == out.shape[:3]
     d = p.desc(x, out, act, residual, clamp)
     prof = _Prof(p, d.B * d.Ho * d.Wo, False, d.out_dtype)
-    rc = _lib.lib().ctdet_conv2d_fwd(C.byref(d), _ptr(x), _ptr(p.w), _ptr(p.scale), _ptr(p.bias), _ptr(residual),
-                                     _ptr(out), _stream())
+    for _ in range(prof.reps()):
+        rc = _lib.lib().ctdet_conv2d_fwd(C.byref(d), _ptr(x), _ptr(p.w), _ptr(p.scale), _ptr(p.bias), _ptr(residual),
+                                         _ptr(out), _stream())
     _lib.check(rc, "ctdet_conv2d_fwd")
     prof.done()
     return out
@@ -216,8 +221,9 @@ def conv1x1_cat(xs, p, out=None, act=ACT_NONE, residual=None, out_dtype=None):
     cin_a = (C.c_int32 * n)(*cins)
     str_a = (C.c_int32 * n)(*[_nhwc_stride(t) for t in xs])
     prof = _Prof(p, B * H * W, False, d.out_dtype)
-    rc = _lib.lib().ctdet_conv1x1_cat_fwd(C.byref(d), ptrs, cin_a, str_a, n, _ptr(p.w), _ptr(p.scale), _ptr(p.bias),
-                                          _ptr(residual), _ptr(out), _stream())
+    for _ in range(prof.reps()):
+        rc = _lib.lib().ctdet_conv1x1_cat_fwd(C.byref(d), ptrs, cin_a, str_a, n, _ptr(p.w), _ptr(p.scale),
+                                              _ptr(p.bias), _ptr(residual), _ptr(out), _stream())
     _lib.check(rc, "ctdet_conv1x1_cat_fwd")
     prof.done()
     return out
@@ -232,9 +238,9 @@ def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_pro
     assert tuple(offset_mask.shape[:3]) == tuple(out.shape[:3])
     d = p.desc(x, out, act, None)
     prof = _Prof(p, d.B * d.Ho * d.Wo, True, d.out_dtype)
-    rc = _lib.lib().ctdet_dcnv2_fwd(C.byref(d), _ptr(x), _ptr(offset_mask), _nhwc_stride(offset_mask), int(mask_is_prob),
-                                    _ptr(p.w),
-                                    _ptr(p.scale), _ptr(p.bias), _ptr(out), _stream())
+    for _ in range(prof.reps()):
+        rc = _lib.lib().ctdet_dcnv2_fwd(C.byref(d), _ptr(x), _ptr(offset_mask), _nhwc_stride(offset_mask),
+                                        int(mask_is_prob), _ptr(p.w), _ptr(p.scale), _ptr(p.bias), _ptr(out), _stream())
     _lib.check(rc, "ctdet_dcnv2_fwd")
     prof.done()
     return out

@@ -115,7 +115,7 @@ def test_heads_match_oracle(tmp_path, dev, precision):
 @pytest.mark.parametrize("precision", ["f32", "f16"])
 def test_eval_forward_end_to_end(tmp_path, dev, precision):
     model, cfg = make_model(tmp_path, precision, seed=3)
-    model.score_threshold = 0.02  # random-init scores sit around sigmoid(-2.19) ~ 0.1
+    model.score_threshold = 0.0  # every top-K entry passes (scores >= 1e-4 after the clamp)
     img = images(3, 96, 128, seed=7)
     inputs = [{"image": img[b], "height": 192, "width": 256} if b == 1 else {"image": img[b]} for b in range(3)]
     out = model(inputs)
@@ -131,15 +131,14 @@ def test_eval_forward_end_to_end(tmp_path, dev, precision):
         inst, inst2 = out[b]["instances"], out2[b]["instances"]
         oh, ow = (192, 256) if b == 1 else (96, 128)
         assert inst.image_size == (oh, ow)
-        bb, ss, cc = O.inference_single_image(rb[b], rs[b], rc[b], 100, 0.02)
+        bb, ss, cc = O.inference_single_image(rb[b], rs[b], rc[b], 100, 0.0)
         bb, keep = O.detector_postprocess(bb, (96, 128), oh, ow)
         assert torch.equal(inst.scores.cpu(), ss[keep])
         assert torch.equal(inst.pred_classes.cpu(), cc[keep])
         assert torch.allclose(inst.pred_boxes.tensor.cpu(), bb[keep], atol=1e-4, rtol=1e-6)
         assert torch.equal(inst.scores, inst2.scores) and torch.equal(inst.pred_boxes.tensor, inst2.pred_boxes.tensor)
-        assert len(inst) > 0
     # the full CPU oracle agrees on the heatmap within the mode's tolerance
-    res, hm_ref, _ = MR.centernet_inference(sd, [i for i in img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, thresh=0.02)
+    res, hm_ref, _ = MR.centernet_inference(sd, [i for i in img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, thresh=0.0)
     perr = (hm_c - hm_ref).abs().max().item()
     print(precision, "e2e heatmap max err", perr)
     assert perr <= (1e-3 if precision == "f16" else 1e-5)
@@ -147,11 +146,11 @@ def test_eval_forward_end_to_end(tmp_path, dev, precision):
 
 def test_ragged_batch_matches_padded_oracle(tmp_path, dev):
     model, cfg = make_model(tmp_path, "f32", seed=5)
-    model.score_threshold = 0.02
+    model.score_threshold = 0.0
     a, b = images(1, 70, 100, seed=1)[0], images(1, 96, 64, seed=2)[0]
     out = model([{"image": a}, {"image": b}])
     sd = cpu_state_dict(model)
-    res, _, _ = MR.centernet_inference(sd, [a, b], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, thresh=0.02)
+    res, _, _ = MR.centernet_inference(sd, [a, b], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, thresh=0.0)
     for i in range(2):
         inst = out[i]["instances"]
         assert inst.image_size == ((70, 100) if i == 0 else (96, 64))
