@@ -23,6 +23,20 @@
 // rows r and r+4 share banks, so the 4 rows {r, r+4, r+8, r+12} get distinct slot XORs.
 __device__ __forceinline__ int swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
 
+// XCD-aware tile mapping (1-D grid of 8*mchunk*nby workgroups).  Workgroups are dealt round-robin over the 8
+// XCDs, each with a private L2: XCD x gets the contiguous pixel-tile range [x*mchunk, (x+1)*mchunk) and walks it
+// with the cout tile innermost, so workgroups that share an input tile (other cout tiles) or halo rows
+// (neighbouring pixel tiles) run on the same L2 close in time.  Placement only affects speed, never results.
+__device__ __forceinline__ bool tile_of_block(int nbx, int nby, int& m_tile, int& n_tile) {
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, sq = lin >> 3;
+  const int mchunk = (nbx + 7) >> 3;
+  n_tile = sq % nby;
+  const int m_local = sq / nby;
+  m_tile = xcd * mchunk + m_local;
+  return m_local < mchunk && m_tile < nbx;
+}
+
 struct DcnSample {
   int off[4];    // element offsets of the 4 corner pixels (already * in_stride), -1 = contributes 0
   float wt[4];   // bilinear weights
@@ -97,7 +111,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wp = wave / WC_, wc = wave % WC_;
-  const int m0 = blockIdx.x * BP, n0 = blockIdx.y * BC;
+  int m_tile, n_tile;
+  if (!tile_of_block((a.M + BP - 1) / BP, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int m0 = m_tile * BP, n0 = n_tile * BC;
   const f16* __restrict__ x = (const f16*)a.x;
   const f16* __restrict__ w = (const f16*)a.w;
 
@@ -312,7 +328,9 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(const ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = wave / WC_, wc = wave % WC_;
-  const int m0 = blockIdx.x * BP, n0 = blockIdx.y * BC;
+  int m_tile, n_tile;
+  if (!tile_of_block((a.M + BP - 1) / BP, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int m0 = m_tile * BP, n0 = n_tile * BC;
   const f16* __restrict__ x = (const f16*)a.x;
   const f16* __restrict__ w = (const f16*)a.w;
   // the zero page pointer is made opaque (lives in a VGPR pair) so that `cond ? real : zero` compiles to a
@@ -446,6 +464,93 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Small-channel layers (DLA base_layer 7x7 3->16, level0 3x3 16->16, level1 3x3 16->32 s2; dla.py:212-220):
+// HBM-bound shapes where an LDS-tiled GEMM is all overhead (4 MFMAs per barrier).  Here every weight fragment of
+// the layer lives in registers for the whole kernel (NK*TC fragments), and the pixel (MFMA B) fragments are read
+// straight from global memory: with Cin*2 <= 32 bytes per pixel, 16 consecutive pixels x one k-group is a
+// contiguous, fully coalesced run.  No LDS, no barriers.  A wave owns 64 consecutive pixels of one image row
+// (requires Wo % 64 == 0, else the generic kernel is used), so b/ho are scalar and no per-lane division exists.
+// ------------------------------------------------------------------------------------------
+template <int TC, int NK, typename TOut>
+__global__ void __launch_bounds__(256) conv_smallc_kernel(const ConvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const f16* __restrict__ x = (const f16*)a.x;
+  const f16* __restrict__ w = (const f16*)a.w;
+  const int px = lane & 15, kg = lane >> 4;
+
+  // all weight fragments: lane supplies A[row = permuted cout][k-group kg] of every K step
+  f16x8 wf[NK][TC];
+#pragma unroll
+  for (int c = 0; c < TC; ++c) {
+    const int cl = 4 * TC * (px >> 2) + 4 * c + (px & 3);
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) wf[kt][c] = *(const f16x8*)(w + (long)cl * a.Kpad + kt * 32 + kg * 8);
+  }
+  // per K step: tap geometry of this lane's k-group (k-group G = kt*4 + kg; 8 channels)
+  int dh[NK], dw[NK], coff[NK];
+  const int gpt = a.Cin >> 3;  // k-groups per tap (1 or 2)
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt) {
+    const int G = kt * 4 + kg;
+    const int tap = G / gpt;
+    const int tr = tap / a.S, ts = tap - tr * a.S;
+    dh[kt] = tr < a.R ? tr * a.dil : (1 << 20);  // K tail: forces the bounds test to fail
+    dw[kt] = ts * a.dil;
+    coff[kt] = (G - tap * gpt) * 8;
+  }
+
+  const int segs_per_row = a.Wo >> 6;
+  const int nseg = a.B * a.Ho * segs_per_row;
+  const int q = lane >> 4;
+  for (int seg = blockIdx.x * 4 + wave_in_block; seg < nseg; seg += gridDim.x * 4) {
+    const int sw = seg % segs_per_row, t = seg / segs_per_row;
+    const int ho = t % a.Ho, b = t / a.Ho;
+    const int hb = ho * a.stride - a.pad;
+    const long img = (long)b * a.H * a.W;
+    f32x4 acc[4][TC];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+      const int hi = hb + dh[kt];
+      const bool hok = hi >= 0 && hi < a.H;
+      f16x8 af[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int wo = sw * 64 + p * 16 + px;
+        const int wi = wo * a.stride - a.pad + dw[kt];
+        const bool ok = hok && wi >= 0 && wi < a.W;
+        const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        af[p] = ok ? *(const f16x8*)(x + (img + (long)hi * a.W + wi) * a.in_stride + coff[kt]) : z;
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kt][c], af[p], acc[p][c], 0, 0, 0);
+    }
+    const int mrow = (b * a.Ho + ho) * a.Wo + sw * 64;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, mrow + p * 16 + px, 4 * TC * q + 4 * c, acc[p][c]);
+  }
+}
+
+template <int TC, int NK, typename TOut>
+static int launch_smallc(const ConvArgs& a, hipStream_t s) {
+  const int nseg = a.B * a.Ho * (a.Wo / 64);
+  int blocks = (nseg + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL((conv_smallc_kernel<TC, NK, TOut>), dim3(blocks), dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // Exact-f32 direct form (parity mode): one thread per (pixel, cout), f32 FMA chain in k order.
 // Weights packed [Kpad][Cout_pad] f32.  Used to pin the algorithm against the oracle at 1e-5;
 // the f16 MFMA kernels above are the throughput path.
@@ -517,7 +622,8 @@ static inline int pick_bc(int cout) {
 
 template <int BP, int BC, int WP, int WC_, bool DEFORM, typename TOut>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
-  dim3 grid((a.M + BP - 1) / BP, a.Cout_pad / BC);
+  const int nbx = (a.M + BP - 1) / BP, nby = a.Cout_pad / BC;
+  dim3 grid(8 * ((nbx + 7) / 8) * nby);
   hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC_, DEFORM, TOut>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
@@ -525,7 +631,8 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
 
 template <int BP, int BC, int WP, int WC_, typename TOut>
 static int launch_dma(const ConvArgs& a, hipStream_t s) {
-  dim3 grid((a.M + BP - 1) / BP, a.Cout_pad / BC);
+  const int nbx = (a.M + BP - 1) / BP, nby = a.Cout_pad / BC;
+  dim3 grid(8 * ((nbx + 7) / 8) * nby);
   hipLaunchKernelGGL((conv_igemm_dma_kernel<BP, BC, WP, WC_, TOut>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
@@ -547,6 +654,13 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   const long tiles256 = ((long)a.M + 255) / 256 * (a.Cout_pad / bc);
   const bool big = tiles256 >= 512;
   CTDET_CHECK(a.R * a.S <= 64, "conv: at most 64 taps (R*S=%d)", a.R * a.S);
+  if ((a.Cin == 8 || a.Cin == 16) && a.nsrc <= 1 && a.Wo % 64 == 0 && a.Cout_pad <= 32 && a.Cout_pad == bc) {
+    const int nk = a.Kpad / 32;
+    if (nk == 13 && bc == 16) return launch_smallc<1, 13, TOut>(a, s);
+    if (nk == 5 && bc == 16) return launch_smallc<1, 5, TOut>(a, s);
+    if (nk == 5 && bc == 32) return launch_smallc<2, 5, TOut>(a, s);
+    if (nk == 13 && bc == 32) return launch_smallc<2, 13, TOut>(a, s);
+  }
   switch (bc) {
     case 16: return launch_dma<256, 16, 4, 1, TOut>(a, s);
     case 32: return big ? launch_dma<256, 32, 4, 1, TOut>(a, s) : launch_dma<128, 32, 4, 1, TOut>(a, s);

@@ -69,8 +69,8 @@ __global__ void __launch_bounds__(256) maxpool2x2_kernel(const T* __restrict__ x
 }
 
 // y[b,oy,ox,c] = skip[b,oy,ox,c] + sum_{ky,kx} x[b,iy,ix,c] * w[c,ky,kx],  oy = iy*f - f/2 + ky, k = 2f:
-// exactly two input rows/cols contribute per output row/col.  w is f32 [C][k][k] (PyTorch
-// ConvTranspose2d weight [C,1,k,k]).
+// exactly two input rows/cols contribute per output row/col.  w is f32 [k][k][C] (the PyTorch
+// ConvTranspose2d weight [C,1,k,k] transposed once on the host so a tap's channels are contiguous).
 template <typename T>
 __global__ void __launch_bounds__(256) dwconvT_add_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                           const T* __restrict__ skip, T* __restrict__ y, int B, int H,
@@ -100,8 +100,13 @@ __global__ void __launch_bounds__(256) dwconvT_add_kernel(const T* __restrict__ 
       const int ix = ix1 - dx, kx = kx1 + dx * f;
       if (ix < 0 || ix >= W) continue;
       const V xv = *(const V*)(x + ((long)(b * H + iy) * W + ix) * in_stride + cv * N);
+      const float* wt = w + (long)(ky * k + kx) * C + cv * N;
 #pragma unroll
-      for (int e = 0; e < N; ++e) acc[e] = fmaf((float)xv[e], w[((cv * N + e) * k + ky) * k + kx], acc[e]);
+      for (int e4 = 0; e4 < N; e4 += 4) {
+        const f32x4 wv = *(const f32x4*)(wt + e4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e4 + e] = fmaf((float)xv[e4 + e], wv[e], acc[e4 + e]);
+      }
     }
   }
   const long opix = (long)(b * Ho + oy) * Wo + ox;

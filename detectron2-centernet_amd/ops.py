@@ -273,11 +273,25 @@ def maxpool2x2(x, out=None):
     return out
 
 
+_DW_CACHE = {}
+
+
+def _dw_weight(weight, Cc, f):
+    """[C,1,2f,2f] -> f32 [2f,2f,C], cached per weight version"""
+    key = (weight.data_ptr(), weight._version)
+    hit = _DW_CACHE.get(key)
+    if hit is None:
+        if len(_DW_CACHE) > 64:
+            _DW_CACHE.clear()
+        hit = _DW_CACHE[key] = weight.detach().reshape(Cc, 2 * f, 2 * f).to(torch.float32).permute(1, 2, 0).contiguous()
+    return hit
+
+
 def dwconvT_add(x, weight, f, skip=None, out=None):
     """ConvTranspose2d(C,C,2f,stride=f,padding=f//2,groups=C)(x) + skip; weight f32 [C,1,2f,2f] or [C,2f,2f]."""
     _require_cuda(x, weight, skip, out)
     B, H, W, Cc = x.shape
-    w = weight.detach().reshape(Cc, 2 * f, 2 * f).to(torch.float32).contiguous()
+    w = _dw_weight(weight, Cc, f)
     if out is None:
         out = torch.empty(B, H * f, W * f, Cc, dtype=x.dtype, device=x.device)
     rc = _lib.lib().ctdet_dwconvT_add(_ptr(x), _ptr(w), _ptr(skip), _ptr(out), dt_of(x), B, H, W, Cc, f,

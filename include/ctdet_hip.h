@@ -77,7 +77,7 @@ int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32
                          int32_t in_stride, int32_t out_stride, void* stream);
 
 /* y = ConvTranspose2d(C, C, 2f, stride=f, padding=f/2, groups=C, bias=False)(x) + skip  (dla.py:162-177).
- * w is f32 [C][2f][2f]; skip may be NULL. */
+ * w is f32 [2f][2f][C] (the ConvTranspose2d weight [C,1,2f,2f] with the channel dim moved last); skip may be NULL. */
 int32_t ctdet_dwconvT_add(const void* x, const float* w, const void* skip, void* y, int32_t dtype, int32_t B,
                           int32_t H, int32_t W, int32_t C, int32_t f, int32_t in_stride, int32_t skip_stride,
                           int32_t out_stride, void* stream);

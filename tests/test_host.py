@@ -1,0 +1,183 @@
+"""CPU tests of the host-side boundary: config/yaml ingestion, registries, structures, catalog, and that the
+C-ABI library loads and exports every symbol include/ctdet_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+BASE = """
+MODEL:
+  META_ARCHITECTURE: "CenterNet"
+  BACKBONE:
+    NAME: "build_dla34_backbone"
+  PIXEL_MEAN: [0.408, 0.447, 0.470]
+  PIXEL_STD: [0.289, 0.274, 0.278]
+VERSION: 2
+"""
+DLA = """
+_BASE_: "./Base-CenterNet.yaml"
+MODEL:
+  CENTERNET:
+    FOCAL_LOSS_ALPHA: [1]
+DATASETS:
+  TRAIN: ("bulb_train",)
+  TEST: ("bulb_val",)
+INPUT:
+  FORMAT: "RGB"
+  MIN_SIZE_TRAIN: (640, 672, 704, 736, 768, 800)
+SOLVER:
+  IMS_PER_BATCH: 2
+  BASE_LR: 2.5e-4
+  STEPS: (159000, 212000)
+  MAX_ITER: 265000
+  CHECKPOINT_PERIOD: 10600
+#TEST:
+#  EVAL_PERIOD: 1
+OUTPUT_DIR: "./output/centernet-bulb-aug"
+VERSION: 2
+"""
+
+
+def _cfg(tmp_path):
+    from detectron2_centernet_amd.config import get_cfg
+
+    (tmp_path / "Base-CenterNet.yaml").write_text(BASE)
+    (tmp_path / "ctdet_dla_34_1x.yaml").write_text(DLA)
+    cfg = get_cfg()
+    cfg.merge_from_file(str(tmp_path / "ctdet_dla_34_1x.yaml"))
+    return cfg
+
+
+def test_yaml_with_base_and_tuple_strings(tmp_path):
+    cfg = _cfg(tmp_path)
+    assert cfg.MODEL.META_ARCHITECTURE == "CenterNet" and cfg.MODEL.BACKBONE.NAME == "build_dla34_backbone"
+    assert cfg.DATASETS.TRAIN == ("bulb_train",) and cfg.INPUT.MIN_SIZE_TRAIN == (640, 672, 704, 736, 768, 800)
+    assert cfg.SOLVER.STEPS == (159000, 212000) and cfg.SOLVER.BASE_LR == 2.5e-4
+    assert cfg.MODEL.CENTERNET.FOCAL_LOSS_ALPHA == [1] and cfg.MODEL.PIXEL_STD == [0.289, 0.274, 0.278]
+    assert cfg.MODEL.CENTERNET.TASK.HM == 80 and cfg.TEST.DETECTIONS_PER_IMAGE == 100
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", "128", "MODEL.DEVICE", "cpu"])
+    assert cfg.SOLVER.IMS_PER_BATCH == 128 and cfg.MODEL.DEVICE == "cpu"
+    with pytest.raises(KeyError):
+        cfg.merge_from_list(["MODEL.NOPE", "1"])
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.MODEL.DEVICE = "cuda"
+    c2 = cfg.clone()
+    c2.defrost()
+    c2.MODEL.DEVICE = "cuda"
+    assert cfg.MODEL.DEVICE == "cpu"
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
+def test_reference_yamls_load_unchanged():
+    from detectron2_centernet_amd.config import get_cfg
+
+    d = "/root/reference/projects/CenterNet/configs/COCO-Detection"
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(d, "ctdet_dla_34_1x.yaml"))
+    assert cfg.MODEL.META_ARCHITECTURE == "CenterNet" and cfg.SOLVER.MAX_ITER == 265000
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(d, "ctdet_res_50_1x.yaml"))
+    assert cfg.MODEL.BACKBONE.NAME == "build_resnet_backbone" and cfg.TEST.EVAL_PERIOD == 18008
+
+
+def test_registries_and_model_construction(tmp_path):
+    from detectron2_centernet_amd.data.catalog import DatasetCatalog, MetadataCatalog, register_synthetic
+    from detectron2_centernet_amd.modeling import BACKBONE_REGISTRY, META_ARCH_REGISTRY, build_model
+    from detectron2_centernet_amd.utils.registry import Registry
+
+    assert META_ARCH_REGISTRY.get("CenterNet").__name__ == "CenterNet"
+    assert callable(BACKBONE_REGISTRY.get("build_dla34_backbone"))
+    with pytest.raises(KeyError):
+        META_ARCH_REGISTRY.get("GeneralizedRCNN")
+    r = Registry("T")
+
+    @r.register()
+    def foo():
+        return 1
+
+    assert r.get("foo") is foo
+    with pytest.raises(AssertionError):
+        r.register(foo)
+
+    cfg = _cfg(tmp_path)
+    cfg.MODEL.DEVICE = "cpu"
+    with pytest.raises(KeyError):
+        DatasetCatalog.get("definitely_not_registered")
+    register_synthetic("bulb_train", num_classes=80)
+    assert len(MetadataCatalog.get("bulb_train").thing_classes) == 80
+    model = build_model(cfg)
+    assert model.num_classes == 80 and model.backbone.down_ratio == 4 and model.size_divisibility == 32
+    assert model.backbone.first_level == 2 and model.backbone.channels[2] == 64
+    assert sum(p.numel() for p in model.parameters()) == 19675892          # SURVEY.md 2.5 / BASELINE.md
+    assert float(model.hm[2].bias.detach()[0]) == pytest.approx(-2.19) and float(model.wh[2].bias.detach().abs().sum()) == 0.0
+    sd = model.state_dict()
+    for k in ("backbone.base.level2.tree1.conv1.weight", "backbone.dla_up.ida_0.proj_1.conv.conv_offset_mask.weight",
+              "backbone.ida_up.node_2.actf.0.running_var", "hm.0.weight", "reg.2.bias", "pixel_mean"):
+        assert k in sd
+    # DCN parameterisation (third-party DCNv2 contract): zero-initialised offset/mask conv, zero bias
+    dcn = model.backbone.ida_up.proj_1.conv
+    assert dcn.conv_offset_mask.weight.abs().sum() == 0 and dcn.bias.abs().sum() == 0
+    assert dcn.conv_offset_mask.out_channels == 27
+
+
+def test_structures():
+    from detectron2_centernet_amd.modeling.postprocessing import detector_postprocess
+    from detectron2_centernet_amd.structures import Boxes, ImageList, Instances
+
+    b = Boxes(torch.tensor([[0.0, 0.0, 10.0, 10.0], [5.0, 5.0, 5.0, 9.0], [-3.0, 2.0, 8.0, 30.0]]))
+    assert b.nonempty().tolist() == [True, False, True] and b.area().tolist() == [100.0, 0.0, 308.0]
+    inst = Instances((20, 20), pred_boxes=b, scores=torch.tensor([0.9, 0.8, 0.7]), pred_classes=torch.tensor([1, 2, 3]))
+    out = detector_postprocess(inst, 40, 10)
+    assert out.image_size == (40, 10) and len(out) == 2
+    assert out.pred_boxes.tensor.tolist() == [[0.0, 0.0, 5.0, 20.0], [0.0, 4.0, 4.0, 40.0]]
+    with pytest.raises(AssertionError):
+        inst.set("bad", torch.zeros(5))
+    il = ImageList.from_tensors([torch.ones(3, 50, 70), torch.ones(3, 64, 33)], 32)
+    assert il.tensor.shape == (2, 3, 64, 96) and il.image_sizes == [(50, 70), (64, 33)]
+    assert il.tensor[0, :, 50:].abs().sum() == 0 and il[1].shape == (3, 64, 33)
+    assert ImageList.padded_size([(50, 70)], 32, 100, 100) == (128, 128)
+    cat = Instances.cat([inst[[0]], inst[[2]]])
+    assert len(cat) == 2 and cat.pred_classes.tolist() == [1, 3]
+
+
+def test_library_exports_every_declared_symbol():
+    from detectron2_centernet_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "ctdet_hip.h")).read()
+    declared = set(re.findall(r"\b(ctdet_[A-Za-z0-9_]+)\s*\(", header))
+    declared -= {"ctdet_conv_desc"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    l = _lib.lib()
+    assert l.ctdet_abi_version() == 1
+    assert [l.ctdet_conv_cout_tile(c) for c in (4, 16, 28, 64, 80, 128, 768)] == [16, 16, 32, 64, 32, 128, 128]
+    assert l.ctdet_decode_workspace_bytes(2) == 2 * l.ctdet_decode_workspace_bytes(1)
+    # argument validation happens before any device work: a null descriptor is rejected with a message
+    assert l.ctdet_conv2d_fwd(None, None, None, None, None, None, None, None) != 0
+    assert b"null" in l.ctdet_last_error()
+
+
+def test_ops_refuse_cpu_tensors():
+    import detectron2_centernet_amd.ops as ops
+
+    with pytest.raises(NotImplementedError):
+        ops.maxpool2x2(torch.zeros(1, 4, 4, 8))
+    with pytest.raises(NotImplementedError):
+        ops.decode(torch.zeros(1, 4, 4, 4), torch.zeros(1, 4, 4, 2), None, 10, 4.0)
+
+
+def test_synthetic_samples_are_deterministic():
+    from detectron2_centernet_amd.data.catalog import synthetic_sample
+
+    a, b = synthetic_sample(3), synthetic_sample(3)
+    assert torch.equal(a["image"], b["image"]) and torch.equal(a["boxes"], b["boxes"])
+    assert a["image"].dtype == torch.uint8 and a["image"].shape == (3, 512, 512)
+    bx = a["boxes"]
+    assert (bx[:, 0] >= 0).all() and (bx[:, 2] <= 512).all() and ((bx[:, 2] - bx[:, 0]) >= 8).all()

@@ -1,0 +1,144 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the reference's own Python functions
+(tests/golden/make_golden.py, run in the build container against /root/reference).  CPU only.
+
+The reference has no tests for this path, so these vectors -- outputs of the reference code
+itself -- are what anchors parity.  DCNv2 arithmetic is the one part with no runnable reference ("parity unpinned").
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctdet_oracle as O
+from oracle import model_ref as MR
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, G)
+from weights import fill_state_dict  # noqa: E402
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def test_g1_gaussian_radius_bit_exact():
+    d = load("g1_gaussian_radius.npz")
+    got = np.array([O.gaussian_radius((int(h), int(w))) for h, w in zip(d["h"], d["w"])])
+    assert np.array_equal(got, d["radius"])
+
+
+def test_g2_gen_heatmap_bit_exact():
+    d = load("g2_gen_heatmap.npz")
+    for i in range(int(d["n_cases"])):
+        r = O.gen_heatmap(d[f"boxes{i}"], d[f"classes{i}"], 128, 128, 80)
+        hm = np.zeros(80 * 128 * 128, dtype=np.float32)
+        hm[d[f"hm_idx{i}"]] = d[f"hm_val{i}"]
+        assert np.array_equal(r["hm"].ravel(), hm), f"case {i}: heatmap differs"
+        for k in ("wh", "reg", "ind", "reg_mask"):
+            assert np.array_equal(r[k], d[f"{k}{i}"]), f"case {i}: {k} differs"
+            assert r[k].dtype == d[f"{k}{i}"].dtype
+
+
+def test_g3_neg_loss_value_and_grad():
+    d = load("g3_neg_loss.npz")
+    for i in range(int(d["n_cases"])):
+        logits = torch.from_numpy(d[f"logits{i}"]).requires_grad_(True)
+        loss = O.focal_loss_from_logits(logits, torch.from_numpy(d[f"gt{i}"]), d[f"alpha{i}"].tolist())
+        loss.backward()
+        assert np.array_equal(loss.detach().numpy(), d[f"loss{i}"])
+        assert np.array_equal(logits.grad.numpy(), d[f"grad{i}"])
+
+
+def test_g4_reg_l1():
+    d = load("g4_reg_l1.npz")
+    out = torch.from_numpy(d["output"]).requires_grad_(True)
+    loss = O.reg_l1_loss(out, torch.from_numpy(d["mask"]), torch.from_numpy(d["ind"]), torch.from_numpy(d["target"]))
+    loss.backward()
+    assert np.array_equal(loss.detach().numpy(), d["loss"])
+    assert np.array_equal(out.grad.numpy(), d["grad"])
+
+
+def test_g5_decode_bit_exact_and_postprocess():
+    d = load("g5_decode.npz")
+    for i in range(int(d["n_cases"])):
+        heat, wh, reg = (torch.from_numpy(d[f"{k}{i}"]) for k in ("heat", "wh", "reg"))
+        b, s, c, _ = O.ctdet_decode(heat, wh, reg, down_ratio=4, K=100)
+        assert np.array_equal(s[0].numpy(), d[f"scores{i}"])
+        assert np.array_equal(c[0].numpy(), d[f"classes{i}"]) and c.dtype == torch.int32
+        assert np.array_equal(b[0].numpy(), d[f"boxes{i}"])
+        H, W = heat.shape[2:]
+        bb, ss, cc = O.inference_single_image(b[0], s[0], c[0], 50, float(d[f"pp_thresh{i}"]))
+        bb, keep = O.detector_postprocess(bb, (H * 4, W * 4), H * 8, W * 6)
+        assert np.array_equal(bb[keep].numpy(), d[f"pp_boxes{i}"])
+        assert np.array_equal(ss[keep].numpy(), d[f"pp_scores{i}"])
+        assert np.array_equal(cc[keep].numpy(), d[f"pp_classes{i}"])
+        assert len(d[f"pp_scores{i}"]) > 0
+    kept = O.nms_keep(torch.from_numpy(d["plateau_heat"]))
+    assert np.array_equal(kept.numpy(), d["plateau_kept"])
+    assert (kept[0, 1, 4:6, 4:6] == 0.9).all()  # every plateau cell survives `hmax == heat`
+
+
+def test_g6_preprocess_and_padding():
+    d = load("g6_preprocess.npz")
+    out, sizes = O.preprocess([torch.from_numpy(d["img0"]), torch.from_numpy(d["img1"])], [0.408, 0.447, 0.470],
+                              [0.289, 0.274, 0.278], 32)
+    assert np.array_equal(out.numpy(), d["batch"])
+    assert [list(s) for s in sizes] == d["sizes"].tolist()
+
+
+def _golden_state_dict():
+    shapes = {}
+    with open(os.path.join(G, "g8_dla34_state_dict_keys.txt")) as f:
+        for line in f:
+            k, shp = line.split(" ", 1)
+            shapes[k] = eval(shp)
+    sd = {k: torch.zeros(s) for k, s in shapes.items()}
+    # the bilinear up-conv weights are kept by fill_state_dict, so they must be the reference initialiser's
+    d = load("g7_dla34.npz")
+    for k, s in shapes.items():
+        if "up_" in k and len(s) == 4 and s[1] == 1:
+            f = s[2] // 2
+            sd[k] = torch.from_numpy(d[f"up_w{f}"])[:1].repeat(s[0], 1, 1, 1)
+    return fill_state_dict(sd, seed=7), shapes
+
+
+def test_g7_dla34_topology_matches_reference_modules():
+    """the functional oracle reproduces the reference's DLA-34 module graph (base levels, Tree/Root recursion,
+    DLAUp/IDAUp ordering, depthwise up-convs); DCN slots use this repo's CPU DCNv2 on both sides."""
+    d = load("g7_dla34.npz")
+    sd, _ = _golden_state_dict()
+    n = MR.Net({"backbone." + k: v for k, v in sd.items()})
+    x = torch.from_numpy(d["x"])
+    with torch.no_grad():
+        base = MR.dla_base(n, "backbone.base", x, (1, 1, 1, 2, 2, 1))
+        y = MR.dla34(n, "backbone", x)
+    for i, m in enumerate(base):
+        ref = d[f"base{i}"]
+        assert m.shape == ref.shape
+        assert np.abs(m.numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), f"base level {i}"
+    for i, m in enumerate(y):
+        ref = d[f"y{i}"]
+        assert np.abs(m.numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), f"ida_up output {i}"
+
+
+def test_g7_fill_up_weights():
+    from detectron2_centernet_amd.modeling.backbone.dla import fill_up_weights
+
+    d = load("g7_dla34.npz")
+    for f in (2, 4):
+        up = torch.nn.ConvTranspose2d(4, 4, f * 2, stride=f, padding=f // 2, groups=4, bias=False)
+        fill_up_weights(up)
+        assert np.array_equal(up.weight.detach().numpy(), d[f"up_w{f}"])
+
+
+def test_g8_state_dict_keys_match_reference():
+    """checkpoint compatibility: the build's DLA34 exposes exactly the reference's keys and shapes."""
+    from detectron2_centernet_amd.config import get_cfg
+    from detectron2_centernet_amd.modeling.backbone.dla import DLA34
+
+    _, shapes = _golden_state_dict()
+    model = DLA34(get_cfg())
+    mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert mine == shapes
