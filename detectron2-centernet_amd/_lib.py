@@ -18,7 +18,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "B", "H", "W", "Cin", "in_stride", "Cout", "Ho", "Wo", "out_stride",
         "R", "S", "stride", "pad", "dil", "Kpad", "Cout_pad",
-        "compute_dtype", "out_dtype", "act", "res_stride")] + [("clamp_lo", C.c_float), ("clamp_hi", C.c_float)]
+        "compute_dtype", "out_dtype", "act", "res_stride")] + [("clamp_lo", C.c_float), ("clamp_hi", C.c_float), ("korder", C.c_int32)]
 
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t

@@ -51,7 +51,9 @@ static int fill_args(const ctdet_conv_desc* d, ConvArgs& a) {
   a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
   a.K = d->R * d->S * d->Cin; a.Kpad = d->Kpad; a.Cout_pad = d->Cout_pad;
   a.M = d->B * d->Ho * d->Wo;
-  a.act = d->act; a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi;
+  a.act = d->act; a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi; a.korder = d->korder;
+  CTDET_CHECK(d->korder == 0 || (d->korder == 1 && d->Cin % 32 == 0 && d->compute_dtype == CTDET_DT_F16),
+              "conv: korder=%d invalid for Cin=%d", d->korder, d->Cin);
   CTDET_CHECK((long)d->B * d->Ho * d->Wo < (1L << 31), "conv: too many output pixels");
   return 0;
 }
@@ -95,6 +97,7 @@ int32_t ctdet_conv1x1_cat_fwd(const ctdet_conv_desc* d, const void* const* xs, c
   CTDET_CHECK(xs && cins && strides && w_packed && y, "conv1x1_cat: null pointer");
   CTDET_CHECK(nsrc >= 1 && nsrc <= 4, "conv1x1_cat: nsrc=%d must be 1..4", nsrc);
   CTDET_CHECK(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0, "conv1x1_cat: only 1x1 stride-1 convs");
+  a.korder = 0;
   const int align = d->compute_dtype == CTDET_DT_F16 ? 8 : 1;
   int cum = 0;
   for (int j = 0; j < 4; ++j) {
@@ -128,6 +131,7 @@ int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* of
   if (a.M == 0) return 0;
   CTDET_CHECK(x && w_packed && y && offset_mask, "dcnv2: null pointer");
   CTDET_CHECK(om_stride >= 3 * d->R * d->S, "dcnv2: om_stride=%d < 3*R*S", om_stride);
+  CTDET_CHECK(d->korder == 0, "dcnv2: weights must be packed tap-major (korder 0)");
   a.x = x; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = nullptr; a.y = y;
   a.om = offset_mask; a.om_stride = om_stride; a.mask_is_prob = mask_is_prob;
   if (d->compute_dtype == CTDET_DT_F16) return launch_conv_f16(a, d->out_dtype, true, (hipStream_t)stream);

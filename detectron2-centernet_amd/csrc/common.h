@@ -58,6 +58,7 @@ struct ConvArgs {
   int M;                // B*Ho*Wo
   int act;
   float clamp_lo, clamp_hi;
+  int korder;           // 0 tap-major, 1 chunk-major (see ctdet_conv_desc)
 };
 
 // argument block of the batched decode (decode.hip)

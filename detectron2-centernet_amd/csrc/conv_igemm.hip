@@ -383,11 +383,17 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(const ConvArgs a) {
     tr = tap / a.S;
     ts = tap - tr * a.S;
   }
+  const bool chunk_major = a.korder == 1;
   auto advance_k = [&]() {
-    c0 += 32;
-    while (c0 >= a.Cin) {
-      c0 -= a.Cin;
-      if (++ts == a.S) { ts = 0; ++tr; }
+    if (chunk_major) {
+      // next tap of the same 32-channel chunk; after the last tap move to the next chunk
+      if (++ts == a.S) { ts = 0; if (++tr == a.R) { tr = 0; c0 += 32; } }
+    } else {
+      c0 += 32;
+      while (c0 >= a.Cin) {
+        c0 -= a.Cin;
+        if (++ts == a.S) { ts = 0; ++tr; }
+      }
     }
   };
 
@@ -406,7 +412,7 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(const ConvArgs a) {
         dma16((kin && rowm[i] >= 0) ? src + rowm[i] * st + (kk - cb0) : zero, sb + i * 4096);
     } else {
       const int tap = tr * a.S + ts;
-      const bool kin = tr < a.R;
+      const bool kin = tr < a.R && c0 < a.Cin;
       const long delta = (long)((tr * a.dil) * a.W + ts * a.dil) * a.in_stride + c0;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i)
@@ -644,7 +650,7 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   CTDET_CHECK(a.Cout_pad % bc == 0 && a.Cout_pad >= a.Cout, "conv: Cout_pad=%d does not match tile %d (Cout=%d)",
               a.Cout_pad, bc, a.Cout);
   if (deform) {
-    CTDET_CHECK(a.Cin % 32 == 0, "dcnv2: Cin=%d must be a multiple of 32", a.Cin);
+    CTDET_CHECK(a.Cin % 32 == 0 && a.korder == 0, "dcnv2: Cin=%d must be a multiple of 32, tap-major weights", a.Cin);
     if (bc == 128) return launch_cfg<128, 128, 2, 2, true, TOut>(a, s);
     if (bc == 64) return launch_cfg<128, 64, 2, 2, true, TOut>(a, s);
     if (bc == 32) return launch_cfg<128, 32, 4, 1, true, TOut>(a, s);
@@ -654,7 +660,7 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   const long tiles256 = ((long)a.M + 255) / 256 * (a.Cout_pad / bc);
   const bool big = tiles256 >= 512;
   CTDET_CHECK(a.R * a.S <= 64, "conv: at most 64 taps (R*S=%d)", a.R * a.S);
-  if ((a.Cin == 8 || a.Cin == 16) && a.nsrc <= 1 && a.Wo % 64 == 0 && a.Cout_pad <= 32 && a.Cout_pad == bc) {
+  if ((a.Cin == 8 || a.Cin == 16) && a.korder == 0 && a.nsrc <= 1 && a.Wo % 64 == 0 && a.Cout_pad <= 32 && a.Cout_pad == bc) {
     const int nk = a.Kpad / 32;
     if (nk == 13 && bc == 16) return launch_smallc<1, 13, TOut>(a, s);
     if (nk == 5 && bc == 16) return launch_smallc<1, 5, TOut>(a, s);

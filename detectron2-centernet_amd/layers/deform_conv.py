@@ -38,7 +38,7 @@ def modulated_deform_conv(input, offset, mask, weight, bias=None, stride=1, padd
     om = torch.zeros(B, Ho, Wo, ops.round_up(3 * kh * kw, 4), dtype=torch.float32, device=input.device)
     om[..., : 2 * kh * kw] = offset.permute(0, 2, 3, 1)
     om[..., 2 * kh * kw: 3 * kh * kw] = mask.permute(0, 2, 3, 1)
-    p = ops.PackedConv(weight, None, bias, stride=stride, pad=padding, dil=dilation, compute=compute)
+    p = ops.PackedConv(weight, None, bias, stride=stride, pad=padding, dil=dilation, compute=compute, tap_major=True)
     y = ops.dcnv2(x, om, p, mask_is_prob=True)
     return hipnn.to_nchw_view(y, weight.shape[0])
 
@@ -98,7 +98,7 @@ class DCN(nn.Module):
         precision even in f16 mode."""
         om = hipnn.conv_module(x, self.conv_offset_mask, None, ACT_NONE, ctx=ctx, out_dtype=torch.float32)
         p = hipnn.packed(self, "dcn", ctx.compute, self.weight, bn, self.bias, self.stride, self.padding,
-                         self.dilation)
+                         self.dilation, tap_major=True)
         return ops.dcnv2(x, om, p, act=act)
 
     def forward(self, x):

@@ -32,7 +32,8 @@ def fold_bn(bn, conv_bias=None):
     return scale, bias
 
 
-def packed(owner, key, compute, weight, bn=None, conv_bias=None, stride=1, pad=0, dil=1, cin_pad=None):
+def packed(owner, key, compute, weight, bn=None, conv_bias=None, stride=1, pad=0, dil=1, cin_pad=None,
+           tap_major=False):
     """PackedConv for (weight, folded bn, bias), cached on `owner` and rebuilt when any tensor changed."""
     cache = owner.__dict__.setdefault("_ctdet_packed", {})
     tensors = [weight, conv_bias]
@@ -48,7 +49,8 @@ def packed(owner, key, compute, weight, bn=None, conv_bias=None, stride=1, pad=0
         scale, bias = fold_bn(bn, conv_bias)
     else:
         scale, bias = None, (conv_bias.detach().float() if conv_bias is not None else None)
-    p = ops.PackedConv(weight, scale, bias, stride=stride, pad=pad, dil=dil, compute=compute, cin_pad=cin_pad)
+    p = ops.PackedConv(weight, scale, bias, stride=stride, pad=pad, dil=dil, compute=compute, cin_pad=cin_pad,
+                       tap_major=tap_major)
     cache[(key, compute)] = (ver, p)
     return p
 

@@ -107,7 +107,8 @@ class PackedConv:
     compute: F16 (MFMA) or F32 (exact).
     """
 
-    def __init__(self, weight, scale=None, bias=None, stride=1, pad=0, dil=1, compute=F16, cin_pad=None):
+    def __init__(self, weight, scale=None, bias=None, stride=1, pad=0, dil=1, compute=F16, cin_pad=None,
+                 tap_major=False):
         _require_cuda(weight)
         Cout, Cin, R, S = weight.shape
         self.Cout, self.R, self.S = Cout, R, S
@@ -121,6 +122,10 @@ class PackedConv:
         w = weight.detach().to(torch.float32).permute(0, 2, 3, 1)  # [Cout,R,S,Cin]
         if self.Cin != Cin:
             w = torch.nn.functional.pad(w, (0, self.Cin - Cin))
+        # k ordering (ctdet_conv_desc.korder): chunk-major keeps the R*S taps of one 32-channel chunk adjacent
+        self.korder = 1 if (compute == F16 and not tap_major and self.Cin % 32 == 0 and R * S > 1) else 0
+        if self.korder == 1:
+            w = w.reshape(Cout, R * S, self.Cin // 32, 32).permute(0, 2, 1, 3)
         w = w.reshape(Cout, K)
         dev = weight.device
         if compute == F16:
@@ -166,6 +171,7 @@ class PackedConv:
         d.compute_dtype, d.out_dtype, d.act = self.compute, dt_of(out), act
         d.res_stride = _nhwc_stride(residual) if residual is not None else 0
         d.clamp_lo, d.clamp_hi = clamp
+        d.korder = self.korder
         return d
 
 
@@ -216,6 +222,7 @@ def conv1x1_cat(xs, p, out=None, act=ACT_NONE, residual=None, out_dtype=None):
     d.compute_dtype, d.out_dtype, d.act = p.compute, dt_of(out), act
     d.res_stride = _nhwc_stride(residual) if residual is not None else 0
     d.clamp_lo, d.clamp_hi = 0.0, 1.0
+    d.korder = 0
     n = len(xs)
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
     cin_a = (C.c_int32 * n)(*cins)
@@ -273,18 +280,18 @@ def maxpool2x2(x, out=None):
     return out
 
 
-_DW_CACHE = {}
-
-
 def _dw_weight(weight, Cc, f):
-    """[C,1,2f,2f] -> f32 [2f,2f,C], cached per weight version"""
-    key = (weight.data_ptr(), weight._version)
-    hit = _DW_CACHE.get(key)
-    if hit is None:
-        if len(_DW_CACHE) > 64:
-            _DW_CACHE.clear()
-        hit = _DW_CACHE[key] = weight.detach().reshape(Cc, 2 * f, 2 * f).to(torch.float32).permute(1, 2, 0).contiguous()
-    return hit
+    """[C,1,2f,2f] -> f32 [2f,2f,C]; cached on the tensor object itself (an address-keyed cache would go stale
+    when the allocator reuses a freed block)."""
+    hit = getattr(weight, "_ctdet_dw", None)
+    if hit is None or hit[0] != (weight.data_ptr(), weight._version):
+        packed = weight.detach().reshape(Cc, 2 * f, 2 * f).to(torch.float32).permute(1, 2, 0).contiguous()
+        hit = ((weight.data_ptr(), weight._version), packed)
+        try:
+            weight._ctdet_dw = hit
+        except AttributeError:
+            pass
+    return hit[1]
 
 
 def dwconvT_add(x, weight, f, skip=None, out=None):

@@ -23,7 +23,7 @@ enum ctdet_dtype { CTDET_DT_F16 = 0, CTDET_DT_F32 = 1, CTDET_DT_U8 = 2 };
 enum ctdet_act { CTDET_AC_NONE = 0, CTDET_AC_RELU = 1, CTDET_AC_SIGMOID_CLAMP = 2 };
 
 /* Geometry of one conv-shaped contraction.
- * compute_dtype F16: x is f16 NHWC, weights f16 packed [Cout_pad][Kpad], k = (r*S+s)*Cin + c,
+ * compute_dtype F16: x is f16 NHWC, weights f16 packed [Cout_pad][Kpad], k ordered per `korder`,
  *   Kpad = roundup(R*S*Cin, 32), Cout_pad = roundup(Cout, tile) with tile = ctdet_conv_cout_tile(Cout);
  *   MFMA f16 x f16 -> f32 accumulate; y is out_dtype (f16 or f32).
  * compute_dtype F32: x, y f32, weights f32 packed [Kpad][Cout_pad] (any Kpad >= K, Cout_pad >= Cout);
@@ -37,6 +37,9 @@ typedef struct ctdet_conv_desc {
   int32_t act;          /* ctdet_act, applied after scale/bias/residual */
   int32_t res_stride;   /* pixel stride of the residual tensor (same dtype as y) */
   float clamp_lo, clamp_hi; /* for CTDET_AC_SIGMOID_CLAMP */
+  int32_t korder;       /* f16 packing order of k: 0 = tap-major  k = (r*S+s)*Cin + c;
+                           1 = chunk-major k = ((c/32)*R*S + r*S+s)*32 + c%32 (needs Cin % 32 == 0; keeps the taps
+                           of one 32-channel chunk adjacent in time => L2-friendly; not for ctdet_dcnv2_fwd) */
 } ctdet_conv_desc;
 
 const char* ctdet_last_error(void);

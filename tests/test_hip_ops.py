@@ -131,7 +131,7 @@ def test_dcnv2(ops, dev, case, mode):
     ref = (ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)).relu()
     comp = ops.F16 if mode == "f16" else ops.F32
     tdt = torch.float16 if mode == "f16" else torch.float32
-    pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=1, pad=1, compute=comp)
+    pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=1, pad=1, compute=comp, tap_major=True)
     om_d = torch.zeros(B, H, W, 32)
     om_d[..., :27] = nhwc(om)
     y = ops.dcnv2(nhwc(x).to(tdt).to(dev), om_d.to(dev), pc, act=ops.ACT_RELU)
