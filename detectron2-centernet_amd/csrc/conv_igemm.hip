@@ -470,6 +470,156 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Uniform-K variant of the LDS-DMA kernel: when Cin (and every concat source) is a multiple of 32, the tap /
+// channel-chunk state of a K step is the same for every lane, so it lives in SGPRs; per lane only a fixed row
+// pointer (+ the lane's k-group offset) and a 32-bit tap-validity mask remain.  This removes ~80 per-lane
+// 64-bit VALU ops per K step and ~70 VGPRs compared with the generic kernel above (which stays for odd channel
+// counts), which is what lets two workgroups share a CU (arch VGPRs + 128 accumulators <= 256).
+// ------------------------------------------------------------------------------------------
+template <int BP, int BC, int WP, int WC_, typename TOut>
+__global__ void __launch_bounds__(256, 2) conv_igemm_uk_kernel(const ConvArgs a) {
+  constexpr int TP = BP / WP / 16;
+  constexpr int TC = BC / WC_ / 16;
+  constexpr int A_LD = BP / 64;
+  constexpr int BCL = BC < 64 ? 64 : BC;
+  constexpr int B_LD = BCL / 64;
+  constexpr int NLOAD = A_LD + B_LD;
+  constexpr int STAGE = (BP + BCL) * 64;
+  constexpr int NST = 3;
+  static_assert(WP * WC_ == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave / WC_, wc = wave % WC_;
+  int m_tile, n_tile;
+  if (!tile_of_block((a.M + BP - 1) / BP, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int m0 = m_tile * BP, n0 = n_tile * BC;
+  const f16* zero = (const f16*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+
+  const int lrow = tid >> 2, slot = tid & 3;
+  const int g = slot ^ swz(lrow);
+  const bool cat = a.nsrc > 1;
+
+  const f16* rowp[A_LD];   // conv: pixel of tap (0,0), + g*8 channels; cat: row of the current source
+  unsigned tapmask[A_LD];  // conv: taps inside the image; cat: bit 0 = row < M
+  int rowm[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = m0 + lrow + 64 * i;
+    const bool ok = m < a.M;
+    const int mm = ok ? m : 0;
+    const int wo = mm % a.Wo, t = mm / a.Wo;
+    const int ho = t % a.Ho, b = t / a.Ho;
+    const int hb = ho * a.stride - a.pad, wb = wo * a.stride - a.pad;
+    rowm[i] = mm;
+    unsigned mk = 0;
+    if (ok) {
+      if (cat) mk = 1u;
+      else
+        for (int r = 0; r < a.R; ++r)
+          for (int s2 = 0; s2 < a.S; ++s2) {
+            const int hi = hb + r * a.dil, wi = wb + s2 * a.dil;
+            if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) mk |= 1u << (r * a.S + s2);
+          }
+    }
+    tapmask[i] = mk;
+    rowp[i] = cat ? (const f16*)a.xs[0] + (long)mm * a.xs_stride[0] + g * 8
+                  : (const f16*)a.x + ((long)b * a.H * a.W + (long)hb * a.W + wb) * a.in_stride + g * 8;
+  }
+  const f16* wptr[B_LD];
+  bool b_ok[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int L = lrow + 64 * j;
+    const int Lw = L % (16 * TC), wv = L / (16 * TC);
+    const int tt = Lw >> 4, r = Lw & 15;
+    const int cl = wv * 16 * TC + 4 * TC * (r >> 2) + 4 * tt + (r & 3);
+    b_ok[j] = L < BC;
+    wptr[j] = (const f16*)a.w + (long)(n0 + (b_ok[j] ? cl : 0)) * a.Kpad + g * 8;
+  }
+
+  // uniform K-step state
+  int tr = 0, ts = 0, cch = 0;  // conv: tap row / col, channel-chunk offset
+  int sj = 0;                   // cat: current source
+  const bool chunk_major = a.korder == 1;
+  auto advance_k = [&]() {
+    if (cat) {
+      cch += 32;
+      const int send = a.xs_cend[sj] - (sj ? a.xs_cend[sj - 1] : 0);
+      if (cch >= send && sj + 1 < a.nsrc) {
+        ++sj;
+        cch = 0;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) rowp[i] = (const f16*)a.xs[sj] + (long)rowm[i] * a.xs_stride[sj] + g * 8;
+      }
+    } else if (chunk_major) {
+      if (++ts == a.S) { ts = 0; if (++tr == a.R) { tr = 0; cch += 32; } }
+    } else {
+      cch += 32;
+      if (cch >= a.Cin) { cch = 0; if (++ts == a.S) { ts = 0; ++tr; } }
+    }
+  };
+  auto issue = [&](int kt, int stage) {
+    char* sb = smem + stage * STAGE + wave * 1024;
+    const int tap = cat ? 0 : tr * a.S + ts;
+    const long dlt = cat ? (long)cch : ((long)(tr * a.dil) * a.W + ts * a.dil) * a.in_stride + cch;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) dma16(((tapmask[i] >> tap) & 1u) ? rowp[i] + dlt : zero, sb + i * 4096);
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      if constexpr (BC >= 64) dma16(wptr[j] + kt * 32, sb + BP * 64 + j * 4096);
+      else dma16(b_ok[j] ? wptr[j] + kt * 32 : zero, sb + BP * 64 + j * 4096);
+    }
+  };
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15;
+  const int frag_off = fr * 64 + (((lane >> 4) ^ swz(fr)) << 4);
+  const int nk = a.Kpad / 32;
+
+  issue(0, 0);
+  advance_k();
+  if (nk > 1) { issue(1, 1); advance_k(); }
+
+  int st_c = 0, st_l = 2;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) { issue(kt + 2, st_l); advance_k(); }
+    const char* base = smem + st_c * STAGE;
+    f16x8 wf[TC];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(base + BP * 64 + (wc * 16 * TC + 16 * c) * 64 + frag_off);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const f16x8 pf = *(const f16x8*)(base + (wp * 16 * TP + 16 * p) * 64 + frag_off);
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf, acc[p][c], 0, 0, 0);
+    }
+    st_c = st_c == NST - 1 ? 0 : st_c + 1;
+    st_l = st_l == NST - 1 ? 0 : st_l + 1;
+  }
+
+  const int q = lane >> 4;
+  const int cb = n0 + wc * 16 * TC + 4 * TC * q;
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int m = m0 + wp * 16 * TP + 16 * p + fr;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cb + 4 * c, acc[p][c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Small-channel layers (DLA base_layer 7x7 3->16, level0 3x3 16->16, level1 3x3 16->32 s2; dla.py:212-220):
 // HBM-bound shapes where an LDS-tiled GEMM is all overhead (4 MFMAs per barrier).  Here every weight fragment of
 // the layer lives in registers for the whole kernel (NK*TC fragments), and the pixel (MFMA B) fragments are read
@@ -644,6 +794,28 @@ static int launch_dma(const ConvArgs& a, hipStream_t s) {
   return 0;
 }
 
+template <int BP, int BC, int WP, int WC_, typename TOut>
+static int launch_uk(const ConvArgs& a, hipStream_t s) {
+  const int nbx = (a.M + BP - 1) / BP, nby = a.Cout_pad / BC;
+  dim3 grid(8 * ((nbx + 7) / 8) * nby);
+  hipLaunchKernelGGL((conv_igemm_uk_kernel<BP, BC, WP, WC_, TOut>), grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+static bool uniform_k_ok(const ConvArgs& a) {
+  if (a.R * a.S > 32 || a.Kpad != a.K) return false;
+  if (a.nsrc > 1) {
+    int prev = 0;
+    for (int j = 0; j < a.nsrc; ++j) {
+      if ((a.xs_cend[j] - prev) % 32) return false;
+      prev = a.xs_cend[j];
+    }
+    return true;
+  }
+  return a.Cin % 32 == 0;
+}
+
 template <typename TOut>
 static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   const int bc = pick_bc(a.Cout);
@@ -666,6 +838,14 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
     if (nk == 5 && bc == 16) return launch_smallc<1, 5, TOut>(a, s);
     if (nk == 5 && bc == 32) return launch_smallc<2, 5, TOut>(a, s);
     if (nk == 13 && bc == 32) return launch_smallc<2, 13, TOut>(a, s);
+  }
+  if (uniform_k_ok(a)) {
+    switch (bc) {
+      case 16: return launch_uk<256, 16, 4, 1, TOut>(a, s);
+      case 32: return big ? launch_uk<256, 32, 4, 1, TOut>(a, s) : launch_uk<128, 32, 4, 1, TOut>(a, s);
+      case 64: return big ? launch_uk<256, 64, 4, 1, TOut>(a, s) : launch_uk<128, 64, 2, 2, TOut>(a, s);
+      case 128: return big ? launch_uk<256, 128, 2, 2, TOut>(a, s) : launch_uk<128, 128, 2, 2, TOut>(a, s);
+    }
   }
   switch (bc) {
     case 16: return launch_dma<256, 16, 4, 1, TOut>(a, s);

@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Dev tool: time one conv-shaped launch (HIP events, repeated launches) -- used to tune the kernels and as the
+target of rocprofv3 --pmc runs.  Not part of the product or of the tests."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from detectron2_centernet_amd import ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", type=int, default=64)
+ap.add_argument("--H", type=int, default=32)
+ap.add_argument("--W", type=int, default=32)
+ap.add_argument("--cin", type=int, default=256)
+ap.add_argument("--cout", type=int, default=256)
+ap.add_argument("--k", type=int, default=3)
+ap.add_argument("--stride", type=int, default=1)
+ap.add_argument("--dcn", action="store_true")
+ap.add_argument("--f32out", action="store_true")
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--tap-major", action="store_true")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+x = torch.randn(a.B, a.H, a.W, a.cin, generator=g).half().to(dev)
+w = (torch.randn(a.cout, a.cin, a.k, a.k, generator=g) / (a.cin * a.k * a.k) ** 0.5).to(dev)
+p = ops.PackedConv(w, None, None, stride=a.stride, pad=a.k // 2, compute=ops.F16, tap_major=a.tap_major or a.dcn)
+od = torch.float32 if a.f32out else torch.float16
+if a.dcn:
+    om = torch.randn(a.B, a.H, a.W, 28, generator=g).to(dev)
+    f = lambda: ops.dcnv2(x, om, p, act=ops.ACT_RELU, out_dtype=od)
+else:
+    f = lambda: ops.conv2d(x, p, act=ops.ACT_RELU, out_dtype=od)
+for _ in range(3):
+    y = f()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.reps):
+    y = f()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / a.reps
+Ho, Wo = y.shape[1], y.shape[2]
+fl = 2.0 * a.B * Ho * Wo * a.cout * a.cin * a.k * a.k
+print(f"{'dcn' if a.dcn else 'conv'} B{a.B} {a.H}x{a.W} {a.cin}->{a.cout} k{a.k} s{a.stride}: {ms*1000:.1f} us  {fl/ms/1e9:.1f} TFLOP/s")
