@@ -41,6 +41,7 @@ struct DcnSample {
   int off[4];    // element offsets of the 4 corner pixels (already * in_stride), -1 = contributes 0
   float wt[4];   // bilinear weights
   float mask;    // sigmoid(mask logit)
+  f16 wm[4];     // f16(wt[q] * mask): the MFMA path blends in packed f16 (v_pk_fma_f16)
 };
 
 // Sampling geometry of one (pixel, tap); follows deform_conv_cuda_kernel.cu:836-861 and :666-699.
@@ -48,6 +49,7 @@ __device__ __forceinline__ void dcn_setup(const ConvArgs& a, bool row_ok, int pi
                                           int tr, int ts, const float* omrow, DcnSample& sp) {
   sp.off[0] = sp.off[1] = sp.off[2] = sp.off[3] = -1;
   sp.wt[0] = sp.wt[1] = sp.wt[2] = sp.wt[3] = 0.f;
+  sp.wm[0] = sp.wm[1] = sp.wm[2] = sp.wm[3] = (f16)0.f;
   sp.mask = 0.f;
   if (!row_ok || tr >= a.R) return;
   const int tap = tr * a.S + ts;
@@ -62,6 +64,8 @@ __device__ __forceinline__ void dcn_setup(const ConvArgs& a, bool row_ok, int pi
   const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
   const float hh = 1.f - lh, hw = 1.f - lw;
   sp.wt[0] = hh * hw; sp.wt[1] = hh * lw; sp.wt[2] = lh * hw; sp.wt[3] = lh * lw;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sp.wm[q] = (f16)(sp.wt[q] * sp.mask);
   if (h_low >= 0 && w_low >= 0) sp.off[0] = (pix_base + h_low * a.W + w_low) * a.in_stride;
   if (h_low >= 0 && w_high <= a.W - 1) sp.off[1] = (pix_base + h_low * a.W + w_high) * a.in_stride;
   if (h_high <= a.H - 1 && w_low >= 0) sp.off[2] = (pix_base + h_high * a.W + w_low) * a.in_stride;
@@ -100,7 +104,7 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs& a, int m, int c,
 }
 
 template <int BP, int BC, int WP, int WC_, bool DEFORM, typename TOut>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs a) {
   constexpr int TP = BP / WP / 16;   // 16-pixel MFMA tiles per wave
   constexpr int TC = BC / WC_ / 16;  // 16-cout MFMA tiles per wave
   constexpr int A_LD = BP / 64;      // pixel rows staged per thread per K step
@@ -214,12 +218,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
       if constexpr (!DEFORM) {
         v = areg[i];
       } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float s = sp[i].wt[0] * (float)creg[i][0][e] + sp[i].wt[1] * (float)creg[i][1][e] +
-                          sp[i].wt[2] * (float)creg[i][2][e] + sp[i].wt[3] * (float)creg[i][3][e];
-          v[e] = (f16)(s * sp[i].mask);
-        }
+        // packed-f16 blend: 4 v_pk_mul/fma_f16 per corner instead of ~10 f32 ops per element; the operand is
+        // rounded to f16 for the MFMA anyway (measured end-to-end heatmap error stays ~1e-5, bar is 1e-3)
+        const f16 w0 = sp[i].wm[0], w1 = sp[i].wm[1], w2 = sp[i].wm[2], w3 = sp[i].wm[3];
+        const f16x8 w0v = {w0, w0, w0, w0, w0, w0, w0, w0}, w1v = {w1, w1, w1, w1, w1, w1, w1, w1};
+        const f16x8 w2v = {w2, w2, w2, w2, w2, w2, w2, w2}, w3v = {w3, w3, w3, w3, w3, w3, w3, w3};
+        v = creg[i][0] * w0v;
+        v = __builtin_elementwise_fma(creg[i][1], w1v, v);
+        v = __builtin_elementwise_fma(creg[i][2], w2v, v);
+        v = __builtin_elementwise_fma(creg[i][3], w3v, v);
       }
       *(f16x8*)(base + (lrow + 64 * i) * 64 + slot * 16) = v;
     }

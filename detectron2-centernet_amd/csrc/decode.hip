@@ -9,17 +9,20 @@
 // canon = c*H*W + y*W + x ascending.  torch.topk's own tie order is unspecified, so ties are
 // where a difference is permitted; fixtures are tie-free or assert the canonical rule.
 //
-// Selection = MSD radix select on the 88-bit key (score bits, ~canon): level 0 uses 4096 fine bins
-// over the sigmoid range [2^-15, 2), further levels (only run for degenerate inputs, they early-exit
-// otherwise) split the remaining 56 bits 14 at a time.  Then the <= K-1 certain + <= CAP uncertain
-// candidates are sorted by one workgroup per image.
+// Selection = MSD radix select on the key (score bits, ~canon), 4096 bins per level: level 0 uses fine bins
+// over the sigmoid range [2^-15, 2); further levels run only while the bin holding the K-th key has more than
+// DEC_CAP entries (near-constant or tied maps) and early-exit otherwise.  They split what level 0 left: for an
+// interior level-0 bin the low 15 score bits + 24 index bits, for the two clamped end bins the full 32 + 24
+// bits, 12 bits per level.  Then the <= K-1 certain + <= CAP uncertain candidates are sorted by one workgroup
+// per image.
 // HBM traffic: heat is read twice (histogram pass, collect pass); 3x3 neighbours come from L1/L2.
 #include "common.h"
+#include <stdlib.h>
 
 #define DEC_CAP 2048            // max uncertain candidates carried to the final sort
 #define DEC_NCAND 4096          // sort width (>= K-1 + DEC_CAP)
-#define DEC_HIST 16384          // bins per level >= 1 (level 0 uses 4096)
-#define DEC_LEVELS 5
+#define DEC_HIST 4096           // bins per level
+#define DEC_LEVELS 6            // 1 + ceil(56 / 12)
 // per-image workspace (uint32 words): [0..31] state, [32..32+DEC_HIST) histogram, then candidates (u64)
 #define DEC_ST_WORDS 32
 #define DEC_WS_WORDS (DEC_ST_WORDS + DEC_HIST + 2 * DEC_NCAND)
@@ -30,8 +33,11 @@ __device__ __forceinline__ int dec_d0(uint32_t bits) {
   const int d = ((int)bits - 0x38000000) >> 15;
   return d < 0 ? 0 : (d > 4095 ? 4095 : d);
 }
-__device__ __forceinline__ uint64_t dec_r56(uint32_t bits, uint32_t canon) {
-  return ((uint64_t)bits << 24) | (uint64_t)(0xFFFFFFu - canon);
+// what is left to order after level 0, left-aligned in 60 bits (5 digits of 12)
+__device__ __forceinline__ uint64_t dec_rest(uint32_t bits, uint32_t canon, bool interior) {
+  const uint64_t inv = (uint64_t)(0xFFFFFFu - canon);
+  return interior ? ((((uint64_t)(bits & 0x7FFFu) << 24) | inv) << 21)   // 39 significant bits
+                  : ((((uint64_t)bits << 24) | inv) << 4);                // 56 significant bits
 }
 
 // visits every positive peak of image b handled by this block: f(bits, canon)
@@ -73,28 +79,30 @@ __global__ void __launch_bounds__(256) dec_init_kernel(DecArgs a) {
   for (int i = threadIdx.x; i < DEC_ST_WORDS + DEC_HIST; i += 256) ws[i] = 0;
 }
 
-__global__ void __launch_bounds__(256) dec_hist_kernel(DecArgs a, int level) {
+__global__ void __launch_bounds__(256) dec_hist_kernel(DecArgs a, int level, int dbg) {
   extern __shared__ uint32_t lh[];
   const int b = blockIdx.y;
   uint32_t* ws = a.ws + (long)b * DEC_WS_WORDS;
   if (ws[ST_RESOLVED]) return;
-  const int nb = level == 0 ? 4096 : DEC_HIST;
+  const int nb = DEC_HIST;
   for (int i = threadIdx.x; i < nb; i += 256) lh[i] = 0;
   __syncthreads();
   const uint32_t p0 = ws[ST_P0];
+  const bool interior = p0 > 0 && p0 < 4095;
   const uint64_t pr = ((uint64_t)ws[ST_PR_HI] << 32) | ws[ST_PR_LO];
   for_each_peak(a, b, [&](uint32_t bits, uint32_t canon) {
     if (level == 0) {
-      atomicAdd(&lh[dec_d0(bits)], 1u);
+      if (!(dbg & 1)) atomicAdd(&lh[dec_d0(bits)], 1u);
     } else {
       if ((uint32_t)dec_d0(bits) != p0) return;
-      const uint64_t r = dec_r56(bits, canon);
-      if (level > 1 && (r >> (56 - 14 * (level - 1))) != pr) return;
-      atomicAdd(&lh[(uint32_t)(r >> (56 - 14 * level)) & 0x3FFFu], 1u);
+      const uint64_t r = dec_rest(bits, canon, interior);
+      if (level > 1 && (r >> (60 - 12 * (level - 1))) != pr) return;
+      atomicAdd(&lh[(uint32_t)(r >> (60 - 12 * level)) & 0xFFFu], 1u);
     }
   });
   __syncthreads();
   uint32_t* gh = ws + DEC_ST_WORDS;
+  if (dbg & 2) return;
   for (int i = threadIdx.x; i < nb; i += 256)
     if (lh[i]) atomicAdd(&gh[i], lh[i]);
 }
@@ -107,10 +115,10 @@ __global__ void __launch_bounds__(1024) dec_scan_kernel(DecArgs a, int level) {
   uint32_t* ws = a.ws + (long)b * DEC_WS_WORDS;
   if (ws[ST_RESOLVED]) return;
   uint32_t* gh = ws + DEC_ST_WORDS;
-  const int nb = level == 0 ? 4096 : DEC_HIST;
-  const int per = nb / 1024;  // 4 or 16 bins per thread, thread t owns bins [t*per, (t+1)*per)
+  const int nb = DEC_HIST;
+  const int per = nb / 1024;  // 4 bins per thread, thread t owns bins [t*per, (t+1)*per)
   const int t = threadIdx.x;
-  uint32_t loc[16];
+  uint32_t loc[4];
   uint32_t s = 0;
   for (int j = 0; j < per; ++j) { loc[j] = gh[t * per + j]; s += loc[j]; }
   part[t] = s;
@@ -151,7 +159,7 @@ __global__ void __launch_bounds__(1024) dec_scan_kernel(DecArgs a, int level) {
       if (level == 0) ws[ST_P0] = T;
       else {
         const uint64_t pr = (((uint64_t)ws[ST_PR_HI] << 32) | ws[ST_PR_LO]);
-        const uint64_t npr = (level == 1 ? 0ull : (pr << 14)) | T;
+        const uint64_t npr = (level == 1 ? 0ull : (pr << 12)) | T;
         ws[ST_PR_LO] = (uint32_t)npr;
         ws[ST_PR_HI] = (uint32_t)(npr >> 32);
       }
@@ -181,7 +189,7 @@ __global__ void __launch_bounds__(256) dec_collect_kernel(DecArgs a) {
       const uint32_t d0 = (uint32_t)dec_d0(bits);
       if (d0 < p0) return;
       if (d0 == p0 && level > 0) {
-        const uint64_t r = dec_r56(bits, canon) >> (56 - 14 * level);
+        const uint64_t r = dec_rest(bits, canon, p0 > 0 && p0 < 4095) >> (60 - 12 * level);
         if (r < pr) return;
       }
     }
@@ -307,8 +315,9 @@ int launch_decode(const DecArgs& a, hipStream_t s) {
   if (chunks > 256) chunks = 256;
   hipLaunchKernelGGL(dec_init_kernel, dim3(a.B), dim3(256), 0, s, a);
   for (int level = 0; level < DEC_LEVELS; ++level) {
-    const size_t lds = (level == 0 ? 4096 : DEC_HIST) * sizeof(uint32_t);
-    hipLaunchKernelGGL(dec_hist_kernel, dim3(chunks, a.B), dim3(256), lds, s, a, level);
+    const size_t lds = DEC_HIST * sizeof(uint32_t);
+    static const int dbg = getenv("CTDET_DEC_DEBUG") ? atoi(getenv("CTDET_DEC_DEBUG")) : 0;
+    hipLaunchKernelGGL(dec_hist_kernel, dim3(chunks, a.B), dim3(256), lds, s, a, level, dbg);
     hipLaunchKernelGGL(dec_scan_kernel, dim3(a.B), dim3(1024), 0, s, a, level);
   }
   hipLaunchKernelGGL(dec_collect_kernel, dim3(chunks, a.B), dim3(256), 0, s, a);
