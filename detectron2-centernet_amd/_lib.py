@@ -18,7 +18,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "B", "H", "W", "Cin", "in_stride", "Cout", "Ho", "Wo", "out_stride",
         "R", "S", "stride", "pad", "dil", "Kpad", "Cout_pad",
-        "compute_dtype", "out_dtype", "act", "res_stride")] + [("clamp_lo", C.c_float), ("clamp_hi", C.c_float), ("korder", C.c_int32)]
+        "compute_dtype", "out_dtype", "act", "res_stride")] + [("clamp_lo", C.c_float), ("clamp_hi", C.c_float), ("korder", C.c_int32), ("in_dil", C.c_int32)]
 
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -42,6 +42,16 @@ SIGNATURES = {
     "ctdet_focal_loss_workspace_bytes": (_sz, [_i64]),
     "ctdet_focal_loss": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ctdet_reg_l1_loss": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _vp]),
+    "ctdet_chan_workspace_bytes": (_sz, [_i32]),
+    "ctdet_bn_train_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _vp, _i32, _vp]),
+    "ctdet_bn_train_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32,
+                                   _vp, _vp, _vp, _vp]),
+    "ctdet_conv_wgrad": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    "ctdet_maxpool2x2_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_dwconvT_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_dcn_cols": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_dcn_col2im_coord": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_sgd_momentum": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _i32, _vp]),
 }
 

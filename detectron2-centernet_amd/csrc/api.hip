@@ -35,15 +35,33 @@ int launch_reg_l1(const float*, int, const uint8_t*, const int64_t*, const float
                   int, hipStream_t);
 int launch_sgd(float*, const float*, float*, long, const float*, float, float, int, hipStream_t);
 
+struct WgradArgs {
+  const f16* x; const f16* dy; float* dw;
+  int B, H, W, Cin, in_stride, Cout, Ho, Wo, dy_stride, R, S, stride, pad, dil, K, M, msplit;
+};
+size_t chan_reduce_workspace_bytes(int C);
+int launch_bn_train_fwd(const f16*, int, const f16*, int, f16*, int, int, int, const float*, const float*, float, float,
+                        float*, float*, float*, float*, float*, float*, void*, int, hipStream_t);
+int launch_bn_train_bwd(const f16*, int, const f16*, int, const f16*, int, const float*, const float*, const float*, int,
+                        int, int, f16*, int, f16*, int, float*, float*, void*, hipStream_t);
+int launch_conv_wgrad(const WgradArgs&, hipStream_t);
+int launch_maxpool2x2_bwd(const f16*, int, const f16*, int, f16*, int, int, int, int, int, hipStream_t);
+int launch_dwconvT_bwd(const f16*, int, const f16*, int, const float*, f16*, int, float*, int, int, int, int, int,
+                       hipStream_t);
+int launch_dcn_cols(const f16*, int, const float*, int, f16*, int, int, int, int, hipStream_t);
+int launch_dcn_col2im_coord(const f16*, const f16*, int, const float*, int, float*, float*, int, int, int, int,
+                            hipStream_t);
+
 static int fill_args(const ctdet_conv_desc* d, ConvArgs& a) {
   CTDET_CHECK(d != nullptr, "conv: null descriptor");
   CTDET_CHECK(d->B >= 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: bad shape B=%d H=%d W=%d Cin=%d Cout=%d",
               d->B, d->H, d->W, d->Cin, d->Cout);
   CTDET_CHECK(d->R > 0 && d->S > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0, "conv: bad kernel geometry");
-  const int ho = (d->H + 2 * d->pad - (d->dil * (d->R - 1) + 1)) / d->stride + 1;
-  const int wo = (d->W + 2 * d->pad - (d->dil * (d->S - 1) + 1)) / d->stride + 1;
-  CTDET_CHECK(ho == d->Ho && wo == d->Wo, "conv: output size %dx%d does not match geometry (expected %dx%d)", d->Ho,
-              d->Wo, ho, wo);
+  const int idl = d->in_dil > 1 ? d->in_dil : 1;
+  const int ho = ((d->H - 1) * idl + 1 + 2 * d->pad - (d->dil * (d->R - 1) + 1)) / d->stride + 1;
+  const int wo = ((d->W - 1) * idl + 1 + 2 * d->pad - (d->dil * (d->S - 1) + 1)) / d->stride + 1;
+  CTDET_CHECK(d->Ho >= ho && d->Ho < ho + idl && d->Wo >= wo && d->Wo < wo + idl,
+              "conv: output size %dx%d does not match geometry (expected %dx%d)", d->Ho, d->Wo, ho, wo);
   CTDET_CHECK(d->in_stride >= d->Cin && d->out_stride >= d->Cout, "conv: pixel strides smaller than channel counts");
   memset(&a, 0, sizeof(a));
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_stride = d->in_stride;
@@ -51,7 +69,7 @@ static int fill_args(const ctdet_conv_desc* d, ConvArgs& a) {
   a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
   a.K = d->R * d->S * d->Cin; a.Kpad = d->Kpad; a.Cout_pad = d->Cout_pad;
   a.M = d->B * d->Ho * d->Wo;
-  a.act = d->act; a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi; a.korder = d->korder;
+  a.act = d->act; a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi; a.korder = d->korder; a.in_dil = idl;
   CTDET_CHECK(d->korder == 0 || (d->korder == 1 && d->Cin % 32 == 0 && d->compute_dtype == CTDET_DT_F16),
               "conv: korder=%d invalid for Cin=%d", d->korder, d->Cin);
   CTDET_CHECK((long)d->B * d->Ho * d->Wo < (1L << 31), "conv: too many output pixels");
@@ -231,6 +249,70 @@ int32_t ctdet_reg_l1_loss(const float* pred, int32_t pred_stride, const uint8_t*
   CTDET_CHECK(pred && mask && ind && target && loss, "reg_l1_loss: null pointer");
   return launch_reg_l1(pred, pred_stride, mask, ind, target, B, N, HW, grad_scale, loss, grad, grad_stride,
                        (hipStream_t)stream);
+}
+
+size_t ctdet_chan_workspace_bytes(int32_t C) { return chan_reduce_workspace_bytes(C); }
+
+int32_t ctdet_bn_train_fwd(const void* y, int32_t y_stride, const void* res, int32_t res_stride, void* z,
+                           int32_t z_stride, int32_t M, int32_t C, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, float* save_mean,
+                           float* save_invstd, float* scale, float* shift, void* workspace, int32_t relu, void* stream) {
+  CTDET_CHECK(y && z && gamma && beta && save_mean && save_invstd && scale && shift && workspace, "bn_train_fwd: null pointer");
+  CTDET_CHECK(M > 0, "bn_train_fwd: empty batch");
+  return launch_bn_train_fwd((const f16*)y, y_stride, (const f16*)res, res_stride, (f16*)z, z_stride, M, C, gamma, beta,
+                             eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift, workspace,
+                             relu, (hipStream_t)stream);
+}
+
+int32_t ctdet_bn_train_bwd(const void* dz, int32_t dz_stride, const void* z, int32_t z_stride, const void* y,
+                           int32_t y_stride, const float* mean, const float* invstd, const float* scale, int32_t M,
+                           int32_t C, int32_t relu, void* dy, int32_t dy_stride, void* dres, int32_t dres_stride,
+                           float* dgamma, float* dbeta, void* workspace, void* stream) {
+  CTDET_CHECK(dz && dy && dgamma && dbeta && workspace, "bn_train_bwd: null pointer");
+  CTDET_CHECK(!relu || z, "bn_train_bwd: relu backward needs z");
+  CTDET_CHECK(!y || (mean && invstd && scale), "bn_train_bwd: statistics missing");
+  return launch_bn_train_bwd((const f16*)dz, dz_stride, (const f16*)z, z_stride, (const f16*)y, y_stride, mean, invstd,
+                             scale, M, C, relu, (f16*)dy, dy_stride, (f16*)dres, dres_stride, dgamma, dbeta, workspace,
+                             (hipStream_t)stream);
+}
+
+int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy, float* dw, void* stream) {
+  CTDET_CHECK(d && x && dy && dw, "conv_wgrad: null pointer");
+  WgradArgs a;
+  a.x = (const f16*)x; a.dy = (const f16*)dy; a.dw = dw;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_stride = d->in_stride; a.Cout = d->Cout; a.Ho = d->Ho;
+  a.Wo = d->Wo; a.dy_stride = d->out_stride; a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+  a.K = d->R * d->S * d->Cin; a.M = d->B * d->Ho * d->Wo; a.msplit = 1;
+  if (a.M == 0) return 0;
+  return launch_conv_wgrad(a, (hipStream_t)stream);
+}
+
+int32_t ctdet_maxpool2x2_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, void* dx,
+                             int32_t dx_stride, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  CTDET_CHECK(x && dz && dx, "maxpool2x2_bwd: null pointer");
+  return launch_maxpool2x2_bwd((const f16*)x, x_stride, (const f16*)dz, dz_stride, (f16*)dx, dx_stride, B, H, W, C,
+                               (hipStream_t)stream);
+}
+
+int32_t ctdet_dwconvT_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, const float* w, void* dx,
+                          int32_t dx_stride, float* dw, int32_t B, int32_t H, int32_t W, int32_t C, int32_t f,
+                          void* stream) {
+  CTDET_CHECK(x && dz && w && dx && dw, "dwconvT_bwd: null pointer");
+  return launch_dwconvT_bwd((const f16*)x, x_stride, (const f16*)dz, dz_stride, w, (f16*)dx, dx_stride, dw, B, H, W, C, f,
+                            (hipStream_t)stream);
+}
+
+int32_t ctdet_dcn_cols(const void* x, int32_t x_stride, const float* om, int32_t om_stride, void* col, int32_t B,
+                       int32_t H, int32_t W, int32_t Cin, void* stream) {
+  CTDET_CHECK(x && om && col, "dcn_cols: null pointer");
+  return launch_dcn_cols((const f16*)x, x_stride, om, om_stride, (f16*)col, B, H, W, Cin, (hipStream_t)stream);
+}
+
+int32_t ctdet_dcn_col2im_coord(const void* dcol, const void* x, int32_t x_stride, const float* om, int32_t om_stride,
+                               float* dx, float* dom, int32_t B, int32_t H, int32_t W, int32_t Cin, void* stream) {
+  CTDET_CHECK(dcol && x && om && dx && dom, "dcn_col2im_coord: null pointer");
+  return launch_dcn_col2im_coord((const f16*)dcol, (const f16*)x, x_stride, om, om_stride, dx, dom, B, H, W, Cin,
+                                 (hipStream_t)stream);
 }
 
 int32_t ctdet_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, const float* lr_dev,

@@ -59,6 +59,7 @@ struct ConvArgs {
   int act;
   float clamp_lo, clamp_hi;
   int korder;           // 0 tap-major, 1 chunk-major (see ctdet_conv_desc)
+  int in_dil;           // input dilation (zero-stuffed input): >1 only for the input-gradient of strided convs
 };
 
 // argument block of the batched decode (decode.hip)

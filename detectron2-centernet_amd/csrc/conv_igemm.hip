@@ -349,9 +349,10 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(const ConvArgs a) {
   const int lrow = tid >> 2, slot = tid & 3;
   const int g = slot ^ swz(lrow);
   // per staged pixel row: element offset of tap (0,0) and a bit mask of the taps that fall inside the image
-  long rowoff[A_LD];
+  int rb[A_LD], rhb[A_LD], rwb[A_LD];
   unsigned long long tapmask[A_LD];
   long rowm[A_LD];
+  const int idl = a.in_dil;
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
     const int m = m0 + lrow + 64 * i;
@@ -360,14 +361,15 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(const ConvArgs a) {
     const int wo = mm % a.Wo, t = mm / a.Wo;
     const int ho = t % a.Ho, b = t / a.Ho;
     const int hb = ho * a.stride - a.pad, wb = wo * a.stride - a.pad;
-    rowoff[i] = ((long)b * a.H * a.W + (long)hb * a.W + wb) * a.in_stride;
+    rb[i] = b; rhb[i] = hb; rwb[i] = wb;
     rowm[i] = ok ? (long)m : -1;
     unsigned long long mk = 0;
     if (ok)
       for (int r = 0; r < a.R; ++r)
         for (int s2 = 0; s2 < a.S; ++s2) {
-          const int hi = hb + r * a.dil, wi = wb + s2 * a.dil;
-          if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) mk |= 1ull << (r * a.S + s2);
+          const int hn = hb + r * a.dil, wn = wb + s2 * a.dil;  // position in the (zero-stuffed) input
+          if (hn >= 0 && wn >= 0 && hn % idl == 0 && wn % idl == 0 && hn / idl < a.H && wn / idl < a.W)
+            mk |= 1ull << (r * a.S + s2);
         }
     tapmask[i] = mk;
   }
@@ -420,10 +422,12 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(const ConvArgs a) {
     } else {
       const int tap = tr * a.S + ts;
       const bool kin = tr < a.R && c0 < a.Cin;
-      const long delta = (long)((tr * a.dil) * a.W + ts * a.dil) * a.in_stride + c0;
 #pragma unroll
-      for (int i = 0; i < A_LD; ++i)
-        dma16((kin && ((tapmask[i] >> tap) & 1ull)) ? x + rowoff[i] + delta : zero, sb + i * 4096);
+      for (int i = 0; i < A_LD; ++i) {
+        const int hi = (rhb[i] + tr * a.dil) / idl, wi = (rwb[i] + ts * a.dil) / idl;
+        dma16((kin && ((tapmask[i] >> tap) & 1ull)) ? x + ((long)(rb[i] * a.H + hi) * a.W + wi) * a.in_stride + c0 : zero,
+              sb + i * 4096);
+      }
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) dma16(b_ok[j] ? w + b_off[j] + kt * 32 : zero, sb + BP * 64 + j * 4096);
@@ -811,7 +815,7 @@ static int launch_uk(const ConvArgs& a, hipStream_t s) {
 }
 
 static bool uniform_k_ok(const ConvArgs& a) {
-  if (a.R * a.S > 32 || a.Kpad != a.K) return false;
+  if (a.R * a.S > 32 || a.Kpad != a.K || a.in_dil != 1) return false;
   if (a.nsrc > 1) {
     int prev = 0;
     for (int j = 0; j < a.nsrc; ++j) {
@@ -828,6 +832,7 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   const int bc = pick_bc(a.Cout);
   CTDET_CHECK(a.Cout_pad % bc == 0 && a.Cout_pad >= a.Cout, "conv: Cout_pad=%d does not match tile %d (Cout=%d)",
               a.Cout_pad, bc, a.Cout);
+  CTDET_CHECK(a.in_dil >= 1 && (!deform || a.in_dil == 1), "conv: bad in_dil %d", a.in_dil);
   if (deform) {
     CTDET_CHECK(a.Cin % 32 == 0 && a.korder == 0, "dcnv2: Cin=%d must be a multiple of 32, tap-major weights", a.Cin);
     if (bc == 128) return launch_cfg<128, 128, 2, 2, true, TOut>(a, s);
@@ -839,7 +844,7 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   const long tiles256 = ((long)a.M + 255) / 256 * (a.Cout_pad / bc);
   const bool big = tiles256 >= 512;
   CTDET_CHECK(a.R * a.S <= 64, "conv: at most 64 taps (R*S=%d)", a.R * a.S);
-  if ((a.Cin == 8 || a.Cin == 16) && a.korder == 0 && a.nsrc <= 1 && a.Wo % 64 == 0 && a.Cout_pad <= 32 && a.Cout_pad == bc) {
+  if ((a.Cin == 8 || a.Cin == 16) && a.in_dil == 1 && a.korder == 0 && a.nsrc <= 1 && a.Wo % 64 == 0 && a.Cout_pad <= 32 && a.Cout_pad == bc) {
     const int nk = a.Kpad / 32;
     if (nk == 13 && bc == 16) return launch_smallc<1, 13, TOut>(a, s);
     if (nk == 5 && bc == 16) return launch_smallc<1, 5, TOut>(a, s);
@@ -876,6 +881,7 @@ int launch_conv_f16(const ConvArgs& a, int out_dtype, bool deform, hipStream_t s
 }
 
 int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s) {
+  CTDET_CHECK(a.in_dil == 1, "conv(f32): input dilation is only implemented on the f16 path");
   CTDET_CHECK((long)a.B * a.H * a.W * a.in_stride < (1L << 31), "conv: input too large for 32-bit element offsets");
   const int CP = (a.Cout + 3) & ~3;
   const long total = (long)a.M * CP;

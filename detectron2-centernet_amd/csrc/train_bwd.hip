@@ -1,0 +1,610 @@
+// Training-side kernels of the conv stack (NHWC, f16 activations, f32 statistics / weight gradients).
+//   BatchNorm2d in training mode (batch statistics, momentum 0.1 running stats) forward and backward, fused with
+//   ReLU and the residual add of DLABasicBlock (detectron2/modeling/backbone/dla.py:59-73, 86-94; deform_conv.py:501-519)
+//   conv weight gradient on MFMA (reduction over pixels, operands read from LDS with ds_read_b64_tr_b16)
+//   MaxPool2d(2) backward, depthwise ConvTranspose2d backward (dla.py:129, 162-177)
+//   DCNv2 backward pieces: column sampler and col2im + coordinate/mask gradients
+//   (detectron2/layers/csrc/deformable/deform_conv_cuda_kernel.cu:786-1066, deform_conv_cuda.cu:929-1129)
+// Input-gradient of plain convs reuses the forward implicit-GEMM kernels with transposed/flipped weights.
+#include "common.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-channel reductions over the M rows of an NHWC tensor: thread = (row lane, 8-channel vector)
+//   mode 0 (BN forward stats):  r0 = sum y,        r1 = sum y^2
+//   mode 1 (BN/act backward):   g = dz * (z > 0 if relu);  r0 = sum g,  r1 = sum g * xhat   (xhat = (y-mean)*invstd)
+// partial[blk][2][C] f32, reduced in fixed order by chan_finalize (f64) => deterministic.
+// ------------------------------------------------------------------------------------------------
+struct ChanRedArgs {
+  const f16* y; int y_stride;      // mode 0: tensor; mode 1: pre-BN conv output (may be null => no xhat term)
+  const f16* dz; int dz_stride;    // mode 1
+  const f16* z; int z_stride;      // mode 1: post-activation output (relu mask), may be null
+  const float* mean; const float* invstd;
+  int M, C, mode, relu;
+  float* partial;
+};
+
+__global__ void __launch_bounds__(256) chan_reduce_kernel(ChanRedArgs a) {
+  __shared__ float red[2][256][8];
+  const int CV = a.C >> 3;
+  const int rows_per_pass = 256 / CV;  // CV in {2,4,8,16,32,64}
+  const int cv = threadIdx.x % CV, rl = threadIdx.x / CV;
+  float s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+  float mu[8], is[8];
+  if (a.mode == 1 && a.y) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { mu[e] = a.mean[cv * 8 + e]; is[e] = a.invstd[cv * 8 + e]; }
+  }
+  if (rl < rows_per_pass) {
+    for (long m = (long)blockIdx.x * rows_per_pass + rl; m < a.M; m += (long)gridDim.x * rows_per_pass) {
+      if (a.mode == 0) {
+        const f16x8 v = *(const f16x8*)(a.y + m * a.y_stride + cv * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s0[e] += f; s1[e] += f * f; }
+      } else {
+        const f16x8 g = *(const f16x8*)(a.dz + m * a.dz_stride + cv * 8);
+        f16x8 zz = g, yy = g;
+        if (a.relu) zz = *(const f16x8*)(a.z + m * a.z_stride + cv * 8);
+        if (a.y) yy = *(const f16x8*)(a.y + m * a.y_stride + cv * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gf = (a.relu && !((float)zz[e] > 0.f)) ? 0.f : (float)g[e];
+          s0[e] += gf;
+          if (a.y) s1[e] += gf * (((float)yy[e] - mu[e]) * is[e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s0[e]; red[1][threadIdx.x][e] = s1[e]; }
+  __syncthreads();
+  if (rl == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int r = 0; r < rows_per_pass; ++r) { t0 += red[0][r * CV + cv][e]; t1 += red[1][r * CV + cv][e]; }
+      a.partial[((long)blockIdx.x * 2 + 0) * a.C + cv * 8 + e] = t0;
+      a.partial[((long)blockIdx.x * 2 + 1) * a.C + cv * 8 + e] = t1;
+    }
+  }
+}
+
+// mode 0: mean/invstd/scale/shift (+ running stats);  mode 1: out0 = sum g (dbeta / dbias), out1 = sum g*xhat (dgamma)
+__global__ void __launch_bounds__(256) chan_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, int M,
+                                                            int mode, float eps, float momentum,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ out0, float* __restrict__ out1,
+                                                            float* __restrict__ scale, float* __restrict__ shift,
+                                                            float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0, s1 = 0;
+  for (int b = 0; b < nblocks; ++b) { s0 += partial[((long)b * 2 + 0) * C + c]; s1 += partial[((long)b * 2 + 1) * C + c]; }
+  if (mode == 0) {
+    const double mean = s0 / M;
+    double var = s1 / M - mean * mean;
+    if (var < 0) var = 0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    out0[c] = (float)mean;
+    out1[c] = (float)invstd;
+    const float sc = gamma[c] * (float)invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      const double unbiased = M > 1 ? var * M / (M - 1) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  } else {
+    out0[c] = (float)s0;
+    out1[c] = (float)s1;
+  }
+}
+
+// z = act(y * scale + shift + res)   (BN apply, f16 in/out)
+__global__ void __launch_bounds__(256) affine_act_kernel(const f16* __restrict__ y, int y_stride,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const f16* __restrict__ res, int res_stride, f16* __restrict__ z,
+                                                         int z_stride, long M, int C, int relu) {
+  const int CV = C >> 3;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * CV) return;
+  const int cv = (int)(idx % CV);
+  const long m = idx / CV;
+  const f16x8 v = *(const f16x8*)(y + m * y_stride + cv * 8);
+  f16x8 r = v;
+  if (res) r = *(const f16x8*)(res + m * res_stride + cv * 8);
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float f = (float)v[e] * scale[cv * 8 + e] + shift[cv * 8 + e];
+    if (res) f += (float)r[e];
+    if (relu) f = fmaxf(f, 0.f);
+    o[e] = (f16)f;
+  }
+  *(f16x8*)(z + m * z_stride + cv * 8) = o;
+}
+
+// BN backward apply: g = dz*(z>0); dy = scale*(g - s0/M - xhat*s1/M); optional dres = g.
+// With y == null (bias+act layers): dy = g.
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const f16* __restrict__ dz, int dz_stride,
+                                                           const f16* __restrict__ z, int z_stride,
+                                                           const f16* __restrict__ y, int y_stride,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ scale, const float* __restrict__ s0,
+                                                           const float* __restrict__ s1, f16* __restrict__ dy, int dy_stride,
+                                                           f16* __restrict__ dres, int dres_stride, long M, int C, int relu) {
+  const int CV = C >> 3;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * CV) return;
+  const int cv = (int)(idx % CV);
+  const long m = idx / CV;
+  const f16x8 g = *(const f16x8*)(dz + m * dz_stride + cv * 8);
+  f16x8 zz = g, yy = g;
+  if (relu) zz = *(const f16x8*)(z + m * z_stride + cv * 8);
+  if (y) yy = *(const f16x8*)(y + m * y_stride + cv * 8);
+  const float invM = 1.f / (float)M;
+  f16x8 o, gr;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cv * 8 + e;
+    const float gf = (relu && !((float)zz[e] > 0.f)) ? 0.f : (float)g[e];
+    gr[e] = (f16)gf;
+    if (y) {
+      const float xh = ((float)yy[e] - mean[c]) * invstd[c];
+      o[e] = (f16)(scale[c] * (gf - s0[c] * invM - xh * s1[c] * invM));
+    } else {
+      o[e] = (f16)gf;
+    }
+  }
+  *(f16x8*)(dy + m * dy_stride + cv * 8) = o;
+  if (dres) *(f16x8*)(dres + m * dres_stride + cv * 8) = gr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv weight gradient:  dW[n][k] += sum_m dY[m][n] * A[m][k],  A = im2col(x), k = (r*S+s)*Cin + c (tap-major).
+// Workgroup tile: 64 couts x 128 k, looping over its share of the pixels 32 at a time.  Both MFMA operands need
+// 8 consecutive *pixels* per lane for one channel, i.e. the transpose of the pixel-major NHWC rows: the LDS tiles
+// stay row-major [pixel][channel] and ds_read_b64_tr_b16 delivers the 4x16 blocks column-major.
+// Results are added to the f32 dW with atomics (split over pixel ranges across workgroups).
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const f16* x; const f16* dy; float* dw;
+  int B, H, W, Cin, in_stride, Cout, Ho, Wo, dy_stride, R, S, stride, pad, dil, K, M, msplit;
+};
+
+__device__ __forceinline__ f16x4 lds_tr_read(const f16* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(f16x4, v);
+}
+
+#define WG_BN 64
+#define WG_BK 128
+#define WG_LDA (WG_BK + 8)  // row padding (elements) to spread banks
+#define WG_LDY (WG_BN + 8)
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) f16 sA[32 * WG_LDA];
+  __shared__ __attribute__((aligned(16))) f16 sY[32 * WG_LDY];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k0 = blockIdx.x * WG_BK, n0 = blockIdx.y * WG_BN;
+  const int wn = wave >> 1, wk = wave & 1;  // wave tile: 32 couts x 64 k
+  const int m_per = ((a.M + a.msplit - 1) / a.msplit + 31) / 32 * 32;
+  const int m_begin = blockIdx.z * m_per;
+  const int m_end = m_begin + m_per < a.M ? m_begin + m_per : a.M;
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // loaders: A tile 32 rows x 128 k = 512 16-byte groups (2 per thread); dY tile 32 x 64 = 256 groups (1 per thread)
+  const int a_row = tid >> 4, a_kg = tid & 15;      // rows a_row, a_row+16 ; k-group a_kg (8 channels)
+  const int y_row = tid >> 3, y_ng = tid & 7;
+  const int kk = k0 + a_kg * 8;
+  const bool k_ok = kk < a.K;
+  const int tap = k_ok ? kk / a.Cin : 0;
+  const int c0 = kk - tap * a.Cin;
+  const int tr = tap / a.S, ts = tap - tr * a.S;
+  const bool n_ok = n0 + y_ng * 8 < a.Cout;
+
+  const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  for (int mb = m_begin; mb < m_end; mb += 32) {
+    f16x8 av[2], yv;
+    const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mb + a_row + 16 * i;
+      av[i] = z8;
+      if (m < m_end && k_ok) {
+        const int wo = m % a.Wo, t = m / a.Wo;
+        const int ho = t % a.Ho, b = t / a.Ho;
+        const int hi = ho * a.stride - a.pad + tr * a.dil, wi = wo * a.stride - a.pad + ts * a.dil;
+        if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W)
+          av[i] = *(const f16x8*)(a.x + ((long)(b * a.H + hi) * a.W + wi) * a.in_stride + c0);
+      }
+    }
+    {
+      const int m = mb + y_row;
+      yv = (m < m_end && n_ok) ? *(const f16x8*)(a.dy + (long)m * a.dy_stride + n0 + y_ng * 8) : z8;
+    }
+    __syncthreads();  // previous iteration's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(f16x8*)(sA + (a_row + 16 * i) * WG_LDA + a_kg * 8) = av[i];
+    *(f16x8*)(sY + y_row * WG_LDY + y_ng * 8) = yv;
+    __syncthreads();
+    // fragments: lane group grp covers pixels 8*grp .. 8*grp+7 (two 4-row blocks); lane 4q+p addresses
+    // row q, columns 4p..4p+3 of a 4x16 block and receives column li of its 4 rows
+    f16x8 fy[2], fa[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f16* base = sY + (8 * grp + q) * WG_LDY + wn * 32 + i * 16 + 4 * p;
+      const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * WG_LDY);
+      fy[i] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f16* base = sA + (8 * grp + q) * WG_LDA + wk * 64 + j * 16 + 4 * p;
+      const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * WG_LDA);
+      fa[j] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[i], fa[j], acc[i][j], 0, 0, 0);
+  }
+  // D[row = cout][col = k]: lane holds rows 4*(lane>>4)+reg, col lane&15
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kcol = k0 + wk * 64 + j * 16 + (lane & 15);
+      if (kcol >= a.K) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 32 + i * 16 + 4 * (lane >> 4) + r;
+        if (n < a.Cout) atomicAdd(a.dw + (long)n * a.K + kcol, acc[i][j][r]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(2,2) backward: the gradient goes to the first maximum in (dy,dx) scan order (PyTorch's argmax rule)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool2x2_bwd_kernel(const f16* __restrict__ x, int x_stride,
+                                                             const f16* __restrict__ dz, int dz_stride,
+                                                             f16* __restrict__ dx, int dx_stride, int B, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, CV = C >> 3;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * Ho * Wo * CV) return;
+  const int cv = (int)(idx % CV);
+  long t = idx / CV;
+  const int wo = (int)(t % Wo); t /= Wo;
+  const int ho = (int)(t % Ho);
+  const int b = (int)(t / Ho);
+  const long p00 = (long)(b * H + 2 * ho) * W + 2 * wo;
+  const long offs[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+  f16x8 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = *(const f16x8*)(x + offs[i] * x_stride + cv * 8);
+  const f16x8 g = *(const f16x8*)(dz + ((long)(b * Ho + ho) * Wo + wo) * dz_stride + cv * 8);
+  f16x8 o[4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int best = 0;
+    float bv = (float)v[0][e];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if ((float)v[i][e] > bv) { bv = (float)v[i][e]; best = i; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i][e] = i == best ? g[e] : (f16)0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *(f16x8*)(dx + offs[i] * dx_stride + cv * 8) = o[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthwise ConvTranspose2d(k=2f, s=f, p=f/2) backward.
+//   dx[b,iy,ix,c]   = sum_{ky,kx} dz[b, iy*f - p + ky, ix*f - p + kx, c] * w[ky][kx][c]
+//   dw[ky][kx][c]  += sum_{b,iy,ix} x[b,iy,ix,c] * dz[b, iy*f - p + ky, ix*f - p + kx, c]   (f32 atomics)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dwconvT_bwd_kernel(const f16* __restrict__ x, int x_stride,
+                                                          const f16* __restrict__ dz, int dz_stride,
+                                                          const float* __restrict__ w, f16* __restrict__ dx, int dx_stride,
+                                                          float* __restrict__ dw, int B, int H, int W, int C, int f) {
+  const int CV = C >> 3, k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f;
+  const int cv = threadIdx.x % CV;
+  const int pl = threadIdx.x / CV, ppb = 256 / CV;  // pixels per block pass
+  float dwacc[8];
+  for (int ky = 0; ky < k; ++ky)
+    for (int kx = 0; kx < k; ++kx) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dwacc[e] = 0.f;
+      const float* wt = w + (long)(ky * k + kx) * C + cv * 8;
+      for (long pix = (long)blockIdx.x * ppb + pl; pix < (long)B * H * W && pl < ppb; pix += (long)gridDim.x * ppb) {
+        const int ix = (int)(pix % W);
+        const long t = pix / W;
+        const int iy = (int)(t % H), b = (int)(t / H);
+        const int oy = iy * f - p + ky, ox = ix * f - p + kx;
+        if (oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
+        const f16x8 g = *(const f16x8*)(dz + ((long)(b * Ho + oy) * Wo + ox) * dz_stride + cv * 8);
+        const f16x8 xv = *(const f16x8*)(x + pix * x_stride + cv * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dwacc[e] += (float)xv[e] * (float)g[e];
+      }
+      if (pl < ppb) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(dw + (long)(ky * k + kx) * C + cv * 8 + e, dwacc[e]);
+      }
+      (void)wt;
+    }
+  // dx pass
+  for (long pix = (long)blockIdx.x * ppb + pl; pix < (long)B * H * W && pl < ppb; pix += (long)gridDim.x * ppb) {
+    const int ix = (int)(pix % W);
+    const long t = pix / W;
+    const int iy = (int)(t % H), b = (int)(t / H);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int oy = iy * f - p + ky;
+      if (oy < 0 || oy >= Ho) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ox = ix * f - p + kx;
+        if (ox < 0 || ox >= Wo) continue;
+        const f16x8 g = *(const f16x8*)(dz + ((long)(b * Ho + oy) * Wo + ox) * dz_stride + cv * 8);
+        const float* wt = w + (long)(ky * k + kx) * C + cv * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)g[e] * wt[e];
+      }
+    }
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)acc[e];
+    *(f16x8*)(dx + pix * dx_stride + cv * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DCNv2 training pieces (3x3, stride 1, pad 1, dil 1, one deformable group)
+// ------------------------------------------------------------------------------------------------
+struct DcnGeom {
+  float w[4];     // bilinear weights hh*hw, hh*lw, lh*hw, lh*lw
+  long off[4];    // corner element offsets or -1
+  float hh, hw, lh, lw, mask;
+  bool inside;
+};
+__device__ __forceinline__ DcnGeom dcn_geom(const float* om, int tap, int b, int ho, int wo, int H, int W, int stride_elems) {
+  DcnGeom g;
+  const int tr = tap / 3, ts = tap - tr * 3;
+  const float h_im = (float)(ho - 1 + tr) + om[2 * tap], w_im = (float)(wo - 1 + ts) + om[2 * tap + 1];
+  g.mask = ctdet_sigmoid_exact(om[18 + tap]);
+  g.inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { g.off[q] = -1; g.w[q] = 0.f; }
+  g.hh = g.hw = g.lh = g.lw = 0.f;
+  if (!g.inside) return g;
+  const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  g.lh = h_im - (float)h_low; g.lw = w_im - (float)w_low; g.hh = 1.f - g.lh; g.hw = 1.f - g.lw;
+  g.w[0] = g.hh * g.hw; g.w[1] = g.hh * g.lw; g.w[2] = g.lh * g.hw; g.w[3] = g.lh * g.lw;
+  const long base = (long)b * H * W;
+  if (h_low >= 0 && w_low >= 0) g.off[0] = (base + (long)h_low * W + w_low) * stride_elems;
+  if (h_low >= 0 && w_high <= W - 1) g.off[1] = (base + (long)h_low * W + w_high) * stride_elems;
+  if (h_high <= H - 1 && w_low >= 0) g.off[2] = (base + (long)h_high * W + w_low) * stride_elems;
+  if (h_high <= H - 1 && w_high <= W - 1) g.off[3] = (base + (long)h_high * W + w_high) * stride_elems;
+  return g;
+}
+
+// col[m][tap*Cin + c] = mask * bilinear(x)   (the `columns` of the reference, f16, tap-major)
+__global__ void __launch_bounds__(256) dcn_cols_kernel(const f16* __restrict__ x, int x_stride, const float* __restrict__ om,
+                                                       int om_stride, f16* __restrict__ col, int B, int H, int W, int Cin) {
+  const int CV = Cin >> 3;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * H * W * 9 * CV;
+  if (idx >= total) return;
+  const int cv = (int)(idx % CV);
+  long t = idx / CV;
+  const int tap = (int)(t % 9);
+  const long m = t / 9;
+  const int wo = (int)(m % W);
+  const long t2 = m / W;
+  const int ho = (int)(t2 % H), b = (int)(t2 / H);
+  const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (g.off[q] >= 0) {
+      const f16x8 v = *(const f16x8*)(x + g.off[q] + cv * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += g.w[q] * (float)v[e];
+    }
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)(acc[e] * g.mask);
+  *(f16x8*)(col + m * (9L * Cin) + (long)tap * Cin + cv * 8) = o;
+}
+
+// given dcol (= W^T dY, [M][9*Cin] f16): dx (f32 atomics), d(offset), d(mask logit) -> dom [M][om_stride] f32
+// one lane group of Cin/8 lanes per (pixel, tap); shuffle reduction over the group.
+__global__ void __launch_bounds__(256) dcn_col2im_coord_kernel(const f16* __restrict__ dcol, const f16* __restrict__ x,
+                                                               int x_stride, const float* __restrict__ om, int om_stride,
+                                                               float* __restrict__ dx, float* __restrict__ dom, int B, int H,
+                                                               int W, int Cin) {
+  const int CV = Cin >> 3;  // 8..64, power of two
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * H * W * 9 * CV;
+  const bool live = idx < total;
+  const long ii = live ? idx : total - 1;
+  const int cv = (int)(ii % CV);
+  long t = ii / CV;
+  const int tap = (int)(t % 9);
+  const long m = t / 9;
+  const int wo = (int)(m % W);
+  const long t2 = m / W;
+  const int ho = (int)(t2 % H), b = (int)(t2 / H);
+  const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride);
+  const f16x8 dc = *(const f16x8*)(dcol + m * (9L * Cin) + (long)tap * Cin + cv * 8);
+  float val_dot = 0.f, dh = 0.f, dwv = 0.f;
+  if (g.inside && live) {
+    f16x8 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (g.off[q] >= 0) v[q] = *(const f16x8*)(x + g.off[q] + cv * 8);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = (float)dc[e];
+      const float v1 = (float)v[0][e], v2 = (float)v[1][e], v3 = (float)v[2][e], v4 = (float)v[3][e];
+      val_dot += d * (g.w[0] * v1 + g.w[1] * v2 + g.w[2] * v3 + g.w[3] * v4);
+      dh += d * (-g.hw * v1 - g.lw * v2 + g.hw * v3 + g.lw * v4);   // d val / d h  (kernel.cu:754-766)
+      dwv += d * (-g.hh * v1 + g.hh * v2 - g.lh * v3 + g.lh * v4);  // d val / d w  (kernel.cu:767-779)
+    }
+    // input gradient: scatter mask * w_q * dcol to the 4 corners (kernel.cu:871-949)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (g.off[q] >= 0) {
+        float* dst = dx + g.off[q] / x_stride * (long)Cin + cv * 8;  // dx is dense [Min][Cin] f32
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(dst + e, g.mask * g.w[q] * (float)dc[e]);
+      }
+  }
+  // reduce the three dot products over the CV lanes of this (pixel, tap)
+  for (int o = CV >> 1; o > 0; o >>= 1) {
+    val_dot += __shfl_down(val_dot, o, 64);
+    dh += __shfl_down(dh, o, 64);
+    dwv += __shfl_down(dwv, o, 64);
+  }
+  if (cv == 0 && live) {
+    float* d = dom + m * om_stride;
+    d[2 * tap] = dh * g.mask;
+    d[2 * tap + 1] = dwv * g.mask;
+    d[18 + tap] = val_dot * g.mask * (1.f - g.mask);  // through the sigmoid of the mask logit
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline unsigned nblk256(long n) { return (unsigned)((n + 255) / 256); }
+
+size_t chan_reduce_workspace_bytes(int C) { return (size_t)1024 * 2 * C * sizeof(float); }
+
+static int chan_blocks(int M, int C) {
+  const int rows = 256 / (C / 8);
+  long nb = ((long)M + rows * 8 - 1) / (rows * 8);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+int launch_bn_train_fwd(const f16* y, int y_stride, const f16* res, int res_stride, f16* z, int z_stride, int M, int C,
+                        const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                        float* running_var, float* mean, float* invstd, float* scale, float* shift, void* workspace,
+                        int relu, hipStream_t s) {
+  CTDET_CHECK(C % 8 == 0 && C / 8 <= 256, "bn: unsupported channel count %d", C);
+  ChanRedArgs a = {};
+  a.y = y; a.y_stride = y_stride; a.M = M; a.C = C; a.mode = 0; a.partial = (float*)workspace;
+  const int nb = chan_blocks(M, C);
+  hipLaunchKernelGGL(chan_reduce_kernel, dim3(nb), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(chan_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, nb, C, M, 0, eps,
+                     momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
+  hipLaunchKernelGGL(affine_act_kernel, dim3(nblk256((long)M * (C / 8))), dim3(256), 0, s, y, y_stride, scale, shift, res,
+                     res_stride, z, z_stride, (long)M, C, relu);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bn_train_bwd(const f16* dz, int dz_stride, const f16* z, int z_stride, const f16* y, int y_stride,
+                        const float* mean, const float* invstd, const float* scale, int M, int C, int relu, f16* dy,
+                        int dy_stride, f16* dres, int dres_stride, float* dgamma, float* dbeta, void* workspace,
+                        hipStream_t s) {
+  CTDET_CHECK(C % 8 == 0 && C / 8 <= 256, "bn_bwd: unsupported channel count %d", C);
+  ChanRedArgs a = {};
+  a.y = y; a.y_stride = y_stride; a.dz = dz; a.dz_stride = dz_stride; a.z = z; a.z_stride = z_stride;
+  a.mean = mean; a.invstd = invstd; a.M = M; a.C = C; a.mode = 1; a.relu = relu; a.partial = (float*)workspace;
+  const int nb = chan_blocks(M, C);
+  hipLaunchKernelGGL(chan_reduce_kernel, dim3(nb), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(chan_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, nb, C, M, 1, 0.f,
+                     0.f, (const float*)nullptr, (const float*)nullptr, dbeta, dgamma, (float*)nullptr, (float*)nullptr,
+                     (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk256((long)M * (C / 8))), dim3(256), 0, s, dz, dz_stride, z, z_stride, y,
+                     y_stride, mean, invstd, scale, dbeta, dgamma, dy, dy_stride, dres, dres_stride, (long)M, C, relu);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
+  WgradArgs a = a0;
+  CTDET_CHECK(a.Cin % 8 == 0 && a.in_stride % 8 == 0 && a.dy_stride % 8 == 0 && a.Cout % 8 == 0,
+              "wgrad: channel counts / strides must be multiples of 8 (Cin=%d Cout=%d)", a.Cin, a.Cout);
+  const int gx = (a.K + WG_BK - 1) / WG_BK, gy = (a.Cout + WG_BN - 1) / WG_BN;
+  int split = 2048 / (gx * gy);
+  if (split < 1) split = 1;
+  const int max_split = (a.M + 255) / 256;
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  a.msplit = split;
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, gy, split), dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_maxpool2x2_bwd(const f16* x, int x_stride, const f16* dz, int dz_stride, f16* dx, int dx_stride, int B, int H,
+                          int W, int C, hipStream_t s) {
+  CTDET_CHECK(C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool_bwd: bad shape");
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(nblk256(total)), dim3(256), 0, s, x, x_stride, dz, dz_stride, dx, dx_stride, B,
+                     H, W, C);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_dwconvT_bwd(const f16* x, int x_stride, const f16* dz, int dz_stride, const float* w, f16* dx, int dx_stride,
+                       float* dw, int B, int H, int W, int C, int f, hipStream_t s) {
+  CTDET_CHECK(C % 8 == 0 && C / 8 <= 256 && f % 2 == 0, "dwconvT_bwd: bad shape C=%d f=%d", C, f);
+  const int ppb = 256 / (C / 8);
+  long nb = ((long)B * H * W + ppb * 16 - 1) / (ppb * 16);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(dwconvT_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, x_stride, dz, dz_stride, w, dx, dx_stride, dw,
+                     B, H, W, C, f);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_dcn_cols(const f16* x, int x_stride, const float* om, int om_stride, f16* col, int B, int H, int W, int Cin,
+                    hipStream_t s) {
+  CTDET_CHECK(Cin % 8 == 0 && om_stride >= 27, "dcn_cols: bad shape");
+  const long total = (long)B * H * W * 9 * (Cin / 8);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(dcn_cols_kernel, dim3(nblk256(total)), dim3(256), 0, s, x, x_stride, om, om_stride, col, B, H, W, Cin);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_dcn_col2im_coord(const f16* dcol, const f16* x, int x_stride, const float* om, int om_stride, float* dx,
+                            float* dom, int B, int H, int W, int Cin, hipStream_t s) {
+  const int CV = Cin / 8;
+  CTDET_CHECK(Cin % 8 == 0 && CV >= 1 && CV <= 64 && (CV & (CV - 1)) == 0, "dcn_col2im: Cin=%d must be 8*2^n <= 512", Cin);
+  const long total = (long)B * H * W * 9 * CV;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3(nblk256(total)), dim3(256), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
+                     B, H, W, Cin);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}

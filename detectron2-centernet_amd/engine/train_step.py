@@ -1,0 +1,131 @@
+"""Training forward of CenterNet on the HIP kernels (the reference: centernet.py:140-159, 191-212, with the DLA-34
+graph of dla.py and DeformConvV2 of deform_conv.py:498-519, all modules in train() mode).
+
+The module tree is walked functionally; every node is an autograd Function from ops_train (HIP kernels forward and
+backward).  Root's torch.cat is materialised here (a device copy) -- the concat-free multi-source kernel is
+inference-only for now.
+"""
+import torch
+
+from .. import ops
+from ..ops_train import BNActFn, ConvFn, DCNFn, DwConvTAddFn, FocalLossFn, MaxPoolFn, RegL1Fn
+
+
+def conv_bn(x, conv, bn, relu=True, res=None):
+    y = ConvFn.apply(x, conv.weight, None, conv.stride[0], conv.padding[0], False, False)
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    return BNActFn.apply(y, bn.weight, bn.bias, res, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
+
+
+def basic_block(m, x, residual=None):
+    if residual is None:
+        residual = x
+    out = conv_bn(x, m.conv1, m.bn1, relu=True)
+    return conv_bn(out, m.conv2, m.bn2, relu=True, res=residual)
+
+
+def root(m, xs):
+    return conv_bn(torch.cat(xs, dim=3), m.conv, m.bn, relu=True, res=xs[0] if m.residual else None)
+
+
+def tree(m, x, residual=None, children=None):
+    children = [] if children is None else children
+    bottom = MaxPoolFn.apply(x) if m.downsample else x
+    residual = conv_bn(bottom, m.project[0], m.project[1], relu=False) if m.project else bottom
+    if m.level_root:
+        children.append(bottom)
+    if m.levels == 1:
+        x1 = basic_block(m.tree1, x, residual)
+        x2 = basic_block(m.tree2, x1)
+        return root(m.root, [x2, x1] + children)
+    x1 = tree(m.tree1, x, residual)
+    children.append(x1)
+    return tree(m.tree2, x1, children=children)
+
+
+def conv_level(seq, x):
+    mods = list(seq)
+    for i in range(0, len(mods), 3):
+        x = conv_bn(x, mods[i], mods[i + 1], relu=True)
+    return x
+
+
+def dla_base(m, x):
+    y = []
+    x = conv_level(m.base_layer, x)
+    for i in range(6):
+        lvl = getattr(m, f"level{i}")
+        x = conv_level(lvl, x) if i < 2 else tree(lvl, x)
+        y.append(x)
+    return y
+
+
+def deform_conv_v2(m, x):
+    dcn, bn = m.conv, m.actf[0]
+    om = ConvFn.apply(x, dcn.conv_offset_mask.weight, dcn.conv_offset_mask.bias, 1, 1, False, True)  # f32 [.,28]
+    y = DCNFn.apply(x, om, dcn.weight, dcn.bias)
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    return BNActFn.apply(y, bn.weight, bn.bias, None, bn.running_mean, bn.running_var, bn.eps, bn.momentum, True)
+
+
+def ida_up(m, layers, startp, endp):
+    for i in range(startp + 1, endp):
+        j = i - startp
+        up, proj, node = getattr(m, f"up_{j}"), getattr(m, f"proj_{j}"), getattr(m, f"node_{j}")
+        t = deform_conv_v2(proj, layers[i])
+        t = DwConvTAddFn.apply(t, up.weight, layers[i - 1], up.stride[0])
+        layers[i] = deform_conv_v2(node, t)
+
+
+def dla_up(m, layers):
+    layers = list(layers)
+    out = [layers[-1]]
+    for i in range(len(layers) - m.startp - 1):
+        ida_up(getattr(m, f"ida_{i}"), layers, len(layers) - i - 2, len(layers))
+        out.insert(0, layers[-1])
+    return out
+
+
+def dla34(m, x):
+    maps = dla_base(m.base, x)
+    ups = dla_up(m.dla_up, maps)
+    y = [ups[i] for i in range(m.last_level - m.first_level)]
+    ida_up(m.ida_up, y, 0, len(y))
+    return y
+
+
+def heads(model, y):
+    out = {}
+    for name in (h.lower() for h in model.heads):
+        fc = getattr(model, name)
+        if model.head_conv > 0:
+            hid = ConvFn.apply(y, fc[0].weight, fc[0].bias, 1, 1, True, False)
+            out[name] = ConvFn.apply(hid, fc[2].weight, fc[2].bias, 1, fc[2].padding[0], False, True)
+        else:
+            out[name] = ConvFn.apply(y, fc.weight, fc.bias, 1, fc.padding[0], False, True)
+    return out
+
+
+def centernet_train_forward(model, batched_inputs):
+    """list[dict] with "image" and "instances" -> {"hm_loss","wh_loss","off_loss"} (0-d tensors with autograd)."""
+    if model.device.type != "cuda":
+        raise NotImplementedError("the CenterNet HIP path has no CPU implementation (MODEL.DEVICE must be cuda)")
+    if model._ctx.compute != ops.F16:
+        raise NotImplementedError("training runs in the f16-MFMA / f32-accumulate mode (HIP_PRECISION: f16)")
+    assert "instances" in batched_inputs[0], "Instance annotations are missing in training!"
+    images, targets = model.preprocess_image(batched_inputs)
+    return train_forward_tensors(model, images.nhwc, targets)
+
+
+def train_forward_tensors(model, x_nhwc, targets):
+    y = dla34(model.backbone, x_nhwc)[-1]
+    z = heads(model, y)
+    C = model.num_classes
+    hm = z["hm"] if z["hm"].shape[3] == C else z["hm"][..., :C].contiguous()
+    hm_loss = FocalLossFn.apply(hm, targets["hm"], model._alpha_tensor())
+    wh_loss = RegL1Fn.apply(z["wh"], targets["reg_mask"], targets["ind"], targets["wh"])
+    off_loss = RegL1Fn.apply(z["reg"], targets["reg_mask"], targets["ind"], targets["reg"])
+    return {"hm_loss": hm_loss * model.hm_weight, "wh_loss": wh_loss * model.wh_weight,
+            "off_loss": off_loss * model.off_weight}

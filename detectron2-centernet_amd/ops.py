@@ -116,6 +116,7 @@ class PackedConv:
         self.Cin_real = Cin
         assert self.Cin >= Cin
         self.stride, self.pad, self.dil, self.compute = stride, pad, dil, compute
+        self.in_dil = 1  # >1: input read as zero-stuffed (input gradient of a strided conv); set by the caller
         self.Cout_eff = round_up(Cout, 4)
         K = R * S * self.Cin
         self.K = K
@@ -161,7 +162,10 @@ class PackedConv:
     def desc(self, x, out, act, residual, clamp=(0.0, 1.0)):
         B, H, W, Cx = x.shape
         assert Cx == self.Cin, f"conv expects {self.Cin} input channels, got {Cx}"
-        Ho, Wo = self.out_hw(H, W)
+        if self.in_dil > 1:
+            Ho, Wo = out.shape[1], out.shape[2]
+        else:
+            Ho, Wo = self.out_hw(H, W)
         assert tuple(out.shape[:3]) == (B, Ho, Wo) and out.shape[3] >= self.Cout_eff, (out.shape, (B, Ho, Wo, self.Cout_eff))
         d = ConvDesc()
         d.B, d.H, d.W, d.Cin, d.in_stride = B, H, W, self.Cin, _nhwc_stride(x)
@@ -172,12 +176,14 @@ class PackedConv:
         d.res_stride = _nhwc_stride(residual) if residual is not None else 0
         d.clamp_lo, d.clamp_hi = clamp
         d.korder = self.korder
+        d.in_dil = self.in_dil
         return d
 
 
 def _alloc_out(x, p, out, out_dtype):
     B, H, W, _ = x.shape
     Ho, Wo = p.out_hw(H, W)
+    assert out is not None or p.in_dil == 1, "input-dilated convs need an explicit output buffer"
     if out is None:
         dt = out_dtype if out_dtype is not None else (torch.float16 if p.compute == F16 else torch.float32)
         out = torch.empty(B, Ho, Wo, p.Cout_eff, dtype=dt, device=x.device)
@@ -223,6 +229,7 @@ def conv1x1_cat(xs, p, out=None, act=ACT_NONE, residual=None, out_dtype=None):
     d.res_stride = _nhwc_stride(residual) if residual is not None else 0
     d.clamp_lo, d.clamp_hi = 0.0, 1.0
     d.korder = 0
+    d.in_dil = 1
     n = len(xs)
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
     cin_a = (C.c_int32 * n)(*cins)

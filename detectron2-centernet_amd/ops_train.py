@@ -1,0 +1,269 @@
+"""Training-side op wrappers (C ABI) and the torch.autograd.Function glue of the CenterNet training path.
+
+Autograd is used as the tape only: every forward and backward body below is one or a few HIP kernel launches.
+Activations and activation-gradients are f16 NHWC, parameters and parameter-gradients f32 (the reference trains in
+f32; mixed precision with f32 accumulation everywhere is this build's throughput mode).  A static loss scale keeps
+small heatmap gradients inside the f16 range: it is applied in the loss backward and removed again on every
+parameter gradient, so `param.grad` and the returned loss values are unscaled.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from ._lib import ConvDesc
+from .ops import ACT_NONE, ACT_RELU, F16, _nhwc_stride, _ptr, _require_cuda, _stream
+
+GRAD_SCALE = 1024.0
+
+
+def _ws(Cc, device):
+    return torch.empty(_lib.lib().ctdet_chan_workspace_bytes(Cc) // 4, dtype=torch.float32, device=device)
+
+
+# ------------------------------------------------------------------------------------------ raw wrappers
+def bn_train_fwd(y, gamma, beta, running_mean, running_var, eps, momentum, res=None, relu=True):
+    B, H, W, Cc = y.shape
+    dev = y.device
+    z = torch.empty(B, H, W, Cc, dtype=torch.float16, device=dev)
+    mean, invstd, scale, shift = (torch.empty(Cc, dtype=torch.float32, device=dev) for _ in range(4))
+    rc = _lib.lib().ctdet_bn_train_fwd(_ptr(y), _nhwc_stride(y), _ptr(res), _nhwc_stride(res) if res is not None else 0,
+                                       _ptr(z), _nhwc_stride(z), B * H * W, Cc, _ptr(gamma), _ptr(beta), float(eps),
+                                       float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd),
+                                       _ptr(scale), _ptr(shift), _ptr(_ws(Cc, dev)), int(relu), _stream())
+    _lib.check(rc, "ctdet_bn_train_fwd")
+    return z, mean, invstd, scale
+
+
+def bn_train_bwd(dz, z, y, mean, invstd, scale, relu=True, want_dres=False):
+    B, H, W, Cc = dz.shape
+    dev = dz.device
+    dy = torch.empty(B, H, W, Cc, dtype=torch.float16, device=dev)
+    dres = torch.empty(B, H, W, Cc, dtype=torch.float16, device=dev) if want_dres else None
+    dgamma = torch.zeros(Cc, dtype=torch.float32, device=dev)
+    dbeta = torch.zeros(Cc, dtype=torch.float32, device=dev)
+    rc = _lib.lib().ctdet_bn_train_bwd(_ptr(dz), _nhwc_stride(dz), _ptr(z), _nhwc_stride(z) if z is not None else 0,
+                                       _ptr(y), _nhwc_stride(y) if y is not None else 0, _ptr(mean), _ptr(invstd),
+                                       _ptr(scale), B * H * W, Cc, int(relu), _ptr(dy), _nhwc_stride(dy), _ptr(dres),
+                                       _nhwc_stride(dres) if dres is not None else 0, _ptr(dgamma), _ptr(dbeta),
+                                       _ptr(_ws(Cc, dev)), _stream())
+    _lib.check(rc, "ctdet_bn_train_bwd")
+    return dy, dres, dgamma, dbeta
+
+
+def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1):
+    """dW f32 [Cout, R*S*Cin] (tap-major) for y = conv(x, W); x, dy f16 NHWC."""
+    B, H, W, Cin = x.shape
+    _, Ho, Wo, Cd = dy.shape
+    assert Cd >= Cout
+    d = ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.in_stride = B, H, W, Cin, _nhwc_stride(x)
+    d.Cout, d.Ho, d.Wo, d.out_stride = Cout, Ho, Wo, _nhwc_stride(dy)
+    d.R, d.S, d.stride, d.pad, d.dil = R, S, stride, pad, dil
+    dw = torch.zeros(Cout, R * S * Cin, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().ctdet_conv_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _stream())
+    _lib.check(rc, "ctdet_conv_wgrad")
+    return dw
+
+
+def maxpool2x2_bwd(x, dz):
+    B, H, W, Cc = x.shape
+    dx = torch.empty(B, H, W, Cc, dtype=torch.float16, device=x.device)
+    rc = _lib.lib().ctdet_maxpool2x2_bwd(_ptr(x), _nhwc_stride(x), _ptr(dz), _nhwc_stride(dz), _ptr(dx), _nhwc_stride(dx),
+                                         B, H, W, Cc, _stream())
+    _lib.check(rc, "ctdet_maxpool2x2_bwd")
+    return dx
+
+
+def dwconvT_bwd(x, dz, weight, f):
+    B, H, W, Cc = x.shape
+    w = ops._dw_weight(weight, Cc, f)
+    dx = torch.empty(B, H, W, Cc, dtype=torch.float16, device=x.device)
+    dw = torch.zeros(2 * f, 2 * f, Cc, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().ctdet_dwconvT_bwd(_ptr(x), _nhwc_stride(x), _ptr(dz), _nhwc_stride(dz), _ptr(w), _ptr(dx),
+                                      _nhwc_stride(dx), _ptr(dw), B, H, W, Cc, f, _stream())
+    _lib.check(rc, "ctdet_dwconvT_bwd")
+    return dx, dw.permute(2, 0, 1).reshape(Cc, 1, 2 * f, 2 * f)
+
+
+def dcn_cols(x, om):
+    B, H, W, Cin = x.shape
+    col = torch.empty(B, H, W, 9 * Cin, dtype=torch.float16, device=x.device)
+    rc = _lib.lib().ctdet_dcn_cols(_ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(col), B, H, W, Cin, _stream())
+    _lib.check(rc, "ctdet_dcn_cols")
+    return col
+
+
+def dcn_col2im_coord(dcol, x, om):
+    B, H, W, Cin = x.shape
+    dx = torch.zeros(B, H, W, Cin, dtype=torch.float32, device=x.device)
+    dom = torch.zeros_like(om)
+    rc = _lib.lib().ctdet_dcn_col2im_coord(_ptr(dcol), _ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(dx),
+                                           _ptr(dom), B, H, W, Cin, _stream())
+    _lib.check(rc, "ctdet_dcn_col2im_coord")
+    return dx, dom
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def _fwd_pack(weight, stride, pad, cin_pad=None, bias=None):
+    return ops.PackedConv(weight, None, bias, stride=stride, pad=pad, compute=F16, cin_pad=cin_pad)
+
+
+def conv_dgrad(dy, weight, stride, pad, in_hw):
+    """dx of y = conv(x, weight): a conv over dy with the taps flipped and in/out channels swapped;
+    stride > 1 reads dy as zero-stuffed (in_dil)."""
+    Cout, Cin, R, S = weight.shape
+    wt = weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()  # [Cin, Cout, R, S]
+    p = ops.PackedConv(wt, None, None, stride=1, pad=R - 1 - pad, compute=F16, tap_major=stride > 1)
+    p.in_dil = stride
+    B = dy.shape[0]
+    dx = torch.empty(B, in_hw[0], in_hw[1], p.Cout_eff, dtype=torch.float16, device=dy.device)
+    ops.conv2d(dy, p, out=dx)
+    return dx if p.Cout_eff == Cin else dx[..., :Cin]
+
+
+def _wgrad_to_oihw(dw, Cout, Cin_real, Cin_used, R, S):
+    g = dw.view(Cout, R, S, Cin_used)[..., :Cin_real].permute(0, 3, 1, 2)
+    return g * (1.0 / GRAD_SCALE)
+
+
+# ------------------------------------------------------------------------------------------ autograd Functions
+class ConvFn(torch.autograd.Function):
+    """y = conv(x, weight) (+bias)(+relu) without BatchNorm; x f16 NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, relu, out_f32):
+        p = _fwd_pack(weight, stride, pad, cin_pad=x.shape[3] if x.shape[3] != weight.shape[1] else None, bias=bias)
+        y = ops.conv2d(x, p, act=ACT_RELU if relu else ACT_NONE, out_dtype=torch.float32 if out_f32 else torch.float16)
+        ctx.cfg = (stride, pad, relu, weight.shape[0], bias is not None)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        stride, pad, relu, Cout, has_bias = ctx.cfg
+        Cout, Cin, R, S = weight.shape
+        if dy.dtype != torch.float16:
+            dy = dy.half()
+        dy = _pad_c(dy.contiguous())          # channel count -> multiple of 8 (padded channels carry zeros)
+        Cw = dy.shape[3]
+        dbias = None
+        if relu or has_bias:
+            dy, _, _, db = bn_train_bwd(dy, _pad_c(y) if relu else None, None, None, None, None, relu=relu)
+            dbias = db[:Cout] * (1.0 / GRAD_SCALE) if has_bias else None
+        dw = conv_wgrad(x, dy, Cw, R, S, stride, pad)[:Cout]
+        dwt = _wgrad_to_oihw(dw, Cout, Cin, x.shape[3], R, S)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wpad = weight if Cw == Cout else torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
+            dx = conv_dgrad(dy, wpad, stride, pad, x.shape[1:3])
+        return dx, dwt, dbias, None, None, None, None
+
+
+def _pad_c(t):
+    """channel count up to a multiple of 8 (kernels vectorise 8 f16 channels)"""
+    if t is None or t.shape[3] % 8 == 0:
+        return t
+    return torch.nn.functional.pad(t, (0, 8 - t.shape[3] % 8))
+
+
+class BNActFn(torch.autograd.Function):
+    """z = relu?(BatchNorm_train(y) + res) with batch statistics (running stats updated in place)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, res, running_mean, running_var, eps, momentum, relu):
+        z, mean, invstd, scale = bn_train_fwd(y, gamma.detach(), beta.detach(), running_mean, running_var, eps, momentum,
+                                              res=res, relu=relu)
+        ctx.relu, ctx.has_res = relu, res is not None
+        ctx.save_for_backward(y, z, mean, invstd, scale)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, z, mean, invstd, scale = ctx.saved_tensors
+        dy, dres, dgamma, dbeta = bn_train_bwd(dz.contiguous(), z, y, mean, invstd, scale, relu=ctx.relu,
+                                               want_dres=ctx.has_res)
+        s = 1.0 / GRAD_SCALE
+        return dy, dgamma * s, dbeta * s, dres, None, None, None, None, None
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.maxpool2x2(x)
+
+    @staticmethod
+    def backward(ctx, dz):
+        (x,) = ctx.saved_tensors
+        return maxpool2x2_bwd(x, dz.contiguous())
+
+
+class DwConvTAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, skip, f):
+        ctx.f = f
+        ctx.save_for_backward(x, weight)
+        return ops.dwconvT_add(x, weight, f, skip=skip)
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, weight = ctx.saved_tensors
+        dz = dz.contiguous()
+        dx, dw = dwconvT_bwd(x, dz, weight, ctx.f)
+        return dx, dw * (1.0 / GRAD_SCALE), dz, None
+
+
+class DCNFn(torch.autograd.Function):
+    """modulated deformable conv (3x3/s1/p1) for training: columns are materialised once (as the reference does,
+    deform_conv_cuda.cu:874-917) so forward, dW and d(columns) are plain 1x1 contractions on the MFMA kernels."""
+
+    @staticmethod
+    def forward(ctx, x, om, weight, bias):
+        Cout, Cin = weight.shape[:2]
+        col = dcn_cols(x, om)
+        wmat = weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)  # tap-major columns
+        p = ops.PackedConv(wmat, None, bias, compute=F16)
+        y = ops.conv2d(col, p)
+        ctx.save_for_backward(x, om, weight, col)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, om, weight, col = ctx.saved_tensors
+        Cout, Cin = weight.shape[:2]
+        dy = dy.contiguous()
+        wmat = weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
+        _, _, _, dbias = bn_train_bwd(dy, None, None, None, None, None, relu=False)
+        dw = conv_wgrad(col, dy, Cout, 1, 1, 1, 0)                       # [Cout, 9*Cin]
+        dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2) * (1.0 / GRAD_SCALE)
+        dcol = conv_dgrad(dy, wmat, 1, 0, x.shape[1:3])                  # [M, 9*Cin]
+        dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om)
+        return dx32.half(), dom, dwt, dbias * (1.0 / GRAD_SCALE)
+
+
+class FocalLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, gt, alpha):
+        loss, stats, grad = ops.focal_loss(logits, gt, alpha, want_grad=True, grad_scale=GRAD_SCALE)
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+class RegL1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, mask, ind, target):
+        loss, grad = ops.reg_l1_loss(pred, mask, ind, target, want_grad=True, grad_scale=GRAD_SCALE)
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None

@@ -40,6 +40,8 @@ typedef struct ctdet_conv_desc {
   int32_t korder;       /* f16 packing order of k: 0 = tap-major  k = (r*S+s)*Cin + c;
                            1 = chunk-major k = ((c/32)*R*S + r*S+s)*32 + c%32 (needs Cin % 32 == 0; keeps the taps
                            of one 32-channel chunk adjacent in time => L2-friendly; not for ctdet_dcnv2_fwd) */
+  int32_t in_dil;       /* 0/1 = none.  >1: the input is read as if zero-stuffed by this factor (input-gradient of a
+                           strided conv expressed as a conv over dY); Ho/Wo may then exceed the formula by < in_dil */
 } ctdet_conv_desc;
 
 const char* ctdet_last_error(void);
@@ -136,6 +138,41 @@ int32_t ctdet_reg_l1_loss(const float* pred, int32_t pred_stride, const uint8_t*
  * so the captured graph stays valid across the WarmupMultiStepLR schedule. */
 int32_t ctdet_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, const float* lr_dev,
                            float momentum, float weight_decay, int32_t first_step, void* stream);
+
+/* ---- training-side entry points (f16 activations, f32 statistics and weight gradients) ------------------------
+ * Input gradients of plain convs are ctdet_conv2d_fwd calls with transposed/flipped weights (in_dil for stride 2). */
+
+/* nn.BatchNorm2d in training mode + optional residual add + ReLU (dla.py:59-73,86-94; deform_conv.py:501-519):
+ * z = act(gamma*(y-mean)*invstd + beta + res); batch statistics over the M rows; running stats updated with
+ * `momentum` (unbiased variance), saved mean/invstd/scale(=gamma*invstd)/shift for the backward. */
+size_t ctdet_chan_workspace_bytes(int32_t C);
+int32_t ctdet_bn_train_fwd(const void* y, int32_t y_stride, const void* res, int32_t res_stride, void* z,
+                           int32_t z_stride, int32_t M, int32_t C, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, float* save_mean,
+                           float* save_invstd, float* scale, float* shift, void* workspace, int32_t relu, void* stream);
+/* backward of the above: g = dz*(z>0) if relu; dgamma = sum g*xhat, dbeta = sum g,
+ * dy = scale*(g - dbeta/M - xhat*dgamma/M); dres (optional) = g.  With y == NULL it is the backward of
+ * "bias + activation" (dy = g, dbeta = bias gradient, dgamma untouched semantics: 0). */
+int32_t ctdet_bn_train_bwd(const void* dz, int32_t dz_stride, const void* z, int32_t z_stride, const void* y,
+                           int32_t y_stride, const float* mean, const float* invstd, const float* scale, int32_t M,
+                           int32_t C, int32_t relu, void* dy, int32_t dy_stride, void* dres, int32_t dres_stride,
+                           float* dgamma, float* dbeta, void* workspace, void* stream);
+/* weight gradient of a conv: dw f32 [Cout][R*S*Cin] (tap-major k) += sum over pixels; dw must be zeroed by the
+ * caller.  Geometry from the descriptor (out_stride = pixel stride of dy). */
+int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy, float* dw, void* stream);
+int32_t ctdet_maxpool2x2_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, void* dx,
+                             int32_t dx_stride, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+/* depthwise ConvTranspose2d backward: dx f16, dw f32 [2f][2f][C] (+=, zeroed by the caller); w as in the forward */
+int32_t ctdet_dwconvT_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, const float* w, void* dx,
+                          int32_t dx_stride, float* dw, int32_t B, int32_t H, int32_t W, int32_t C, int32_t f,
+                          void* stream);
+/* DCNv2 3x3/s1/p1 training pieces: columns [M][9*Cin] f16 (= modulated_deformable_im2col, kernel.cu:786-868) and the
+ * backward through the sampler (col2im :871-949 + coordinate/mask gradients :952-1066): dcol [M][9*Cin] f16 ->
+ * dx f32 dense [B*H*W][Cin] (+= atomics, zeroed by the caller), dom f32 [M][om_stride] (offset and mask-logit grads) */
+int32_t ctdet_dcn_cols(const void* x, int32_t x_stride, const float* om, int32_t om_stride, void* col, int32_t B,
+                       int32_t H, int32_t W, int32_t Cin, void* stream);
+int32_t ctdet_dcn_col2im_coord(const void* dcol, const void* x, int32_t x_stride, const float* om, int32_t om_stride,
+                               float* dx, float* dom, int32_t B, int32_t H, int32_t W, int32_t Cin, void* stream);
 
 #ifdef __cplusplus
 }

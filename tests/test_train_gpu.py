@@ -1,0 +1,213 @@
+"""GPU parity of the training-side kernels and of the whole CenterNet training forward/backward against the CPU
+oracle (torch autograd through the oracle's functional model).  Activations/gradients are f16 on the device, so
+gradient comparisons use f16-sized tolerances (inputs are f16-representable, accumulation is f32)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ctdet_oracle as O
+from oracle import model_ref as MR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import detectron2_centernet_amd.ops as ops
+    import detectron2_centernet_amd.ops_train as ot
+
+    return ops, ot
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def h16(t):
+    return t.half().float()
+
+
+def close(got, ref, tol, what=""):
+    err = (got - ref).abs().max().item()
+    scale = max(1e-6, ref.abs().max().item())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("C,res,relu", [(16, False, True), (64, True, True), (128, False, False), (80, False, True)])
+def test_bn_train_fwd_bwd(T, dev, C, res, relu):
+    ops, ot = T
+    g = torch.Generator().manual_seed(C)
+    y = h16(torch.randn(3, C, 10, 12, generator=g) * 2 + 0.5).requires_grad_(True)
+    r = h16(torch.randn(3, C, 10, 12, generator=g)).requires_grad_(True) if res else None
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, generator=g).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    ref = F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    if res:
+        ref = ref + r
+    if relu:
+        ref = ref.relu()
+    dz = h16(torch.randn(ref.shape, generator=g))
+    ref.backward(dz)
+    rm_d, rv_d = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    z, mean, invstd, scale = ot.bn_train_fwd(nhwc(y.detach()).half().to(dev), gamma.detach().to(dev), beta.detach().to(dev),
+                                             rm_d, rv_d, 1e-5, 0.1, res=nhwc(r.detach()).half().to(dev) if res else None,
+                                             relu=relu)
+    close(nchw(z.float().cpu()), ref.detach(), 2e-3, "bn fwd")
+    close(rm_d.cpu(), rm, 1e-4, "running_mean")
+    close(rv_d.cpu(), rv, 1e-4, "running_var")
+    dy, dres, dgamma, dbeta = ot.bn_train_bwd(nhwc(dz).half().to(dev), z, nhwc(y.detach()).half().to(dev), mean, invstd,
+                                              scale, relu=relu, want_dres=res)
+    close(nchw(dy.float().cpu()), y.grad, 6e-3, "bn dy")
+    close(dgamma.cpu(), gamma.grad, 3e-3, "dgamma")
+    close(dbeta.cpu(), beta.grad, 3e-3, "dbeta")
+    if res:
+        close(nchw(dres.float().cpu()), r.grad, 2e-3, "dres")
+
+
+WG_CASES = [(2, 12, 14, 64, 64, 3, 1, 1), (1, 16, 16, 32, 64, 3, 2, 1), (2, 9, 9, 128, 128, 3, 1, 1),
+            (1, 8, 8, 256, 64, 1, 1, 0), (2, 20, 20, 16, 32, 3, 2, 1), (1, 16, 24, 8, 16, 7, 1, 3),
+            (2, 6, 6, 576, 64, 1, 1, 0)]
+
+
+@pytest.mark.parametrize("case", WG_CASES)
+def test_conv_wgrad_and_dgrad(T, dev, case):
+    ops, ot = T
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = h16(torch.randn(B, Cin, H, W, generator=g)).requires_grad_(True)
+    w = h16(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = h16(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    dw = ot.conv_wgrad(nhwc(x.detach()).half().to(dev), nhwc(dy).half().to(dev), Cout, k, k, s, p)
+    got = dw.view(Cout, k, k, Cin).permute(0, 3, 1, 2).cpu()
+    close(got, w.grad, 2e-3, "dW")
+    dx = ot.conv_dgrad(nhwc(dy).half().to(dev), w.detach().to(dev), s, p, (H, W))
+    close(nchw(dx.float().cpu()), x.grad, 3e-3, "dX")
+
+
+def test_maxpool_and_dwconvT_bwd(T, dev):
+    ops, ot = T
+    g = torch.Generator().manual_seed(5)
+    x = h16(torch.randn(2, 64, 8, 12, generator=g)).requires_grad_(True)
+    y = F.max_pool2d(x, 2, 2)
+    dz = h16(torch.randn(y.shape, generator=g))
+    y.backward(dz)
+    dx = ot.maxpool2x2_bwd(nhwc(x.detach()).half().to(dev), nhwc(dz).half().to(dev))
+    assert torch.equal(nchw(dx.float().cpu()), x.grad)
+    for f in (2, 4):
+        x = h16(torch.randn(2, 64, 6, 5, generator=g)).requires_grad_(True)
+        w = torch.rand(64, 1, 2 * f, 2 * f, generator=g).requires_grad_(True)
+        y = F.conv_transpose2d(x, w, None, stride=f, padding=f // 2, groups=64)
+        dz = h16(torch.randn(y.shape, generator=g))
+        y.backward(dz)
+        dx, dw = ot.dwconvT_bwd(nhwc(x.detach()).half().to(dev), nhwc(dz).half().to(dev), w.detach().to(dev), f)
+        close(nchw(dx.float().cpu()), x.grad, 2e-3, "dwconvT dx")
+        close(dw.cpu(), w.grad, 2e-3, "dwconvT dw")
+
+
+@pytest.mark.parametrize("case", [(2, 10, 12, 64, 64, 2.0), (1, 8, 8, 128, 64, 1.0), (1, 6, 7, 256, 128, 3.0)])
+def test_dcn_training_fwd_bwd(T, dev, case):
+    ops, ot = T
+    B, H, W, Cin, Cout, off_std = case
+    g = torch.Generator().manual_seed(Cin + H)
+    x = h16(torch.randn(B, Cin, H, W, generator=g)).requires_grad_(True)
+    w = h16(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).requires_grad_(True)
+    bias = torch.randn(Cout, generator=g).requires_grad_(True)
+    om = torch.randn(B, 27, H, W, generator=g)
+    om[:, :18] *= off_std
+    om.requires_grad_(True)
+    y = O.dcnv2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, bias, 1, 1, 1)
+    dy = h16(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    xd = nhwc(x.detach()).half().to(dev).requires_grad_(True)
+    omd = torch.zeros(B, H, W, 28)
+    omd[..., :27] = nhwc(om.detach())
+    omd = omd.to(dev).requires_grad_(True)
+    wd = w.detach().to(dev).requires_grad_(True)
+    bd = bias.detach().to(dev).requires_grad_(True)
+    yd = ot.DCNFn.apply(xd, omd, wd, bd)
+    close(nchw(yd.float().cpu()), y.detach(), 5e-3, "dcn fwd")
+    yd.backward(nhwc(dy).half().to(dev) * ot.GRAD_SCALE)
+    S = ot.GRAD_SCALE
+    close(nchw(xd.grad.float().cpu()) / S, x.grad, 1e-2, "dcn dx")
+    close(nchw(omd.grad[..., :27].cpu()) / S, om.grad, 1e-2, "dcn d(offset, mask)")
+    close(wd.grad.cpu(), w.grad, 5e-3, "dcn dW")
+    close(bd.grad.cpu(), bias.grad, 3e-3, "dcn dbias")
+
+
+def test_conv_bias_relu_fn(T, dev):
+    ops, ot = T
+    g = torch.Generator().manual_seed(9)
+    x = h16(torch.randn(2, 64, 10, 10, generator=g)).requires_grad_(True)
+    w = h16(torch.randn(256, 64, 3, 3, generator=g) / 24).requires_grad_(True)
+    b = torch.randn(256, generator=g).requires_grad_(True)
+    w2 = h16(torch.randn(2, 256, 1, 1, generator=g) / 16).requires_grad_(True)
+    b2 = torch.randn(2, generator=g).requires_grad_(True)
+    out = F.conv2d(F.conv2d(x, w, b, 1, 1).relu(), w2, b2)
+    dz = torch.randn(out.shape, generator=g) * 1e-2
+    out.backward(dz)
+    leaves = [t.detach().to(dev).requires_grad_(True) for t in (w, b, w2, b2)]
+    xd = nhwc(x.detach()).half().to(dev).requires_grad_(True)
+    hid = ot.ConvFn.apply(xd, leaves[0], leaves[1], 1, 1, True, False)
+    o = ot.ConvFn.apply(hid, leaves[2], leaves[3], 1, 0, False, True)
+    close(nchw(o[..., :2].cpu()), out.detach(), 3e-3, "fwd")
+    o.backward(torch.nn.functional.pad(nhwc(dz), (0, 2)).to(dev) * ot.GRAD_SCALE)
+    for got, ref, name in zip(leaves, (w, b, w2, b2), ("w", "b", "w2", "b2")):
+        close(got.grad.cpu(), ref.grad, 8e-3, name)
+    close(nchw(xd.grad.float().cpu()) / ot.GRAD_SCALE, x.grad, 8e-3, "dx")
+
+
+def test_full_training_step_matches_oracle(tmp_path, dev):
+    """losses within 1e-3 and every parameter gradient direction/magnitude against torch autograd through the
+    oracle (BatchNorm in training mode, DCN offsets non-zero)."""
+    from test_model_gpu import cpu_state_dict, make_model
+    from detectron2_centernet_amd.data.catalog import synthetic_sample
+    from detectron2_centernet_amd.structures import Boxes, Instances
+
+    model, cfg = make_model(tmp_path, "f16", seed=11)
+    model.train()
+    sd0 = cpu_state_dict(model)
+    inputs = []
+    for i in range(2):
+        smp = synthetic_sample(i, size=128, num_classes=80, max_boxes=6)
+        inst = Instances((128, 128))
+        inst.gt_boxes = Boxes(smp["boxes"])
+        inst.gt_classes = smp["classes"]
+        inputs.append({"image": smp["image"], "instances": inst})
+    losses = model(inputs)
+    total = sum(losses.values())
+    total.backward()
+    # oracle
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+          for k, v in sd0.items()}
+    x_ref, _ = O.preprocess([d["image"] for d in inputs], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 32)
+    z = MR.centernet_forward(sd, x_ref, training=True)
+    targets = [O.gen_heatmap(d["instances"].gt_boxes.tensor, d["instances"].gt_classes, 32, 32, 80) for d in inputs]
+    ref = MR.centernet_losses(z, targets, [1.0])
+    sum(ref.values()).backward()
+    for k in ("hm_loss", "wh_loss", "off_loss"):
+        got, want = losses[k].item(), ref[k].item()
+        print(k, got, want)
+        assert abs(got - want) <= 2e-3 * max(1.0, abs(want)), (k, got, want)
+    bad = []
+    for name, p in model.named_parameters():
+        gref = sd[name].grad
+        assert p.grad is not None, name
+        gg = p.grad.float().cpu()
+        if gref is None or gref.abs().max() == 0:
+            continue
+        cos = torch.nn.functional.cosine_similarity(gg.flatten(), gref.flatten(), dim=0).item()
+        ratio = (gg.norm() / gref.norm()).item()
+        if cos < 0.98 or not (0.9 < ratio < 1.1):
+            bad.append((name, round(cos, 4), round(ratio, 4)))
+    print("params with poor gradient agreement:", bad[:20], len(bad))
+    assert len(bad) <= 4, bad
+    # BatchNorm running statistics were updated like nn.BatchNorm2d(momentum=0.1) does
+    bn = model.backbone.base.base_layer[1]
+    assert int(bn.num_batches_tracked) == 1 and not torch.allclose(bn.running_mean.cpu(), sd0["backbone.base.base_layer.1.running_mean"])
