@@ -1,0 +1,3 @@
+from .train_loop import SimpleTrainer
+
+__all__ = ["SimpleTrainer"]

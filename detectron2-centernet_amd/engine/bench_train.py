@@ -1,0 +1,63 @@
+"""Training leg of bench.py: BASELINE.json configs[2]/[3] -- DLA-34 CenterNet, 512x512, batch 16 per GPU, synthetic
+COCO-shaped targets; one step = device target generation + forward + losses + backward + (bucketed RCCL all-reduce
+when WORLD_SIZE > 1) + SGD update + LR schedule."""
+import time
+
+import torch
+
+from ..data.catalog import synthetic_sample
+from .train_loop import SimpleTrainer
+
+
+def synthetic_batch(B, size, rank, device, num_classes=80, max_boxes=32):
+    imgs, boxes, classes, counts = [], torch.zeros(B, max_boxes, 4), torch.zeros(B, max_boxes, dtype=torch.int64), []
+    for b in range(B):
+        s = synthetic_sample(rank * 100000 + b, size=size, num_classes=num_classes, max_boxes=max_boxes)
+        imgs.append(s["image"])
+        n = s["boxes"].shape[0]
+        boxes[b, :n], classes[b, :n] = s["boxes"], s["classes"]
+        counts.append(n)
+    return (torch.stack(imgs).to(device), boxes.to(device), classes.to(device),
+            torch.tensor(counts, dtype=torch.int32, device=device))
+
+
+def run_train_bench(model, cfg, args, B, rank, world, device, dist):
+    cfg.SOLVER.IMS_PER_BATCH = B * world
+    trainer = SimpleTrainer(model, None, cfg)
+    images, boxes, classes, counts = synthetic_batch(B, args.size, rank, device)
+    for _ in range(args.warmup):
+        trainer.run_step_tensors(images, boxes, classes, counts)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.run_step_tensors(images, boxes, classes, counts)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = trainer.metrics()
+    return {
+        "metric": "images/sec at 512x512 (train bs=16/GPU)" if (B == 16 and args.size == 512) else
+                  f"images/sec at {args.size}x{args.size} (train bs={B}/GPU)",
+        "value": world * B * args.steps / elapsed,
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f16",
+        "data": "synthetic",
+        "config": {"workload": f"DLA-34 CenterNet train step (targets+fwd+loss+bwd+allreduce+SGD), {B}x3x{args.size}x"
+                               f"{args.size} per GPU, 80 classes, f16 activations / f32 master weights",
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "final_losses": losses},
+    }

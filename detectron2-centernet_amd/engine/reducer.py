@@ -1,0 +1,75 @@
+"""Data-parallel gradient exchange: bucketed all-reduce of the flat gradient buffer, overlapped with backward.
+
+Reference: torch DistributedDataParallel wrapped around the model (detectron2/engine/defaults.py:279-285; NCCL).
+Here: one process per GPU, `torch.distributed` (backend "nccl" == RCCL on ROCm, "gloo" in the CPU tests); the
+gradients already live in one contiguous buffer in backward order (solver.FlatSGD), cut into a few large buckets
+(default 32 MB: one node's xGMI mesh is point-to-point, large messages keep every link busy).  A bucket's
+all-reduce is launched from the autograd hook of the last parameter that becomes ready in it, so communication
+runs while earlier layers are still back-propagating.  Gradients are pre-divided by the world size on the producer
+side (ops_train.PARAM_GRAD_DIV), so SUM gives the mean like DDP; BatchNorm statistics and loss normalisers stay
+per-GPU like the reference.
+"""
+import torch
+import torch.distributed as dist
+
+
+class BucketedReducer:
+    def __init__(self, optimizer, bucket_bytes=32 << 20, process_group=None):
+        self.opt, self.group = optimizer, process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.buckets = []  # [start, end, n_params]
+        self.bucket_of = []
+        cur = None
+        for i, (off, n) in enumerate(optimizer.offsets):
+            if cur is None or (off + n - cur[0]) * 4 > bucket_bytes and cur[2] > 0:
+                cur = [off, off, 0]
+                self.buckets.append(cur)
+            cur[1] = off + n
+            cur[2] += 1
+            self.bucket_of.append(len(self.buckets) - 1)
+        self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        if self.world > 1:
+            for i, p in enumerate(optimizer.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        b = self.bucket_of[i]
+
+        def hook(param):
+            self._ready[b] += 1
+            if self._ready[b] == self.buckets[b][2] and not self._launched[b]:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        self._launched[b] = True
+        self._handles.append(dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                             async_op=True))
+
+    def prepare(self):
+        """call before backward"""
+        self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+
+    def finish(self):
+        """call after backward: launches buckets that contain unused parameters, waits for all of them"""
+        if self.world == 1:
+            return
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+
+    def broadcast_parameters(self, buffers=()):
+        """DDP's initial synchronisation: rank 0's parameters (and BN buffers) to everyone."""
+        if self.world == 1:
+            return
+        dist.broadcast(self.opt.flat_param, src=0, group=self.group)
+        for b in buffers:
+            dist.broadcast(b, src=0, group=self.group)

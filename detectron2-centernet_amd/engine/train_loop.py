@@ -1,0 +1,59 @@
+"""SimpleTrainer.run_step (detectron2/engine/train_loop.py:212-251) for the HIP training path."""
+import time
+
+import torch
+
+from .. import ops_train
+from ..solver import WarmupMultiStepLR, build_optimizer
+from .reducer import BucketedReducer
+
+
+class SimpleTrainer:
+    """model(data) -> loss dict; sum; zero_grad; backward (bucketed all-reduce overlapped); SGD step; LR schedule.
+
+    Per-iteration metrics are kept on the device and only fetched when `metrics()` is called: the reference does a
+    `.item()` sync plus a Gloo pickle gather every step (train_loop.py:261-290), which this build avoids."""
+
+    def __init__(self, model, data_loader, cfg, optimizer=None, process_group=None):
+        model.train()
+        self.model, self.cfg = model, cfg
+        self._data_iter = iter(data_loader) if data_loader is not None else None
+        self.optimizer = optimizer or build_optimizer(cfg, model)
+        self.reducer = BucketedReducer(self.optimizer, process_group=process_group)
+        ops_train.set_world_size(self.reducer.world)
+        self.reducer.broadcast_parameters([b for b in model.buffers() if b.dtype.is_floating_point])
+        self.scheduler = WarmupMultiStepLR(self.optimizer, cfg.SOLVER.STEPS, cfg.SOLVER.GAMMA, cfg.SOLVER.WARMUP_FACTOR,
+                                           cfg.SOLVER.WARMUP_ITERS, cfg.SOLVER.WARMUP_METHOD)
+        self.iter = 0
+        self.last_losses = None
+
+    def run_step(self, data=None):
+        assert self.model.training, "[SimpleTrainer] model was changed to eval mode!"
+        start = time.perf_counter()
+        if data is None:
+            data = next(self._data_iter)
+        self.data_time = time.perf_counter() - start
+        return self._finish_step(self.model(data))
+
+    def run_step_tensors(self, images, boxes, classes, counts):
+        """device-resident batch (uint8 [B,3,H,W], boxes f32 [B,N,4], classes i64 [B,N], counts i32 [B])"""
+        return self._finish_step(self.model.train_batch_tensor(images, boxes, classes, counts))
+
+    def _finish_step(self, loss_dict):
+        losses = sum(loss_dict.values())
+        self.optimizer.zero_grad()
+        self.reducer.prepare()
+        losses.backward()
+        self.reducer.finish()
+        self.optimizer.step()
+        self.scheduler.step()
+        self.iter += 1
+        self.last_losses = {k: v.detach() for k, v in loss_dict.items()}
+        return self.last_losses
+
+    def metrics(self):
+        """host copy of the last losses; raises like train_loop.py:253-259 on non-finite values"""
+        out = {k: float(v) for k, v in self.last_losses.items()}
+        if not all(torch.isfinite(torch.tensor(list(out.values())))):
+            raise FloatingPointError(f"Loss became infinite or NaN at iteration={self.iter}!\nloss_dict = {out}")
+        return out

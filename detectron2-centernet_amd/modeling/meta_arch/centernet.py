@@ -346,6 +346,17 @@ class CenterNet(nn.Module):
         return {"hm_loss": hm_loss[0] * self.hm_weight, "wh_loss": wh_loss[0] * self.wh_weight,
                 "off_loss": off_loss[0] * self.off_weight}
 
+    def train_batch_tensor(self, images, boxes, classes, counts):
+        """training forward on a device-resident batch: images uint8/float [B,3,H,W] (0..255), boxes f32 [B,N,4] XYXY
+        in input pixels, classes i64 [B,N], counts i32 [B].  Returns the loss dict (0-d tensors with autograd)."""
+        from ...engine.train_step import train_forward_tensors
+        B, _, H, W = images.shape
+        Hp, Wp = ImageList.padded_size([(H, W)], self.size_divisibility)
+        x = ops.preprocess(images, self._mean_host, self._std_host, Hp, Wp, out_dtype=self._ctx.dtype)
+        dr = self.backbone.down_ratio
+        targets = ops.gaussian_targets(boxes, classes, counts, Hp // dr, Wp // dr, self.num_classes)
+        return train_forward_tensors(self, x, targets)
+
     def _forward_train(self, batched_inputs):
         from ...engine.train_step import centernet_train_forward
         return centernet_train_forward(self, batched_inputs)

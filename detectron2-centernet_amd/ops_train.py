@@ -15,6 +15,14 @@ from ._lib import ConvDesc
 from .ops import ACT_NONE, ACT_RELU, F16, _nhwc_stride, _ptr, _require_cuda, _stream
 
 GRAD_SCALE = 1024.0
+# parameter gradients are multiplied by PARAM_GRAD_MULT = 1 / (GRAD_SCALE * world_size): removes the loss scale and
+# pre-divides by the data-parallel world size so a SUM all-reduce yields the mean (what DDP does)
+PARAM_GRAD_MULT = 1.0 / GRAD_SCALE
+
+
+def set_world_size(world):
+    global PARAM_GRAD_MULT
+    PARAM_GRAD_MULT = 1.0 / (GRAD_SCALE * max(1, int(world)))
 
 
 def _ws(Cc, device):
@@ -124,7 +132,7 @@ def conv_dgrad(dy, weight, stride, pad, in_hw):
 
 def _wgrad_to_oihw(dw, Cout, Cin_real, Cin_used, R, S):
     g = dw.view(Cout, R, S, Cin_used)[..., :Cin_real].permute(0, 3, 1, 2)
-    return g * (1.0 / GRAD_SCALE)
+    return g * PARAM_GRAD_MULT
 
 
 # ------------------------------------------------------------------------------------------ autograd Functions
@@ -151,7 +159,7 @@ class ConvFn(torch.autograd.Function):
         dbias = None
         if relu or has_bias:
             dy, _, _, db = bn_train_bwd(dy, _pad_c(y) if relu else None, None, None, None, None, relu=relu)
-            dbias = db[:Cout] * (1.0 / GRAD_SCALE) if has_bias else None
+            dbias = db[:Cout] * PARAM_GRAD_MULT if has_bias else None
         dw = conv_wgrad(x, dy, Cw, R, S, stride, pad)[:Cout]
         dwt = _wgrad_to_oihw(dw, Cout, Cin, x.shape[3], R, S)
         dx = None
@@ -184,7 +192,7 @@ class BNActFn(torch.autograd.Function):
         y, z, mean, invstd, scale = ctx.saved_tensors
         dy, dres, dgamma, dbeta = bn_train_bwd(dz.contiguous(), z, y, mean, invstd, scale, relu=ctx.relu,
                                                want_dres=ctx.has_res)
-        s = 1.0 / GRAD_SCALE
+        s = PARAM_GRAD_MULT
         return dy, dgamma * s, dbeta * s, dres, None, None, None, None, None
 
 
@@ -212,7 +220,7 @@ class DwConvTAddFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dz = dz.contiguous()
         dx, dw = dwconvT_bwd(x, dz, weight, ctx.f)
-        return dx, dw * (1.0 / GRAD_SCALE), dz, None
+        return dx, dw * PARAM_GRAD_MULT, dz, None
 
 
 class DCNFn(torch.autograd.Function):
@@ -237,10 +245,10 @@ class DCNFn(torch.autograd.Function):
         wmat = weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
         _, _, _, dbias = bn_train_bwd(dy, None, None, None, None, None, relu=False)
         dw = conv_wgrad(col, dy, Cout, 1, 1, 1, 0)                       # [Cout, 9*Cin]
-        dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2) * (1.0 / GRAD_SCALE)
+        dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2) * PARAM_GRAD_MULT
         dcol = conv_dgrad(dy, wmat, 1, 0, x.shape[1:3])                  # [M, 9*Cin]
         dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om)
-        return dx32.half(), dom, dwt, dbias * (1.0 / GRAD_SCALE)
+        return dx32.half(), dom, dwt, dbias * PARAM_GRAD_MULT
 
 
 class FocalLossFn(torch.autograd.Function):
@@ -259,7 +267,8 @@ class FocalLossFn(torch.autograd.Function):
 class RegL1Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, mask, ind, target):
-        loss, grad = ops.reg_l1_loss(pred, mask, ind, target, want_grad=True, grad_scale=GRAD_SCALE)
+        grad = torch.zeros_like(pred)  # pred may carry padded channels (only the first two are used)
+        loss, grad = ops.reg_l1_loss(pred, mask, ind, target, want_grad=True, grad_scale=GRAD_SCALE, grad=grad)
         ctx.save_for_backward(grad)
         return loss[0]
 

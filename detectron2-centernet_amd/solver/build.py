@@ -1,0 +1,101 @@
+"""SGD with momentum over flat parameter / gradient / momentum buffers, updated by the HIP kernel `sgd_kernel`.
+
+Hyper-parameter grouping follows detectron2/solver/build.py:93-137: norm-layer parameters use WEIGHT_DECAY_NORM,
+`bias` parameters use BASE_LR*BIAS_LR_FACTOR and WEIGHT_DECAY_BIAS, everything else BASE_LR / WEIGHT_DECAY;
+momentum SOLVER.MOMENTUM, no Nesterov (defaults.py).  Design for MI355X: all parameters live in ONE contiguous f32
+buffer ordered by reverse registration (roughly the order backward produces gradients), so (i) one kernel launch per
+hyper-parameter group updates everything, (ii) the gradient buffer is directly the RCCL all-reduce operand, cut
+into large contiguous buckets (engine/reducer.py).
+"""
+import torch
+
+from .. import ops
+
+NORM_TYPES = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.SyncBatchNorm,
+              torch.nn.GroupNorm, torch.nn.InstanceNorm2d, torch.nn.LayerNorm, torch.nn.LocalResponseNorm)
+
+
+def param_groups(cfg, model):
+    """[(param, lr_factor, weight_decay)] in module order (solver/build.py:100-131)."""
+    out, memo = [], set()
+    for module in model.modules():
+        for key, value in module.named_parameters(recurse=False):
+            if not value.requires_grad or value in memo:
+                continue
+            memo.add(value)
+            lr_factor, wd = 1.0, cfg.SOLVER.WEIGHT_DECAY
+            if isinstance(module, NORM_TYPES):
+                wd = cfg.SOLVER.WEIGHT_DECAY_NORM
+            elif key == "bias":
+                lr_factor = cfg.SOLVER.BIAS_LR_FACTOR
+                wd = cfg.SOLVER.WEIGHT_DECAY_BIAS
+            out.append((value, float(lr_factor), float(wd)))
+    return out
+
+
+class FlatSGD:
+    def __init__(self, groups, base_lr, momentum=0.9, device=None):
+        """groups: [(param, lr_factor, weight_decay)].  Parameters are re-pointed into one flat buffer."""
+        self.base_lr, self.momentum = float(base_lr), float(momentum)
+        groups = list(reversed(groups))  # heads first: the order gradients become ready in backward
+        # contiguous segments per (lr_factor, wd) would break the backward-order layout; instead keep the order and
+        # record maximal runs of equal hyper-parameters (a handful for DLA-34: weights / norm+bias alternate per layer
+        # type, so runs are merged by sorting *within* a bucket-sized window only if adjacent).  Simplest exact form:
+        # one run per change of (lr_factor, wd).
+        self.params = [g[0] for g in groups]
+        device = device or self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat_param = torch.empty(total, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.flat_mom = torch.zeros(total, dtype=torch.float32, device=device)
+        self.offsets, self.runs = [], []
+        off = 0
+        for p, lf, wd in groups:
+            n = p.numel()
+            self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[off:off + n].view_as(p.data)
+            p.grad = self.flat_grad[off:off + n].view_as(p.data)
+            if self.runs and self.runs[-1][2] == lf and self.runs[-1][3] == wd:
+                self.runs[-1][1] = off + n
+            else:
+                self.runs.append([off, off + n, lf, wd])
+            self.offsets.append((off, n))
+            off += n
+        self.lr_factors = sorted({r[2] for r in self.runs})
+        self._lr_dev = {lf: torch.zeros(1, dtype=torch.float32, device=device) for lf in self.lr_factors}
+        self._first = True
+        self.set_lr_factor(1.0)
+
+    def set_lr_factor(self, f):
+        self._sched_factor = float(f)
+        for lf, t in self._lr_dev.items():
+            t.fill_(self.base_lr * lf * self._sched_factor)
+
+    @property
+    def lr(self):
+        return self.base_lr * self._sched_factor
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p, (off, n) in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                p.grad = self.flat_grad[off:off + n].view_as(p.data)
+
+    def step(self):
+        for a, b, lf, wd in self.runs:
+            ops.sgd_momentum_(self.flat_param[a:b], self.flat_grad[a:b], self.flat_mom[a:b], self._lr_dev[lf],
+                              self.momentum, wd, self._first)
+        self._first = False
+        for p in self.params:  # raw-pointer update: tell autograd / the packed-weight caches the values changed
+            torch.autograd.graph.increment_version(p)
+
+    def state_dict(self):
+        return {"momentum": self.flat_mom.clone(), "first": self._first}
+
+    def load_state_dict(self, sd):
+        self.flat_mom.copy_(sd["momentum"])
+        self._first = sd["first"]
+
+
+def build_optimizer(cfg, model):
+    return FlatSGD(param_groups(cfg, model), cfg.SOLVER.BASE_LR, cfg.SOLVER.MOMENTUM)

@@ -36,6 +36,21 @@ class Net:
         return (p + ".weight") in self.sd
 
 
+class NetF16(Net):
+    """Net whose conv and BatchNorm outputs are rounded to f16 with a straight-through gradient: the CPU model of
+    the device path's f16 activation storage (used to separate rounding effects from kernel errors in tests)."""
+
+    @staticmethod
+    def _r(t):
+        return t + (t.half().float() - t).detach()
+
+    def conv(self, p, x, stride=1, pad=0, dil=1):
+        return self._r(super().conv(p, x, stride, pad, dil))
+
+    def bn(self, p, x):
+        return self._r(super().bn(p, x))
+
+
 def basic_block(n, p, x, stride, residual=None):
     """dla.py:59-73."""
     if residual is None:
@@ -124,9 +139,11 @@ def centernet_heads(n, y, heads=("hm", "wh", "reg"), final_pad=0):
     return {h: n.conv(f"{h}.2", F.relu(n.conv(f"{h}.0", y, 1, 1)), 1, final_pad) for h in heads}
 
 
-def centernet_forward(sd, images_nchw, training=False, levels=(1, 1, 1, 2, 2, 1)):
+def centernet_forward(sd, images_nchw, training=False, levels=(1, 1, 1, 2, 2, 1), f16_activations=False):
     """normalised padded batch [B,3,H,W] -> raw head outputs {hm (logits), wh, reg} (NCHW)."""
-    n = Net(sd, training)
+    n = (NetF16 if f16_activations else Net)(sd, training)
+    if f16_activations:
+        images_nchw = images_nchw.half().float()
     y = dla34(n, "backbone", images_nchw, levels)[-1]
     return centernet_heads(n, y)
 
