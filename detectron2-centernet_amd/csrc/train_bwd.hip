@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(ChanRedArgs a) {
 }
 
 // mode 0: mean/invstd/scale/shift (+ running stats);  mode 1: out0 = sum g (dbeta / dbias), out1 = sum g*xhat (dgamma)
+// one wave per channel: lanes stride over the block partials, fixed-order f64 shuffle reduction (deterministic)
 __global__ void __launch_bounds__(256) chan_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, int M,
                                                             int mode, float eps, float momentum,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -86,10 +87,14 @@ __global__ void __launch_bounds__(256) chan_finalize_kernel(const float* __restr
                                                             float* __restrict__ scale, float* __restrict__ shift,
                                                             float* __restrict__ running_mean,
                                                             float* __restrict__ running_var) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   double s0 = 0, s1 = 0;
-  for (int b = 0; b < nblocks; ++b) { s0 += partial[((long)b * 2 + 0) * C + c]; s1 += partial[((long)b * 2 + 1) * C + c]; }
+  for (int b = lane; b < nblocks; b += 64) { s0 += partial[((long)b * 2 + 0) * C + c]; s1 += partial[((long)b * 2 + 1) * C + c]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_down(s0, o, 64); s1 += __shfl_down(s1, o, 64); }
+  if (lane != 0) return;
   if (mode == 0) {
     const double mean = s0 / M;
     double var = s1 / M - mean * mean;
@@ -322,34 +327,44 @@ __global__ void __launch_bounds__(256) dwconvT_bwd_kernel(const f16* __restrict_
                                                           const f16* __restrict__ dz, int dz_stride,
                                                           const float* __restrict__ w, f16* __restrict__ dx, int dx_stride,
                                                           float* __restrict__ dw, int B, int H, int W, int C, int f) {
+  extern __shared__ float sdw[];  // [k*k][C]
   const int CV = C >> 3, k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f;
-  const int cv = threadIdx.x % CV;
-  const int pl = threadIdx.x / CV, ppb = 256 / CV;  // pixels per block pass
-  float dwacc[8];
-  for (int ky = 0; ky < k; ++ky)
-    for (int kx = 0; kx < k; ++kx) {
+  for (int i = threadIdx.x; i < k * k * C; i += 256) sdw[i] = 0.f;
+  __syncthreads();
+  // dw: walk the OUTPUT pixels once; each (oy,ox) touches exactly 2x2 (input pixel, tap) pairs
+  const long nout = (long)B * Ho * Wo * CV;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nout; idx += (long)gridDim.x * 256) {
+    const int cv = (int)(idx % CV);
+    long t = idx / CV;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const f16x8 g = *(const f16x8*)(dz + ((long)(b * Ho + oy) * Wo + ox) * dz_stride + cv * 8);
+    const int iy1 = (oy + p) / f, ky1 = (oy + p) - f * iy1;
+    const int ix1 = (ox + p) / f, kx1 = (ox + p) - f * ix1;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dwacc[e] = 0.f;
-      const float* wt = w + (long)(ky * k + kx) * C + cv * 8;
-      for (long pix = (long)blockIdx.x * ppb + pl; pix < (long)B * H * W && pl < ppb; pix += (long)gridDim.x * ppb) {
-        const int ix = (int)(pix % W);
-        const long t = pix / W;
-        const int iy = (int)(t % H), b = (int)(t / H);
-        const int oy = iy * f - p + ky, ox = ix * f - p + kx;
-        if (oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
-        const f16x8 g = *(const f16x8*)(dz + ((long)(b * Ho + oy) * Wo + ox) * dz_stride + cv * 8);
-        const f16x8 xv = *(const f16x8*)(x + pix * x_stride + cv * 8);
+    for (int dy = 0; dy < 2; ++dy) {
+      const int iy = iy1 - dy, ky = ky1 + dy * f;
+      if (iy < 0 || iy >= H) continue;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dwacc[e] += (float)xv[e] * (float)g[e];
+      for (int dxx = 0; dxx < 2; ++dxx) {
+        const int ix = ix1 - dxx, kx = kx1 + dxx * f;
+        if (ix < 0 || ix >= W) continue;
+        const f16x8 xv = *(const f16x8*)(x + ((long)(b * H + iy) * W + ix) * x_stride + cv * 8);
+        float* acc = sdw + (ky * k + kx) * C + cv * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(acc + e, (float)xv[e] * (float)g[e]);
       }
-      if (pl < ppb) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(dw + (long)(ky * k + kx) * C + cv * 8 + e, dwacc[e]);
-      }
-      (void)wt;
     }
-  // dx pass
-  for (long pix = (long)blockIdx.x * ppb + pl; pix < (long)B * H * W && pl < ppb; pix += (long)gridDim.x * ppb) {
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < k * k * C; i += 256)
+    if (sdw[i] != 0.f) atomicAdd(dw + i, sdw[i]);
+  // dx: gather the k x k output window of every input pixel
+  const long nin = (long)B * H * W * CV;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nin; idx += (long)gridDim.x * 256) {
+    const int cv = (int)(idx % CV);
+    const long pix = idx / CV;
     const int ix = (int)(pix % W);
     const long t = pix / W;
     const int iy = (int)(t % H), b = (int)(t / H);
@@ -437,62 +452,53 @@ __global__ void __launch_bounds__(256) dcn_cols_kernel(const f16* __restrict__ x
   *(f16x8*)(col + m * (9L * Cin) + (long)tap * Cin + cv * 8) = o;
 }
 
-// given dcol (= W^T dY, [M][9*Cin] f16): dx (f32 atomics), d(offset), d(mask logit) -> dom [M][om_stride] f32
-// one lane group of Cin/8 lanes per (pixel, tap); shuffle reduction over the group.
+// given dcol (= W^T dY, [M][9*Cin] f16): dx (f32 atomics), d(offset), d(mask logit) -> dom [M][om_stride] f32.
+// One wave per (pixel, tap) pass over the channels, one lane per channel: every atomic wave-instruction adds 64
+// consecutive floats (256 contiguous bytes, the shape the memory-side atomic units run at full rate with); the
+// three per-(pixel,tap) dot products are wave reductions.
 __global__ void __launch_bounds__(256) dcn_col2im_coord_kernel(const f16* __restrict__ dcol, const f16* __restrict__ x,
                                                                int x_stride, const float* __restrict__ om, int om_stride,
                                                                float* __restrict__ dx, float* __restrict__ dom, int B, int H,
                                                                int W, int Cin) {
-  const int CV = Cin >> 3;  // 8..64, power of two
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long total = (long)B * H * W * 9 * CV;
-  const bool live = idx < total;
-  const long ii = live ? idx : total - 1;
-  const int cv = (int)(ii % CV);
-  long t = ii / CV;
-  const int tap = (int)(t % 9);
-  const long m = t / 9;
-  const int wo = (int)(m % W);
-  const long t2 = m / W;
-  const int ho = (int)(t2 % H), b = (int)(t2 / H);
-  const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride);
-  const f16x8 dc = *(const f16x8*)(dcol + m * (9L * Cin) + (long)tap * Cin + cv * 8);
-  float val_dot = 0.f, dh = 0.f, dwv = 0.f;
-  if (g.inside && live) {
-    f16x8 v[4];
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwork = (long)B * H * W * 9;
+  for (long wk = wave_id; wk < nwork; wk += (long)gridDim.x * 4) {
+    const int tap = (int)(wk % 9);
+    const long m = wk / 9;
+    const int wo = (int)(m % W);
+    const long t2 = m / W;
+    const int ho = (int)(t2 % H), b = (int)(t2 / H);
+    const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride);  // wave-uniform
+    float val_dot = 0.f, dh = 0.f, dwv = 0.f;
+    if (g.inside) {
+      const f16* dcp = dcol + m * (9L * Cin) + (long)tap * Cin;
+      for (int c = lane; c < Cin; c += 64) {
+        const float d = (float)dcp[c];
+        float v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      v[q] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      if (g.off[q] >= 0) v[q] = *(const f16x8*)(x + g.off[q] + cv * 8);
-    }
+        for (int q = 0; q < 4; ++q) v[q] = g.off[q] >= 0 ? (float)x[g.off[q] + c] : 0.f;
+        val_dot += d * (g.w[0] * v[0] + g.w[1] * v[1] + g.w[2] * v[2] + g.w[3] * v[3]);
+        dh += d * (-g.hw * v[0] - g.lw * v[1] + g.hw * v[2] + g.lw * v[3]);   // d val / d h  (kernel.cu:754-766)
+        dwv += d * (-g.hh * v[0] + g.hh * v[1] - g.lh * v[2] + g.lh * v[3]);  // d val / d w  (kernel.cu:767-779)
+        const float dm = d * g.mask;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float d = (float)dc[e];
-      const float v1 = (float)v[0][e], v2 = (float)v[1][e], v3 = (float)v[2][e], v4 = (float)v[3][e];
-      val_dot += d * (g.w[0] * v1 + g.w[1] * v2 + g.w[2] * v3 + g.w[3] * v4);
-      dh += d * (-g.hw * v1 - g.lw * v2 + g.hw * v3 + g.lw * v4);   // d val / d h  (kernel.cu:754-766)
-      dwv += d * (-g.hh * v1 + g.hh * v2 - g.lh * v3 + g.lh * v4);  // d val / d w  (kernel.cu:767-779)
-    }
-    // input gradient: scatter mask * w_q * dcol to the 4 corners (kernel.cu:871-949)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (g.off[q] >= 0) {
-        float* dst = dx + g.off[q] / x_stride * (long)Cin + cv * 8;  // dx is dense [Min][Cin] f32
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(dst + e, g.mask * g.w[q] * (float)dc[e]);
+        for (int q = 0; q < 4; ++q)  // input gradient scatter (kernel.cu:871-949)
+          if (g.off[q] >= 0) atomicAdd(dx + g.off[q] / x_stride * (long)Cin + c, g.w[q] * dm);
       }
-  }
-  // reduce the three dot products over the CV lanes of this (pixel, tap)
-  for (int o = CV >> 1; o > 0; o >>= 1) {
-    val_dot += __shfl_down(val_dot, o, 64);
-    dh += __shfl_down(dh, o, 64);
-    dwv += __shfl_down(dwv, o, 64);
-  }
-  if (cv == 0 && live) {
-    float* d = dom + m * om_stride;
-    d[2 * tap] = dh * g.mask;
-    d[2 * tap + 1] = dwv * g.mask;
-    d[18 + tap] = val_dot * g.mask * (1.f - g.mask);  // through the sigmoid of the mask logit
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      val_dot += __shfl_down(val_dot, o, 64);
+      dh += __shfl_down(dh, o, 64);
+      dwv += __shfl_down(dwv, o, 64);
+    }
+    if (lane == 0) {
+      float* d = dom + m * om_stride;
+      d[2 * tap] = dh * g.mask;
+      d[2 * tap + 1] = dwv * g.mask;
+      d[18 + tap] = val_dot * g.mask * (1.f - g.mask);  // through the sigmoid of the mask logit
+    }
   }
 }
 
@@ -520,7 +526,7 @@ int launch_bn_train_fwd(const f16* y, int y_stride, const f16* res, int res_stri
   a.y = y; a.y_stride = y_stride; a.M = M; a.C = C; a.mode = 0; a.partial = (float*)workspace;
   const int nb = chan_blocks(M, C);
   hipLaunchKernelGGL(chan_reduce_kernel, dim3(nb), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(chan_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, nb, C, M, 0, eps,
+  hipLaunchKernelGGL(chan_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)workspace, nb, C, M, 0, eps,
                      momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
   hipLaunchKernelGGL(affine_act_kernel, dim3(nblk256((long)M * (C / 8))), dim3(256), 0, s, y, y_stride, scale, shift, res,
                      res_stride, z, z_stride, (long)M, C, relu);
@@ -538,7 +544,7 @@ int launch_bn_train_bwd(const f16* dz, int dz_stride, const f16* z, int z_stride
   a.mean = mean; a.invstd = invstd; a.M = M; a.C = C; a.mode = 1; a.relu = relu; a.partial = (float*)workspace;
   const int nb = chan_blocks(M, C);
   hipLaunchKernelGGL(chan_reduce_kernel, dim3(nb), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(chan_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, nb, C, M, 1, 0.f,
+  hipLaunchKernelGGL(chan_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)workspace, nb, C, M, 1, 0.f,
                      0.f, (const float*)nullptr, (const float*)nullptr, dbeta, dgamma, (float*)nullptr, (float*)nullptr,
                      (float*)nullptr, (float*)nullptr);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk256((long)M * (C / 8))), dim3(256), 0, s, dz, dz_stride, z, z_stride, y,
@@ -576,12 +582,13 @@ int launch_maxpool2x2_bwd(const f16* x, int x_stride, const f16* dz, int dz_stri
 
 int launch_dwconvT_bwd(const f16* x, int x_stride, const f16* dz, int dz_stride, const float* w, f16* dx, int dx_stride,
                        float* dw, int B, int H, int W, int C, int f, hipStream_t s) {
-  CTDET_CHECK(C % 8 == 0 && C / 8 <= 256 && f % 2 == 0, "dwconvT_bwd: bad shape C=%d f=%d", C, f);
-  const int ppb = 256 / (C / 8);
-  long nb = ((long)B * H * W + ppb * 16 - 1) / (ppb * 16);
-  if (nb > 2048) nb = 2048;
+  CTDET_CHECK(C % 8 == 0 && f % 2 == 0, "dwconvT_bwd: bad shape C=%d f=%d", C, f);
+  const size_t lds = (size_t)4 * f * f * C * sizeof(float);
+  CTDET_CHECK(lds <= 64 * 1024, "dwconvT_bwd: k*k*C=%d too large for the LDS accumulator", 4 * f * f * C);
+  long nb = ((long)B * H * f * W * f * (C / 8) + 256 * 8 - 1) / (256 * 8);
+  if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(dwconvT_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, x_stride, dz, dz_stride, w, dx, dx_stride, dw,
+  hipLaunchKernelGGL(dwconvT_bwd_kernel, dim3((unsigned)nb), dim3(256), lds, s, x, x_stride, dz, dz_stride, w, dx, dx_stride, dw,
                      B, H, W, C, f);
   CTDET_LAUNCH_CHECK();
   return 0;
@@ -599,11 +606,12 @@ int launch_dcn_cols(const f16* x, int x_stride, const float* om, int om_stride, 
 
 int launch_dcn_col2im_coord(const f16* dcol, const f16* x, int x_stride, const float* om, int om_stride, float* dx,
                             float* dom, int B, int H, int W, int Cin, hipStream_t s) {
-  const int CV = Cin / 8;
-  CTDET_CHECK(Cin % 8 == 0 && CV >= 1 && CV <= 64 && (CV & (CV - 1)) == 0, "dcn_col2im: Cin=%d must be 8*2^n <= 512", Cin);
-  const long total = (long)B * H * W * 9 * CV;
-  if (total == 0) return 0;
-  hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3(nblk256(total)), dim3(256), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
+  CTDET_CHECK(Cin % 8 == 0, "dcn_col2im: Cin=%d must be a multiple of 8", Cin);
+  const long nwork = (long)B * H * W * 9;
+  if (nwork == 0) return 0;
+  long nb = (nwork + 3) / 4;
+  if (nb > 256 * 32) nb = 256 * 32;
+  hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3((unsigned)nb), dim3(256), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
                      B, H, W, Cin);
   CTDET_LAUNCH_CHECK();
   return 0;
