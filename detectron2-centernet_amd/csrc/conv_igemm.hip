@@ -18,6 +18,7 @@
 // registers (the loader must zero-fill padding and, for DCNv2, blend four corners), double
 // buffered, one barrier per 32-deep K step.
 #include "common.h"
+#include <type_traits>
 
 // slot permutation for 64-byte LDS rows read as 16-row fragments by ds_read_b128:
 // rows r and r+4 share banks, so the 4 rows {r, r+4, r+8, r+12} get distinct slot XORs.
@@ -487,7 +488,7 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(const ConvArgs a) {
 // 64-bit VALU ops per K step and ~70 VGPRs compared with the generic kernel above (which stays for odd channel
 // counts), which is what lets two workgroups share a CU (arch VGPRs + 128 accumulators <= 256).
 // ------------------------------------------------------------------------------------------
-template <int BP, int BC, int WP, int WC_, typename TOut>
+template <int BP, int BC, int WP, int WC_, bool CAT, typename TOut>
 __global__ void __launch_bounds__(256, 2) conv_igemm_uk_kernel(const ConvArgs a) {
   constexpr int TP = BP / WP / 16;
   constexpr int TC = BC / WC_ / 16;
@@ -511,78 +512,82 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_uk_kernel(const ConvArgs a)
 
   const int lrow = tid >> 2, slot = tid & 3;
   const int g = slot ^ swz(lrow);
-  const bool cat = a.nsrc > 1;
 
-  const f16* rowp[A_LD];   // conv: pixel of tap (0,0), + g*8 channels; cat: row of the current source
-  unsigned tapmask[A_LD];  // conv: taps inside the image; cat: bit 0 = row < M
+  const f16* rowp[A_LD];   // conv: pixel of tap (0,0) + g*8 channels; cat: row of the current source + g*8
+  unsigned tapmask[A_LD];  // conv: bit t = tap t inside the image; cat: bit 0 = row < M
   int rowm[A_LD];
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
     const int m = m0 + lrow + 64 * i;
     const bool ok = m < a.M;
     const int mm = ok ? m : 0;
-    const int wo = mm % a.Wo, t = mm / a.Wo;
-    const int ho = t % a.Ho, b = t / a.Ho;
-    const int hb = ho * a.stride - a.pad, wb = wo * a.stride - a.pad;
     rowm[i] = mm;
     unsigned mk = 0;
-    if (ok) {
-      if (cat) mk = 1u;
-      else
+    if constexpr (CAT) {
+      mk = ok ? 1u : 0u;
+      rowp[i] = (const f16*)a.xs[0] + (long)mm * a.xs_stride[0] + g * 8;
+    } else {
+      const int wo = mm % a.Wo, t = mm / a.Wo;
+      const int ho = t % a.Ho, b = t / a.Ho;
+      const int hb = ho * a.stride - a.pad, wb = wo * a.stride - a.pad;
+      if (ok)
         for (int r = 0; r < a.R; ++r)
           for (int s2 = 0; s2 < a.S; ++s2) {
             const int hi = hb + r * a.dil, wi = wb + s2 * a.dil;
             if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) mk |= 1u << (r * a.S + s2);
           }
+      rowp[i] = (const f16*)a.x + ((long)b * a.H * a.W + (long)hb * a.W + wb) * a.in_stride + g * 8;
     }
     tapmask[i] = mk;
-    rowp[i] = cat ? (const f16*)a.xs[0] + (long)mm * a.xs_stride[0] + g * 8
-                  : (const f16*)a.x + ((long)b * a.H * a.W + (long)hb * a.W + wb) * a.in_stride + g * 8;
   }
   const f16* wptr[B_LD];
-  bool b_ok[B_LD];
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
     const int L = lrow + 64 * j;
     const int Lw = L % (16 * TC), wv = L / (16 * TC);
     const int tt = Lw >> 4, r = Lw & 15;
     const int cl = wv * 16 * TC + 4 * TC * (r >> 2) + 4 * tt + (r & 3);
-    b_ok[j] = L < BC;
-    wptr[j] = (const f16*)a.w + (long)(n0 + (b_ok[j] ? cl : 0)) * a.Kpad + g * 8;
+    // rows beyond BC (only when BC < 64) re-read packed row 0: harmless, their LDS rows are never consumed
+    wptr[j] = (const f16*)a.w + (long)(n0 + (L < BC ? cl : 0)) * a.Kpad + g * 8;
   }
 
-  // uniform K-step state
-  int tr = 0, ts = 0, cch = 0;  // conv: tap row / col, channel-chunk offset
-  int sj = 0;                   // cat: current source
-  const bool chunk_major = a.korder == 1;
+  // ---- uniform (scalar) K-step state, advanced incrementally ----
+  // conv (chunk-major k): walk the S taps of a row (+step_s), then the next row (+step_r), then the next
+  // 32-channel chunk (+step_c); `dlt` is the element offset added to every row pointer, `tbit` the tap's mask bit.
+  const long step_s = (long)a.dil * a.in_stride;
+  const long step_r = ((long)a.dil * a.W - (long)(a.S - 1) * a.dil) * a.in_stride;
+  const long step_c = 32 - ((long)(a.R - 1) * a.dil * a.W + (long)(a.S - 1) * a.dil) * a.in_stride;
+  long dlt = 0;
+  unsigned tbit = 1u;
+  int ts = 0, tr = 0;
+  int sj = 0, sleft = CAT ? a.xs_cend[0] : 0;  // cat: current source and channels left in it
+  long woff = 0;                               // element offset into the packed weight rows
   auto advance_k = [&]() {
-    if (cat) {
-      cch += 32;
-      const int send = a.xs_cend[sj] - (sj ? a.xs_cend[sj - 1] : 0);
-      if (cch >= send && sj + 1 < a.nsrc) {
+    woff += 32;
+    if constexpr (CAT) {
+      dlt += 32;
+      sleft -= 32;
+      if (sleft == 0 && sj + 1 < a.nsrc) {
         ++sj;
-        cch = 0;
+        sleft = a.xs_cend[sj] - a.xs_cend[sj - 1];
+        dlt = 0;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) rowp[i] = (const f16*)a.xs[sj] + (long)rowm[i] * a.xs_stride[sj] + g * 8;
       }
-    } else if (chunk_major) {
-      if (++ts == a.S) { ts = 0; if (++tr == a.R) { tr = 0; cch += 32; } }
     } else {
-      cch += 32;
-      if (cch >= a.Cin) { cch = 0; if (++ts == a.S) { ts = 0; ++tr; } }
+      if (++ts < a.S) { dlt += step_s; tbit <<= 1; }
+      else {
+        ts = 0;
+        if (++tr < a.R) { dlt += step_r; tbit <<= 1; }
+        else { tr = 0; dlt += step_c; tbit = 1u; }
+      }
     }
   };
-  auto issue = [&](int kt, int stage) {
-    char* sb = smem + stage * STAGE + wave * 1024;
-    const int tap = cat ? 0 : tr * a.S + ts;
-    const long dlt = cat ? (long)cch : ((long)(tr * a.dil) * a.W + ts * a.dil) * a.in_stride + cch;
+  auto issue = [&](char* sb) {  // sb: this wave's slice of the target stage
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) dma16(((tapmask[i] >> tap) & 1u) ? rowp[i] + dlt : zero, sb + i * 4096);
+    for (int i = 0; i < A_LD; ++i) dma16((tapmask[i] & tbit) ? rowp[i] + dlt : zero, sb + i * 4096);
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) {
-      if constexpr (BC >= 64) dma16(wptr[j] + kt * 32, sb + BP * 64 + j * 4096);
-      else dma16(b_ok[j] ? wptr[j] + kt * 32 : zero, sb + BP * 64 + j * 4096);
-    }
+    for (int j = 0; j < B_LD; ++j) dma16(wptr[j] + woff, sb + BP * 64 + j * 4096);
   };
 
   f32x4 acc[TP][TC];
@@ -593,31 +598,43 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_uk_kernel(const ConvArgs a)
 
   const int fr = lane & 15;
   const int frag_off = fr * 64 + (((lane >> 4) ^ swz(fr)) << 4);
+  const char* fragA = smem + (wp * 16 * TP) * 64 + frag_off;            // pixel fragments of this wave
+  const char* fragB = smem + BP * 64 + (wc * 16 * TC) * 64 + frag_off;  // weight fragments of this wave
+  char* dmab = smem + wave * 1024;
   const int nk = a.Kpad / 32;
 
-  issue(0, 0);
+  issue(dmab);
   advance_k();
-  if (nk > 1) { issue(1, 1); advance_k(); }
+  if (nk > 1) { issue(dmab + STAGE); advance_k(); }
 
-  int st_c = 0, st_l = 2;
-  for (int kt = 0; kt < nk; ++kt) {
+  // one K step on compile-time stage ST (compute) / SL (prefetch target): LDS offsets become immediates
+  auto kstep = [&](int kt, auto st_c, auto st_l) {
+    constexpr int ST = decltype(st_c)::value, SL = decltype(st_l)::value;
     if (kt + 1 < nk) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) { issue(kt + 2, st_l); advance_k(); }
-    const char* base = smem + st_c * STAGE;
+    if (kt + 2 < nk) { issue(dmab + SL * STAGE); advance_k(); }
     f16x8 wf[TC];
 #pragma unroll
-    for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(base + BP * 64 + (wc * 16 * TC + 16 * c) * 64 + frag_off);
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(fragB + ST * STAGE + c * 1024);
 #pragma unroll
     for (int p = 0; p < TP; ++p) {
-      const f16x8 pf = *(const f16x8*)(base + (wp * 16 * TP + 16 * p) * 64 + frag_off);
+      const f16x8 pf = *(const f16x8*)(fragA + ST * STAGE + p * 1024);
 #pragma unroll
       for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf, acc[p][c], 0, 0, 0);
     }
-    st_c = st_c == NST - 1 ? 0 : st_c + 1;
-    st_l = st_l == NST - 1 ? 0 : st_l + 1;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  int kt = 0;
+  for (; kt + 2 < nk; kt += 3) {
+    kstep(kt, I0{}, I2{});
+    kstep(kt + 1, I1{}, I0{});
+    kstep(kt + 2, I2{}, I1{});
   }
+  if (kt < nk) { kstep(kt, I0{}, I2{}); ++kt; }
+  if (kt < nk) { kstep(kt, I1{}, I0{}); ++kt; }
 
   const int q = lane >> 4;
   const int cb = n0 + wc * 16 * TC + 4 * TC * q;
@@ -809,13 +826,17 @@ template <int BP, int BC, int WP, int WC_, typename TOut>
 static int launch_uk(const ConvArgs& a, hipStream_t s) {
   const int nbx = (a.M + BP - 1) / BP, nby = a.Cout_pad / BC;
   dim3 grid(8 * ((nbx + 7) / 8) * nby);
-  hipLaunchKernelGGL((conv_igemm_uk_kernel<BP, BC, WP, WC_, TOut>), grid, dim3(256), 0, s, a);
+  if (a.nsrc > 1)
+    hipLaunchKernelGGL((conv_igemm_uk_kernel<BP, BC, WP, WC_, true, TOut>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_igemm_uk_kernel<BP, BC, WP, WC_, false, TOut>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
 
 static bool uniform_k_ok(const ConvArgs& a) {
   if (a.R * a.S > 32 || a.Kpad != a.K || a.in_dil != 1) return false;
+  if (a.korder == 0 && a.R * a.S > 1) return false;  // the uniform-K kernel walks k chunk-major
   if (a.nsrc > 1) {
     int prev = 0;
     for (int j = 0; j < a.nsrc; ++j) {
