@@ -19,6 +19,7 @@
 // buffered, one barrier per 32-deep K step.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 // slot permutation for 64-byte LDS rows read as 16-row fragments by ds_read_b128:
 // rows r and r+4 share banks, so the 4 rows {r, r+4, r+8, r+12} get distinct slot XORs.
@@ -585,9 +586,9 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_uk_kernel(const ConvArgs a)
   };
   auto issue = [&](char* sb) {  // sb: this wave's slice of the target stage
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) dma16((tapmask[i] & tbit) ? rowp[i] + dlt : zero, sb + i * 4096);
+    for (int i = 0; i < A_LD; ++i) dma16(((tapmask[i] & tbit) && !(a.act & 64)) ? rowp[i] + dlt : zero, sb + i * 4096);
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) dma16(wptr[j] + woff, sb + BP * 64 + j * 4096);
+    for (int j = 0; j < B_LD; ++j) dma16((a.act & 128) ? zero : wptr[j] + woff, sb + BP * 64 + j * 4096);
   };
 
   f32x4 acc[TP][TC];
@@ -645,6 +646,189 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_uk_kernel(const ConvArgs a)
 #pragma unroll
     for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cb + 4 * c, acc[p][c]);
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Halo-resident 3x3 / stride 1 / pad 1 convolution (every DLABasicBlock conv, the DCN offset/mask convs, the fused
+// head conv, and their input gradients): a workgroup owns an 8x32-pixel output tile of one image and walks K
+// chunk-major.  For each 32-channel chunk the (8+2) x (32+2) input window is brought into LDS ONCE (6 DMA
+// instructions per thread) and all nine taps read their pixel fragments from it at shifted addresses; only the
+// 32-deep weight tile of each (chunk, tap) streams through a 3-stage ring.  Compared with the per-tap staging of
+// the kernels above this issues 2-3x fewer LDS-DMA instructions per MFMA (the measured limiter: the plain kernel
+// tops out at 44% / 23% of MFMA peak even with all loads served from one L1 line) and fetches each input byte from
+// L2 once per cout tile instead of nine times.
+// LDS: halo[2] x {main [10 rows][32 px][64 B] swizzled like the tiles above, side [10][left,right][64 B]} + ring[3].
+// ------------------------------------------------------------------------------------------
+template <int BC, int WP, int WC_, typename TOut>
+__global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const ConvArgs a) {
+  constexpr int TH = 8, TW = 32, BP = TH * TW;
+  constexpr int TP = BP / WP / 16;      // 16-pixel tiles per wave
+  constexpr int TC = BC / WC_ / 16;
+  constexpr int ROWS_W = TH / WP;       // tile rows per wave
+  constexpr int BCL = BC < 64 ? 64 : BC;
+  constexpr int B_LD = BCL / 64;
+  constexpr int HMAIN = 10 * 32 * 64, HSIDE = 4096, HBUF = HMAIN + HSIDE;
+  constexpr int WST = BCL * 64;
+  static_assert(WP * WC_ == 4 && TP == 2 * ROWS_W, "wave layout");
+  __shared__ __attribute__((aligned(16))) char smem[2 * HBUF + 3 * WST];
+  char* const ring = smem + 2 * HBUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave / WC_, wc = wave % WC_;
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  int m_tile, n_tile;
+  if (!tile_of_block(a.B * tiles_y * tiles_x, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int tx0 = (m_tile % tiles_x) * TW;
+  const int ty0 = ((m_tile / tiles_x) % tiles_y) * TH;
+  const int b = m_tile / (tiles_x * tiles_y);
+  const int n0 = n_tile * BC;
+  const f16* zero = (const f16*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+  const f16* ximg = (const f16*)a.x + (long)b * a.H * a.W * a.in_stride;
+
+  // ---- halo loader: 5 main pieces + 1 side piece per thread and chunk ----
+  // main piece i of thread t: pid = t + 256 i -> halo row (t>>7) + 2i, pixel (t>>2)&31, slot t&3: rows two apart,
+  // so one base pointer + a uniform row-pair stride suffice
+  const int hslot = tid & 3, hpx = (tid >> 2) & 31, hr0 = tid >> 7;
+  const int y0 = ty0 - 1 + hr0;
+  const f16* hp0 = ximg + ((long)y0 * a.W + tx0 + hpx) * a.in_stride + (hslot ^ swz(hpx)) * 8;
+  const long row2 = 2L * a.W * a.in_stride;
+  unsigned hmask = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) hmask |= (y0 + 2 * i >= 0 && y0 + 2 * i < a.H) ? (1u << i) : 0u;
+  const f16* hps;
+  {
+    const int side = (tid >> 2) & 1, hr = tid >> 3;   // [hr 0..9][side][slot], tid < 80
+    const int y = ty0 - 1 + hr, x = side ? tx0 + TW : tx0 - 1;
+    const bool ok = tid < 80 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    hps = ximg + ((long)(ok ? y : 0) * a.W + (ok ? x : 0)) * a.in_stride + hslot * 8;
+    hmask |= ok ? 32u : 0u;
+  }
+  const int lrow = tid >> 2;
+  const int gw = hslot ^ swz(lrow);
+  const f16* wptr[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int L = lrow + 64 * j;
+    const int Lw = L % (16 * TC), wv = L / (16 * TC);
+    const int tt = Lw >> 4, r = Lw & 15;
+    const int cl = wv * 16 * TC + 4 * TC * (r >> 2) + 4 * tt + (r & 3);
+    wptr[j] = (const f16*)a.w + (long)(n0 + (L < BC ? cl : 0)) * a.Kpad + gw * 8;
+  }
+  auto issue_halo = [&](int chunk, int hb) {
+    char* dst = smem + hb * HBUF + wave * 1024;
+    const long coff = (long)chunk * 32;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dma16((hmask & (1u << i)) ? hp0 + i * row2 + coff : zero, dst + i * 4096);
+    dma16((hmask & 32u) ? hps + coff : zero, smem + hb * HBUF + HMAIN + wave * 1024);
+  };
+  auto issue_w = [&](int kt, int st) {
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) dma16(wptr[j] + (long)kt * 32, ring + st * WST + wave * 1024 + j * 4096);
+  };
+
+  // ---- fragment addressing: per lane one LDS base per (px-tile half e, tap column s) with the wave's first tile
+  // row folded in; interior lanes then use immediates for (tile row + tap row) * 2048.  The single edge lane of
+  // (e=0,s=0) [left halo column] and (e=1,s=2) [right halo column] reads the side region (row stride 128). ----
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int row0 = wp * ROWS_W;
+  int abase[2][3];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+      const int X = 16 * e + l15 + s2 - 1;
+      if (X < 0) abase[e][s2] = HMAIN + kg * 16 + row0 * 128;
+      else if (X > 31) abase[e][s2] = HMAIN + 64 + kg * 16 + row0 * 128;
+      else abase[e][s2] = X * 64 + ((kg ^ swz(X)) << 4) + row0 * 2048;
+    }
+  const int estride0 = (l15 == 0) ? 128 : 2048;    // row stride of this lane for (e=0, s=0)
+  const int estride1 = (l15 == 15) ? 128 : 2048;   // ... for (e=1, s=2)
+  const int fr_off = l15 * 64 + ((kg ^ swz(l15)) << 4);
+  const char* fragB = ring + (wc * 16 * TC) * 64 + fr_off;
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nch = a.Cin / 32, nk = nch * 9;
+  issue_halo(0, 0);
+  issue_w(0, 0);
+  issue_w(1, 1);
+
+  // one K step = tap T of the current chunk; tap, ring stage (9 % 3 == 0) and halo buffer are compile time
+  auto kstep = [&](int kt, int chunk, auto tapc, auto hbc) {
+    constexpr int T = decltype(tapc)::value, HB = decltype(hbc)::value;
+    constexpr int R_ = T / 3, S_ = T % 3, ST = T % 3, SL = (T + 2) % 3;
+    // outstanding DMAs allowed while waiting for weights(kt): the younger weight tile (B_LD) and, right after a
+    // halo prefetch was queued behind it (T == 1), those 6 as well
+    if (kt + 1 < nk) { if (T == 1) wait_vmcnt<B_LD + 6>(); else wait_vmcnt<B_LD>(); }
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (T == 0 && chunk + 1 < nch) issue_halo(chunk + 1, HB ^ 1);
+    if (kt + 2 < nk) issue_w(kt + 2, SL);
+    const char* hbuf = smem + HB * HBUF;
+    f16x8 wf[TC];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(fragB + ST * WST + c * 1024);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const int e = p & 1, lr = p >> 1;
+      int off;
+      if (e == 0 && S_ == 0) off = abase[0][0] + (lr + R_) * estride0;
+      else if (e == 1 && S_ == 2) off = abase[1][2] + (lr + R_) * estride1;
+      else off = abase[e][S_] + (lr + R_) * 2048;
+      const f16x8 pf = *(const f16x8*)(hbuf + off);
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf, acc[p][c], 0, 0, 0);
+    }
+  };
+  auto chunk_steps = [&](int kt, int chunk, auto hbc) {
+    kstep(kt + 0, chunk, std::integral_constant<int, 0>{}, hbc);
+    kstep(kt + 1, chunk, std::integral_constant<int, 1>{}, hbc);
+    kstep(kt + 2, chunk, std::integral_constant<int, 2>{}, hbc);
+    kstep(kt + 3, chunk, std::integral_constant<int, 3>{}, hbc);
+    kstep(kt + 4, chunk, std::integral_constant<int, 4>{}, hbc);
+    kstep(kt + 5, chunk, std::integral_constant<int, 5>{}, hbc);
+    kstep(kt + 6, chunk, std::integral_constant<int, 6>{}, hbc);
+    kstep(kt + 7, chunk, std::integral_constant<int, 7>{}, hbc);
+    kstep(kt + 8, chunk, std::integral_constant<int, 8>{}, hbc);
+  };
+  int chunk = 0;
+  for (; chunk + 1 < nch; chunk += 2) {
+    chunk_steps(chunk * 9, chunk, std::integral_constant<int, 0>{});
+    chunk_steps(chunk * 9 + 9, chunk + 1, std::integral_constant<int, 1>{});
+  }
+  if (chunk < nch) chunk_steps(chunk * 9, chunk, std::integral_constant<int, 0>{});
+
+  const int q = lane >> 4;
+  const int cb = n0 + wc * 16 * TC + 4 * TC * q;
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int y = ty0 + row0 + (p >> 1), x = tx0 + 16 * (p & 1) + l15;
+    const int m = (b * a.H + y) * a.W + x;
+#pragma unroll
+    for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cb + 4 * c, acc[p][c]);
+  }
+}
+
+template <int BC, int WP, int WC_, typename TOut>
+static int launch_halo(const ConvArgs& a, hipStream_t s) {
+  const int nbx = a.B * (a.H / 8) * (a.W / 32), nby = a.Cout_pad / BC;
+  dim3 grid(8 * ((nbx + 7) / 8) * nby);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<BC, WP, WC_, TOut>), grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+static bool halo_ok(const ConvArgs& a) {
+  return a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.in_dil == 1 && a.nsrc <= 1 &&
+         a.korder == 1 && a.Cin % 32 == 0 && a.Kpad == a.K && a.H % 8 == 0 && a.W % 32 == 0 && a.Ho == a.H &&
+         a.Wo == a.W && !getenv("CTDET_NO_HALO");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -871,6 +1055,13 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
     if (nk == 5 && bc == 16) return launch_smallc<1, 5, TOut>(a, s);
     if (nk == 5 && bc == 32) return launch_smallc<2, 5, TOut>(a, s);
     if (nk == 13 && bc == 32) return launch_smallc<2, 13, TOut>(a, s);
+  }
+  if (halo_ok(a)) {
+    switch (bc) {
+      case 32: return launch_halo<32, 4, 1, TOut>(a, s);
+      case 64: return launch_halo<64, 4, 1, TOut>(a, s);
+      case 128: return launch_halo<128, 2, 2, TOut>(a, s);
+    }
   }
   if (uniform_k_ok(a)) {
     switch (bc) {
