@@ -30,7 +30,7 @@ SIGNATURES = {
     "ctdet_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctdet_conv1x1_cat_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctdet_dcnv2_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
-    "ctdet_preprocess": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _vp]),
+    "ctdet_preprocess": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp]),
     "ctdet_maxpool2x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_dwconvT_add": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_decode_workspace_bytes": (_sz, [_i32]),

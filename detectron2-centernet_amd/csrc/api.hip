@@ -17,7 +17,7 @@ void ctdet_set_error(const char* fmt, ...) {
 }
 
 // launchers from the kernel files
-int launch_preprocess(const void*, int, void*, int, int, int, int, int, int, long, const float*, const float*, int,
+int launch_preprocess(const void*, int, void*, int, int, int, int, int, int, long, const float*, const float*, int, int,
                       hipStream_t);
 int launch_maxpool2x2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
 int launch_dwconvT_add(const void*, const float*, const void*, void*, int, int, int, int, int, int, int, int, int,
@@ -163,10 +163,10 @@ int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* of
 
 int32_t ctdet_preprocess(const void* img, int32_t img_dtype, void* out, int32_t out_dtype, int32_t B, int32_t H,
                          int32_t W, int32_t Hp, int32_t Wp, int64_t img_batch_stride, const float* mean3,
-                         const float* std3, int32_t out_stride, void* stream) {
+                         const float* std3, int32_t out_stride, int32_t border, void* stream) {
   CTDET_CHECK(img && out && mean3 && std3, "preprocess: null pointer");
   return launch_preprocess(img, img_dtype, out, out_dtype, B, H, W, Hp, Wp, (long)img_batch_stride, mean3, std3,
-                           out_stride, (hipStream_t)stream);
+                           out_stride, border, (hipStream_t)stream);
 }
 
 int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,

@@ -839,7 +839,7 @@ static bool halo_ok(const ConvArgs& a) {
 // contiguous, fully coalesced run.  No LDS, no barriers.  A wave owns 64 consecutive pixels of one image row
 // (requires Wo % 64 == 0, else the generic kernel is used), so b/ho are scalar and no per-lane division exists.
 // ------------------------------------------------------------------------------------------
-template <int TC, int NK, typename TOut>
+template <int TC, int NK, bool NOCHECK, typename TOut>
 __global__ void __launch_bounds__(256) conv_smallc_kernel(const ConvArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -856,17 +856,22 @@ __global__ void __launch_bounds__(256) conv_smallc_kernel(const ConvArgs a) {
     for (int kt = 0; kt < NK; ++kt) wf[kt][c] = *(const f16x8*)(w + (long)cl * a.Kpad + kt * 32 + kg * 8);
   }
   // per K step: tap geometry of this lane's k-group (k-group G = kt*4 + kg; 8 channels)
-  int dh[NK], dw[NK], coff[NK];
+  int dh[NK], dw[NK], koff[NK];
   const int gpt = a.Cin >> 3;  // k-groups per tap (1 or 2)
 #pragma unroll
   for (int kt = 0; kt < NK; ++kt) {
     const int G = kt * 4 + kg;
     const int tap = G / gpt;
     const int tr = tap / a.S, ts = tap - tr * a.S;
-    dh[kt] = tr < a.R ? tr * a.dil : (1 << 20);  // K tail: forces the bounds test to fail
-    dw[kt] = ts * a.dil;
-    coff[kt] = (G - tap * gpt) * 8;
+    const bool tail = tr >= a.R;  // K tail: weights are zero there; NOCHECK reads tap (0,0) instead
+    dh[kt] = tail ? (NOCHECK ? 0 : (1 << 20)) : tr * a.dil;
+    dw[kt] = tail ? 0 : ts * a.dil;
+    // byte offset of this k-group relative to the lane's pixel of tap (0,0)
+    koff[kt] = ((dh[kt] * a.W + dw[kt]) * a.in_stride + (tail ? 0 : (G - tap * gpt) * 8)) * 2;
   }
+  int poff[4];  // byte offset of px-tile p's pixel relative to the segment's first pixel
+#pragma unroll
+  for (int p = 0; p < 4; ++p) poff[p] = (p * 16 + px) * a.stride * a.in_stride * 2;
 
   const int segs_per_row = a.Wo >> 6;
   const int nseg = a.B * a.Ho * segs_per_row;
@@ -876,6 +881,8 @@ __global__ void __launch_bounds__(256) conv_smallc_kernel(const ConvArgs a) {
     const int ho = t % a.Ho, b = t / a.Ho;
     const int hb = ho * a.stride - a.pad;
     const long img = (long)b * a.H * a.W;
+    // scalar base: pixel (hb, first column of the segment - pad); per-lane parts are 32-bit byte offsets
+    const char* sbase = (const char*)(x + (img + (long)hb * a.W + (sw * 64 * a.stride - a.pad)) * a.in_stride);
     f32x4 acc[4][TC];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -883,16 +890,21 @@ __global__ void __launch_bounds__(256) conv_smallc_kernel(const ConvArgs a) {
       for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt) {
-      const int hi = hb + dh[kt];
-      const bool hok = hi >= 0 && hi < a.H;
       f16x8 af[4];
+      if constexpr (NOCHECK) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int wo = sw * 64 + p * 16 + px;
-        const int wi = wo * a.stride - a.pad + dw[kt];
-        const bool ok = hok && wi >= 0 && wi < a.W;
-        const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        af[p] = ok ? *(const f16x8*)(x + (img + (long)hi * a.W + wi) * a.in_stride + coff[kt]) : z;
+        for (int p = 0; p < 4; ++p) af[p] = *(const f16x8*)(sbase + (unsigned)(koff[kt] + poff[p]));
+      } else {
+        const int hi = hb + dh[kt];
+        const bool hok = hi >= 0 && hi < a.H;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int wo = sw * 64 + p * 16 + px;
+          const int wi = wo * a.stride - a.pad + dw[kt];
+          const bool ok = hok && wi >= 0 && wi < a.W;
+          const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+          af[p] = ok ? *(const f16x8*)(sbase + (koff[kt] + poff[p])) : z;
+        }
       }
 #pragma unroll
       for (int p = 0; p < 4; ++p)
@@ -913,7 +925,10 @@ static int launch_smallc(const ConvArgs& a, hipStream_t s) {
   const int nseg = a.B * a.Ho * (a.Wo / 64);
   int blocks = (nseg + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL((conv_smallc_kernel<TC, NK, TOut>), dim3(blocks), dim3(256), 0, s, a);
+  if (a.pad == 0)  // pre-padded input (zero frame in memory): every tap of every pixel is in bounds
+    hipLaunchKernelGGL((conv_smallc_kernel<TC, NK, true, TOut>), dim3(blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_smallc_kernel<TC, NK, false, TOut>), dim3(blocks), dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
 }

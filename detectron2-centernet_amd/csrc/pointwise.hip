@@ -10,7 +10,7 @@ template <typename TIn, typename TOut>
 __global__ void __launch_bounds__(256) preprocess_kernel(const TIn* __restrict__ img, TOut* __restrict__ out, int B,
                                                          int H, int W, int Hp, int Wp, long img_batch_stride,
                                                          float m0, float m1, float m2, float s0, float s1, float s2,
-                                                         int out_stride) {
+                                                         int out_stride, int border) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const long total = (long)B * Hp * Wp;
   if (idx >= total) return;
@@ -27,7 +27,9 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const TIn* __restrict__
     v[1] = ((float)p[plane] / 255.f - m1) / s1;
     v[2] = ((float)p[2 * plane] / 255.f - m2) / s2;
   }
-  TOut* o = out + idx * out_stride;
+  // `border` > 0: the output buffer is [B, Hp+2*border, Wp+2*border] with a zero frame the caller cleared once
+  // (lets the 7x7 stem run as a pad-0 convolution without bounds checks); only the interior is written here
+  TOut* o = out + (((long)b * (Hp + 2 * border) + hy + border) * (Wp + 2 * border) + wx + border) * out_stride;
   if constexpr (sizeof(TOut) == 2) {
     f16x8 r = {(f16)v[0], (f16)v[1], (f16)v[2], 0, 0, 0, 0, 0};
     *(f16x8*)o = r;
@@ -125,14 +127,15 @@ __global__ void __launch_bounds__(256) dwconvT_add_kernel(const T* __restrict__ 
 static inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
 
 int launch_preprocess(const void* img, int img_dtype, void* out, int out_dtype, int B, int H, int W, int Hp, int Wp,
-                      long img_batch_stride, const float* mean, const float* stdv, int out_stride, hipStream_t s) {
+                      long img_batch_stride, const float* mean, const float* stdv, int out_stride, int border,
+                      hipStream_t s) {
   CTDET_CHECK(out_stride >= 8 && out_stride % 8 == 0, "preprocess: out_stride=%d must be a multiple of 8", out_stride);
-  CTDET_CHECK(Hp >= H && Wp >= W, "preprocess: padded size smaller than image");
+  CTDET_CHECK(Hp >= H && Wp >= W && border >= 0, "preprocess: padded size smaller than image");
   const long total = (long)B * Hp * Wp;
   if (total == 0) return 0;
 #define PP(TI, TO)                                                                                               \
   hipLaunchKernelGGL((preprocess_kernel<TI, TO>), dim3(nblk(total)), dim3(256), 0, s, (const TI*)img, (TO*)out, \
-                     B, H, W, Hp, Wp, img_batch_stride, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], out_stride)
+                     B, H, W, Hp, Wp, img_batch_stride, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], out_stride, border)
   if (img_dtype == CTDET_U8 && out_dtype == CTDET_F16) PP(uint8_t, f16);
   else if (img_dtype == CTDET_U8 && out_dtype == CTDET_F32) PP(uint8_t, float);
   else if (img_dtype == CTDET_F32 && out_dtype == CTDET_F16) PP(float, f16);

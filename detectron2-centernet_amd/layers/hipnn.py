@@ -56,11 +56,12 @@ def packed(owner, key, compute, weight, bn=None, conv_bias=None, stride=1, pad=0
 
 
 def conv_module(x, conv, bn=None, act=ACT_NONE, residual=None, ctx=None, out=None, out_dtype=None, cin_pad=None,
-                clamp=(0.0, 1.0)):
-    """act(bn(conv(x)) + residual) for an nn.Conv2d container `conv` (groups=1), x NHWC."""
+                clamp=(0.0, 1.0), prepadded=False):
+    """act(bn(conv(x)) + residual) for an nn.Conv2d container `conv` (groups=1), x NHWC.
+    prepadded: x already carries the conv's zero padding as a frame in memory -> run with pad 0."""
     assert conv.groups == 1 and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]
-    p = packed(conv, "conv", ctx.compute, conv.weight, bn, conv.bias, conv.stride[0], conv.padding[0],
-               conv.dilation[0], cin_pad)
+    p = packed(conv, "conv_p0" if prepadded else "conv", ctx.compute, conv.weight, bn, conv.bias, conv.stride[0],
+               0 if prepadded else conv.padding[0], conv.dilation[0], cin_pad)
     return ops.conv2d(x, p, out=out, act=act, residual=residual, out_dtype=out_dtype, clamp=clamp)
 
 

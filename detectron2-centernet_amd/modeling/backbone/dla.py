@@ -193,16 +193,18 @@ class DLA(Backbone):
         return nn.Sequential(*modules)
 
     @staticmethod
-    def _conv_level_forward(seq, x, ctx, cin_pad=None):
+    def _conv_level_forward(seq, x, ctx, cin_pad=None, prepadded=False):
         mods = list(seq)
         for i in range(0, len(mods), 3):
-            x = hipnn.conv_module(x, mods[i], mods[i + 1], ACT_RELU, ctx=ctx, cin_pad=cin_pad if i == 0 else None)
+            x = hipnn.conv_module(x, mods[i], mods[i + 1], ACT_RELU, ctx=ctx, cin_pad=cin_pad if i == 0 else None,
+                                  prepadded=prepadded and i == 0)
         return x
 
-    def hip_forward(self, x, ctx):
-        """x: NHWC [B,H,W,8] (3 image channels + zero padding) -> the six level outputs (NHWC)."""
+    def hip_forward(self, x, ctx, prepadded=False):
+        """x: NHWC [B,H,W,8] (3 image channels + zero padding) -> the six level outputs (NHWC).
+        prepadded: x is [B,H+6,W+6,8] with a zero frame of 3 pixels (the stem's padding, see ops.preprocess)."""
         y = []
-        x = self._conv_level_forward(self.base_layer, x, ctx, cin_pad=x.shape[3])
+        x = self._conv_level_forward(self.base_layer, x, ctx, cin_pad=x.shape[3], prepadded=prepadded)
         for i in range(6):
             lvl = getattr(self, "level{}".format(i))
             x = self._conv_level_forward(lvl, x, ctx) if i < 2 else lvl.hip_forward(x, ctx)
@@ -244,9 +246,9 @@ class DLA34(Backbone):
     def size_divisibility(self):
         return self.size_div
 
-    def hip_forward(self, x, ctx):
+    def hip_forward(self, x, ctx, prepadded=False):
         """x: NHWC [B,H,W,8] normalised image -> list of NHWC maps; the last one is the [B,H/4,W/4,64] head input."""
-        x = self.base.hip_forward(x, ctx)
+        x = self.base.hip_forward(x, ctx, prepadded)
         x = self.dla_up.hip_forward(x, ctx)
         # the reference clones these maps (dla.py:311-313) because IDAUp mutates in place; buffers here are
         # never written twice, so no copy is needed

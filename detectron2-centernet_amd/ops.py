@@ -22,24 +22,32 @@ PROFILE = []
 PROFILE_REP = 5   # each profiled launch is issued this many times back to back between one event pair
 
 
-def _kernel_name(p, M, deform, out_dt):
-    """mirrors the tile selection of launch_conv_f16_t() in csrc/conv_igemm.hip"""
+def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
+    """mirrors the kernel selection of launch_conv_f16_t() in csrc/conv_igemm.hip"""
     if p.compute != F16:
         return "conv_direct_f32<dcn>" if deform else "conv_direct_f32<conv>"
     bc = _lib.lib().ctdet_conv_cout_tile(p.Cout_eff)
+    o = "f16" if out_dt == F16 else "f32"
     if deform:
-        bp = 128
-    else:
-        big = ((M + 255) // 256) * (p.Cout_pad // bc) >= 512
-        bp = 256 if (big or bc == 16) else 128
-    return f"conv_igemm<{bp}x{bc},{'dcn' if deform else 'conv'},{'f16' if out_dt == F16 else 'f32'}>"
+        return f"conv_igemm_kernel<128x{bc},dcn,{o}>"
+    H, W = (x_shape[1], x_shape[2]) if x_shape is not None else (0, 0)
+    big = ((M + 255) // 256) * (p.Cout_pad // bc) >= 512
+    bp = 256 if (big or bc == 16) else 128
+    if (p.R == 3 and p.S == 3 and p.stride == 1 and p.pad == 1 and p.dil == 1 and p.in_dil == 1 and nsrc <= 1
+            and p.korder == 1 and H % 8 == 0 and W % 32 == 0 and bc in (32, 64, 128)):
+        return f"conv3x3_halo_kernel<256x{bc},{o}>"
+    if p.Cin in (8, 16) and p.korder == 0 and nsrc <= 1 and W and (W // p.stride) % 64 == 0 and p.Cout_pad <= 32:
+        return f"conv_smallc_kernel<Cout{bc},K{p.Kpad},{o}>"
+    if p.Kpad == p.K and p.R * p.S <= 32 and p.in_dil == 1 and (p.korder == 1 or p.R * p.S == 1) and p.Cin % 32 == 0:
+        return f"conv_igemm_uk_kernel<{bp}x{bc},{'cat' if nsrc > 1 else 'conv'},{o}>"
+    return f"conv_igemm_dma_kernel<{bp}x{bc},{o}>"
 
 
 class _Prof:
-    def __init__(self, p, M, deform, out_dt):
+    def __init__(self, p, M, deform, out_dt, x_shape=None, nsrc=1):
         self.on = PROFILE_ON
         if self.on:
-            self.name = _kernel_name(p, M, deform, out_dt)
+            self.name = _kernel_name(p, M, deform, out_dt, x_shape, nsrc)
             self.flops = 2.0 * M * p.Cout * p.R * p.S * p.Cin_real
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
@@ -198,7 +206,7 @@ def conv2d(x, p, out=None, act=ACT_NONE, residual=None, out_dtype=None, clamp=(0
     if residual is not None:
         assert residual.dtype == out.dtype and residual.shape[:3] == out.shape[:3]
     d = p.desc(x, out, act, residual, clamp)
-    prof = _Prof(p, d.B * d.Ho * d.Wo, False, d.out_dtype)
+    prof = _Prof(p, d.B * d.Ho * d.Wo, False, d.out_dtype, x.shape)
     for _ in range(prof.reps()):
         rc = _lib.lib().ctdet_conv2d_fwd(C.byref(d), _ptr(x), _ptr(p.w), _ptr(p.scale), _ptr(p.bias), _ptr(residual),
                                          _ptr(out), _stream())
@@ -234,7 +242,7 @@ def conv1x1_cat(xs, p, out=None, act=ACT_NONE, residual=None, out_dtype=None):
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
     cin_a = (C.c_int32 * n)(*cins)
     str_a = (C.c_int32 * n)(*[_nhwc_stride(t) for t in xs])
-    prof = _Prof(p, B * H * W, False, d.out_dtype)
+    prof = _Prof(p, B * H * W, False, d.out_dtype, xs[0].shape, len(xs))
     for _ in range(prof.reps()):
         rc = _lib.lib().ctdet_conv1x1_cat_fwd(C.byref(d), ptrs, cin_a, str_a, n, _ptr(p.w), _ptr(p.scale),
                                               _ptr(p.bias), _ptr(residual), _ptr(out), _stream())
@@ -260,18 +268,23 @@ def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_pro
     return out
 
 
-def preprocess(images, mean, std, Hp, Wp, out_dtype=torch.float16, out=None, partial=False):
+def preprocess(images, mean, std, Hp, Wp, out_dtype=torch.float16, out=None, partial=False, border=0):
     """images: [B,3,H,W] uint8/float32 CHW on device -> normalised NHWC [B,Hp,Wp,8] (3 channels used).
-    `out` may be a batch-slice of a larger padded buffer (ragged batches: one call per image)."""
+    `out` may be a batch-slice of a larger padded buffer (ragged batches: one call per image).
+    border > 0: `out` is a caller-owned [B,Hp+2b,Wp+2b,8] buffer whose zero frame was cleared once."""
     _require_cuda(images)
     B, Cc, H, W = images.shape
     assert Cc == 3 and images.stride(3) == 1 and images.stride(2) == W and images.stride(1) == H * W
     if out is None:
-        out = torch.empty(B, Hp, Wp, 8, dtype=out_dtype, device=images.device)
+        if border:
+            out = torch.zeros(B, Hp + 2 * border, Wp + 2 * border, 8, dtype=out_dtype, device=images.device)
+        else:
+            out = torch.empty(B, Hp, Wp, 8, dtype=out_dtype, device=images.device)
+    assert tuple(out.shape[1:3]) == (Hp + 2 * border, Wp + 2 * border)
     m = (C.c_float * 3)(*[float(v) for v in mean])
     s = (C.c_float * 3)(*[float(v) for v in std])
     rc = _lib.lib().ctdet_preprocess(_ptr(images), dt_of(images), _ptr(out), dt_of(out), B, H, W, Hp, Wp,
-                                     images.stride(0), m, s, _nhwc_stride(out), _stream())
+                                     images.stride(0), m, s, _nhwc_stride(out), int(border), _stream())
     _lib.check(rc, "ctdet_preprocess")
     return out
 
