@@ -150,7 +150,7 @@ int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* of
   if (a.M == 0) return 0;
   CTDET_CHECK(x && w_packed && y && offset_mask, "dcnv2: null pointer");
   CTDET_CHECK(om_stride >= 3 * d->R * d->S, "dcnv2: om_stride=%d < 3*R*S", om_stride);
-  CTDET_CHECK(d->korder == 0, "dcnv2: weights must be packed tap-major (korder 0)");
+  // korder 0: tap-major weights -> gather-from-global kernel; korder 1: chunk-major -> LDS-window kernel
   a.x = x; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = nullptr; a.y = y;
   a.om = offset_mask; a.om_stride = om_stride; a.mask_is_prob = mask_is_prob;
   if (d->compute_dtype == CTDET_DT_F16) return launch_conv_f16(a, d->out_dtype, true, (hipStream_t)stream);

@@ -105,6 +105,17 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs& a, int m, int c,
   }
 }
 
+// DCNv2 tiles are 8 x 16 pixel patches (when the map allows) instead of 128-pixel row strips: the bilinear-corner
+// gathers of neighbouring pixels/taps then overlap inside a ~23 KB window that stays in the 32 KB L1.
+__device__ __forceinline__ int dcn_pixel_of(const ConvArgs& a, int m) {
+  if ((a.Wo & 15) || (a.Ho & 7)) return m;
+  const int tiles_x = a.Wo >> 4, tiles_y = a.Ho >> 3;
+  const int t = m >> 7, l = m & 127;
+  const int tx = t % tiles_x, r = t / tiles_x;
+  const int ty = r % tiles_y, b = r / tiles_y;
+  return (b * a.Ho + ty * 8 + (l >> 4)) * a.Wo + tx * 16 + (l & 15);
+}
+
 template <int BP, int BC, int WP, int WC_, bool DEFORM, typename TOut>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs a) {
   constexpr int TP = BP / WP / 16;   // 16-pixel MFMA tiles per wave
@@ -130,9 +141,9 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs a) {
   bool a_ok[A_LD];
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
-    const int m = m0 + lrow + 64 * i;
-    a_ok[i] = m < a.M;
-    const int mm = a_ok[i] ? m : 0;
+    const int mlin = m0 + lrow + 64 * i;
+    a_ok[i] = mlin < a.M;
+    const int mm = a_ok[i] ? (DEFORM ? dcn_pixel_of(a, mlin) : mlin) : 0;
     const int wo = mm % a.Wo, t = mm / a.Wo;
     const int ho = t % a.Ho, b = t / a.Ho;
     a_pix[i] = b * a.H * a.W;
@@ -165,9 +176,9 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs a) {
     if constexpr (DEFORM) {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
-        const int m = m0 + lrow + 64 * i;
-        dcn_setup(a, a_ok[i], a_pix[i], a_hb[i], a_wb[i], tr, ts, a.om + (long)(a_ok[i] ? m : 0) * a.om_stride,
-                  sp[i]);
+        const int mlin = m0 + lrow + 64 * i;
+        const int m = a_ok[i] ? dcn_pixel_of(a, mlin) : 0;
+        dcn_setup(a, a_ok[i], a_pix[i], a_hb[i], a_wb[i], tr, ts, a.om + (long)m * a.om_stride, sp[i]);
       }
     }
   };
@@ -293,8 +304,9 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs a) {
   const int cb = n0 + wc * 16 * TC + 4 * TC * q;
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
-    const int m = m0 + wp * 16 * TP + 16 * p + fr;
-    if (m >= a.M) continue;
+    const int mlin = m0 + wp * 16 * TP + 16 * p + fr;
+    if (mlin >= a.M) continue;
+    const int m = DEFORM ? dcn_pixel_of(a, mlin) : mlin;
 #pragma unroll
     for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cb + 4 * c, acc[p][c]);
   }
@@ -315,10 +327,14 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// One 16-byte-per-lane global->LDS DMA (global_load_lds_dwordx4: LDS address = M0 + lane*16).  Issued through inline
+// asm on purpose: the compiler's waitcnt pass treats every LDS read as possibly aliasing every outstanding
+// __builtin_amdgcn_global_load_lds and puts s_waitcnt vmcnt(0) in front of it, which serialises the multi-stage
+// rings below.  All consumers here order DMA -> LDS read themselves (wait_vmcnt<N>() + s_barrier before the first
+// read of a stage, lgkmcnt(0) + s_barrier before a stage is overwritten).
 __device__ __forceinline__ void dma16(const void* g, char* lds_wave_base) {
-  asm volatile("" : "+v"(g));  // materialise the selected address: exactly one DMA instruction per call
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory", "m0");
 }
 
 template <int BP, int BC, int WP, int WC_, typename TOut>
@@ -832,6 +848,287 @@ static bool halo_ok(const ConvArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// DCNv2 (3x3 / s1 / p1) with the bilinear gathers served from LDS.  The global-gather kernel above is bound by
+// L1 bandwidth (36 KB of 16-byte corner loads per 32-deep K step against 64 B/clk/CU); here a workgroup owns an
+// 8x16-pixel output tile, and for every 32-channel chunk the input window of the tile (+-1 for the taps, +-4 margin
+// for the learned offsets: 18x26 pixels, 30 KB) is brought into LDS once by DMA.  All 9 taps x 4 corners then read
+// it with ds_read_b128 (256 B/clk/CU).  Sampling geometry (corner offset, validity bits, f16 weight*mask) is
+// computed once per (pixel, tap) and kept in 27 VGPRs across the chunks.  If any in-image corner of the tile falls
+// outside the window, the whole workgroup takes the gather-from-global path instead (block-uniform, exact).
+// ------------------------------------------------------------------------------------------
+// packed-f16 blend steps with the bilinear weight taken from one half of a register holding two of them (VOP3P
+// op_sel broadcast), so that the 36 weights of a pixel stay in 18 VGPRs instead of being splat into 144
+__device__ __forceinline__ unsigned pk_mul_wlo(unsigned v, unsigned w) {
+  unsigned r;
+  asm("v_pk_mul_f16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(v), "v"(w));
+  return r;
+}
+__device__ __forceinline__ unsigned pk_fma_wlo(unsigned v, unsigned w, unsigned c) {
+  unsigned r;
+  asm("v_pk_fma_f16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(v), "v"(w), "v"(c));
+  return r;
+}
+__device__ __forceinline__ unsigned pk_fma_whi(unsigned v, unsigned w, unsigned c) {
+  unsigned r;
+  asm("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(v), "v"(w), "v"(c));
+  return r;
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 dcn_blend(const u32x4& v0, const u32x4& v1, const u32x4& v2, const u32x4& v3,
+                                           unsigned w01, unsigned w23) {
+  u32x4 r;
+  r.x = pk_fma_whi(v3.x, w23, pk_fma_wlo(v2.x, w23, pk_fma_whi(v1.x, w01, pk_mul_wlo(v0.x, w01))));
+  r.y = pk_fma_whi(v3.y, w23, pk_fma_wlo(v2.y, w23, pk_fma_whi(v1.y, w01, pk_mul_wlo(v0.y, w01))));
+  r.z = pk_fma_whi(v3.z, w23, pk_fma_wlo(v2.z, w23, pk_fma_whi(v1.z, w01, pk_mul_wlo(v0.z, w01))));
+  r.w = pk_fma_whi(v3.w, w23, pk_fma_wlo(v2.w, w23, pk_fma_whi(v1.w, w01, pk_mul_wlo(v0.w, w01))));
+  return r;
+}
+
+template <int BC, int WP, int WC_, int NST, typename TOut>
+__global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
+  constexpr int TH = 8, TW = 16, BP = 128, MG = 4;
+  constexpr int WR = TH + 2 + 2 * MG, WCOLS = TW + 2 + 2 * MG;  // 18 x 26 window pixels
+  constexpr int NPIECE = WR * WCOLS * 4;                        // 1872 16-byte pieces
+  constexpr int W_LD = (NPIECE + 255) / 256;                    // 8 DMA rounds; the last one only on waves 0-1
+  constexpr int WINB = ((NPIECE + 63) / 64) * 1024;             // 30720
+  constexpr int TP = BP / WP / 16, TC = BC / WC_ / 16;
+  constexpr int BCL = BC < 64 ? 64 : BC, B_LD = BCL / 64, WST = BCL * 64;
+  constexpr int PF = NST - 1;                                   // weight stages in flight ahead of the consumer
+  static_assert(WP * WC_ == 4, "4 waves");
+  static_assert(WINB + 2 * BP * 64 + NST * WST + 16 <= 81920, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) char smem[WINB + 2 * BP * 64 + NST * WST];
+  char* const win = smem;
+  char* const atile = smem + WINB;
+  char* const ring = smem + WINB + 2 * BP * 64;
+  __shared__ int s_dirty;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave / WC_, wc = wave % WC_;
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  int m_tile, n_tile;
+  if (!tile_of_block(a.B * tiles_y * tiles_x, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int tx0 = (m_tile % tiles_x) * TW;
+  const int ty0 = ((m_tile / tiles_x) % tiles_y) * TH;
+  const int b = m_tile / (tiles_x * tiles_y);
+  const int n0 = n_tile * BC;
+  const f16* zero = (const f16*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+  const f16* ximg = (const f16*)a.x + (long)b * a.H * a.W * a.in_stride;
+  const int wy0 = ty0 - 1 - MG, wx0 = tx0 - 1 - MG;  // image coordinates of window pixel (0,0)
+  const int nch = a.Cin / 32, nk = nch * 9;
+
+  // ---- loaders ----
+  const int lrow = tid >> 2, slotw = tid & 3;
+  const int gwk = slotw ^ swz(lrow);
+  const f16* wptr[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int L = lrow + 64 * j;
+    const int Lw = L % (16 * TC), wv = L / (16 * TC);
+    const int tt = Lw >> 4, r = Lw & 15;
+    const int cl = wv * 16 * TC + 4 * TC * (r >> 2) + 4 * tt + (r & 3);
+    wptr[j] = (const f16*)a.w + (long)(n0 + (L < BC ? cl : 0)) * a.Kpad + gwk * 8;
+  }
+  auto issue_w = [&](int kt) {
+    const int st = kt % NST;
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) dma16(wptr[j] + (long)kt * 32, ring + st * WST + wave * 1024 + j * 4096);
+  };
+  // element offset (chunk 0) of the 16-byte window piece each DMA round of this lane fetches; -1 = zero fill
+  int wofs[W_LD];
+#pragma unroll
+  for (int i = 0; i < W_LD; ++i) {
+    const int pid = tid + 256 * i;
+    const int pw = pid >> 2, sl = pid & 3;
+    const int wr = pw / WCOLS, wcn = pw - wr * WCOLS;
+    const int y = wy0 + wr, x = wx0 + wcn;
+    const bool ok = pid < NPIECE && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    wofs[i] = ok ? (y * a.W + x) * a.in_stride + sl * 8 : -1;
+  }
+  auto issue_window = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < W_LD; ++i) {
+      if (i < W_LD - 1 || (wave * 64 + 256 * i) * 16 < WINB)  // wave-uniform: the last round ends with the window
+        dma16(wofs[i] >= 0 ? ximg + wofs[i] + chunk * 32 : zero, win + (wave * 64 + 256 * i) * 16);
+    }
+  };
+  // the window of chunk 0 and the first PF weight stages go out before anything else: their latency covers the
+  // offset/mask loads and the geometry set-up below
+  issue_window(0);
+#pragma unroll
+  for (int i = 0; i < PF; ++i)
+    if (i < nk) issue_w(i);
+
+  // ---- this thread's pixel (two k-groups of it) and its sampling geometry for the 9 taps ----
+  const int pl = tid >> 1, kg0 = (tid & 1) * 2;    // tile-local pixel 0..127, k-groups kg0, kg0+1
+  const int py = ty0 + (pl >> 4), pxx = tx0 + (pl & 15);
+  const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
+  float omv[28];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const float4 v = ((const float4*)omrow)[i];
+    omv[4 * i] = v.x; omv[4 * i + 1] = v.y; omv[4 * i + 2] = v.z; omv[4 * i + 3] = v.w;
+  }
+  unsigned gofs[9];           // window byte offset of corner (h_low, w_low)
+  unsigned gw01[9], gw23[9];  // f16 pairs: w0|w1, w2|w3  (bilinear weight * sigmoid(mask), 0 for invalid corners)
+  bool out_of_window = false;
+  if (tid == 0) s_dirty = 0;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int tr = t / 3, ts = t % 3;
+    const float h_im = (float)(py - 1 + tr) + omv[2 * t], w_im = (float)(pxx - 1 + ts) + omv[2 * t + 1];
+    const float mraw = omv[18 + t];
+    const float mk = a.mask_is_prob ? mraw : __builtin_amdgcn_rcpf(1.f + __expf(-mraw));
+    unsigned off = 0;
+    float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+      const float fh = floorf(h_im), fw = floorf(w_im);
+      const int h_low = (int)fh, w_low = (int)fw;
+      const float lh = h_im - fh, lw = w_im - fw, hh = 1.f - lh, hw = 1.f - lw;
+      const bool r0 = h_low >= 0, r1 = h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
+      // corners outside the image contribute 0 (deform_conv_cuda_kernel.cu:259-266): zero their weights
+      w0 = (r0 && c0) ? hh * hw * mk : 0.f; w1 = (r0 && c1) ? hh * lw * mk : 0.f;
+      w2 = (r1 && c0) ? lh * hw * mk : 0.f; w3 = (r1 && c1) ? lh * lw * mk : 0.f;
+      const int wr = h_low - wy0, wcn = w_low - wx0;  // window coordinates of corner 0
+      // every in-image corner must lie inside the window rows/cols [0, WR) x [0, WCOLS)
+      if (((r0 && (c0 || c1)) && (wr < 0 || wr >= WR)) || ((r1 && (c0 || c1)) && (wr + 1 < 0 || wr + 1 >= WR)) ||
+          ((c0 && (r0 || r1)) && (wcn < 0 || wcn >= WCOLS)) || ((c1 && (r0 || r1)) && (wcn + 1 < 0 || wcn + 1 >= WCOLS)))
+        out_of_window = true;
+      off = (unsigned)((wr * WCOLS + wcn) * 64) & 0xFFFFu;
+    }
+    gofs[t] = off;
+    const f16 h0 = (f16)w0, h1 = (f16)w1, h2 = (f16)w2, h3 = (f16)w3;
+    gw01[t] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    gw23[t] = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
+  }
+  __syncthreads();
+  if (out_of_window) s_dirty = 1;
+  __syncthreads();
+  const bool slow = s_dirty != 0;  // block-uniform
+
+  // A-tile row of this thread's pixel; slot swizzle as in the tiled kernels
+  const int arow = pl * 64;
+  const int aslot0 = ((kg0 ^ swz(pl)) << 4), aslot1 = (((kg0 + 1) ^ swz(pl)) << 4);
+  // A tile (sampled * mask, f16) of tap t -> buffer ab.  Fast: corners from the LDS window, no validity selects
+  // (the window is zero-filled outside the image and invalid corners carry weight 0; in a clean tile every corner
+  // of a valid sample lies inside the window).
+  auto build_fast = [&](int t, int ab) {
+    const char* c0p = win + gofs[t] + kg0 * 16;
+    char* dst = atile + ab * (BP * 64) + arow;
+    const u32x4 p0 = *(const u32x4*)(c0p), p1 = *(const u32x4*)(c0p + 64);
+    const u32x4 p2 = *(const u32x4*)(c0p + WCOLS * 64), p3 = *(const u32x4*)(c0p + WCOLS * 64 + 64);
+    const u32x4 q0 = *(const u32x4*)(c0p + 16), q1 = *(const u32x4*)(c0p + 80);
+    const u32x4 q2 = *(const u32x4*)(c0p + WCOLS * 64 + 16), q3 = *(const u32x4*)(c0p + WCOLS * 64 + 80);
+    *(u32x4*)(dst + aslot0) = dcn_blend(p0, p1, p2, p3, gw01[t], gw23[t]);
+    *(u32x4*)(dst + aslot1) = dcn_blend(q0, q1, q2, q3, gw01[t], gw23[t]);
+  };
+  // Slow: same arithmetic, corners straight from global memory (samples beyond the window margin)
+  auto build_slow = [&](int t, int chunk, int ab) {
+    const int tr = t / 3, ts = t % 3;
+    const float h_im = (float)(py - 1 + tr) + omrow[2 * t], w_im = (float)(pxx - 1 + ts) + omrow[2 * t + 1];
+    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+    const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W;
+    const bool r0 = valid && h_low >= 0, r1 = valid && h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
+    char* dst = atile + ab * (BP * 64) + arow;
+    // corners outside the image read the zero page (their weights are 0 as well): plain global pointers, no selects
+    // on the loaded values
+    const long o0 = ((long)h_low * a.W + w_low) * a.in_stride, o2 = o0 + (long)a.W * a.in_stride;
+    const f16* base = ximg + chunk * 32 + kg0 * 8;
+    const f16* c0p = (r0 && c0) ? base + o0 : zero;
+    const f16* c1p = (r0 && c1) ? base + o0 + a.in_stride : zero;
+    const f16* c2p = (r1 && c0) ? base + o2 : zero;
+    const f16* c3p = (r1 && c1) ? base + o2 + a.in_stride : zero;
+    typedef const u32x4 __attribute__((address_space(1)))* gp16;  // global_load, not flat (the selects hide the space)
+    const u32x4 p0 = *(gp16)c0p, p1 = *(gp16)c1p, p2 = *(gp16)c2p, p3 = *(gp16)c3p;
+    const u32x4 q0 = *(gp16)(c0p + 8), q1 = *(gp16)(c1p + 8), q2 = *(gp16)(c2p + 8), q3 = *(gp16)(c3p + 8);
+    *(u32x4*)(dst + aslot0) = dcn_blend(p0, p1, p2, p3, gw01[t], gw23[t]);
+    *(u32x4*)(dst + aslot1) = dcn_blend(q0, q1, q2, q3, gw01[t], gw23[t]);
+  };
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15;
+  const int frag_off = fr * 64 + (((lane >> 4) ^ swz(fr)) << 4);
+  const char* fragA = atile + (wp * 16 * TP) * 64 + frag_off;
+  const char* fragB = ring + (wc * 16 * TC) * 64 + frag_off;
+
+  // A tile of step 0: the window must be complete for every wave (explicit wait + barrier)
+  if (!slow) { wait_vmcnt<0>(); __syncthreads(); build_fast(0, 0); }
+  else build_slow(0, 0, 0);
+
+  // K step kt = (chunk, tap T): weights(kt) + A(kt) are consumed; A(kt+1) is built while the MFMAs run
+  auto kstep = [&](int kt, int chunk, auto tapc) {
+    constexpr int T = decltype(tapc)::value;
+    const int ab = kt & 1;
+    const int st = kt % NST;
+    if (kt + PF - 1 < nk) wait_vmcnt<(PF - 1) * B_LD>(); else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // A(kt) complete, weights(kt) landed, everyone left step kt-1
+    if (kt + PF < nk) issue_w(kt + PF);                // into the stage step kt-1 consumed
+    f16x8 wf[TC], pf[TP];
+    const char* ap = fragA + ab * (BP * 64);
+#pragma unroll
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(fragB + st * WST + c * 1024);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) pf[p] = *(const f16x8*)(ap + p * 1024);
+    if (T < 8) {
+      if (!slow) build_fast(T + 1, ab ^ 1); else build_slow(T + 1, chunk, ab ^ 1);
+    } else if (chunk + 1 < nch && !slow) {
+      issue_window(chunk + 1);                         // every build of this chunk is done (barrier above)
+    }
+#pragma unroll
+    for (int p = 0; p < TP; ++p)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf[p], acc[p][c], 0, 0, 0);
+    if (T == 8 && chunk + 1 < nch) {
+      // first A tile of the next chunk: needs its window (fast path) -- waited for behind this step's MFMAs
+      if (!slow) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        build_fast(0, ab ^ 1);
+      } else {
+        build_slow(0, chunk + 1, ab ^ 1);
+      }
+    }
+  };
+  for (int chunk = 0; chunk < nch; ++chunk) {
+    const int kt = chunk * 9;
+    kstep(kt + 0, chunk, std::integral_constant<int, 0>{});
+    kstep(kt + 1, chunk, std::integral_constant<int, 1>{});
+    kstep(kt + 2, chunk, std::integral_constant<int, 2>{});
+    kstep(kt + 3, chunk, std::integral_constant<int, 3>{});
+    kstep(kt + 4, chunk, std::integral_constant<int, 4>{});
+    kstep(kt + 5, chunk, std::integral_constant<int, 5>{});
+    kstep(kt + 6, chunk, std::integral_constant<int, 6>{});
+    kstep(kt + 7, chunk, std::integral_constant<int, 7>{});
+    kstep(kt + 8, chunk, std::integral_constant<int, 8>{});
+  }
+
+  const int q = lane >> 4;
+  const int cb = n0 + wc * 16 * TC + 4 * TC * q;
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int l = wp * 16 * TP + 16 * p + fr;  // tile-local pixel
+    const int m = (b * a.H + ty0 + (l >> 4)) * a.W + tx0 + (l & 15);
+#pragma unroll
+    for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cb + 4 * c, acc[p][c]);
+  }
+}
+
+template <int BC, int WP, int WC_, typename TOut>
+static int launch_dcn_window(const ConvArgs& a, hipStream_t s) {
+  const int nbx = a.B * (a.H / 8) * (a.W / 16), nby = a.Cout_pad / BC;
+  dim3 grid(8 * ((nbx + 7) / 8) * nby);
+  hipLaunchKernelGGL((dcn_window_kernel<BC, WP, WC_, (BC > 64 ? 4 : 8), TOut>), grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // Small-channel layers (DLA base_layer 7x7 3->16, level0 3x3 16->16, level1 3x3 16->32 s2; dla.py:212-220):
 // HBM-bound shapes where an LDS-tiled GEMM is all overhead (4 MFMAs per barrier).  Here every weight fragment of
 // the layer lives in registers for the whole kernel (NK*TC fragments), and the pixel (MFMA B) fragments are read
@@ -841,22 +1138,26 @@ static bool halo_ok(const ConvArgs& a) {
 // ------------------------------------------------------------------------------------------
 template <int TC, int NK, bool NOCHECK, typename TOut>
 __global__ void __launch_bounds__(256) conv_smallc_kernel(const ConvArgs a) {
+  // all weights of the layer in LDS: [16*TC couts][NK*32 + 8 pad] f16 (row pitch 16-byte aligned, odd in 16-byte
+  // slots so the 16-row fragment reads spread over the banks)
+  constexpr int WPITCH = NK * 32 + 8;
+  __shared__ __attribute__((aligned(16))) f16 sw[16 * TC * WPITCH];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const f16* __restrict__ x = (const f16*)a.x;
-  const f16* __restrict__ w = (const f16*)a.w;
   const int px = lane & 15, kg = lane >> 4;
-
-  // all weight fragments: lane supplies A[row = permuted cout][k-group kg] of every K step
-  f16x8 wf[NK][TC];
-#pragma unroll
-  for (int c = 0; c < TC; ++c) {
-    const int cl = 4 * TC * (px >> 2) + 4 * c + (px & 3);
-#pragma unroll
-    for (int kt = 0; kt < NK; ++kt) wf[kt][c] = *(const f16x8*)(w + (long)cl * a.Kpad + kt * 32 + kg * 8);
+  for (int i = threadIdx.x; i < 16 * TC * NK * 4; i += 256) {
+    const int row = i / (NK * 4), g8 = i % (NK * 4);
+    *(f16x8*)(sw + row * WPITCH + g8 * 8) = *(const f16x8*)((const f16*)a.w + (long)row * a.Kpad + g8 * 8);
   }
+  __syncthreads();
+  // fragment row of this lane for cout tile c: permuted cout (see the epilogue mapping of the tiled kernels)
+  const f16* wrow[TC];
+#pragma unroll
+  for (int c = 0; c < TC; ++c) wrow[c] = sw + (4 * TC * (px >> 2) + 4 * c + (px & 3)) * WPITCH + kg * 8;
+
   // per K step: tap geometry of this lane's k-group (k-group G = kt*4 + kg; 8 channels)
-  int dh[NK], dw[NK], koff[NK];
+  int dh[NOCHECK ? 1 : NK], dw[NOCHECK ? 1 : NK], koff[NK];
   const int gpt = a.Cin >> 3;  // k-groups per tap (1 or 2)
 #pragma unroll
   for (int kt = 0; kt < NK; ++kt) {
@@ -864,10 +1165,11 @@ __global__ void __launch_bounds__(256) conv_smallc_kernel(const ConvArgs a) {
     const int tap = G / gpt;
     const int tr = tap / a.S, ts = tap - tr * a.S;
     const bool tail = tr >= a.R;  // K tail: weights are zero there; NOCHECK reads tap (0,0) instead
-    dh[kt] = tail ? (NOCHECK ? 0 : (1 << 20)) : tr * a.dil;
-    dw[kt] = tail ? 0 : ts * a.dil;
+    const int dhk = tail ? (NOCHECK ? 0 : (1 << 20)) : tr * a.dil;
+    const int dwk = tail ? 0 : ts * a.dil;
+    if constexpr (!NOCHECK) { dh[kt] = dhk; dw[kt] = dwk; }
     // byte offset of this k-group relative to the lane's pixel of tap (0,0)
-    koff[kt] = ((dh[kt] * a.W + dw[kt]) * a.in_stride + (tail ? 0 : (G - tap * gpt) * 8)) * 2;
+    koff[kt] = (((tail ? 0 : dhk) * a.W + dwk) * a.in_stride + (tail ? 0 : (G - tap * gpt) * 8)) * 2;
   }
   int poff[4];  // byte offset of px-tile p's pixel relative to the segment's first pixel
 #pragma unroll
@@ -877,20 +1179,13 @@ __global__ void __launch_bounds__(256) conv_smallc_kernel(const ConvArgs a) {
   const int nseg = a.B * a.Ho * segs_per_row;
   const int q = lane >> 4;
   for (int seg = blockIdx.x * 4 + wave_in_block; seg < nseg; seg += gridDim.x * 4) {
-    const int sw = seg % segs_per_row, t = seg / segs_per_row;
+    const int sw_ = seg % segs_per_row, t = seg / segs_per_row;
     const int ho = t % a.Ho, b = t / a.Ho;
     const int hb = ho * a.stride - a.pad;
     const long img = (long)b * a.H * a.W;
     // scalar base: pixel (hb, first column of the segment - pad); per-lane parts are 32-bit byte offsets
-    const char* sbase = (const char*)(x + (img + (long)hb * a.W + (sw * 64 * a.stride - a.pad)) * a.in_stride);
-    f32x4 acc[4][TC];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < NK; ++kt) {
-      f16x8 af[4];
+    const char* sbase = (const char*)(x + (img + (long)hb * a.W + (sw_ * 64 * a.stride - a.pad)) * a.in_stride);
+    auto load_frags = [&](int kt, f16x8 (&af)[4]) {
       if constexpr (NOCHECK) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) af[p] = *(const f16x8*)(sbase + (unsigned)(koff[kt] + poff[p]));
@@ -899,20 +1194,35 @@ __global__ void __launch_bounds__(256) conv_smallc_kernel(const ConvArgs a) {
         const bool hok = hi >= 0 && hi < a.H;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-          const int wo = sw * 64 + p * 16 + px;
+          const int wo = sw_ * 64 + p * 16 + px;
           const int wi = wo * a.stride - a.pad + dw[kt];
           const bool ok = hok && wi >= 0 && wi < a.W;
           const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
           af[p] = ok ? *(const f16x8*)(sbase + (koff[kt] + poff[p])) : z;
         }
       }
+    };
+    f32x4 acc[4][TC];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 afA[4], afB[4];
+    load_frags(0, afA);
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+      // pixel fragments of step kt+1 are requested before the MFMAs of step kt (explicit one-step prefetch)
+      if (kt + 1 < NK) { if (kt & 1) load_frags(kt + 1, afA); else load_frags(kt + 1, afB); }
+      f16x8 wf[TC];
+#pragma unroll
+      for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(wrow[c] + kt * 32);
 #pragma unroll
       for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int c = 0; c < TC; ++c)
-          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kt][c], af[p], acc[p][c], 0, 0, 0);
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], (kt & 1) ? afB[p] : afA[p], acc[p][c], 0, 0, 0);
     }
-    const int mrow = (b * a.Ho + ho) * a.Wo + sw * 64;
+    const int mrow = (b * a.Ho + ho) * a.Wo + sw_ * 64;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -1053,6 +1363,15 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   CTDET_CHECK(a.Cout_pad % bc == 0 && a.Cout_pad >= a.Cout, "conv: Cout_pad=%d does not match tile %d (Cout=%d)",
               a.Cout_pad, bc, a.Cout);
   CTDET_CHECK(a.in_dil >= 1 && (!deform || a.in_dil == 1), "conv: bad in_dil %d", a.in_dil);
+  if (deform && a.korder == 1) {
+    // chunk-major weights: LDS-window kernel (3x3/s1/p1, map divisible by the 8x16 tile)
+    CTDET_CHECK(a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Cin % 32 == 0 && a.H % 8 == 0 &&
+                    a.W % 16 == 0 && a.Kpad == a.K && a.om_stride % 4 == 0 && ((size_t)a.om & 15) == 0,
+                "dcnv2(window): unsupported geometry");
+    if (bc == 128) return launch_dcn_window<128, 2, 2, TOut>(a, s);
+    if (bc == 64) return launch_dcn_window<64, 2, 2, TOut>(a, s);
+    CTDET_CHECK(false, "dcnv2(window): unsupported Cout=%d", a.Cout);
+  }
   if (deform) {
     CTDET_CHECK(a.Cin % 32 == 0 && a.korder == 0, "dcnv2: Cin=%d must be a multiple of 32, tap-major weights", a.Cin);
     if (bc == 128) return launch_cfg<128, 128, 2, 2, true, TOut>(a, s);

@@ -97,8 +97,12 @@ class DCN(nn.Module):
         """x NHWC -> act(bn(dcn(x))) NHWC; the offset/mask conv writes f32 so sampling coordinates keep full
         precision even in f16 mode."""
         om = hipnn.conv_module(x, self.conv_offset_mask, None, ACT_NONE, ctx=ctx, out_dtype=torch.float32)
-        p = hipnn.packed(self, "dcn", ctx.compute, self.weight, bn, self.bias, self.stride, self.padding,
-                         self.dilation, tap_major=True)
+        # chunk-major weights select the LDS-window kernel (8x16 output tiles); other shapes gather from global
+        window = (ctx.compute == F16 and ops.DCN_WINDOW and self.kernel_size == (3, 3) and self.stride == 1
+                  and self.padding == 1 and self.dilation == 1 and self.in_channels % 32 == 0
+                  and x.shape[1] % 8 == 0 and x.shape[2] % 16 == 0)
+        p = hipnn.packed(self, "dcn_cm" if window else "dcn", ctx.compute, self.weight, bn, self.bias, self.stride,
+                         self.padding, self.dilation, tap_major=not window)
         return ops.dcnv2(x, om, p, act=act)
 
     def forward(self, x):

@@ -6,6 +6,7 @@ buffer (that is how Root's ``torch.cat`` (reference dla.py:88) is made free: pro
 into their slice of the concat buffer).
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -29,14 +30,15 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
     bc = _lib.lib().ctdet_conv_cout_tile(p.Cout_eff)
     o = "f16" if out_dt == F16 else "f32"
     if deform:
-        return f"conv_igemm_kernel<128x{bc},dcn,{o}>"
+        return f"dcn_window_kernel<128x{bc},{o}>" if p.korder == 1 else f"conv_igemm_kernel<128x{bc},dcn,{o}>"
     H, W = (x_shape[1], x_shape[2]) if x_shape is not None else (0, 0)
     big = ((M + 255) // 256) * (p.Cout_pad // bc) >= 512
     bp = 256 if (big or bc == 16) else 128
     if (p.R == 3 and p.S == 3 and p.stride == 1 and p.pad == 1 and p.dil == 1 and p.in_dil == 1 and nsrc <= 1
             and p.korder == 1 and H % 8 == 0 and W % 32 == 0 and bc in (32, 64, 128)):
         return f"conv3x3_halo_kernel<256x{bc},{o}>"
-    if p.Cin in (8, 16) and p.korder == 0 and nsrc <= 1 and W and (W // p.stride) % 64 == 0 and p.Cout_pad <= 32:
+    Wo = (W + 2 * p.pad - p.dil * (p.S - 1) - 1) // p.stride + 1 if W else 0
+    if p.Cin in (8, 16) and p.korder == 0 and nsrc <= 1 and Wo and Wo % 64 == 0 and p.Cout_pad <= 32:
         return f"conv_smallc_kernel<Cout{bc},K{p.Kpad},{o}>"
     if p.Kpad == p.K and p.R * p.S <= 32 and p.in_dil == 1 and (p.korder == 1 or p.R * p.S == 1) and p.Cin % 32 == 0:
         return f"conv_igemm_uk_kernel<{bp}x{bc},{'cat' if nsrc > 1 else 'conv'},{o}>"
@@ -249,6 +251,9 @@ def conv1x1_cat(xs, p, out=None, act=ACT_NONE, residual=None, out_dtype=None):
     _lib.check(rc, "ctdet_conv1x1_cat_fwd")
     prof.done()
     return out
+
+
+DCN_WINDOW = os.environ.get("CTDET_NO_DCN_WINDOW", "0") != "1"
 
 
 def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_prob=False):

@@ -142,6 +142,45 @@ def test_dcnv2(ops, dev, case, mode):
     assert err <= tol * max(1.0, ref.abs().max().item()), f"max err {err}"
 
 
+# LDS-window kernel (chunk-major weights): off_std 0/1/2 stay inside the +-4 px window margin (fast path), 6 and 12
+# push samples outside it so some / all workgroups take the gather-from-global path; both must agree with the oracle.
+DCN_WINDOW_CASES = [(2, 16, 32, 64, 64, 1.0), (1, 8, 16, 128, 64, 0.0), (2, 16, 16, 64, 64, 6.0),
+                    (1, 8, 32, 256, 128, 2.0), (1, 24, 16, 128, 128, 3.0), (1, 8, 16, 512, 256, 12.0),
+                    (1, 16, 48, 64, 40, 2.5)]
+
+
+@pytest.mark.parametrize("case", DCN_WINDOW_CASES)
+def test_dcnv2_window(ops, dev, case):
+    B, H, W, Cin, Cout, off_std = case
+    g = torch.Generator().manual_seed(Cin + Cout + H + 1)
+    x = h16(torch.randn(B, Cin, H, W, generator=g))
+    w = h16(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    om = torch.randn(B, 27, H, W, generator=g)
+    om[:, :18] *= off_std
+    om[:, 0, 0, 0] = -0.0
+    om[:, 1, 0, 0] = -1.0
+    om[:, 2, -1, -1] = 1.0
+    om[:, 4, 3, 5] = 4.0      # exactly on the window edge
+    om[:, 5, 3, 5] = -4.0
+    bias = torch.randn(Cout, generator=g)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    ref = O.dcnv2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, None, 1, 1, 1)
+    ref = (ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)).relu()
+    pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=1, pad=1, compute=ops.F16)
+    assert pc.korder == 1
+    om_d = torch.zeros(B, H, W, 28)
+    om_d[..., :27] = nhwc(om)
+    xd = nhwc(x).half().to(dev)
+    y = ops.dcnv2(xd, om_d.to(dev), pc, act=ops.ACT_RELU)
+    got = nchw(y[..., :Cout].float().cpu())
+    err = (got - ref).abs().max().item()
+    assert err <= 6e-3 * max(1.0, ref.abs().max().item()), f"max err {err}"
+    # and against the gather-from-global kernel on the same operands (only the f32 accumulation order differs)
+    pt = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=1, pad=1, compute=ops.F16, tap_major=True)
+    y2 = ops.dcnv2(xd, om_d.to(dev), pt, act=ops.ACT_RELU)
+    assert (y.float() - y2.float()).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("tdt", [torch.float16, torch.float32])
 def test_maxpool_and_dwconvT(ops, dev, tdt):
     g = torch.Generator().manual_seed(7)

@@ -19,6 +19,8 @@ ap.add_argument("--cout", type=int, default=256)
 ap.add_argument("--k", type=int, default=3)
 ap.add_argument("--stride", type=int, default=1)
 ap.add_argument("--dcn", action="store_true")
+ap.add_argument("--window", action="store_true")
+ap.add_argument("--off-std", type=float, default=1.0)
 ap.add_argument("--f32out", action="store_true")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--tap-major", action="store_true")
@@ -27,10 +29,12 @@ dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 x = torch.randn(a.B, a.H, a.W, a.cin, generator=g).half().to(dev)
 w = (torch.randn(a.cout, a.cin, a.k, a.k, generator=g) / (a.cin * a.k * a.k) ** 0.5).to(dev)
-p = ops.PackedConv(w, None, None, stride=a.stride, pad=a.k // 2, compute=ops.F16, tap_major=a.tap_major or a.dcn)
+p = ops.PackedConv(w, None, None, stride=a.stride, pad=a.k // 2, compute=ops.F16, tap_major=a.tap_major or (a.dcn and not a.window))
 od = torch.float32 if a.f32out else torch.float16
 if a.dcn:
-    om = torch.randn(a.B, a.H, a.W, 28, generator=g).to(dev)
+    om = torch.randn(a.B, a.H, a.W, 28, generator=g)
+    om[..., :18] *= a.off_std
+    om = om.to(dev)
     f = lambda: ops.dcnv2(x, om, p, act=ops.ACT_RELU, out_dtype=od)
 else:
     f = lambda: ops.conv2d(x, p, act=ops.ACT_RELU, out_dtype=od)
