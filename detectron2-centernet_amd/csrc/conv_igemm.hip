@@ -874,37 +874,60 @@ __device__ __forceinline__ unsigned pk_fma_whi(unsigned v, unsigned w, unsigned 
   return r;
 }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// r = v0*w0 + v1*w1 + v2*w2 + v3*w3 on 8 packed f16 lanes (w01 = w0|w1<<16, w23 = w2|w3<<16), rounding after every
+// step like the separate v_pk ops.  One asm block, the four dword chains interleaved, so that consecutive
+// instructions are independent and no hazard nops are needed between them.
 __device__ __forceinline__ u32x4 dcn_blend(const u32x4& v0, const u32x4& v1, const u32x4& v2, const u32x4& v3,
                                            unsigned w01, unsigned w23) {
+  unsigned r0, r1, r2, r3;
+  asm("v_pk_mul_f16 %0, %4, %20 op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f16 %1, %5, %20 op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f16 %2, %6, %20 op_sel_hi:[1,0]\n\t"
+      "v_pk_mul_f16 %3, %7, %20 op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f16 %0, %8, %20, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f16 %1, %9, %20, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f16 %2, %10, %20, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f16 %3, %11, %20, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f16 %0, %12, %21, %0 op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f16 %1, %13, %21, %1 op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f16 %2, %14, %21, %2 op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f16 %3, %15, %21, %3 op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f16 %0, %16, %21, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f16 %1, %17, %21, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f16 %2, %18, %21, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f16 %3, %19, %21, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y), "v"(v1.z), "v"(v1.w), "v"(v2.x), "v"(v2.y),
+        "v"(v2.z), "v"(v2.w), "v"(v3.x), "v"(v3.y), "v"(v3.z), "v"(v3.w), "v"(w01), "v"(w23));
   u32x4 r;
-  r.x = pk_fma_whi(v3.x, w23, pk_fma_wlo(v2.x, w23, pk_fma_whi(v1.x, w01, pk_mul_wlo(v0.x, w01))));
-  r.y = pk_fma_whi(v3.y, w23, pk_fma_wlo(v2.y, w23, pk_fma_whi(v1.y, w01, pk_mul_wlo(v0.y, w01))));
-  r.z = pk_fma_whi(v3.z, w23, pk_fma_wlo(v2.z, w23, pk_fma_whi(v1.z, w01, pk_mul_wlo(v0.z, w01))));
-  r.w = pk_fma_whi(v3.w, w23, pk_fma_wlo(v2.w, w23, pk_fma_whi(v1.w, w01, pk_mul_wlo(v0.w, w01))));
+  r.x = r0; r.y = r1; r.z = r2; r.w = r3;
   return r;
 }
 
-template <int BC, int WP, int WC_, int NST, typename TOut>
+template <int BC, int NST, typename TOut>
 __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
   constexpr int TH = 8, TW = 16, BP = 128, MG = 4;
   constexpr int WR = TH + 2 + 2 * MG, WCOLS = TW + 2 + 2 * MG;  // 18 x 26 window pixels
   constexpr int NPIECE = WR * WCOLS * 4;                        // 1872 16-byte pieces
   constexpr int W_LD = (NPIECE + 255) / 256;                    // 8 DMA rounds; the last one only on waves 0-1
   constexpr int WINB = ((NPIECE + 63) / 64) * 1024;             // 30720
-  constexpr int TP = BP / WP / 16, TC = BC / WC_ / 16;
-  constexpr int BCL = BC < 64 ? 64 : BC, B_LD = BCL / 64, WST = BCL * 64;
+  constexpr int GEOW = 9 * BP * 8, GEOO = 9 * BP * 4;           // staged geometry: 4 f16 weights, window offset
+  constexpr int TP = 2, TC = BC / 16;                           // wave = 32 pixels (2 tile rows) x all BC couts
+  constexpr int B_LD = BC / 64, WST = BC * 64;
   constexpr int PF = NST - 1;                                   // weight stages in flight ahead of the consumer
-  static_assert(WP * WC_ == 4, "4 waves");
-  static_assert(WINB + 2 * BP * 64 + NST * WST + 16 <= 81920, "two workgroups per CU");
-  __shared__ __attribute__((aligned(16))) char smem[WINB + 2 * BP * 64 + NST * WST];
+  static_assert(BC % 64 == 0, "BC");
+  constexpr int SBB = 2 * BC * 4;                               // per-cout scale, bias (f32) for the epilogue
+  constexpr bool WPRE = BC == 64;                               // weight fragments fetched one step ahead
+  static_assert(WINB + GEOW + GEOO + NST * WST + SBB <= 81920, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) char smem[WINB + GEOW + GEOO + NST * WST + SBB];
   char* const win = smem;
-  char* const atile = smem + WINB;
-  char* const ring = smem + WINB + 2 * BP * 64;
-  __shared__ int s_dirty;
+  char* const geow = smem + WINB;
+  char* const geoo = smem + WINB + GEOW;
+  char* const ring = smem + WINB + GEOW + GEOO;
+  float* const sbuf = (float*)(smem + WINB + GEOW + GEOO + NST * WST);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wp = wave / WC_, wc = wave % WC_;
   const int tiles_x = a.W / TW, tiles_y = a.H / TH;
   int m_tile, n_tile;
   if (!tile_of_block(a.B * tiles_y * tiles_x, a.Cout_pad / BC, m_tile, n_tile)) return;
@@ -924,11 +947,10 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
   const f16* wptr[B_LD];
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
-    const int L = lrow + 64 * j;
-    const int Lw = L % (16 * TC), wv = L / (16 * TC);
-    const int tt = Lw >> 4, r = Lw & 15;
-    const int cl = wv * 16 * TC + 4 * TC * (r >> 2) + 4 * tt + (r & 3);
-    wptr[j] = (const f16*)a.w + (long)(n0 + (L < BC ? cl : 0)) * a.Kpad + gwk * 8;
+    const int L = lrow + 64 * j;                 // LDS row; holds cout cl so that lane (fr, q) finds couts 4*TC*q.. contiguous
+    const int tt = L >> 4, r = L & 15;
+    const int cl = 4 * TC * (r >> 2) + 4 * tt + (r & 3);
+    wptr[j] = (const f16*)a.w + (long)(n0 + cl) * a.Kpad + gwk * 8;
   }
   auto issue_w = [&](int kt) {
     const int st = kt % NST;
@@ -944,7 +966,9 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
     const int wr = pw / WCOLS, wcn = pw - wr * WCOLS;
     const int y = wy0 + wr, x = wx0 + wcn;
     const bool ok = pid < NPIECE && y >= 0 && y < a.H && x >= 0 && x < a.W;
-    wofs[i] = ok ? (y * a.W + x) * a.in_stride + sl * 8 : -1;
+    // LDS slot sl of a pixel in an odd window row holds channel group sl^2: the 16 lanes of one ds_read_b128 phase
+    // (8 pixels of one group q, 8 of another, over two rows) then touch 16 different 16-byte bank groups
+    wofs[i] = ok ? (y * a.W + x) * a.in_stride + (sl ^ (2 * (wr & 1))) * 8 : -1;
   }
   auto issue_window = [&](int chunk) {
 #pragma unroll
@@ -960,90 +984,121 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
   for (int i = 0; i < PF; ++i)
     if (i < nk) issue_w(i);
 
-  // ---- this thread's pixel (two k-groups of it) and its sampling geometry for the 9 taps ----
-  const int pl = tid >> 1, kg0 = (tid & 1) * 2;    // tile-local pixel 0..127, k-groups kg0, kg0+1
-  const int py = ty0 + (pl >> 4), pxx = tx0 + (pl & 15);
-  const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
-  float omv[28];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const float4 v = ((const float4*)omrow)[i];
-    omv[4 * i] = v.x; omv[4 * i + 1] = v.y; omv[4 * i + 2] = v.z; omv[4 * i + 3] = v.w;
+  if (tid < BC) {
+    const int c = n0 + tid;
+    sbuf[tid] = (a.scale && c < a.Cout) ? a.scale[c] : 1.f;
+    sbuf[BC + tid] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
   }
-  unsigned gofs[9];           // window byte offset of corner (h_low, w_low)
-  unsigned gw01[9], gw23[9];  // f16 pairs: w0|w1, w2|w3  (bilinear weight * sigmoid(mask), 0 for invalid corners)
-  bool out_of_window = false;
-  if (tid == 0) s_dirty = 0;
+  // ---- sampling geometry, once per (pixel, tap): thread = pixel gp, taps gh, gh+2, ... ----
+  {
+    const int gp = tid & 127, gh = tid >> 7;
+    const int py = ty0 + (gp >> 4), pxx = tx0 + (gp & 15);
+    const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
+    float oh[5], ow[5], om_[5];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int tr = t / 3, ts = t % 3;
-    const float h_im = (float)(py - 1 + tr) + omv[2 * t], w_im = (float)(pxx - 1 + ts) + omv[2 * t + 1];
-    const float mraw = omv[18 + t];
-    const float mk = a.mask_is_prob ? mraw : __builtin_amdgcn_rcpf(1.f + __expf(-mraw));
-    unsigned off = 0;
-    float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
-    if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
-      const float fh = floorf(h_im), fw = floorf(w_im);
-      const int h_low = (int)fh, w_low = (int)fw;
-      const float lh = h_im - fh, lw = w_im - fw, hh = 1.f - lh, hw = 1.f - lw;
-      const bool r0 = h_low >= 0, r1 = h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
-      // corners outside the image contribute 0 (deform_conv_cuda_kernel.cu:259-266): zero their weights
-      w0 = (r0 && c0) ? hh * hw * mk : 0.f; w1 = (r0 && c1) ? hh * lw * mk : 0.f;
-      w2 = (r1 && c0) ? lh * hw * mk : 0.f; w3 = (r1 && c1) ? lh * lw * mk : 0.f;
-      const int wr = h_low - wy0, wcn = w_low - wx0;  // window coordinates of corner 0
-      // every in-image corner must lie inside the window rows/cols [0, WR) x [0, WCOLS)
-      if (((r0 && (c0 || c1)) && (wr < 0 || wr >= WR)) || ((r1 && (c0 || c1)) && (wr + 1 < 0 || wr + 1 >= WR)) ||
-          ((c0 && (r0 || r1)) && (wcn < 0 || wcn >= WCOLS)) || ((c1 && (r0 || r1)) && (wcn + 1 < 0 || wcn + 1 >= WCOLS)))
-        out_of_window = true;
-      off = (unsigned)((wr * WCOLS + wcn) * 64) & 0xFFFFu;
+    for (int i = 0; i < 5; ++i) {
+      const int t = 2 * i + gh;
+      const bool on = t < 9;
+      oh[i] = on ? omrow[2 * t] : 0.f; ow[i] = on ? omrow[2 * t + 1] : 0.f; om_[i] = on ? omrow[18 + t] : 0.f;
     }
-    gofs[t] = off;
-    const f16 h0 = (f16)w0, h1 = (f16)w1, h2 = (f16)w2, h3 = (f16)w3;
-    gw01[t] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-    gw23[t] = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int t = 2 * i + gh;
+      if (t < 9) {
+        const int tr = t / 3, ts = t - 3 * tr;
+        const float h_im = (float)(py - 1 + tr) + oh[i], w_im = (float)(pxx - 1 + ts) + ow[i];
+        const float mk = a.mask_is_prob ? om_[i] : __builtin_amdgcn_rcpf(1.f + __expf(-om_[i]));
+        const float fh = floorf(h_im), fw = floorf(w_im);
+        const int h_low = (int)fh, w_low = (int)fw;
+        const float lh = h_im - fh, lw = w_im - fw, hh = 1.f - lh, hw = 1.f - lw;
+        const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W;
+        const bool r0 = valid && h_low >= 0, r1 = valid && h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
+        // corners outside the image contribute 0 (deform_conv_cuda_kernel.cu:259-266): zero their weights
+        const float w0 = (r0 && c0) ? hh * hw * mk : 0.f, w1 = (r0 && c1) ? hh * lw * mk : 0.f;
+        const float w2 = (r1 && c0) ? lh * hw * mk : 0.f, w3 = (r1 && c1) ? lh * lw * mk : 0.f;
+        const int wr = h_low - wy0, wcn = w_low - wx0;  // window coordinates of corner 0
+        // in a valid sample every in-image corner must lie inside the window; out-of-image corners then do too
+        // (they are 1 px outside the image, the window reaches 5 px past the tile and is zero-filled there)
+        const bool inside = wr >= 0 && wr + 1 < WR && wcn >= 0 && wcn + 1 < WCOLS;
+        const bool oow = valid && !inside;
+        const unsigned off = (valid && inside) ? (unsigned)((wr * WCOLS + wcn) * 64) : 0u;
+        const f16 h0 = (f16)w0, h1 = (f16)w1, h2 = (f16)w2, h3 = (f16)w3;
+        uint2 wv;
+        wv.x = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+        wv.y = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
+        *(uint2*)(geow + (t * BP + gp) * 8) = wv;
+        *(unsigned*)(geoo + (t * BP + gp) * 4) = off | ((unsigned)(wr & 1) << 16) | (oow ? 0x80000000u : 0u);
+      }
+    }
   }
-  __syncthreads();
-  if (out_of_window) s_dirty = 1;
-  __syncthreads();
-  const bool slow = s_dirty != 0;  // block-uniform
+  wait_vmcnt<0>();     // window of chunk 0 (and the first weight stages) landed for this wave's DMAs
+  __syncthreads();     // ... and for everyone's; geometry staged
+  // ---- consumer mapping: lane (fr, q) blends tile pixel (row 2*wave + fr/8, col 8p + fr%8), channels 8q..8q+7 of
+  // the chunk: exactly the B-operand fragment of mfma_f32_16x16x32_f16 for the wave's pixel tile p (2 rows x 8) ----
+  const int fr = lane & 15, q = lane >> 4;
+  const int prow = 2 * wave + (fr >> 3), pcol = fr & 7;
+  unsigned gofs[TP][9], gw01[TP][9], gw23[TP][9];
+  unsigned oow_bits = 0;
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int px = prow * 16 + 8 * p + pcol;
+      const uint2 wv = *(const uint2*)(geow + (t * BP + px) * 8);
+      const unsigned o = *(const unsigned*)(geoo + (t * BP + px) * 4);
+      gw01[p][t] = wv.x; gw23[p][t] = wv.y;
+      gofs[p][t] = (o & 0xFFFFu) + ((q ^ (2 * ((o >> 16) & 1u))) << 4);
+      oow_bits |= (o >> 31) << t;
+    }
+  // taps for which some lane of this wave samples outside the window take the global-gather path (wave-uniform)
+  unsigned slow_taps = 0;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+    if (__builtin_amdgcn_ballot_w64((oow_bits >> t) & 1u) != 0) slow_taps |= 1u << t;
+  slow_taps = __builtin_amdgcn_readfirstlane(slow_taps);
 
-  // A-tile row of this thread's pixel; slot swizzle as in the tiled kernels
-  const int arow = pl * 64;
-  const int aslot0 = ((kg0 ^ swz(pl)) << 4), aslot1 = (((kg0 + 1) ^ swz(pl)) << 4);
-  // A tile (sampled * mask, f16) of tap t -> buffer ab.  Fast: corners from the LDS window, no validity selects
-  // (the window is zero-filled outside the image and invalid corners carry weight 0; in a clean tile every corner
-  // of a valid sample lies inside the window).
-  auto build_fast = [&](int t, int ab) {
-    const char* c0p = win + gofs[t] + kg0 * 16;
-    char* dst = atile + ab * (BP * 64) + arow;
-    const u32x4 p0 = *(const u32x4*)(c0p), p1 = *(const u32x4*)(c0p + 64);
-    const u32x4 p2 = *(const u32x4*)(c0p + WCOLS * 64), p3 = *(const u32x4*)(c0p + WCOLS * 64 + 64);
-    const u32x4 q0 = *(const u32x4*)(c0p + 16), q1 = *(const u32x4*)(c0p + 80);
-    const u32x4 q2 = *(const u32x4*)(c0p + WCOLS * 64 + 16), q3 = *(const u32x4*)(c0p + WCOLS * 64 + 80);
-    *(u32x4*)(dst + aslot0) = dcn_blend(p0, p1, p2, p3, gw01[t], gw23[t]);
-    *(u32x4*)(dst + aslot1) = dcn_blend(q0, q1, q2, q3, gw01[t], gw23[t]);
+  typedef const u32x4 __attribute__((address_space(1)))* gp16;
+  // fast gather: the 4 corner fragments of tap t for both pixel tiles, from the LDS window (blended later, behind
+  // the MFMAs of the current step)
+  auto gather_lds = [&](int t, u32x4 (&v)[TP][4]) {
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const char* c0p = win + gofs[p][t];
+      const char* c2p = win + (gofs[p][t] ^ 32u) + WCOLS * 64;  // next window row: the other slot swizzle
+      v[p][0] = *(const u32x4*)(c0p);
+      v[p][1] = *(const u32x4*)(c0p + 64);
+      v[p][2] = *(const u32x4*)(c2p);
+      v[p][3] = *(const u32x4*)(c2p + 64);
+    }
   };
-  // Slow: same arithmetic, corners straight from global memory (samples beyond the window margin)
-  auto build_slow = [&](int t, int chunk, int ab) {
+  // slow gather (some lane of the wave samples outside the window for this tap): corners from global memory,
+  // blended right away so that no global load is pending when control flow joins the fast path again (the
+  // compiler would otherwise put vmcnt(0) waits -- which also wait for the weight prefetch -- into the fast path).
+  // Corner coordinates are recomputed from the offsets with the arithmetic of the staging pass; corners outside
+  // the image read the zero page, their weights are 0 as well.
+  auto gather_global = [&](int t, int chunk, f16x8 (&pf)[TP]) {
     const int tr = t / 3, ts = t % 3;
-    const float h_im = (float)(py - 1 + tr) + omrow[2 * t], w_im = (float)(pxx - 1 + ts) + omrow[2 * t + 1];
-    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-    const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W;
-    const bool r0 = valid && h_low >= 0, r1 = valid && h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
-    char* dst = atile + ab * (BP * 64) + arow;
-    // corners outside the image read the zero page (their weights are 0 as well): plain global pointers, no selects
-    // on the loaded values
-    const long o0 = ((long)h_low * a.W + w_low) * a.in_stride, o2 = o0 + (long)a.W * a.in_stride;
-    const f16* base = ximg + chunk * 32 + kg0 * 8;
-    const f16* c0p = (r0 && c0) ? base + o0 : zero;
-    const f16* c1p = (r0 && c1) ? base + o0 + a.in_stride : zero;
-    const f16* c2p = (r1 && c0) ? base + o2 : zero;
-    const f16* c3p = (r1 && c1) ? base + o2 + a.in_stride : zero;
-    typedef const u32x4 __attribute__((address_space(1)))* gp16;  // global_load, not flat (the selects hide the space)
-    const u32x4 p0 = *(gp16)c0p, p1 = *(gp16)c1p, p2 = *(gp16)c2p, p3 = *(gp16)c3p;
-    const u32x4 q0 = *(gp16)(c0p + 8), q1 = *(gp16)(c1p + 8), q2 = *(gp16)(c2p + 8), q3 = *(gp16)(c3p + 8);
-    *(u32x4*)(dst + aslot0) = dcn_blend(p0, p1, p2, p3, gw01[t], gw23[t]);
-    *(u32x4*)(dst + aslot1) = dcn_blend(q0, q1, q2, q3, gw01[t], gw23[t]);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const int py = ty0 + prow, pxx = tx0 + 8 * p + pcol;
+      const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
+      const float h_im = (float)(py - 1 + tr) + omrow[2 * t], w_im = (float)(pxx - 1 + ts) + omrow[2 * t + 1];
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W;
+      const bool r0 = valid && h_low >= 0, r1 = valid && h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
+      const long o0 = ((long)h_low * a.W + w_low) * a.in_stride, o2 = o0 + (long)a.W * a.in_stride;
+      const f16* base = ximg + chunk * 32 + q * 8;
+      const u32x4 v0 = *(gp16)((r0 && c0) ? base + o0 : zero);
+      const u32x4 v1 = *(gp16)((r0 && c1) ? base + o0 + a.in_stride : zero);
+      const u32x4 v2 = *(gp16)((r1 && c0) ? base + o2 : zero);
+      const u32x4 v3 = *(gp16)((r1 && c1) ? base + o2 + a.in_stride : zero);
+      pf[p] = __builtin_bit_cast(f16x8, dcn_blend(v0, v1, v2, v3, gw01[p][t], gw23[p][t]));
+    }
+  };
+  auto blend_lds = [&](int t, const u32x4 (&v)[TP][4], f16x8 (&pf)[TP]) {
+#pragma unroll
+    for (int p = 0; p < TP; ++p)
+      pf[p] = __builtin_bit_cast(f16x8, dcn_blend(v[p][0], v[p][1], v[p][2], v[p][3], gw01[p][t], gw23[p][t]));
   };
 
   f32x4 acc[TP][TC];
@@ -1051,48 +1106,66 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
   for (int p = 0; p < TP; ++p)
 #pragma unroll
     for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int fr = lane & 15;
-  const int frag_off = fr * 64 + (((lane >> 4) ^ swz(fr)) << 4);
-  const char* fragA = atile + (wp * 16 * TP) * 64 + frag_off;
-  const char* fragB = ring + (wc * 16 * TC) * 64 + frag_off;
+  const char* fragB = ring + fr * 64 + ((q ^ swz(fr)) << 4);
 
-  // A tile of step 0: the window must be complete for every wave (explicit wait + barrier)
-  if (!slow) { wait_vmcnt<0>(); __syncthreads(); build_fast(0, 0); }
-  else build_slow(0, 0, 0);
+  f16x8 pf[TP];  // B operands (sampled * mask) of the step about to run
+  {
+    u32x4 raw[TP][4];
+    if (!(slow_taps & 1u)) { gather_lds(0, raw); blend_lds(0, raw, pf); }
+    else gather_global(0, 0, pf);
+  }
 
-  // K step kt = (chunk, tap T): weights(kt) + A(kt) are consumed; A(kt+1) is built while the MFMAs run
+  // K step kt = (chunk, tap T): MFMAs of tap T against weight stage kt, with the gather + blend of tap T+1 around
+  // them.  WPRE: the weight fragments of step kt+1 are fetched during step kt, so the barrier of step kt also
+  // vouches for stage kt+1 (one stage less in flight).
+  f16x8 wf[TC];
+  if constexpr (WPRE) {
+#pragma unroll
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(fragB + c * 1024);  // stage 0 (landed: prologue wait)
+  }
   auto kstep = [&](int kt, int chunk, auto tapc) {
     constexpr int T = decltype(tapc)::value;
-    const int ab = kt & 1;
-    const int st = kt % NST;
-    if (kt + PF - 1 < nk) wait_vmcnt<(PF - 1) * B_LD>(); else wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // A(kt) complete, weights(kt) landed, everyone left step kt-1
+    constexpr int TN = (T + 1) % 9;                    // tap whose operands are produced during this step
+    constexpr int KEEP = WPRE ? PF - 2 : PF - 1;       // younger weight stages that may still be in flight
+    const bool more = T < 8;                           // T == 8: the next tap belongs to the next chunk (see below)
+    const bool slow_next = (slow_taps >> TN) & 1u;     // wave-uniform
+    if (kt + PF - 1 < nk) wait_vmcnt<KEEP * B_LD>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                      // stage kt (WPRE: kt+1) landed for all; everyone left step kt-1
     if (kt + PF < nk) issue_w(kt + PF);                // into the stage step kt-1 consumed
-    f16x8 wf[TC], pf[TP];
-    const char* ap = fragA + ab * (BP * 64);
+    if (T == 8 && chunk + 1 < nch) issue_window(chunk + 1);  // every wave's gathers of this chunk are complete
+    f16x8 wfn[TC], pfn[TP];
+    u32x4 raw[TP][4];
+    if constexpr (WPRE) {
+      if (kt + 1 < nk) {
+        const int st = (kt + 1) % NST;
 #pragma unroll
-    for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(fragB + st * WST + c * 1024);
+        for (int c = 0; c < TC; ++c) wfn[c] = *(const f16x8*)(fragB + st * WST + c * 1024);
+      }
+    } else {
+      const int st = kt % NST;
 #pragma unroll
-    for (int p = 0; p < TP; ++p) pf[p] = *(const f16x8*)(ap + p * 1024);
-    if (T < 8) {
-      if (!slow) build_fast(T + 1, ab ^ 1); else build_slow(T + 1, chunk, ab ^ 1);
-    } else if (chunk + 1 < nch && !slow) {
-      issue_window(chunk + 1);                         // every build of this chunk is done (barrier above)
+      for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(fragB + st * WST + c * 1024);
+    }
+    if (more) {
+      if (!slow_next) gather_lds(TN, raw); else gather_global(TN, chunk, pfn);
     }
 #pragma unroll
     for (int p = 0; p < TP; ++p)
 #pragma unroll
       for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf[p], acc[p][c], 0, 0, 0);
-    if (T == 8 && chunk + 1 < nch) {
-      // first A tile of the next chunk: needs its window (fast path) -- waited for behind this step's MFMAs
-      if (!slow) {
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        build_fast(0, ab ^ 1);
-      } else {
-        build_slow(0, chunk + 1, ab ^ 1);
-      }
+    if (more) {
+      if (!slow_next) blend_lds(TN, raw, pfn);
+    } else if (chunk + 1 < nch) {
+      wait_vmcnt<0>();                                 // next chunk's window, behind this step's MFMAs
+      __builtin_amdgcn_s_barrier();
+      if (!slow_next) { gather_lds(0, raw); blend_lds(0, raw, pfn); }
+      else gather_global(0, chunk + 1, pfn);
+    }
+#pragma unroll
+    for (int p = 0; p < TP; ++p) pf[p] = pfn[p];
+    if constexpr (WPRE) {
+#pragma unroll
+      for (int c = 0; c < TC; ++c) wf[c] = wfn[c];
     }
   };
   for (int chunk = 0; chunk < nch; ++chunk) {
@@ -1108,14 +1181,44 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
     kstep(kt + 8, chunk, std::integral_constant<int, 8>{});
   }
 
-  const int q = lane >> 4;
-  const int cb = n0 + wc * 16 * TC + 4 * TC * q;
+  // epilogue: lane holds 4*TC consecutive couts of 2 pixels; scale/bias from LDS, 16-byte stores
+  const int cl = 4 * TC * q;  // first cout of this lane inside the BC tile
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
-    const int l = wp * 16 * TP + 16 * p + fr;  // tile-local pixel
-    const int m = (b * a.H + ty0 + (l >> 4)) * a.W + tx0 + (l & 15);
+    const long m = (long)(b * a.H + ty0 + prow) * a.W + tx0 + 8 * p + pcol;
+    TOut* yp = (TOut*)a.y + m * a.out_stride + n0 + cl;
 #pragma unroll
-    for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cb + 4 * c, acc[p][c]);
+    for (int c = 0; c < TC; c += 2) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int cc = cl + 4 * c + j;
+        float t = acc[p][c + (j >> 2)][j & 3] * sbuf[cc] + sbuf[BC + cc];
+        if (a.act == CTDET_ACT_RELU) t = fmaxf(t, 0.f);
+        else if (a.act == CTDET_ACT_SIGMOID_CLAMP) t = fminf(fmaxf(ctdet_sigmoid_exact(t), a.clamp_lo), a.clamp_hi);
+        v[j] = t;
+      }
+      if (n0 + cl + 4 * c + 8 <= a.Cout) {
+        if constexpr (sizeof(TOut) == 2) {
+          f16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
+          *(f16x8*)(yp + 4 * c) = o;
+        } else {
+          *(f32x4*)(yp + 4 * c) = (f32x4){v[0], v[1], v[2], v[3]};
+          *(f32x4*)(yp + 4 * c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        }
+      } else if (n0 + cl + 4 * c + 4 <= a.Cout) {   // Cout % 4 == 0: a group of 4 is all-in or all-out
+        if constexpr (sizeof(TOut) == 2) {
+          f16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (f16)v[j];
+          *(f16x4*)(yp + 4 * c) = o;
+        } else {
+          *(f32x4*)(yp + 4 * c) = (f32x4){v[0], v[1], v[2], v[3]};
+        }
+      }
+    }
   }
 }
 
@@ -1123,7 +1226,7 @@ template <int BC, int WP, int WC_, typename TOut>
 static int launch_dcn_window(const ConvArgs& a, hipStream_t s) {
   const int nbx = a.B * (a.H / 8) * (a.W / 16), nby = a.Cout_pad / BC;
   dim3 grid(8 * ((nbx + 7) / 8) * nby);
-  hipLaunchKernelGGL((dcn_window_kernel<BC, WP, WC_, (BC > 64 ? 4 : 8), TOut>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((dcn_window_kernel<BC, (BC > 64 ? 4 : 8), TOut>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
@@ -1366,7 +1469,8 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   if (deform && a.korder == 1) {
     // chunk-major weights: LDS-window kernel (3x3/s1/p1, map divisible by the 8x16 tile)
     CTDET_CHECK(a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Cin % 32 == 0 && a.H % 8 == 0 &&
-                    a.W % 16 == 0 && a.Kpad == a.K && a.om_stride % 4 == 0 && ((size_t)a.om & 15) == 0,
+                    a.W % 16 == 0 && a.Kpad == a.K && a.om_stride % 4 == 0 && ((size_t)a.om & 15) == 0 && !a.res &&
+                    a.out_stride % 8 == 0 && ((size_t)a.y & 15) == 0,
                 "dcnv2(window): unsupported geometry");
     if (bc == 128) return launch_dcn_window<128, 2, 2, TOut>(a, s);
     if (bc == 64) return launch_dcn_window<64, 2, 2, TOut>(a, s);
