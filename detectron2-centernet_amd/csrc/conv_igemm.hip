@@ -105,6 +105,73 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs& a, int m, int c,
   }
 }
 
+// Cout (relative to the wave's first one) held in accumulator element i of cout tile c by the lanes of quad-group q
+// (q = lane / 16).  Tiles pair up: a lane owns 8 consecutive couts per pair, so one 16-byte store per lane lets the
+// four q-lanes of a pixel write 64 contiguous bytes (whole 32-byte sectors; the 8-byte pieces of the unpaired layout
+// left every sector to be completed by four separate store instructions, and the store tail of a tile cost as much
+// as a dozen K steps).  The weight loaders place LDS row (tile tt, row r) = cout_of(tt, r / 4, r % 4) to match.
+template <int TC>
+__device__ __forceinline__ constexpr int cout_of(int c, int q, int i) {
+  if (TC % 2 == 0) return (c >> 1) * 32 + q * 8 + (c & 1) * 4 + i;
+  return 4 * TC * q + 4 * c + i;
+}
+
+// scale/bias/residual/activation + store of the TC accumulator tiles one lane holds for output pixel m;
+// cbase = first cout of the wave.
+template <typename TOut, int TC>
+__device__ __forceinline__ void epilogue_tiles(const ConvArgs& a, int m, int cbase, int q, const f32x4 (&acc)[TC]) {
+  if constexpr (TC % 2 != 0) {
+#pragma unroll
+    for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cbase + cout_of<TC>(c, q, 0), acc[c]);
+  } else {
+    constexpr int VEC = 16 / sizeof(TOut);  // elements per 16-byte store
+    const bool wide = (a.out_stride % VEC) == 0 && (((size_t)a.y) & 15) == 0 &&
+                      (!a.res || ((a.res_stride % VEC) == 0 && (((size_t)a.res) & 15) == 0));
+#pragma unroll
+    for (int h = 0; h < TC / 2; ++h) {
+      const int c0 = cbase + h * 32 + q * 8;
+      if (!wide || c0 + 8 > a.Cout) {
+        epilogue_store4<TOut>(a, m, c0, acc[2 * h]);
+        epilogue_store4<TOut>(a, m, c0 + 4, acc[2 * h + 1]);
+        continue;
+      }
+      f32x4 v0 = acc[2 * h], v1 = acc[2 * h + 1];
+      if (a.scale) { v0 = v0 * *(const f32x4*)(a.scale + c0); v1 = v1 * *(const f32x4*)(a.scale + c0 + 4); }
+      if (a.bias) { v0 = v0 + *(const f32x4*)(a.bias + c0); v1 = v1 + *(const f32x4*)(a.bias + c0 + 4); }
+      if (a.res) {
+        const TOut* rp = (const TOut*)a.res + (long)m * a.res_stride + c0;
+        if constexpr (sizeof(TOut) == 2) {
+          const f16x8 r = *(const f16x8*)rp;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v0[j] += (float)r[j]; v1[j] += (float)r[4 + j]; }
+        } else {
+          v0 = v0 + *(const f32x4*)rp; v1 = v1 + *(const f32x4*)(rp + 4);
+        }
+      }
+      if (a.act == CTDET_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); }
+      } else if (a.act == CTDET_ACT_SIGMOID_CLAMP) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v0[j] = fminf(fmaxf(ctdet_sigmoid_exact(v0[j]), a.clamp_lo), a.clamp_hi);
+          v1[j] = fminf(fmaxf(ctdet_sigmoid_exact(v1[j]), a.clamp_lo), a.clamp_hi);
+        }
+      }
+      TOut* yp = (TOut*)a.y + (long)m * a.out_stride + c0;
+      if constexpr (sizeof(TOut) == 2) {
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = (f16)v0[j]; o[4 + j] = (f16)v1[j]; }
+        *(f16x8*)yp = o;
+      } else {
+        *(f32x4*)yp = v0;
+        *(f32x4*)(yp + 4) = v1;
+      }
+    }
+  }
+}
+
 // DCNv2 tiles are 8 x 16 pixel patches (when the map allows) instead of 128-pixel row strips: the bilinear-corner
 // gathers of neighbouring pixels/taps then overlap inside a ~23 KB window that stays in the 32 KB L1.
 __device__ __forceinline__ int dcn_pixel_of(const ConvArgs& a, int m) {
@@ -157,7 +224,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs a) {
     const int L = lrow + 64 * j;
     const int Lw = L % (16 * TC), wv = L / (16 * TC);
     const int tt = Lw >> 4, r = Lw & 15;
-    const int cl = wv * 16 * TC + 4 * TC * (r >> 2) + 4 * tt + (r & 3);
+    const int cl = wv * 16 * TC + cout_of<TC>(tt, r >> 2, r & 3);
     b_off[j] = (long)(n0 + cl) * a.Kpad + g * 8;
   }
   const bool b_ld = lrow < BC;
@@ -301,14 +368,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs a) {
 
   // ---- epilogue: lane holds couts [cb, cb+4*TC) of pixel m for every pixel tile ----
   const int q = lane >> 4;
-  const int cb = n0 + wc * 16 * TC + 4 * TC * q;
+  const int cb = n0 + wc * 16 * TC;
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
     const int mlin = m0 + wp * 16 * TP + 16 * p + fr;
     if (mlin >= a.M) continue;
     const int m = DEFORM ? dcn_pixel_of(a, mlin) : mlin;
-#pragma unroll
-    for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cb + 4 * c, acc[p][c]);
+    epilogue_tiles<TOut, TC>(a, m, cb, q, acc[p]);
   }
 }
 
@@ -398,7 +464,7 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(const ConvArgs a) {
     const int L = lrow + 64 * j;
     const int Lw = L % (16 * TC), wv = L / (16 * TC);
     const int tt = Lw >> 4, r = Lw & 15;
-    const int cl = wv * 16 * TC + 4 * TC * (r >> 2) + 4 * tt + (r & 3);
+    const int cl = wv * 16 * TC + cout_of<TC>(tt, r >> 2, r & 3);
     b_ok[j] = L < BC;
     b_off[j] = (long)(n0 + (b_ok[j] ? cl : 0)) * a.Kpad + g * 8;
   }
@@ -488,13 +554,12 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(const ConvArgs a) {
   }
 
   const int q = lane >> 4;
-  const int cb = n0 + wc * 16 * TC + 4 * TC * q;
+  const int cb = n0 + wc * 16 * TC;
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
     const int m = m0 + wp * 16 * TP + 16 * p + fr;
     if (m >= a.M) continue;
-#pragma unroll
-    for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cb + 4 * c, acc[p][c]);
+    epilogue_tiles<TOut, TC>(a, m, cb, q, acc[p]);
   }
 }
 
@@ -563,7 +628,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_uk_kernel(const ConvArgs a)
     const int L = lrow + 64 * j;
     const int Lw = L % (16 * TC), wv = L / (16 * TC);
     const int tt = Lw >> 4, r = Lw & 15;
-    const int cl = wv * 16 * TC + 4 * TC * (r >> 2) + 4 * tt + (r & 3);
+    const int cl = wv * 16 * TC + cout_of<TC>(tt, r >> 2, r & 3);
     // rows beyond BC (only when BC < 64) re-read packed row 0: harmless, their LDS rows are never consumed
     wptr[j] = (const f16*)a.w + (long)(n0 + (L < BC ? cl : 0)) * a.Kpad + g * 8;
   }
@@ -654,13 +719,12 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_uk_kernel(const ConvArgs a)
   if (kt < nk) { kstep(kt, I1{}, I0{}); ++kt; }
 
   const int q = lane >> 4;
-  const int cb = n0 + wc * 16 * TC + 4 * TC * q;
+  const int cb = n0 + wc * 16 * TC;
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
     const int m = m0 + wp * 16 * TP + 16 * p + fr;
     if (m >= a.M) continue;
-#pragma unroll
-    for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cb + 4 * c, acc[p][c]);
+    epilogue_tiles<TOut, TC>(a, m, cb, q, acc[p]);
   }
 }
 
@@ -729,7 +793,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const ConvArgs a) 
     const int L = lrow + 64 * j;
     const int Lw = L % (16 * TC), wv = L / (16 * TC);
     const int tt = Lw >> 4, r = Lw & 15;
-    const int cl = wv * 16 * TC + 4 * TC * (r >> 2) + 4 * tt + (r & 3);
+    const int cl = wv * 16 * TC + cout_of<TC>(tt, r >> 2, r & 3);
     wptr[j] = (const f16*)a.w + (long)(n0 + (L < BC ? cl : 0)) * a.Kpad + gw * 8;
   }
   auto issue_halo = [&](int chunk, int hb) {
@@ -822,13 +886,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const ConvArgs a) 
   if (chunk < nch) chunk_steps(chunk * 9, chunk, std::integral_constant<int, 0>{});
 
   const int q = lane >> 4;
-  const int cb = n0 + wc * 16 * TC + 4 * TC * q;
+  const int cb = n0 + wc * 16 * TC;
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
     const int y = ty0 + row0 + (p >> 1), x = tx0 + 16 * (p & 1) + l15;
     const int m = (b * a.H + y) * a.W + x;
-#pragma unroll
-    for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cb + 4 * c, acc[p][c]);
+    epilogue_tiles<TOut, TC>(a, m, cb, q, acc[p]);
   }
 }
 
@@ -949,7 +1012,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
   for (int j = 0; j < B_LD; ++j) {
     const int L = lrow + 64 * j;                 // LDS row; holds cout cl so that lane (fr, q) finds couts 4*TC*q.. contiguous
     const int tt = L >> 4, r = L & 15;
-    const int cl = 4 * TC * (r >> 2) + 4 * tt + (r & 3);
+    const int cl = cout_of<TC>(tt, r >> 2, r & 3);
     wptr[j] = (const f16*)a.w + (long)(n0 + cl) * a.Kpad + gwk * 8;
   }
   auto issue_w = [&](int kt) {
@@ -1181,41 +1244,41 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
     kstep(kt + 8, chunk, std::integral_constant<int, 8>{});
   }
 
-  // epilogue: lane holds 4*TC consecutive couts of 2 pixels; scale/bias from LDS, 16-byte stores
-  const int cl = 4 * TC * q;  // first cout of this lane inside the BC tile
+  // epilogue: per cout-tile pair h a lane holds 8 consecutive couts (cout_of) of 2 pixels; scale/bias from LDS,
+  // 16-byte stores
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
     const long m = (long)(b * a.H + ty0 + prow) * a.W + tx0 + 8 * p + pcol;
-    TOut* yp = (TOut*)a.y + m * a.out_stride + n0 + cl;
 #pragma unroll
-    for (int c = 0; c < TC; c += 2) {
+    for (int h = 0; h < TC / 2; ++h) {
+      const int cl = h * 32 + q * 8;  // first of the lane's 8 couts inside the BC tile
+      TOut* yp = (TOut*)a.y + m * a.out_stride + n0 + cl;
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int cc = cl + 4 * c + j;
-        float t = acc[p][c + (j >> 2)][j & 3] * sbuf[cc] + sbuf[BC + cc];
+        float t = acc[p][2 * h + (j >> 2)][j & 3] * sbuf[cl + j] + sbuf[BC + cl + j];
         if (a.act == CTDET_ACT_RELU) t = fmaxf(t, 0.f);
         else if (a.act == CTDET_ACT_SIGMOID_CLAMP) t = fminf(fmaxf(ctdet_sigmoid_exact(t), a.clamp_lo), a.clamp_hi);
         v[j] = t;
       }
-      if (n0 + cl + 4 * c + 8 <= a.Cout) {
+      if (n0 + cl + 8 <= a.Cout) {
         if constexpr (sizeof(TOut) == 2) {
           f16x8 o;
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
-          *(f16x8*)(yp + 4 * c) = o;
+          *(f16x8*)yp = o;
         } else {
-          *(f32x4*)(yp + 4 * c) = (f32x4){v[0], v[1], v[2], v[3]};
-          *(f32x4*)(yp + 4 * c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+          *(f32x4*)yp = (f32x4){v[0], v[1], v[2], v[3]};
+          *(f32x4*)(yp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
         }
-      } else if (n0 + cl + 4 * c + 4 <= a.Cout) {   // Cout % 4 == 0: a group of 4 is all-in or all-out
+      } else if (n0 + cl + 4 <= a.Cout) {   // Cout % 4 == 0: a group of 4 is all-in or all-out
         if constexpr (sizeof(TOut) == 2) {
           f16x4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = (f16)v[j];
-          *(f16x4*)(yp + 4 * c) = o;
+          *(f16x4*)yp = o;
         } else {
-          *(f32x4*)(yp + 4 * c) = (f32x4){v[0], v[1], v[2], v[3]};
+          *(f32x4*)yp = (f32x4){v[0], v[1], v[2], v[3]};
         }
       }
     }
