@@ -1410,6 +1410,104 @@ static int launch_smallc(const ConvArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Small-channel layers, LDS-window form.  conv_smallc_kernel above re-reads every input pixel R*S times through L1
+// (the 7x7 stem 49 times): rocprof shows it L1-bandwidth bound at ~7x its HBM time.  Here a workgroup owns a TH x TW
+// output tile, brings the (TH*s + R - s) x (TW*s + R - s) input window into LDS once (dense rows, 16 or 32 bytes per
+// pixel) and every MFMA B fragment is one ds_read_b128 from it: lane (pixel, k-group) reads the 8 channels of tap
+// (r, s) at window pixel (y*s + r, x*s + s').  The weight fragments of the whole layer stay in registers (NK*TC*4
+// VGPRs).  One LDS address register per K step and lane; tile row/column offsets are instruction immediates.
+// ------------------------------------------------------------------------------------------
+template <int R, int CIN, int TC, int STRIDE, bool NOCHECK, typename TOut>
+__global__ void __launch_bounds__(256) conv_win_kernel(const ConvArgs a) {
+  constexpr int TH = STRIDE == 1 ? 16 : 8, TW = STRIDE == 1 ? 64 : 32;
+  constexpr int WH = (TH - 1) * STRIDE + R, WW = (TW - 1) * STRIDE + R;
+  constexpr int PB = CIN * 2;                       // bytes per pixel
+  constexpr int PPR = WW * PB / 16;                 // 16-byte pieces per window row
+  constexpr int NP = WH * PPR, ROUNDS = (NP + 255) / 256;
+  constexpr int K = R * R * CIN, NK = (K + 31) / 32;
+  constexpr int GPT = CIN / 8;                      // k-groups per tap
+  constexpr int NT = TW / 16, RW = TH / 4;          // pixel tiles per tile row; tile rows per wave
+  __shared__ __attribute__((aligned(16))) char win[ROUNDS * 4096];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, q = lane >> 4;
+  const int tiles_x = a.Wo / TW, tiles_y = a.Ho / TH;
+  const int tx0 = (blockIdx.x % tiles_x) * TW;
+  const int ty0 = ((blockIdx.x / tiles_x) % tiles_y) * TH;
+  const int b = blockIdx.x / (tiles_x * tiles_y);
+  const f16* zero = (const f16*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+  const f16* ximg = (const f16*)a.x + (long)b * a.H * a.W * a.in_stride;
+  const int iy0 = ty0 * STRIDE - a.pad, ix0 = tx0 * STRIDE - a.pad;   // image coordinates of window pixel (0,0)
+
+  // ---- window DMA: piece pid -> window row pid / PPR, 16-byte column pid % PPR (pixels are contiguous in memory:
+  // in_stride == CIN) ----
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    const int pid = tid + 256 * i;
+    const int wr = pid / PPR, cp = pid - wr * PPR;
+    const int y = iy0 + wr, x = ix0 + cp / (PB / 16);
+    bool ok = pid < NP;
+    if constexpr (!NOCHECK) ok = ok && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    dma16(ok ? ximg + ((long)y * a.W + ix0) * CIN + cp * 8 : zero, win + (wave * 64 + 256 * i) * 16);
+  }
+
+  // ---- weights: fragment (kt, c) of this lane = 8 k of cout row cout_of(c, fr/4, fr%4), straight into registers ----
+  f16x8 wf[NK][TC];
+#pragma unroll
+  for (int c = 0; c < TC; ++c) {
+    const f16* wr = (const f16*)a.w + (long)cout_of<TC>(c, fr >> 2, fr & 3) * a.Kpad + q * 8;
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) wf[kt][c] = *(const f16x8*)(wr + kt * 32);
+  }
+  // ---- per K step: LDS byte address of this lane's k-group for tile pixel (row 0 of the wave, column fr) ----
+  int kaddr[NK];
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt) {
+    const int G = kt * 4 + q;
+    const int tap = G / GPT;
+    const bool tail = tap >= R * R;                  // K tail: zero weights; read tap (0,0)
+    const int tr = tail ? 0 : tap / R, ts = tail ? 0 : tap - (tap / R) * R;
+    kaddr[kt] = ((wave * RW * STRIDE + tr) * WW + fr * STRIDE + ts) * PB + (tail ? 0 : (G - tap * GPT) * 16);
+  }
+  wait_vmcnt<0>();
+  __syncthreads();
+
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) {
+#pragma unroll
+    for (int tc = 0; tc < NT; ++tc) {
+      constexpr int dummy = 0; (void)dummy;
+      const int toff = (rr * STRIDE * WW + tc * 16 * STRIDE) * PB;   // compile time after unrolling
+      f32x4 acc[TC];
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < NK; ++kt) {
+        const f16x8 pf = *(const f16x8*)(win + kaddr[kt] + toff);
+#pragma unroll
+        for (int c = 0; c < TC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kt][c], pf, acc[c], 0, 0, 0);
+      }
+      const int m = (b * a.Ho + ty0 + wave * RW + rr) * a.Wo + tx0 + tc * 16 + fr;
+      epilogue_tiles<TOut, TC>(a, m, 0, q, acc);
+    }
+  }
+}
+
+template <int R, int CIN, int TC, int STRIDE, typename TOut>
+static int launch_win(const ConvArgs& a, hipStream_t s) {
+  constexpr int TH = STRIDE == 1 ? 16 : 8, TW = STRIDE == 1 ? 64 : 32;
+  const int blocks = a.B * (a.Ho / TH) * (a.Wo / TW);
+  if (a.pad == 0)  // pre-padded input (zero frame in memory): every tap of every pixel is in bounds
+    hipLaunchKernelGGL((conv_win_kernel<R, CIN, TC, STRIDE, true, TOut>), dim3(blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_win_kernel<R, CIN, TC, STRIDE, false, TOut>), dim3(blocks), dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // Exact-f32 direct form (parity mode): one thread per (pixel, cout), f32 FMA chain in k order.
 // Weights packed [Kpad][Cout_pad] f32.  Used to pin the algorithm against the oracle at 1e-5;
 // the f16 MFMA kernels above are the throughput path.
@@ -1552,6 +1650,15 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   CTDET_CHECK(a.R * a.S <= 64, "conv: at most 64 taps (R*S=%d)", a.R * a.S);
   if ((a.Cin == 8 || a.Cin == 16) && a.in_dil == 1 && a.korder == 0 && a.nsrc <= 1 && a.Wo % 64 == 0 && a.Cout_pad <= 32 && a.Cout_pad == bc) {
     const int nk = a.Kpad / 32;
+    // LDS-window form for the three DLA base layers (tile-divisible maps, contiguous pixels)
+    if (!getenv("CTDET_NO_WIN") && a.R == a.S && a.dil == 1 && a.in_stride == a.Cin && a.Kpad == nk * 32) {
+      if (a.R == 7 && a.Cin == 8 && bc == 16 && a.stride == 1 && a.Ho % 16 == 0 && a.Wo % 64 == 0 && (a.pad == 0 || a.pad == 3))
+        return launch_win<7, 8, 1, 1, TOut>(a, s);
+      if (a.R == 3 && a.Cin == 16 && bc == 16 && a.stride == 1 && a.Ho % 16 == 0 && a.Wo % 64 == 0 && a.pad == 1)
+        return launch_win<3, 16, 1, 1, TOut>(a, s);
+      if (a.R == 3 && a.Cin == 16 && bc == 32 && a.stride == 2 && a.Ho % 8 == 0 && a.Wo % 32 == 0 && a.pad == 1)
+        return launch_win<3, 16, 2, 2, TOut>(a, s);
+    }
     if (nk == 13 && bc == 16) return launch_smallc<1, 13, TOut>(a, s);
     if (nk == 5 && bc == 16) return launch_smallc<1, 5, TOut>(a, s);
     if (nk == 5 && bc == 32) return launch_smallc<2, 5, TOut>(a, s);

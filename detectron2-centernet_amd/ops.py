@@ -39,6 +39,11 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
         return f"conv3x3_halo_kernel<256x{bc},{o}>"
     Wo = (W + 2 * p.pad - p.dil * (p.S - 1) - 1) // p.stride + 1 if W else 0
     if p.Cin in (8, 16) and p.korder == 0 and nsrc <= 1 and Wo and Wo % 64 == 0 and p.Cout_pad <= 32:
+        Ho = (H + 2 * p.pad - p.dil * (p.R - 1) - 1) // p.stride + 1
+        win = ((p.R, p.Cin, bc, p.stride) in ((7, 8, 16, 1), (3, 16, 16, 1)) and Ho % 16 == 0) or \
+              ((p.R, p.Cin, bc, p.stride) == (3, 16, 32, 2) and Ho % 8 == 0 and Wo % 32 == 0)
+        if win and p.R == p.S and p.dil == 1 and os.environ.get("CTDET_NO_WIN") is None:
+            return f"conv_win_kernel<{p.R}x{p.R},Cin{p.Cin},Cout{bc},s{p.stride},{o}>"
         return f"conv_smallc_kernel<Cout{bc},K{p.Kpad},{o}>"
     if p.Kpad == p.K and p.R * p.S <= 32 and p.in_dil == 1 and (p.korder == 1 or p.R * p.S == 1) and p.Cin % 32 == 0:
         return f"conv_igemm_uk_kernel<{bp}x{bc},{'cat' if nsrc > 1 else 'conv'},{o}>"

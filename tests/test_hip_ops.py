@@ -108,6 +108,31 @@ def test_stem_7x7(ops, dev):
         assert (nchw(y.float().cpu()) - ref).abs().max() < tol * ref.abs().max()
 
 
+# LDS-window small-channel kernel (conv_win_kernel): the three DLA base layers at tile-divisible sizes, including
+# image borders (zero fill by the DMA source select) and the pre-padded stem (pad 0 on a framed input)
+@pytest.mark.parametrize("case", [("stem", 7, 3, 8, 16, 1, 3), ("stem_prepad", 7, 3, 8, 16, 1, 0),
+                                  ("level0", 3, 16, 16, 16, 1, 1), ("level1", 3, 16, 16, 32, 2, 1)])
+def test_conv_window_small_channels(ops, dev, case):
+    name, R, cin, cin_pad, cout, stride, pad = case
+    g = torch.Generator().manual_seed(R + cout + stride)
+    B, H, W = 2, 32 * stride, 128 * stride
+    x = h16(torch.randn(B, cin, H, W, generator=g))
+    w = h16(torch.randn(cout, cin, R, R, generator=g) / (cin * R * R) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = (F.conv2d(x, w, None, stride, R // 2) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)).relu()
+    fr = R // 2 if pad == 0 else 0           # frame carried in memory by the pre-padded variant
+    xn = torch.zeros(B, H + 2 * fr, W + 2 * fr, cin_pad)
+    xn[:, fr:fr + H, fr:fr + W, :cin] = nhwc(x)
+    pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=stride, pad=pad, compute=ops.F16,
+                        cin_pad=cin_pad, tap_major=True)
+    y = ops.conv2d(xn.half().to(dev), pc, act=ops.ACT_RELU)
+    got = nchw(y[..., :cout].float().cpu())
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    assert err < 3e-3 * max(1.0, ref.abs().max().item()), f"{name}: max err {err}"
+
+
 DCN_CASES = [(2, 12, 14, 64, 64, 2.0), (1, 9, 9, 128, 64, 0.0), (2, 8, 10, 128, 128, 4.0), (1, 6, 6, 256, 256, 1.0),
              (1, 7, 5, 512, 256, 8.0)]
 
