@@ -228,9 +228,17 @@ def main():
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
             total_ms = sum(v["ms"] for v in agg.values())
             total_fl = sum(v["flops"] for v in agg.values())
+            # HBM bytes per launch of that kernel: not measurable from inside this process; taken from the committed
+            # PMC summary (profiles/r01_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the same
+            # forward, corrected as MI355X_MICROARCH.md prescribes) when it covers the kernel, else null
+            traffic = None
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+            if B == 64 and args.size == 512 and os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f)["bytes_per_launch"].get(name)
             result["roofline"] = {
                 "bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": None, "launches_per_step": a["launches"], "kernel_ms_per_step": a["ms"],
+                "traffic": traffic, "launches_per_step": a["launches"], "kernel_ms_per_step": a["ms"],
                 "all_conv_kernels": {"ms_per_step": total_ms, "achieved": total_fl / (total_ms * 1e-3) / 1e12,
                                      "frac": total_fl / (total_ms * 1e-3) / 1e12 / peak},
                 "per_kernel": {k: {"ms": round(v["ms"], 4), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
