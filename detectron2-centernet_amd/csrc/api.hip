@@ -70,7 +70,7 @@ static int fill_args(const ctdet_conv_desc* d, ConvArgs& a) {
   a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
   a.K = d->R * d->S * d->Cin; a.Kpad = d->Kpad; a.Cout_pad = d->Cout_pad;
   a.M = d->B * d->Ho * d->Wo;
-  a.act = d->act | (getenv("CTDET_DBG_ACT") ? atoi(getenv("CTDET_DBG_ACT")) : 0); a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi; a.korder = d->korder; a.in_dil = idl;
+  a.act = d->act; a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi; a.korder = d->korder; a.in_dil = idl;
   CTDET_CHECK(d->korder == 0 || (d->korder == 1 && d->Cin % 32 == 0 && d->compute_dtype == CTDET_DT_F16),
               "conv: korder=%d invalid for Cin=%d", d->korder, d->Cin);
   CTDET_CHECK((long)d->B * d->Ho * d->Wo < (1L << 31), "conv: too many output pixels");

@@ -667,9 +667,9 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_uk_kernel(const ConvArgs a)
   };
   auto issue = [&](char* sb) {  // sb: this wave's slice of the target stage
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) dma16(((tapmask[i] & tbit) && !(a.act & 64)) ? rowp[i] + dlt : zero, sb + i * 4096);
+    for (int i = 0; i < A_LD; ++i) dma16((tapmask[i] & tbit) ? rowp[i] + dlt : zero, sb + i * 4096);
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) dma16((a.act & 128) ? zero : wptr[j] + woff, sb + BP * 64 + j * 4096);
+    for (int j = 0; j < B_LD; ++j) dma16(wptr[j] + woff, sb + BP * 64 + j * 4096);
   };
 
   f32x4 acc[TP][TC];

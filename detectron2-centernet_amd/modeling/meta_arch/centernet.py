@@ -230,6 +230,13 @@ class CenterNet(nn.Module):
     def infer_batch_tensor(self, images, out_sizes=None):
         """Fast path for an already-batched device tensor [B,3,H,W] (uint8 or float32, 0..255): one copy + one
         graph replay.  Returns the same list of {"instances": Instances} as forward()."""
+        return self.infer_batch_tensor_async(images, out_sizes).result()
+
+    def infer_batch_tensor_async(self, images, out_sizes=None):
+        """Enqueue one eval step (input copy, graph replay, snapshot of the outputs, async read-back of the
+        per-image detection counts) and return a handle; `handle.result()` waits for that step only and builds the
+        Instances.  A serving loop keeps one step in flight (`h2 = async(next); h1.result()`), so the host work of
+        building 64 Instances and the count read-back overlap the next batch on the GPU."""
         B, _, H, W = images.shape
         Hp, Wp = ImageList.padded_size([(H, W)], self.size_divisibility)
         img_dtype = torch.uint8 if images.dtype == torch.uint8 else torch.float32
@@ -239,29 +246,23 @@ class CenterNet(nn.Module):
             eng = self._engines[key] = _EvalEngine(self, B, H, W, Hp, Wp, img_dtype, self.use_hip_graph)
         eng.images.copy_(images, non_blocking=True)
         inputs = [{} if out_sizes is None else {"height": out_sizes[b][0], "width": out_sizes[b][1]} for b in range(B)]
-        return self._finish_eval(eng, inputs, [(H, W)] * B)
+        return self._launch_eval(eng, inputs, [(H, W)] * B)
 
     def _finish_eval(self, eng, batched_inputs, sizes):
-        B = len(sizes)
-        params = torch.empty(B, 4, dtype=torch.float32)
-        out_sizes = []
-        for b, (inp, size) in enumerate(zip(batched_inputs, sizes)):
-            oh, ow = inp.get("height", size[0]), inp.get("width", size[1])
-            out_sizes.append((oh, ow))
-            params[b, 0], params[b, 1], params[b, 2], params[b, 3] = ow / size[1], oh / size[0], ow, oh
-        eng.img_params.copy_(params, non_blocking=True)
+        return self._launch_eval(eng, batched_inputs, sizes).result()
+
+    def _launch_eval(self, eng, batched_inputs, sizes):
+        out_sizes = tuple((inp.get("height", size[0]), inp.get("width", size[1])) for inp, size in zip(batched_inputs, sizes))
+        pkey = (out_sizes, tuple(sizes))
+        if getattr(eng, "_params_key", None) != pkey:  # rescale parameters change only with the requested sizes
+            params = torch.tensor([[ow / size[1], oh / size[0], ow, oh] for (oh, ow), size in zip(out_sizes, sizes)],
+                                  dtype=torch.float32)
+            eng.img_params.copy_(params, non_blocking=False)
+            eng._params_key = pkey
         boxes, scores, classes, counts = eng()
-        counts = counts.tolist()  # the only host<->device synchronisation of the eval step
-        boxes, scores, classes = boxes.clone(), scores.clone(), classes.clone()
-        results = []
-        for b in range(B):
-            n = counts[b]
-            r = Instances(out_sizes[b])
-            r.pred_boxes = Boxes(boxes[b, :n])
-            r.scores = scores[b, :n]
-            r.pred_classes = classes[b, :n]
-            results.append({"instances": r})
-        return results
+        # snapshot on the launch stream: the next replay may overwrite the engine's output buffers
+        h = _EvalHandle(boxes.clone(), scores.clone(), classes.clone(), counts, out_sizes)
+        return h
 
     def _forward_eval_ragged(self, batched_inputs, imgs, sizes, Hp, Wp):
         """images of different sizes: per-image preprocess launches into the zero-padded batch, eager launches."""
@@ -388,3 +389,26 @@ class CenterNet(nn.Module):
     def inference_single_image(self, output, image_size):
         """centernet.py:236-266 (batch of one)."""
         return self.inference(output, [image_size])[0]
+
+
+class _EvalHandle:
+    """One in-flight eval step: device snapshots of the outputs + a pinned host copy of the counts."""
+
+    def __init__(self, boxes, scores, classes, counts, out_sizes):
+        self.boxes, self.scores, self.classes, self.out_sizes = boxes, scores, classes, out_sizes
+        self.counts_host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
+        self.counts_host.copy_(counts, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def result(self):
+        self.event.synchronize()  # the only host<->device synchronisation of the eval step
+        counts = self.counts_host.tolist()
+        results = []
+        for b, n in enumerate(counts):
+            r = Instances(self.out_sizes[b])
+            r.pred_boxes = Boxes(self.boxes[b, :n])
+            r.scores = self.scores[b, :n]
+            r.pred_classes = self.classes[b, :n]
+            results.append({"instances": r})
+        return results

@@ -144,6 +144,29 @@ def test_eval_forward_end_to_end(tmp_path, dev, precision):
     assert perr <= (1e-3 if precision == "f16" else 1e-5)
 
 
+def test_async_steps_in_flight_match_sync(tmp_path, dev):
+    """two eval steps in flight (the serving loop of bench.py): each handle returns the result of ITS batch even
+    though the engine's output buffers were overwritten by the later replay, and a changed output size is honoured"""
+    model, cfg = make_model(tmp_path, "f16", seed=5)
+    model.score_threshold = 0.0
+    a, b = images(2, 64, 96, seed=1).to(dev), images(2, 64, 96, seed=2).to(dev)
+    ra = model.infer_batch_tensor(a)
+    rb = model.infer_batch_tensor(b, out_sizes=[(128, 192), (64, 96)])
+    ha = model.infer_batch_tensor_async(a)
+    hb = model.infer_batch_tensor_async(b, out_sizes=[(128, 192), (64, 96)])
+    hc = model.infer_batch_tensor_async(a)
+    for ref, got in ((ra, ha.result()), (rb, hb.result()), (ra, hc.result())):
+        for x, y in zip(ref, got):
+            ix, iy = x["instances"], y["instances"]
+            assert ix.image_size == iy.image_size
+            assert torch.equal(ix.scores, iy.scores) and torch.equal(ix.pred_classes, iy.pred_classes)
+            assert torch.equal(ix.pred_boxes.tensor, iy.pred_boxes.tensor)
+    # the two batches are distinguishable (image 0 of b is rescaled 2x), so a handle returning the other step's
+    # buffers would have failed above
+    assert rb[0]["instances"].image_size == (128, 192)
+    assert not torch.equal(ra[0]["instances"].pred_boxes.tensor, rb[0]["instances"].pred_boxes.tensor)
+
+
 def test_ragged_batch_matches_padded_oracle(tmp_path, dev):
     model, cfg = make_model(tmp_path, "f32", seed=5)
     model.score_threshold = 0.0
