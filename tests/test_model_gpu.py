@@ -149,6 +149,7 @@ def test_async_steps_in_flight_match_sync(tmp_path, dev):
     though the engine's output buffers were overwritten by the later replay, and a changed output size is honoured"""
     model, cfg = make_model(tmp_path, "f16", seed=5)
     model.score_threshold = 0.0
+    model.wh[2].bias.data.fill_(3.0)  # positive box sizes: a random-init wh head mostly yields empty (dropped) boxes
     a, b = images(2, 64, 96, seed=1).to(dev), images(2, 64, 96, seed=2).to(dev)
     ra = model.infer_batch_tensor(a)
     rb = model.infer_batch_tensor(b, out_sizes=[(128, 192), (64, 96)])
@@ -164,6 +165,7 @@ def test_async_steps_in_flight_match_sync(tmp_path, dev):
     # the two batches are distinguishable (image 0 of b is rescaled 2x), so a handle returning the other step's
     # buffers would have failed above
     assert rb[0]["instances"].image_size == (128, 192)
+    assert len(ra[0]["instances"]) > 0 and len(rb[0]["instances"]) > 0
     assert not torch.equal(ra[0]["instances"].pred_boxes.tensor, rb[0]["instances"].pred_boxes.tensor)
 
 
