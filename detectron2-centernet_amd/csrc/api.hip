@@ -20,6 +20,7 @@ void ctdet_set_error(const char* fmt, ...) {
 int launch_preprocess(const void*, int, void*, int, int, int, int, int, int, long, const float*, const float*, int, int,
                       hipStream_t);
 int launch_maxpool2x2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
+int launch_maxpool3x3s2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
 int launch_dwconvT_add(const void*, const float*, const void*, void*, int, int, int, int, int, int, int, int, int,
                        hipStream_t);
 size_t decode_workspace_bytes(int B);
@@ -173,6 +174,12 @@ int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32
                          int32_t in_stride, int32_t out_stride, void* stream) {
   CTDET_CHECK(x && y, "maxpool2x2: null pointer");
   return launch_maxpool2x2(x, y, dtype, B, H, W, C, in_stride, out_stride, (hipStream_t)stream);
+}
+
+int32_t ctdet_maxpool3x3s2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
+                           int32_t in_stride, int32_t out_stride, void* stream) {
+  CTDET_CHECK(x && y, "maxpool3x3s2: null pointer");
+  return launch_maxpool3x3s2(x, y, dtype, B, H, W, C, in_stride, out_stride, (hipStream_t)stream);
 }
 
 int32_t ctdet_dwconvT_add(const void* x, const float* w, const void* skip, void* y, int32_t dtype, int32_t B,

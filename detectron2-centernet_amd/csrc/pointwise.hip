@@ -70,6 +70,43 @@ __global__ void __launch_bounds__(256) maxpool2x2_kernel(const T* __restrict__ x
   *(V*)(y + ((long)(b * Ho + ho) * Wo + wo) * out_stride + cv * N) = r;
 }
 
+// BasicStem pooling of the ResNet backbones: F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+// (detectron2/modeling/backbone/resnet.py:341-345); padded taps are skipped (= -inf padding).
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W,
+                                                           int C, int in_stride, int out_stride) {
+  using V = typename Vec<T>::type;
+  constexpr int N = Vec<T>::N;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, CV = C / N;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * Ho * Wo * CV) return;
+  const int cv = (int)(idx % CV);
+  long t = idx / CV;
+  const int wo = (int)(t % Wo); t /= Wo;
+  const int ho = (int)(t % Ho);
+  const int b = (int)(t / Ho);
+  float m[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) m[e] = -INFINITY;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int yy = 2 * ho + dy;
+    if (yy < 0 || yy >= H) continue;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int xx = 2 * wo + dx;
+      if (xx < 0 || xx >= W) continue;
+      const V v = *(const V*)(x + ((long)(b * H + yy) * W + xx) * in_stride + cv * N);
+#pragma unroll
+      for (int e = 0; e < N; ++e) m[e] = (float)v[e] > m[e] ? (float)v[e] : m[e];
+    }
+  }
+  V r;
+#pragma unroll
+  for (int e = 0; e < N; ++e) r[e] = (T)m[e];
+  *(V*)(y + ((long)(b * Ho + ho) * Wo + wo) * out_stride + cv * N) = r;
+}
+
 // y[b,oy,ox,c] = skip[b,oy,ox,c] + sum_{ky,kx} x[b,iy,ix,c] * w[c,ky,kx],  oy = iy*f - f/2 + ky, k = 2f:
 // exactly two input rows/cols contribute per output row/col.  w is f32 [k][k][C] (the PyTorch
 // ConvTranspose2d weight [C,1,k,k] transposed once on the host so a tap's channels are contiguous).
@@ -160,6 +197,23 @@ int launch_maxpool2x2(const void* x, void* y, int dtype, int B, int H, int W, in
     hipLaunchKernelGGL((maxpool2x2_kernel<float>), dim3(nblk(total)), dim3(256), 0, s, (const float*)x, (float*)y, B, H,
                        W, C, in_stride, out_stride);
   else CTDET_CHECK(false, "maxpool2x2: bad dtype %d", dtype);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, int in_stride, int out_stride,
+                        hipStream_t s) {
+  const int N = dtype == CTDET_F16 ? 8 : 4;
+  CTDET_CHECK(C % N == 0 && in_stride % N == 0 && out_stride % N == 0, "maxpool3x3s2: channels must be multiples of %d", N);
+  const long total = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / N);
+  if (total == 0) return 0;
+  if (dtype == CTDET_F16)
+    hipLaunchKernelGGL((maxpool3x3s2_kernel<f16>), dim3(nblk(total)), dim3(256), 0, s, (const f16*)x, (f16*)y, B, H, W, C,
+                       in_stride, out_stride);
+  else if (dtype == CTDET_F32)
+    hipLaunchKernelGGL((maxpool3x3s2_kernel<float>), dim3(nblk(total)), dim3(256), 0, s, (const float*)x, (float*)y, B,
+                       H, W, C, in_stride, out_stride);
+  else CTDET_CHECK(false, "maxpool3x3s2: bad dtype %d", dtype);
   CTDET_LAUNCH_CHECK();
   return 0;
 }

@@ -44,7 +44,7 @@ def packed(owner, key, compute, weight, bn=None, conv_bias=None, stride=1, pad=0
     if hit is not None and hit[0] == ver:
         return hit[1]
     if bn is not None:
-        if bn.training:
+        if bn.training and not getattr(bn, "frozen", False):
             raise RuntimeError("BatchNorm folding requires eval mode (training uses the batch-statistics path)")
         scale, bias = fold_bn(bn, conv_bias)
     else:

@@ -123,11 +123,18 @@ class CenterNet(nn.Module):
 
         self.backbone_type = backbone_type.split("_")[1]
         self.backbone = build_backbone(cfg)
-        if self.backbone_type != "dla34":
-            raise NotImplementedError(
-                f"backbone '{backbone_type}': only the DLA-34 path is built in this round (SURVEY.md 8(a) a21 is next)")
-        self.size_divisibility = self.backbone.size_divisibility
-        cin = self.backbone.channels[self.backbone.first_level]
+        if self.backbone_type == "resnet":
+            # centernet.py:71-108: res4 -> two (ConvTranspose2d 4x4 s2 p1, BN, ReLU) stages -> heads on 256 channels
+            self.backbone.down_ratio = 4
+            self.size_divisibility = 16
+            self.deconv_layers = self._make_deconv_layer(self.backbone._out_feature_channels["res4"], 2, [256, 256],
+                                                         [4, 4])
+            cin, final_kernel = 256, 1
+        elif self.backbone_type == "dla34":
+            self.size_divisibility = self.backbone.size_divisibility
+            cin = self.backbone.channels[self.backbone.first_level]
+        else:
+            raise NotImplementedError(f"backbone '{backbone_type}': DLA-34 and ResNet are built (SURVEY.md 8(a))")
         self.head_conv = head_conv
         for head in self.heads:
             classes = self.heads[head]
@@ -148,8 +155,42 @@ class CenterNet(nn.Module):
                 else:
                     fill_fc_weights(fc)
             self.__setattr__(head.lower(), fc)
+        if self.backbone_type == "resnet":
+            self.init_weights()
         self._engines = {}
         self.use_hip_graph = True
+
+    @staticmethod
+    def _make_deconv_layer(inplanes, num_layers, num_filters, num_kernels):
+        """centernet.py:268-293."""
+        assert num_layers == len(num_filters) == len(num_kernels)
+        layers = []
+        for i in range(num_layers):
+            planes = num_filters[i]
+            layers.append(nn.ConvTranspose2d(inplanes, planes, kernel_size=num_kernels[i], stride=2, padding=1,
+                                             output_padding=0, bias=False))
+            layers.append(nn.BatchNorm2d(planes, momentum=0.1))
+            layers.append(nn.ReLU(inplace=True))
+            inplanes = planes
+        return nn.Sequential(*layers)
+
+    def init_weights(self):
+        """centernet.py:295-320 without the network fetch of the ImageNet checkpoint (no network here; real weights
+        come from MODEL.WEIGHTS / load_state_dict)."""
+        for m in self.deconv_layers.modules():
+            if isinstance(m, nn.ConvTranspose2d):
+                nn.init.normal_(m.weight, std=0.001)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        for head in self.heads:
+            for m in getattr(self, head.lower()).modules():
+                if isinstance(m, nn.Conv2d) and m.weight.shape[0] == self.heads[head]:
+                    if "hm" in head.lower():
+                        nn.init.constant_(m.bias, -2.19)
+                    else:
+                        nn.init.normal_(m.weight, std=0.001)
+                        nn.init.constant_(m.bias, 0)
 
     @property
     def device(self):
@@ -193,8 +234,28 @@ class CenterNet(nn.Module):
         cache[(key, self._ctx.compute)] = (ver, p)
         return p
 
+    def _deconv_forward(self, y):
+        """deconv_layers on NHWC: each (ConvTranspose2d, BatchNorm2d, ReLU) triple is one kernel launch."""
+        mods = list(self.deconv_layers)
+        for i in range(0, len(mods), 3):
+            up, bn = mods[i], mods[i + 1]
+            cache = up.__dict__.setdefault("_ctdet_packed", {})
+            ver = hipnn._versions(up.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            slot = cache.get(self._ctx.compute)
+            if slot is None or slot[0] != ver:
+                slot = cache[self._ctx.compute] = (ver, {})
+            scale, bias = hipnn.fold_bn(bn)
+            y = ops.conv_transpose2d(y, up.weight, scale, bias, up.stride[0], up.padding[0], self._ctx.compute,
+                                     act=ACT_RELU, cache=slot[1])
+            if y.shape[3] != up.out_channels:
+                y = y[..., :up.out_channels]
+        return y
+
     def _network_outputs(self, x_nhwc, apply_sigmoid, prepadded=False):
-        y = self.backbone.hip_forward(x_nhwc, self._ctx, prepadded)[-1]
+        if self.backbone_type == "resnet":
+            y = self._deconv_forward(self.backbone.hip_forward(x_nhwc, self._ctx, prepadded)["res4"])
+        else:
+            y = self.backbone.hip_forward(x_nhwc, self._ctx, prepadded)[-1]
         z = self._head_outputs(y, apply_sigmoid)
         hm = z["hm"]
         assert hm.shape[3] == self.num_classes or hm.shape[3] == ops.round_up(self.num_classes, 4)
@@ -353,6 +414,8 @@ class CenterNet(nn.Module):
         """training forward on a device-resident batch: images uint8/float [B,3,H,W] (0..255), boxes f32 [B,N,4] XYXY
         in input pixels, classes i64 [B,N], counts i32 [B].  Returns the loss dict (0-d tensors with autograd)."""
         from ...engine.train_step import train_forward_tensors
+        if self.backbone_type != "dla34":
+            raise NotImplementedError("training is built for the DLA-34 path; the ResNet config runs inference only")
         B, _, H, W = images.shape
         Hp, Wp = ImageList.padded_size([(H, W)], self.size_divisibility)
         x = ops.preprocess(images, self._mean_host, self._std_host, Hp, Wp, out_dtype=self._ctx.dtype)

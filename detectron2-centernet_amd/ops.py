@@ -299,6 +299,43 @@ def preprocess(images, mean, std, Hp, Wp, out_dtype=torch.float16, out=None, par
     return out
 
 
+def maxpool3x3s2(x, out=None):
+    """F.max_pool2d(x, 3, stride=2, padding=1) on NHWC (BasicStem, resnet.py:341-345)."""
+    _require_cuda(x, out)
+    B, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc, dtype=x.dtype, device=x.device)
+    rc = _lib.lib().ctdet_maxpool3x3s2(_ptr(x), _ptr(out), dt_of(x), B, H, W, Cc, _nhwc_stride(x), _nhwc_stride(out),
+                                       _stream())
+    _lib.check(rc, "ctdet_maxpool3x3s2")
+    return out
+
+
+def conv_transpose2d(x, weight, scale, bias, stride, padding, compute, act=ACT_NONE, cache=None):
+    """Dense nn.ConvTranspose2d (weight [Cin, Cout, k, k], output_padding 0) + per-channel scale/bias + act on NHWC:
+    a stride-1 convolution with the flipped kernel over the zero-stuffed input (pad k-1-p).  The f16 kernels read
+    the input as zero-stuffed in place (`in_dil`); the exact-f32 mode materialises the stuffed tensor."""
+    _require_cuda(x, weight)
+    Cin, Cout, k, k2 = weight.shape
+    assert k == k2 and x.shape[3] == Cin
+    p = cache.get("p") if cache is not None else None
+    if p is None:
+        wc = weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()  # [Cout, Cin, k, k]
+        p = PackedConv(wc, scale, bias, stride=1, pad=k - 1 - padding, compute=compute, tap_major=True)
+        if cache is not None:
+            cache["p"] = p
+    B, H, W, _ = x.shape
+    Ho, Wo = (H - 1) * stride - 2 * padding + k, (W - 1) * stride - 2 * padding + k
+    out = torch.empty(B, Ho, Wo, p.Cout_eff, dtype=x.dtype, device=x.device)
+    if compute == F16:
+        p.in_dil = stride
+        return conv2d(x, p, out=out, act=act)
+    xd = torch.zeros(B, (H - 1) * stride + 1, (W - 1) * stride + 1, Cin, dtype=x.dtype, device=x.device)
+    xd[:, ::stride, ::stride] = x
+    p.in_dil = 1
+    return conv2d(xd, p, out=out, act=act)
+
+
 def maxpool2x2(x, out=None):
     _require_cuda(x, out)
     B, H, W, Cc = x.shape

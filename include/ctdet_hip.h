@@ -83,6 +83,11 @@ int32_t ctdet_preprocess(const void* img, int32_t img_dtype, void* out, int32_t 
 int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
                          int32_t in_stride, int32_t out_stride, void* stream);
 
+/* F.max_pool2d(x, 3, stride=2, padding=1) of BasicStem (detectron2/modeling/backbone/resnet.py:341-345), NHWC;
+ * output [B, (H-1)/2+1, (W-1)/2+1, C]; padded taps do not take part. */
+int32_t ctdet_maxpool3x3s2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
+                           int32_t in_stride, int32_t out_stride, void* stream);
+
 /* y = ConvTranspose2d(C, C, 2f, stride=f, padding=f/2, groups=C, bias=False)(x) + skip  (dla.py:162-177).
  * w is f32 [2f][2f][C] (the ConvTranspose2d weight [C,1,2f,2f] with the channel dim moved last); skip may be NULL. */
 int32_t ctdet_dwconvT_add(const void* x, const float* w, const void* skip, void* y, int32_t dtype, int32_t B,

@@ -148,6 +148,68 @@ def centernet_forward(sd, images_nchw, training=False, levels=(1, 1, 1, 2, 2, 1)
     return centernet_heads(n, y)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# ResNet + deconv path.  Pinned by tests/golden/g9_resnet50.npz, generated from the reference's
+# own `ResNet`/`BottleneckBlock`/`BasicStem` and `CenterNet._make_deconv_layer`.
+def frozen_bn(sd, p, x, eps=1e-5):
+    """detectron2/layers/batch_norm.py:32-52 (FrozenBatchNorm2d, all four tensors are buffers)."""
+    scale = sd[p + ".weight"] * (sd[p + ".running_var"] + eps).rsqrt()
+    bias = sd[p + ".bias"] - sd[p + ".running_mean"] * scale
+    return x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
+
+
+def _conv_norm(sd, p, x, stride=1, pad=0):
+    return frozen_bn(sd, p + ".norm", F.conv2d(x, sd[p + ".weight"], None, stride, pad))
+
+
+def bottleneck_block(sd, p, x, stride, stride_in_1x1=True):
+    """resnet.py:115-214: 1x1 -> 3x3 -> 1x1, the stride sits on the first 1x1 when STRIDE_IN_1X1."""
+    s1, s3 = (stride, 1) if stride_in_1x1 else (1, stride)
+    out = F.relu(_conv_norm(sd, p + ".conv1", x, s1))
+    out = F.relu(_conv_norm(sd, p + ".conv2", out, s3, 1))
+    out = _conv_norm(sd, p + ".conv3", out)
+    sc = _conv_norm(sd, p + ".shortcut", x, stride) if (p + ".shortcut.weight") in sd else x
+    return F.relu(out + sc)
+
+
+def basic_res_block(sd, p, x, stride):
+    """resnet.py:32-112 (R18 / R34)."""
+    out = F.relu(_conv_norm(sd, p + ".conv1", x, stride, 1))
+    out = _conv_norm(sd, p + ".conv2", out, 1, 1)
+    sc = _conv_norm(sd, p + ".shortcut", x, stride) if (p + ".shortcut.weight") in sd else x
+    return F.relu(out + sc)
+
+
+def resnet_features(sd, p, x, blocks=(3, 4, 6), bottleneck=True, stride_in_1x1=True):
+    """BasicStem (resnet.py:322-347) + res2.. stages (resnet.py:609-642) -> last built stage (res4 for 3 stages)."""
+    x = F.relu(_conv_norm(sd, p + ".stem.conv1", x, 2, 3))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    for si, nblk in enumerate(blocks):
+        for bi in range(nblk):
+            stride = 2 if (bi == 0 and si > 0) else 1
+            name = f"{p}.res{si + 2}.{bi}"
+            x = bottleneck_block(sd, name, x, stride, stride_in_1x1) if bottleneck else basic_res_block(sd, name, x, stride)
+    return x
+
+
+def deconv_layers(sd, p, x):
+    """centernet.py:268-293: (ConvTranspose2d 4x4 s2 p1 no bias, BatchNorm2d, ReLU) x 2, eval mode."""
+    i = 0
+    while f"{p}.{i}.weight" in sd:
+        x = F.conv_transpose2d(x, sd[f"{p}.{i}.weight"], None, stride=2, padding=1)
+        q = f"{p}.{i + 1}"
+        x = F.relu(F.batch_norm(x, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"],
+                                False, 0.1, 1e-5))
+        i += 3
+    return x
+
+
+def centernet_resnet_forward(sd, images_nchw, blocks=(3, 4, 6)):
+    """centernet.py:140-154 for backbone_type == 'resnet': res4 -> deconv_layers -> heads (1x1 final convs)."""
+    y = deconv_layers(sd, "deconv_layers", resnet_features(sd, "backbone", images_nchw, blocks))
+    return centernet_heads(Net(sd), y)
+
+
 def centernet_losses(z, targets, alpha, hm_w=1.0, wh_w=0.1, off_w=1.0):
     """centernet.py:191-212: targets = list of gen_heatmap dicts (numpy)."""
     gt_hm = torch.stack([torch.from_numpy(t["hm"]) for t in targets])

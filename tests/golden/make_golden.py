@@ -319,6 +319,41 @@ def main():
     with open(os.path.join(HERE, "g8_dla34_state_dict_keys.txt"), "w") as f:
         for k in keys:
             f.write(f"{k} {tuple(model.state_dict()[k].shape)}\n")
+    # ---------------- G9: ResNet-50 (res4, FrozenBN, stride in 1x1) + CenterNet deconv layers ----
+    bn_mod = load("detectron2.layers.batch_norm")
+    for n in ("FrozenBatchNorm2d", "get_norm", "NaiveSyncBatchNorm"):
+        setattr(sys.modules["detectron2.layers"], n, getattr(bn_mod, n))
+    sys.modules["detectron2.layers"].ModulatedDeformConv = deform.ModulatedDeformConv
+    sys.modules["detectron2.layers"].DeformConv = deform.DeformConv
+    resnet = load("detectron2.modeling.backbone.resnet")
+    torch.manual_seed(9)
+    stem = resnet.BasicStem(in_channels=3, out_channels=64, norm="FrozenBN")
+    stages, cin, cout, bott = [], 64, 256, 64
+    for idx, nblk in enumerate([3, 4, 6]):            # res2..res4 (OUT_FEATURES = ["res4"]), resnet.py:609-642
+        first_stride = 1 if idx == 0 else 2
+        stages.append(resnet.ResNet.make_stage(block_class=resnet.BottleneckBlock, num_blocks=nblk,
+                                               stride_per_block=[first_stride] + [1] * (nblk - 1), in_channels=cin,
+                                               out_channels=cout, norm="FrozenBN", bottleneck_channels=bott,
+                                               stride_in_1x1=True, dilation=1, num_groups=1))
+        cin, cout, bott = cout, cout * 2, bott * 2
+    r50 = resnet.ResNet(stem, stages, out_features=["res4"]).freeze(2)
+    deconv = cn.CenterNet._make_deconv_layer(None, 1024, 2, [256, 256], [4, 4])
+    r50.eval(); deconv.eval()
+    sd_r = fill_state_dict(r50.state_dict(), seed=9)
+    r50.load_state_dict(sd_r)
+    sd_d = fill_state_dict(deconv.state_dict(), seed=10)
+    deconv.load_state_dict(sd_d)
+    gg = torch.Generator().manual_seed(900)
+    x = torch.randn(1, 3, 64, 96, generator=gg)
+    with torch.no_grad():
+        res4 = r50(x)["res4"]
+        up = deconv(res4)
+    np.savez_compressed(os.path.join(HERE, "g9_resnet50.npz"), x=x.numpy(), res4=res4.numpy(), up=up.numpy())
+    with open(os.path.join(HERE, "g9_resnet50_state_dict_keys.txt"), "w") as f:
+        for k in sorted(r50.state_dict().keys()):
+            f.write(f"backbone.{k} {tuple(r50.state_dict()[k].shape)}\n")
+        for k in sorted(deconv.state_dict().keys()):
+            f.write(f"deconv_layers.{k} {tuple(deconv.state_dict()[k].shape)}\n")
     print("golden vectors written to", HERE)
 
 

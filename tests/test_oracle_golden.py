@@ -142,3 +142,31 @@ def test_g8_state_dict_keys_match_reference():
     model = DLA34(get_cfg())
     mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     assert mine == shapes
+
+
+def test_g9_resnet50_res4_and_deconv_match_reference():
+    """oracle restatement of ResNet-50 (FrozenBN, stride in 1x1) + the CenterNet deconv layers vs the outputs of the
+    reference's own modules (tests/golden/make_golden.py G9), and the state-dict key list"""
+    import types
+
+    import torch
+
+    from oracle import model_ref as MR
+    from weights import fill_state_dict
+
+    g = np.load(os.path.join(G, "g9_resnet50.npz"))
+    shapes = {}
+    for line in open(os.path.join(G, "g9_resnet50_state_dict_keys.txt")):
+        k, shp = line.split(" ", 1)
+        shapes[k] = tuple(int(v) for v in shp.strip().strip("()").split(",") if v.strip())
+    bb = {k[len("backbone."):]: torch.zeros(s) for k, s in shapes.items() if k.startswith("backbone.")}
+    dc = {k[len("deconv_layers."):]: torch.zeros(s) for k, s in shapes.items() if k.startswith("deconv_layers.")}
+    sd = {"backbone." + k: v for k, v in fill_state_dict(bb, seed=9).items()}
+    sd.update({"deconv_layers." + k: v for k, v in fill_state_dict(dc, seed=10).items()})
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        res4 = MR.resnet_features(sd, "backbone", x)
+        up = MR.deconv_layers(sd, "deconv_layers", res4)
+    assert res4.shape == g["res4"].shape and up.shape == g["up"].shape
+    assert np.abs(res4.numpy() - g["res4"]).max() <= 1e-5 * max(1.0, np.abs(g["res4"]).max())
+    assert np.abs(up.numpy() - g["up"]).max() <= 1e-5 * max(1.0, np.abs(g["up"]).max())

@@ -1,0 +1,146 @@
+"""SURVEY 8a row a21 on the GPU: the ResNet-50 CenterNet config (`ctdet_res_50_1x.yaml`: res4 with FrozenBN, two
+ConvTranspose stages, 256-channel heads) through the HIP kernels vs the CPU oracle (oracle/model_ref.py, pinned to
+the reference's own modules by tests/golden/g9_resnet50.npz).  Plus the two ops this path adds."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ctdet_oracle as O
+from oracle import model_ref as MR
+
+pytestmark = pytest.mark.gpu
+
+RES50_YAML = """
+_BASE_: "./Base-CenterNet.yaml"
+MODEL:
+  BACKBONE:
+    NAME: "build_resnet_backbone"
+  CENTERNET:
+    FOCAL_LOSS_ALPHA: [1]
+DATASETS:
+  TRAIN: ("bulb_train",)
+  TEST: ("bulb_val",)
+INPUT:
+  FORMAT: "RGB"
+  MIN_SIZE_TRAIN: (640, 672, 704, 736, 768, 800)
+SOLVER:
+  IMS_PER_BATCH: 2
+  BASE_LR: 2.5e-4
+  STEPS: (225100, 337650)
+  MAX_ITER: 450200
+  CHECKPOINT_PERIOD: 9004
+TEST:
+  EVAL_PERIOD: 18008
+OUTPUT_DIR: "./output"
+VERSION: 2
+"""
+BASE = """
+MODEL:
+  META_ARCHITECTURE: "CenterNet"
+  PIXEL_MEAN: [0.408, 0.447, 0.470]
+  PIXEL_STD: [0.289, 0.274, 0.278]
+VERSION: 2
+"""
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from detectron2_centernet_amd import ops as _ops
+    return _ops
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.float32])
+@pytest.mark.parametrize("hw", [(16, 24), (15, 9)])
+def test_maxpool3x3s2(ops, dev, tdt, hw):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 16, *hw, generator=g).half().float()
+    y = ops.maxpool3x3s2(nhwc(x).to(tdt).to(dev))
+    assert torch.equal(nchw(y.float().cpu()), F.max_pool2d(x, 3, 2, 1))
+
+
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+def test_conv_transpose2d_dense(ops, dev, mode):
+    g = torch.Generator().manual_seed(12)
+    B, Cin, Cout, H, W = 2, 64, 32, 6, 10
+    x = torch.randn(B, Cin, H, W, generator=g).half().float()
+    w = (torch.randn(Cin, Cout, 4, 4, generator=g) / (Cin * 4) ** 0.5).half().float()
+    scale, bias = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref = (F.conv_transpose2d(x, w, None, stride=2, padding=1) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)).relu()
+    comp = ops.F16 if mode == "f16" else ops.F32
+    tdt = torch.float16 if mode == "f16" else torch.float32
+    y = ops.conv_transpose2d(nhwc(x).to(tdt).to(dev), w.to(dev), scale.to(dev), bias.to(dev), 2, 1, comp,
+                             act=ops.ACT_RELU)
+    got = nchw(y[..., :Cout].float().cpu())
+    assert got.shape == ref.shape == (B, Cout, 2 * H, 2 * W)
+    tol = 3e-3 if mode == "f16" else 1e-5
+    assert (got - ref).abs().max() <= tol * max(1.0, ref.abs().max())
+
+
+def _make(tmp_path, precision):
+    from detectron2_centernet_amd.config import get_cfg
+    from detectron2_centernet_amd.data.catalog import register_synthetic
+    from detectron2_centernet_amd.modeling import build_model
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from weights import fill_state_dict
+
+    (tmp_path / "Base-CenterNet.yaml").write_text(BASE)
+    (tmp_path / "ctdet_res_50_1x.yaml").write_text(RES50_YAML)
+    cfg = get_cfg()
+    cfg.merge_from_file(str(tmp_path / "ctdet_res_50_1x.yaml"))
+    cfg.MODEL.CENTERNET.HIP_PRECISION = precision
+    register_synthetic("bulb_train", num_classes=80)
+    model = build_model(cfg).eval()
+    # name-keyed deterministic weights: non-trivial FrozenBN statistics; the deconv / final head weights get a
+    # realistic scale (the reference initialises them with std 0.001, which would hide errors)
+    sd = fill_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, seed=21)
+    model.load_state_dict({k: v.to(model.device) for k, v in sd.items()})
+    return model, cfg, sd
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_resnet50_centernet_eval_matches_oracle(tmp_path, dev, precision):
+    model, cfg, sd = _make(tmp_path, precision)
+    assert model.size_divisibility == 16 and model.backbone.down_ratio == 4
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (2, 3, 96, 128), generator=g, dtype=torch.uint8)
+    model.score_threshold = 0.0
+    out = model([{"image": img[b]} for b in range(2)])
+    eng = next(iter(model._engines.values()))
+    hm, wh, reg = [t.float().cpu().permute(0, 3, 1, 2) for t in eng.out]
+    assert hm.shape == (2, 80, 24, 32)
+    x, sizes = O.preprocess([i for i in img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 16)
+    sdf = {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        z = MR.centernet_resnet_forward(sdf, x)
+    hm_ref = torch.clamp(torch.sigmoid(z["hm"]), 1e-4, 1 - 1e-4)
+    err_hm = (hm - hm_ref).abs().max().item()
+    err_wh = (wh - z["wh"]).abs().max().item() / max(1.0, z["wh"].abs().max().item())
+    err_reg = (reg - z["reg"]).abs().max().item() / max(1.0, z["reg"].abs().max().item())
+    print(precision, "resnet50 heatmap err", err_hm, "wh rel", err_wh, "reg rel", err_reg)
+    if precision == "f32":
+        assert err_hm <= 1e-5 and err_wh <= 2e-4 and err_reg <= 2e-4
+    else:
+        assert err_hm <= 1e-3 and err_wh <= 2e-2 and err_reg <= 2e-2
+    # decode + postprocess parity on the HIP heatmap (bit-exact indices / scores)
+    rb, rs, rc, _ = O.ctdet_decode(hm, wh, reg, down_ratio=4, K=100)
+    for b in range(2):
+        inst = out[b]["instances"]
+        bb, ss, cc = O.inference_single_image(rb[b], rs[b], rc[b], 100, 0.0)
+        bb, keep = O.detector_postprocess(bb, (96, 128), 96, 128)
+        assert torch.equal(inst.scores.cpu(), ss[keep]) and torch.equal(inst.pred_classes.cpu(), cc[keep])
+        assert torch.allclose(inst.pred_boxes.tensor.cpu(), bb[keep], atol=1e-4, rtol=1e-6)
