@@ -113,7 +113,9 @@ def test_maxpool_and_dwconvT_bwd(T, dev):
         close(dw.cpu(), w.grad, 2e-3, "dwconvT dw")
 
 
-@pytest.mark.parametrize("case", [(2, 10, 12, 64, 64, 2.0), (1, 8, 8, 128, 64, 1.0), (1, 6, 7, 256, 128, 3.0)])
+# the last three shapes are tile-divisible and run the LDS-window col2im kernel (std 7: many samples leave the window)
+@pytest.mark.parametrize("case", [(2, 10, 12, 64, 64, 2.0), (1, 8, 8, 128, 64, 1.0), (1, 6, 7, 256, 128, 3.0),
+                                  (2, 16, 32, 64, 64, 1.5), (1, 8, 16, 128, 64, 7.0), (1, 16, 16, 64, 128, 0.0)])
 def test_dcn_training_fwd_bwd(T, dev, case):
     ops, ot = T
     B, H, W, Cin, Cout, off_std = case
@@ -141,6 +143,31 @@ def test_dcn_training_fwd_bwd(T, dev, case):
     close(nchw(omd.grad[..., :27].cpu()) / S, om.grad, 1e-2, "dcn d(offset, mask)")
     close(wd.grad.cpu(), w.grad, 5e-3, "dcn dW")
     close(bd.grad.cpu(), bias.grad, 3e-3, "dcn dbias")
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1.0, 3e3])
+def test_dcn_col2im_window_fixed_point_vs_atomics(T, dev, scale):
+    """the LDS-window scatter accumulates d(input) in per-tile fixed point: against the f32-atomics kernel on the same
+    operands it must agree to 2^-17 of the largest gradient magnitude for tiny, unit and huge (near f16 max) dcol"""
+    import os
+    ops, ot = T
+    g = torch.Generator().manual_seed(3)
+    B, H, W, Cin = 2, 16, 32, 64
+    x = torch.randn(B, H, W, Cin, generator=g).half().to(dev)
+    dcol = (torch.randn(B, H, W, 9 * Cin, generator=g) * scale).half().to(dev)
+    om = torch.randn(B, H, W, 28, generator=g)
+    om[..., :18] *= 2.5
+    om = om.to(dev)
+    dx_w, dom_w = ot.dcn_col2im_coord(dcol, x, om)
+    os.environ["CTDET_NO_COL2IM_WINDOW"] = "1"
+    try:
+        dx_a, dom_a = ot.dcn_col2im_coord(dcol, x, om)
+    finally:
+        del os.environ["CTDET_NO_COL2IM_WINDOW"]
+    mx = dx_a.abs().max().item()
+    assert mx > 0
+    assert (dx_w - dx_a).abs().max().item() <= mx * 2.0 ** -15
+    assert (dom_w - dom_a).abs().max().item() <= dom_a.abs().max().item() * 1e-4
 
 
 def test_conv_bias_relu_fn(T, dev):

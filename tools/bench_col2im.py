@@ -1,0 +1,30 @@
+"""microbench of the DCNv2 backward scatter (d(input), d(offset), d(mask)): python tools/bench_col2im.py B H W Cin [off_std]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import detectron2_centernet_amd  # noqa: F401,E402
+from detectron2_centernet_amd import ops_train as ot  # noqa: E402
+
+B, H, W, Cin = [int(v) for v in sys.argv[1:5]]
+std = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+x = torch.randn(B, H, W, Cin, generator=g).half().to(dev)
+dcol = torch.randn(B, H, W, 9 * Cin, generator=g).half().to(dev)
+om = torch.randn(B, H, W, 28, generator=g)
+om[..., :18] *= std
+om = om.to(dev)
+for _ in range(2):
+    ot.dcn_col2im_coord(dcol, x, om)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    ot.dcn_col2im_coord(dcol, x, om)
+e1.record()
+torch.cuda.synchronize()
+print(f"col2im B{B} {H}x{W} Cin{Cin} off_std {std}: {e0.elapsed_time(e1) / 5 * 1000:.0f} us "
+      f"({'window' if not os.environ.get('CTDET_NO_COL2IM_WINDOW') else 'atomics'})")
