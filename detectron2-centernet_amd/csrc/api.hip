@@ -21,6 +21,7 @@ int launch_preprocess(const void*, int, void*, int, int, int, int, int, int, lon
                       hipStream_t);
 int launch_maxpool2x2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
 int launch_maxpool3x3s2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
+int launch_pack_weights(const float*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_dwconvT_add(const void*, const float*, const void*, void*, int, int, int, int, int, int, int, int, int,
                        hipStream_t);
 size_t decode_workspace_bytes(int B);
@@ -180,6 +181,12 @@ int32_t ctdet_maxpool3x3s2(const void* x, void* y, int32_t dtype, int32_t B, int
                            int32_t in_stride, int32_t out_stride, void* stream) {
   CTDET_CHECK(x && y, "maxpool3x3s2: null pointer");
   return launch_maxpool3x3s2(x, y, dtype, B, H, W, C, in_stride, out_stride, (hipStream_t)stream);
+}
+
+int32_t ctdet_pack_weights(const float* w, void* packed, int32_t O, int32_t I, int32_t R, int32_t S, int32_t chans_pad,
+                           int32_t rows_pad, int32_t Kpad, int32_t korder, int32_t transposed, void* stream) {
+  CTDET_CHECK(w && packed, "pack_weights: null pointer");
+  return launch_pack_weights(w, packed, O, I, R, S, chans_pad, rows_pad, Kpad, korder, transposed, (hipStream_t)stream);
 }
 
 int32_t ctdet_dwconvT_add(const void* x, const float* w, const void* skip, void* y, int32_t dtype, int32_t B,

@@ -107,6 +107,30 @@ __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const T* __restrict__
   *(V*)(y + ((long)(b * Ho + ho) * Wo + wo) * out_stride + cv * N) = r;
 }
 
+// Weight packing for the f16 conv kernels in one launch: f32 OIHW parameter -> f16 [Cout_pad][Kpad] with the K order
+// the kernels expect (korder 0: k = tap*Cin_pad + c; korder 1: k = ((c/32)*R*S + tap)*32 + c%32), zero padding
+// included.  transposed != 0 packs the input-gradient form instead: rows = original input channels, k-channels =
+// original output channels, taps flipped (dX = conv(dY, W^T flipped)).  Replaces a chain of ~8 small torch kernels
+// per conv and training step (permute, pad, reshape, zeros, cast, copy).
+__global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ w, f16* __restrict__ out, int O, int I,
+                                                           int R, int S, int rows, int chans, int chans_pad, int rows_pad,
+                                                           int Kpad, int korder, int transposed) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)rows_pad * Kpad) return;
+  const int row = (int)(idx / Kpad), k = (int)(idx % Kpad);
+  const int RS = R * S;
+  int tap, c;
+  if (korder == 0) { tap = k / chans_pad; c = k - tap * chans_pad; }
+  else { const int chunk = k / (RS * 32), rem = k - chunk * (RS * 32); tap = rem >> 5; c = chunk * 32 + (rem & 31); }
+  float v = 0.f;
+  if (row < rows && tap < RS && c < chans) {
+    const int r = tap / S, s2 = tap - r * S;
+    if (!transposed) v = w[(((long)row * I + c) * R + r) * S + s2];
+    else v = w[(((long)c * I + row) * R + (R - 1 - r)) * S + (S - 1 - s2)];
+  }
+  out[idx] = (f16)v;
+}
+
 // y[b,oy,ox,c] = skip[b,oy,ox,c] + sum_{ky,kx} x[b,iy,ix,c] * w[c,ky,kx],  oy = iy*f - f/2 + ky, k = 2f:
 // exactly two input rows/cols contribute per output row/col.  w is f32 [k][k][C] (the PyTorch
 // ConvTranspose2d weight [C,1,k,k] transposed once on the host so a tap's channels are contiguous).
@@ -214,6 +238,19 @@ int launch_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, 
     hipLaunchKernelGGL((maxpool3x3s2_kernel<float>), dim3(nblk(total)), dim3(256), 0, s, (const float*)x, (float*)y, B,
                        H, W, C, in_stride, out_stride);
   else CTDET_CHECK(false, "maxpool3x3s2: bad dtype %d", dtype);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_pack_weights(const float* w, void* out, int O, int I, int R, int S, int chans_pad, int rows_pad, int Kpad,
+                        int korder, int transposed, hipStream_t s) {
+  const int rows = transposed ? I : O, chans = transposed ? O : I;
+  CTDET_CHECK(chans_pad >= chans && rows_pad >= rows && Kpad >= R * S * chans_pad, "pack_weights: padded sizes too small");
+  CTDET_CHECK(korder == 0 || (korder == 1 && chans_pad % 32 == 0), "pack_weights: chunk-major needs channels %% 32 == 0");
+  const long total = (long)rows_pad * Kpad;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(nblk(total)), dim3(256), 0, s, w, (f16*)out, O, I, R, S, rows, chans, chans_pad,
+                     rows_pad, Kpad, korder, transposed);
   CTDET_LAUNCH_CHECK();
   return 0;
 }

@@ -67,9 +67,19 @@ class _EvalEngine:
         self._run()                      # warm-up: packs weights, sizes the allocator
         torch.cuda.synchronize()
         if use_graph:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._run()
+            # no garbage collection while the stream is capturing: a collection that happens to free device objects of
+            # an earlier engine (graphs, events) inside the capture aborts the process
+            import gc
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._run()
+            finally:
+                if gc_was_on:
+                    gc.enable()
             self.graph = g
 
     def _run(self):

@@ -123,9 +123,15 @@ class PackedConv:
     """
 
     def __init__(self, weight, scale=None, bias=None, stride=1, pad=0, dil=1, compute=F16, cin_pad=None,
-                 tap_major=False):
+                 tap_major=False, transposed=False):
+        """transposed: pack the input-gradient operand of `weight` (rows = its input channels, taps flipped) -- the
+        conv that maps dY to dX; f16 only."""
         _require_cuda(weight)
-        Cout, Cin, R, S = weight.shape
+        if transposed:
+            assert compute == F16 and scale is None and bias is None
+            Cin, Cout, R, S = weight.shape
+        else:
+            Cout, Cin, R, S = weight.shape
         self.Cout, self.R, self.S = Cout, R, S
         self.Cin = cin_pad if cin_pad is not None else Cin
         self.Cin_real = Cin
@@ -135,15 +141,33 @@ class PackedConv:
         self.Cout_eff = round_up(Cout, 4)
         K = R * S * self.Cin
         self.K = K
+        dev = weight.device
+        self.korder = 1 if (compute == F16 and not tap_major and self.Cin % 32 == 0 and R * S > 1) else 0
+        if compute == F16 and weight.dtype == torch.float32 and weight.is_contiguous():
+            # one packing kernel instead of the torch chain below
+            if self.Cin % 8:
+                raise ValueError(f"f16 path needs Cin % 8 == 0 (got {self.Cin}); pass cin_pad")
+            tile = _lib.lib().ctdet_conv_cout_tile(self.Cout_eff)
+            self.Kpad = round_up(K, 32)
+            self.Cout_pad = round_up(self.Cout_eff, tile)
+            wp = torch.empty(self.Cout_pad, self.Kpad, dtype=torch.float16, device=dev)
+            O, I = weight.shape[0], weight.shape[1]
+            rc = _lib.lib().ctdet_pack_weights(_ptr(weight.detach()), _ptr(wp), O, I, R, S, self.Cin, self.Cout_pad,
+                                               self.Kpad, self.korder, int(transposed), _stream())
+            _lib.check(rc, "ctdet_pack_weights")
+            self.w = wp
+            self.scale = self._pad_vec(scale, 1.0, dev)
+            self.bias = self._pad_vec(bias, 0.0, dev)
+            return
+        if transposed:
+            weight = weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()
         w = weight.detach().to(torch.float32).permute(0, 2, 3, 1)  # [Cout,R,S,Cin]
         if self.Cin != Cin:
             w = torch.nn.functional.pad(w, (0, self.Cin - Cin))
         # k ordering (ctdet_conv_desc.korder): chunk-major keeps the R*S taps of one 32-channel chunk adjacent
-        self.korder = 1 if (compute == F16 and not tap_major and self.Cin % 32 == 0 and R * S > 1) else 0
         if self.korder == 1:
             w = w.reshape(Cout, R * S, self.Cin // 32, 32).permute(0, 2, 1, 3)
         w = w.reshape(Cout, K)
-        dev = weight.device
         if compute == F16:
             if self.Cin % 8:
                 raise ValueError(f"f16 path needs Cin % 8 == 0 (got {self.Cin}); pass cin_pad")
@@ -159,15 +183,18 @@ class PackedConv:
             wp[:K, :Cout] = w.t()
         self.w = wp.contiguous()
 
-        def _pad(v, fill):
-            if v is None:
-                return None
-            o = torch.full((self.Cout_eff,), fill, dtype=torch.float32, device=dev)
-            o[:Cout] = v.detach().to(torch.float32)
-            return o
+        self.scale = self._pad_vec(scale, 1.0, dev)
+        self.bias = self._pad_vec(bias, 0.0, dev)
 
-        self.scale = _pad(scale, 1.0)
-        self.bias = _pad(bias, 0.0)
+    def _pad_vec(self, v, fill, dev):
+        if v is None:
+            return None
+        v = v.detach().to(torch.float32)
+        if v.shape[0] == self.Cout_eff:
+            return v.contiguous()
+        o = torch.full((self.Cout_eff,), fill, dtype=torch.float32, device=dev)
+        o[:self.Cout] = v
+        return o
 
     def out_hw(self, H, W):
         Ho = (H + 2 * self.pad - (self.dil * (self.R - 1) + 1)) // self.stride + 1

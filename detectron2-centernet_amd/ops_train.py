@@ -121,8 +121,8 @@ def conv_dgrad(dy, weight, stride, pad, in_hw):
     """dx of y = conv(x, weight): a conv over dy with the taps flipped and in/out channels swapped;
     stride > 1 reads dy as zero-stuffed (in_dil)."""
     Cout, Cin, R, S = weight.shape
-    wt = weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()  # [Cin, Cout, R, S]
-    p = ops.PackedConv(wt, None, None, stride=1, pad=R - 1 - pad, compute=F16, tap_major=stride > 1)
+    p = ops.PackedConv(weight.detach(), None, None, stride=1, pad=R - 1 - pad, compute=F16, tap_major=stride > 1,
+                       transposed=True)
     p.in_dil = stride
     B = dy.shape[0]
     dx = torch.empty(B, in_hw[0], in_hw[1], p.Cout_eff, dtype=torch.float16, device=dy.device)

@@ -88,6 +88,13 @@ int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32
 int32_t ctdet_maxpool3x3s2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
                            int32_t in_stride, int32_t out_stride, void* stream);
 
+/* Packs an f32 OIHW conv weight [O,I,R,S] (nn.Conv2d.weight as the reference stores it) into the f16 [rows_pad][Kpad]
+ * operand of ctdet_conv2d_fwd / ctdet_dcnv2_fwd, zero padding included.  korder as in ctdet_conv_desc.  transposed = 0:
+ * rows = O, channels = I (chans_pad >= I).  transposed = 1: the input-gradient operand (rows = I, channels = O, taps
+ * flipped), i.e. dX = conv(dY, packed) -- what autograd of nn.Conv2d computes. */
+int32_t ctdet_pack_weights(const float* w, void* packed, int32_t O, int32_t I, int32_t R, int32_t S, int32_t chans_pad,
+                           int32_t rows_pad, int32_t Kpad, int32_t korder, int32_t transposed, void* stream);
+
 /* y = ConvTranspose2d(C, C, 2f, stride=f, padding=f/2, groups=C, bias=False)(x) + skip  (dla.py:162-177).
  * w is f32 [2f][2f][C] (the ConvTranspose2d weight [C,1,2f,2f] with the channel dim moved last); skip may be NULL. */
 int32_t ctdet_dwconvT_add(const void* x, const float* w, const void* skip, void* y, int32_t dtype, int32_t B,
