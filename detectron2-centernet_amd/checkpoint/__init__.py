@@ -1,0 +1,3 @@
+from .detection_checkpoint import DetectionCheckpointer
+
+__all__ = ["DetectionCheckpointer"]

@@ -206,6 +206,17 @@ class CenterNet(nn.Module):
     def device(self):
         return self.pixel_mean.device
 
+    # captured eval graphs reference the packed (BatchNorm-folded) weights of the moment of capture: drop them whenever
+    # the parameters can have changed -- a checkpoint load, or a return from training mode
+    def load_state_dict(self, *args, **kwargs):
+        self._engines = {}
+        return super().load_state_dict(*args, **kwargs)
+
+    def train(self, mode=True):
+        if mode != self.training:
+            self._engines = {}
+        return super().train(mode)
+
     # ------------------------------------------------------------------ network (NHWC, HIP kernels)
     def _head_outputs(self, y, apply_sigmoid):
         """y NHWC [B,h,w,64] -> dict head -> f32 NHWC buffer (channels padded to a multiple of 4)."""

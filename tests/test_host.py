@@ -181,3 +181,65 @@ def test_synthetic_samples_are_deterministic():
     assert a["image"].dtype == torch.uint8 and a["image"].shape == (3, 512, 512)
     bx = a["boxes"]
     assert (bx[:, 0] >= 0).all() and (bx[:, 2] <= 512).all() and ((bx[:, 2] - bx[:, 0]) >= 8).all()
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    """`.pth` files in the reference's layout ({"model": state_dict, "iteration": n}, `module.`
+    prefixes from DDP, `last_checkpoint` file) load key-for-key; shape mismatches are skipped and reported"""
+    import torch
+
+    from detectron2_centernet_amd.checkpoint import DetectionCheckpointer
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Conv2d(3, 4, 3)
+            self.bn = torch.nn.BatchNorm2d(4)
+            self.register_buffer("pixel_mean", torch.zeros(3, 1, 1))
+
+    torch.manual_seed(0)
+    src, dst = Net(), Net()
+    ck = DetectionCheckpointer(src, str(tmp_path))
+    path = ck.save("model_0000009", iteration=9)
+    assert open(tmp_path / "last_checkpoint").read() == "model_0000009.pth"
+    raw = torch.load(path, weights_only=False)
+    assert set(raw) == {"model", "iteration"} and set(raw["model"]) == set(src.state_dict())
+    extra = DetectionCheckpointer(dst, str(tmp_path)).resume_or_load("", resume=True)
+    assert extra == {"iteration": 9}
+    for k, v in src.state_dict().items():
+        assert torch.equal(v, dst.state_dict()[k])
+    # a DDP-saved file with a wrong-shaped tensor, one missing and one unexpected key
+    sd = {"module." + k: v.clone() for k, v in src.state_dict().items()}
+    sd["module.conv.weight"] = torch.zeros(4, 3, 5, 5)
+    del sd["module.bn.bias"], sd["module.pixel_mean"]
+    sd["module.extra"] = torch.zeros(1)
+    torch.save({"model": sd}, tmp_path / "ddp.pth")
+    c2 = DetectionCheckpointer(Net())
+    c2.load(str(tmp_path / "ddp.pth"))
+    assert c2.incompatible.missing_keys == ["conv.weight", "bn.bias"] or set(c2.incompatible.missing_keys) == {"conv.weight", "bn.bias"}
+    assert c2.incompatible.unexpected_keys == ["extra"]
+    assert c2.incompatible.incorrect_shapes[0][0] == "conv.weight"
+
+
+def test_coco_json_handoff():
+    """XYWH boxes, python scalars, contiguous -> dataset category ids"""
+    import json
+
+    import torch
+
+    from detectron2_centernet_amd.evaluation import instances_to_coco_json, results_to_coco_json
+    from detectron2_centernet_amd.structures import Boxes, Instances
+
+    inst = Instances((480, 640))
+    inst.pred_boxes = Boxes(torch.tensor([[10.0, 20.0, 110.0, 70.0], [0.5, 1.5, 2.5, 4.0]]))
+    inst.scores = torch.tensor([0.9, 0.25])
+    inst.pred_classes = torch.tensor([3, 0])
+    js = instances_to_coco_json(inst, 42)
+    assert js == [{"image_id": 42, "category_id": 3, "bbox": [10.0, 20.0, 100.0, 50.0], "score": js[0]["score"]},
+                  {"image_id": 42, "category_id": 0, "bbox": [0.5, 1.5, 2.0, 2.5], "score": 0.25}]
+    assert abs(js[0]["score"] - 0.9) < 1e-6
+    json.dumps(js)  # plain python types only
+    empty = Instances((4, 4))
+    empty.pred_boxes, empty.scores, empty.pred_classes = Boxes(torch.zeros(0, 4)), torch.zeros(0), torch.zeros(0, dtype=torch.long)
+    flat = results_to_coco_json([{"instances": inst}, {"instances": empty}], [42, 43], {1: 0, 7: 1, 9: 2, 17: 3})
+    assert [r["category_id"] for r in flat] == [17, 1] and all(r["image_id"] == 42 for r in flat)
