@@ -31,6 +31,7 @@ SIGNATURES = {
     "ctdet_conv1x1_cat_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctdet_dcnv2_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ctdet_preprocess": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp]),
+    "ctdet_head_fused_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "ctdet_maxpool2x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_maxpool3x3s2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_pack_weights": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -81,3 +82,11 @@ def check(rc, what):
     if rc != 0:
         msg = lib().ctdet_last_error()
         raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+class HeadDesc(C.Structure):
+    """mirrors ctdet_head_desc"""
+    _fields_ = [("nheads", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+                ("in_stride", C.c_int32), ("w2", C.c_void_p * 4), ("b2", C.c_void_p * 4), ("y", C.c_void_p * 4),
+                ("y_stride", C.c_int32 * 4), ("cout", C.c_int32 * 4), ("act", C.c_int32 * 4),
+                ("clamp_lo", C.c_float), ("clamp_hi", C.c_float)]

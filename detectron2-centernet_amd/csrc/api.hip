@@ -171,6 +171,21 @@ int32_t ctdet_preprocess(const void* img, int32_t img_dtype, void* out, int32_t 
                            out_stride, border, (hipStream_t)stream);
 }
 
+int32_t ctdet_head_fused_fwd(const ctdet_head_desc* d, const void* x, const void* w1, const float* b1, void* stream) {
+  CTDET_CHECK(d && x && w1 && b1, "head_fused: null pointer");
+  HeadArgs a = {};
+  a.x = x; a.w1 = w1; a.b1 = b1;
+  a.nheads = d->nheads; a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_stride = d->in_stride;
+  a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi;
+  CTDET_CHECK(d->nheads >= 1 && d->nheads <= 4, "head_fused: nheads=%d out of range", d->nheads);
+  for (int h = 0; h < d->nheads; ++h) {
+    CTDET_CHECK(d->w2[h] && d->b2[h] && d->y[h], "head_fused: head %d: null pointer", h);
+    a.w2[h] = d->w2[h]; a.b2[h] = (const float*)d->b2[h]; a.y[h] = (float*)d->y[h];
+    a.y_stride[h] = d->y_stride[h]; a.cout[h] = d->cout[h]; a.act[h] = d->act[h];
+  }
+  return launch_head_fused(a, (hipStream_t)stream);
+}
+
 int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
                          int32_t in_stride, int32_t out_stride, void* stream) {
   CTDET_CHECK(x && y, "maxpool2x2: null pointer");

@@ -62,6 +62,20 @@ struct ConvArgs {
   int in_dil;           // input dilation (zero-stuffed input): >1 only for the input-gradient of strided convs
 };
 
+// argument block of the fused CenterNet head kernel (conv_igemm.hip): per head 3x3 conv Cin->256 + bias + ReLU, then
+// 1x1 conv 256->cout + bias (+ sigmoid/clamp), the 256-channel hidden map staying in registers
+struct HeadArgs {
+  const void* x;          // f16 [B,H,W,in_stride]
+  const void* w1;         // f16 packed chunk-major [nheads*256][9*Cin]
+  const float* b1;        // [nheads*256]
+  const void* w2[4];      // f16 [round_up(cout,16)][256]
+  const float* b2[4];     // f32 [round_up(cout,16)]
+  float* y[4];            // f32 [B,H,W,y_stride]
+  int y_stride[4], cout[4], act[4];
+  int nheads, B, H, W, Cin, in_stride;
+  float clamp_lo, clamp_hi;
+};
+
 // argument block of the batched decode (decode.hip)
 struct DecArgs {
   const float* heat; const float* wh; const float* reg;
@@ -77,4 +91,5 @@ __device__ __forceinline__ float ctdet_sigmoid_exact(float v) { return 1.0f / (1
 
 // launchers implemented in the .hip files (return 0 or negative errno)
 int launch_conv_f16(const ConvArgs& a, int out_dtype, bool deform, hipStream_t s);
+int launch_head_fused(const HeadArgs& a, hipStream_t s);
 int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s);

@@ -904,6 +904,221 @@ static int launch_halo(const ConvArgs& a, hipStream_t s) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused CenterNet head (centernet.py:115-121, 151-154): per head  out = W2 * relu(conv3x3(x, W1) + b1) + b2.
+// The reference (and the first version here) writes the 256-channel hidden map of every head to memory and reads it
+// back for the 1x1: 3 x 537 MB written + read per 64 images, the largest single item of HBM traffic in the step.
+// Here a workgroup owns an 8x16 pixel tile of ONE head and all 256 hidden channels: wave w holds rows 2w, 2w+1 of the
+// tile (2 pixel tiles) x 256 hidden (16 cout tiles) = 128 accumulator registers, the same count as the 256x128 halo
+// kernel above, whose K loop this is (input window of a 32-channel chunk in LDS once, 9 taps read it at shifted
+// addresses, weights through a 3-stage LDS-DMA ring).  Because a lane ends up with 8 consecutive hidden channels of a
+// pixel per cout-tile pair (cout_of), relu(acc + b1) rounded to f16 IS the MFMA B fragment of the second GEMM: the
+// 1x1 runs on the registers (W2 fragments straight from global/L2), no cross-wave reduction, and only the final
+// maps are stored.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) head_fused_kernel(const HeadArgs a) {
+  constexpr int TH = 8, TW = 16, HID = 256, TC = HID / 16, TP = 2;
+  constexpr int HMAIN = 3 * 4096, HSIDE = 4096, HBUF = HMAIN + HSIDE;   // main [12 rows][16 px][64 B] (10 used), side
+  constexpr int WST = HID * 64, B_LD = HID / 64;
+  static_assert(2 * HBUF + 3 * WST <= 81920, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) char smem[2 * HBUF + 3 * WST];
+  char* const ring = smem + 2 * HBUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  int m_tile, head;
+  if (!tile_of_block(a.B * tiles_y * tiles_x, a.nheads, m_tile, head)) return;
+  const int tx0 = (m_tile % tiles_x) * TW;
+  const int ty0 = ((m_tile / tiles_x) % tiles_y) * TH;
+  const int b = m_tile / (tiles_x * tiles_y);
+  const f16* zero = (const f16*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+  const f16* ximg = (const f16*)a.x + (long)b * a.H * a.W * a.in_stride;
+
+  // ---- halo loader: 3 main pieces (rows r, r+4, r+8) + 1 side piece per thread and chunk ----
+  const int hslot = tid & 3, hpx = (tid >> 2) & 15, hr0 = tid >> 6;
+  const int y0 = ty0 - 1 + hr0;
+  const f16* hp0 = ximg + ((long)y0 * a.W + tx0 + hpx) * a.in_stride + (hslot ^ swz(hpx)) * 8;
+  const long row4 = 4L * a.W * a.in_stride;
+  unsigned hmask = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) hmask |= (hr0 + 4 * i < TH + 2 && y0 + 4 * i >= 0 && y0 + 4 * i < a.H) ? (1u << i) : 0u;
+  const f16* hps;
+  {
+    const int side = (tid >> 2) & 1, hr = tid >> 3;   // [hr 0..9][side][slot], tid < 80
+    const int y = ty0 - 1 + hr, x = side ? tx0 + TW : tx0 - 1;
+    const bool ok = tid < 80 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    hps = ximg + ((long)(ok ? y : 0) * a.W + (ok ? x : 0)) * a.in_stride + hslot * 8;
+    hmask |= ok ? 8u : 0u;
+  }
+  const int Kpad = 9 * a.Cin;
+  const int lrow = tid >> 2;
+  const int gw = hslot ^ swz(lrow);
+  const f16* wptr[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int L = lrow + 64 * j;
+    const int tt = L >> 4, r = L & 15;
+    wptr[j] = (const f16*)a.w1 + (long)(head * HID + cout_of<TC>(tt, r >> 2, r & 3)) * Kpad + gw * 8;
+  }
+  auto issue_halo = [&](int chunk, int hb) {
+    char* dst = smem + hb * HBUF + wave * 1024;
+    const long coff = (long)chunk * 32;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dma16((hmask & (1u << i)) ? hp0 + i * row4 + coff : zero, dst + i * 4096);
+    dma16((hmask & 8u) ? hps + coff : zero, smem + hb * HBUF + HMAIN + wave * 1024);
+  };
+  auto issue_w = [&](int kt, int st) {
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) dma16(wptr[j] + (long)kt * 32, ring + st * WST + wave * 1024 + j * 4096);
+  };
+
+  // ---- fragment addressing (one pixel tile per tile row): lane column l15, tap column s -> window column l15+s-1 ----
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int row0 = wave * TP;
+  int abase[3];
+#pragma unroll
+  for (int s2 = 0; s2 < 3; ++s2) {
+    const int X = l15 + s2 - 1;
+    if (X < 0) abase[s2] = HMAIN + kg * 16 + row0 * 128;
+    else if (X > 15) abase[s2] = HMAIN + 64 + kg * 16 + row0 * 128;
+    else abase[s2] = X * 64 + ((kg ^ swz(X)) << 4) + row0 * 1024;
+  }
+  const int estride0 = (l15 == 0) ? 128 : 1024;    // row stride of this lane for tap column 0
+  const int estride2 = (l15 == 15) ? 128 : 1024;   // ... for tap column 2
+  const char* fragB = ring + l15 * 64 + ((kg ^ swz(l15)) << 4);
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nch = a.Cin / 32, nk = nch * 9;
+  issue_halo(0, 0);
+  issue_w(0, 0);
+  issue_w(1, 1);
+
+  auto kstep = [&](int kt, int chunk, auto tapc, auto hbc) {
+    constexpr int T = decltype(tapc)::value, HB = decltype(hbc)::value;
+    constexpr int R_ = T / 3, S_ = T % 3, ST = T % 3, SL = (T + 2) % 3;
+    if (kt + 1 < nk) { if (T == 1) wait_vmcnt<B_LD + 4>(); else wait_vmcnt<B_LD>(); }
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (T == 0 && chunk + 1 < nch) issue_halo(chunk + 1, HB ^ 1);
+    if (kt + 2 < nk) issue_w(kt + 2, SL);
+    const char* hbuf = smem + HB * HBUF;
+    f16x8 pf[TP];
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      int off;
+      if (S_ == 0) off = abase[0] + (p + R_) * estride0;
+      else if (S_ == 2) off = abase[2] + (p + R_) * estride2;
+      else off = abase[1] + (p + R_) * 1024;
+      pf[p] = *(const f16x8*)(hbuf + off);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f16x8 wf[TC / 2];
+#pragma unroll
+      for (int c = 0; c < TC / 2; ++c) wf[c] = *(const f16x8*)(fragB + ST * WST + (half * (TC / 2) + c) * 1024);
+#pragma unroll
+      for (int c = 0; c < TC / 2; ++c)
+#pragma unroll
+        for (int p = 0; p < TP; ++p)
+          acc[p][half * (TC / 2) + c] =
+              __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf[p], acc[p][half * (TC / 2) + c], 0, 0, 0);
+    }
+  };
+  auto chunk_steps = [&](int kt, int chunk, auto hbc) {
+    kstep(kt + 0, chunk, std::integral_constant<int, 0>{}, hbc);
+    kstep(kt + 1, chunk, std::integral_constant<int, 1>{}, hbc);
+    kstep(kt + 2, chunk, std::integral_constant<int, 2>{}, hbc);
+    kstep(kt + 3, chunk, std::integral_constant<int, 3>{}, hbc);
+    kstep(kt + 4, chunk, std::integral_constant<int, 4>{}, hbc);
+    kstep(kt + 5, chunk, std::integral_constant<int, 5>{}, hbc);
+    kstep(kt + 6, chunk, std::integral_constant<int, 6>{}, hbc);
+    kstep(kt + 7, chunk, std::integral_constant<int, 7>{}, hbc);
+    kstep(kt + 8, chunk, std::integral_constant<int, 8>{}, hbc);
+  };
+  int chunk = 0;
+  for (; chunk + 1 < nch; chunk += 2) {
+    chunk_steps(chunk * 9, chunk, std::integral_constant<int, 0>{});
+    chunk_steps(chunk * 9 + 9, chunk + 1, std::integral_constant<int, 1>{});
+  }
+  if (chunk < nch) chunk_steps(chunk * 9, chunk, std::integral_constant<int, 0>{});
+
+  // ---- hidden = relu(acc + b1) as f16 B fragments: frag[p][hb] = hidden channels hb*32 + kg*8 .. +8 of pixel l15 ----
+  const float* b1 = a.b1 + head * HID;
+  f16x8 frag[TP][TC / 2];
+#pragma unroll
+  for (int hb = 0; hb < TC / 2; ++hb) {
+    const f32x4 ba = *(const f32x4*)(b1 + hb * 32 + kg * 8), bb = *(const f32x4*)(b1 + hb * 32 + kg * 8 + 4);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      f16x8 f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[j] = (f16)fmaxf(acc[p][2 * hb][j] + ba[j], 0.f);
+        f[4 + j] = (f16)fmaxf(acc[p][2 * hb + 1][j] + bb[j], 0.f);
+      }
+      frag[p][hb] = f;
+    }
+  }
+  // ---- 1x1: out tile ot (16 outputs) = sum over the 8 hidden blocks of W2[ot][hb] x frag[.][hb] ----
+  const f16* w2 = (const f16*)a.w2[head];
+  const float* b2 = a.b2[head];
+  float* yh = a.y[head];
+  const int ystride = a.y_stride[head], cout = a.cout[head], act = a.act[head];
+  const int ntile2 = (cout + 15) >> 4;
+  for (int ot = 0; ot < ntile2; ++ot) {
+    f32x4 o[TP];
+#pragma unroll
+    for (int p = 0; p < TP; ++p) o[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f16* wrow = w2 + (long)(ot * 16 + l15) * HID + kg * 8;
+#pragma unroll
+    for (int hb = 0; hb < TC / 2; ++hb) {
+      const f16x8 wa = *(const f16x8*)(wrow + hb * 32);
+#pragma unroll
+      for (int p = 0; p < TP; ++p) o[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, frag[p][hb], o[p], 0, 0, 0);
+    }
+    const int c0 = ot * 16 + 4 * kg;               // this lane's 4 outputs
+    if (c0 < ((cout + 3) & ~3)) {
+      const f32x4 bv = *(const f32x4*)(b2 + c0);
+#pragma unroll
+      for (int p = 0; p < TP; ++p) {
+        f32x4 v = o[p] + bv;
+        if (act == CTDET_ACT_RELU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        } else if (act == CTDET_ACT_SIGMOID_CLAMP) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(ctdet_sigmoid_exact(v[j]), a.clamp_lo), a.clamp_hi);
+        }
+        const long m = (long)(b * a.H + ty0 + row0 + p) * a.W + tx0 + l15;
+        *(f32x4*)(yh + m * ystride + c0) = v;
+      }
+    }
+  }
+}
+
+int launch_head_fused(const HeadArgs& a, hipStream_t s) {
+  CTDET_CHECK(a.nheads >= 1 && a.nheads <= 4, "head_fused: 1..4 heads");
+  CTDET_CHECK(a.Cin % 32 == 0 && a.H % 8 == 0 && a.W % 16 == 0 && a.in_stride % 8 == 0,
+              "head_fused: needs Cin %% 32 == 0 and a map divisible by 8x16 (Cin=%d, %dx%d)", a.Cin, a.H, a.W);
+  for (int h = 0; h < a.nheads; ++h)
+    CTDET_CHECK(a.cout[h] >= 1 && a.cout[h] <= 256 && a.y_stride[h] % 4 == 0 && a.y_stride[h] >= ((a.cout[h] + 3) & ~3) &&
+                    (((size_t)a.y[h]) & 15) == 0,
+                "head_fused: head %d: bad output (cout %d, stride %d)", h, a.cout[h], a.y_stride[h]);
+  const int nbx = a.B * (a.H / 8) * (a.W / 16);
+  dim3 grid(8 * ((nbx + 7) / 8) * a.nheads);
+  hipLaunchKernelGGL(head_fused_kernel, grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
 static bool halo_ok(const ConvArgs& a) {
   return a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.in_dil == 1 && a.nsrc <= 1 &&
          a.korder == 1 && a.Cin % 32 == 0 && a.Kpad == a.K && a.H % 8 == 0 && a.W % 32 == 0 && a.Ho == a.H &&

@@ -223,6 +223,22 @@ class CenterNet(nn.Module):
         ctx = self._ctx
         names = [h.lower() for h in self.heads]
         out = {}
+        fused = (self.head_conv == ops.PackedHeads.HID and ctx.compute == F16 and ops.HEADS_FUSED
+                 and y.shape[3] % 32 == 0 and y.shape[1] % 8 == 0 and y.shape[2] % 16 == 0 and len(names) <= 4
+                 and all(getattr(self, n)[2].kernel_size == (1, 1) for n in names))
+        if fused:
+            # 3x3 + ReLU + 1x1 of every head in one kernel: the 256-channel hidden maps never reach memory
+            fcs = [getattr(self, n) for n in names]
+            acts = [ACT_SIGMOID_CLAMP if (apply_sigmoid and n == "hm") else ACT_NONE for n in names]
+            cache = self.__dict__.setdefault("_ctdet_packed", {})
+            ver = tuple((t.data_ptr(), t._version) for fc in fcs for t in (fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias))
+            hit = cache.get(("heads_fused", tuple(acts)))
+            if hit is None or hit[0] != ver:
+                ph = ops.PackedHeads([fc[0].weight for fc in fcs], [fc[0].bias for fc in fcs],
+                                     [fc[2].weight for fc in fcs], [fc[2].bias for fc in fcs], acts)
+                hit = cache[("heads_fused", tuple(acts))] = (ver, ph)
+            outs = ops.heads_fused(y, hit[1], clamp=(1e-4, 1 - 1e-4))
+            return dict(zip(names, outs))
         if self.head_conv > 0:
             convs = [getattr(self, n)[0] for n in names]
             # the first convs of all heads share their input: one conv with concatenated output channels

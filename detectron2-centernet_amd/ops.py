@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, F16, F32, U8, ConvDesc
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, F16, F32, U8, ConvDesc, HeadDesc
 
 _TORCH_DT = {F16: torch.float16, F32: torch.float32}
 
@@ -51,11 +51,11 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
 
 
 class _Prof:
-    def __init__(self, p, M, deform, out_dt, x_shape=None, nsrc=1):
+    def __init__(self, p, M, deform, out_dt, x_shape=None, nsrc=1, name=None, flops=None):
         self.on = PROFILE_ON
         if self.on:
-            self.name = _kernel_name(p, M, deform, out_dt, x_shape, nsrc)
-            self.flops = 2.0 * M * p.Cout * p.R * p.S * p.Cin_real
+            self.name = name if name is not None else _kernel_name(p, M, deform, out_dt, x_shape, nsrc)
+            self.flops = flops if flops is not None else 2.0 * M * p.Cout * p.R * p.S * p.Cin_real
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
 
@@ -286,6 +286,7 @@ def conv1x1_cat(xs, p, out=None, act=ACT_NONE, residual=None, out_dtype=None):
 
 
 DCN_WINDOW = os.environ.get("CTDET_NO_DCN_WINDOW", "0") != "1"
+HEADS_FUSED = os.environ.get("CTDET_NO_FUSED_HEADS", "0") != "1"
 
 
 def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_prob=False):
@@ -324,6 +325,57 @@ def preprocess(images, mean, std, Hp, Wp, out_dtype=torch.float16, out=None, par
                                      images.stride(0), m, s, _nhwc_stride(out), int(border), _stream())
     _lib.check(rc, "ctdet_preprocess")
     return out
+
+
+class PackedHeads:
+    """weights of the fused CenterNet heads (ctdet_head_fused_fwd): first convs [256, Cin, 3, 3] + bias per head, final
+    1x1 convs [cout, 256, 1, 1] + bias per head, acts per head."""
+
+    HID = 256
+
+    def __init__(self, first_weights, first_biases, final_weights, final_biases, acts):
+        n = len(first_weights)
+        assert 1 <= n <= 4 and all(w.shape[0] == self.HID and tuple(w.shape[2:]) == (3, 3) for w in first_weights)
+        assert all(tuple(w.shape[1:]) == (self.HID, 1, 1) for w in final_weights)
+        dev = first_weights[0].device
+        self.n, self.Cin, self.acts = n, first_weights[0].shape[1], list(acts)
+        self.p1 = PackedConv(torch.cat([w.detach().float() for w in first_weights], 0).contiguous(), None, None, stride=1,
+                             pad=1, compute=F16)
+        assert self.p1.korder == 1 and self.p1.Kpad == 9 * self.Cin
+        self.b1 = torch.cat([b.detach().float() for b in first_biases]).contiguous()
+        self.couts = [w.shape[0] for w in final_weights]
+        self.w2, self.b2 = [], []
+        for w, b in zip(final_weights, final_biases):
+            c = w.shape[0]
+            wp = torch.zeros(round_up(c, 16), self.HID, dtype=torch.float16, device=dev)
+            wp[:c] = w.detach().reshape(c, self.HID).half()
+            bp = torch.zeros(round_up(c, 16), dtype=torch.float32, device=dev)
+            bp[:c] = b.detach().float()
+            self.w2.append(wp)
+            self.b2.append(bp)
+
+
+def heads_fused(x, ph, clamp=(0.0, 1.0), outs=None):
+    """x f16 NHWC [B,H,W,Cin] -> list of f32 NHWC maps [B,H,W,round_up(cout,4)], one per head."""
+    _require_cuda(x)
+    assert x.dtype == torch.float16 and x.shape[3] == ph.Cin
+    B, H, W, _ = x.shape
+    if outs is None:
+        outs = [torch.empty(B, H, W, round_up(c, 4), dtype=torch.float32, device=x.device) for c in ph.couts]
+    d = HeadDesc()
+    d.nheads, d.B, d.H, d.W, d.Cin, d.in_stride = ph.n, B, H, W, ph.Cin, _nhwc_stride(x)
+    for h in range(ph.n):
+        d.w2[h], d.b2[h], d.y[h] = ph.w2[h].data_ptr(), ph.b2[h].data_ptr(), outs[h].data_ptr()
+        d.y_stride[h], d.cout[h], d.act[h] = _nhwc_stride(outs[h]), ph.couts[h], ph.acts[h]
+    d.clamp_lo, d.clamp_hi = clamp
+    M = B * H * W
+    prof = _Prof(None, M, False, F32, name="head_fused_kernel<128x256,f16>",
+                 flops=sum(2.0 * M * PackedHeads.HID * (9 * ph.Cin + c) for c in ph.couts))
+    for _ in range(prof.reps()):
+        rc = _lib.lib().ctdet_head_fused_fwd(C.byref(d), _ptr(x), _ptr(ph.p1.w), _ptr(ph.b1), _stream())
+    _lib.check(rc, "ctdet_head_fused_fwd")
+    prof.done()
+    return outs
 
 
 def maxpool3x3s2(x, out=None):

@@ -79,6 +79,22 @@ int32_t ctdet_preprocess(const void* img, int32_t img_dtype, void* out, int32_t 
                          int32_t W, int32_t Hp, int32_t Wp, int64_t img_batch_stride, const float* mean3,
                          const float* std3, int32_t out_stride, int32_t border, void* stream);
 
+/* Fused CenterNet head (detectron2/modeling/meta_arch/centernet.py:115-121,151-154): for every head h
+ *   y[h] = act_h( W2_h * relu(conv3x3_p1(x, W1_h) + b1_h) + b2_h ),   hidden width 256,
+ * without materialising the hidden maps.  x: f16 NHWC [B,H,W,in_stride] (Cin % 32 == 0, H % 8 == 0, W % 16 == 0);
+ * w1: the nheads 3x3 weights concatenated along Cout and packed chunk-major (ctdet_pack_weights korder 1) [nheads*256]
+ * [9*Cin]; b1 f32 [nheads*256]; w2[h]: f16 row-major [round_up(cout,16)][256] (zero rows beyond cout); b2[h] f32
+ * [round_up(cout,16)]; y[h]: f32 NHWC [B,H,W,y_stride[h]] (round_up(cout,4) channels written). */
+typedef struct ctdet_head_desc {
+  int32_t nheads, B, H, W, Cin, in_stride;
+  const void* w2[4];
+  const void* b2[4];
+  void* y[4];
+  int32_t y_stride[4], cout[4], act[4];
+  float clamp_lo, clamp_hi;
+} ctdet_head_desc;
+int32_t ctdet_head_fused_fwd(const ctdet_head_desc* d, const void* x, const void* w1, const float* b1, void* stream);
+
 /* nn.MaxPool2d(2, stride=2) on NHWC (dla.py:128-129). */
 int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
                          int32_t in_stride, int32_t out_stride, void* stream);

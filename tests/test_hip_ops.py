@@ -133,6 +133,32 @@ def test_conv_window_small_channels(ops, dev, case):
     assert err < 3e-3 * max(1.0, ref.abs().max().item()), f"{name}: max err {err}"
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, (80, 2, 2)), (1, 8, 16, 64, (5,)), (1, 24, 16, 128, (20, 2, 2, 7))])
+def test_heads_fused(ops, dev, case):
+    """fused 3x3 + ReLU + 1x1 heads vs torch (f16 operands, f32 accumulation; the hidden map is rounded to f16 as in
+    the unfused path), hm head with sigmoid + clamp, image borders included"""
+    B, H, W, Cin, couts = case
+    g = torch.Generator().manual_seed(Cin + len(couts))
+    x = h16(torch.randn(B, Cin, H, W, generator=g))
+    w1 = [h16(torch.randn(256, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5) for _ in couts]
+    b1 = [torch.randn(256, generator=g) * 0.3 for _ in couts]
+    w2 = [h16(torch.randn(c, 256, 1, 1, generator=g) / 16) for c in couts]
+    b2 = [torch.randn(c, generator=g) for c in couts]
+    acts = [ops.ACT_SIGMOID_CLAMP if i == 0 else ops.ACT_NONE for i in range(len(couts))]
+    ph = ops.PackedHeads([w.to(dev) for w in w1], [b.to(dev) for b in b1], [w.to(dev) for w in w2],
+                         [b.to(dev) for b in b2], acts)
+    outs = ops.heads_fused(nhwc(x).half().to(dev), ph, clamp=(1e-4, 1 - 1e-4))
+    for i, c in enumerate(couts):
+        hid = h16(F.conv2d(x, w1[i], b1[i], 1, 1).relu())
+        ref = F.conv2d(hid, w2[i], b2[i])
+        if i == 0:
+            ref = torch.clamp(torch.sigmoid(ref), 1e-4, 1 - 1e-4)
+        got = nchw(outs[i][..., :c].cpu())
+        assert got.shape == ref.shape
+        err = (got - ref).abs().max().item()
+        assert err <= 3e-3 * max(1.0, ref.abs().max().item()), f"head {i}: max err {err}"
+
+
 DCN_CASES = [(2, 12, 14, 64, 64, 2.0), (1, 9, 9, 128, 64, 0.0), (2, 8, 10, 128, 128, 4.0), (1, 6, 6, 256, 256, 1.0),
              (1, 7, 5, 512, 256, 8.0)]
 
