@@ -324,44 +324,64 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_kernel(const f16* __restri
 //   dx[b,iy,ix,c]   = sum_{ky,kx} dz[b, iy*f - p + ky, ix*f - p + kx, c] * w[ky][kx][c]
 //   dw[ky][kx][c]  += sum_{b,iy,ix} x[b,iy,ix,c] * dz[b, iy*f - p + ky, ix*f - p + kx, c]   (f32 atomics)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) dwconvT_bwd_kernel(const f16* __restrict__ x, int x_stride,
-                                                          const f16* __restrict__ dz, int dz_stride,
-                                                          const float* __restrict__ w, f16* __restrict__ dx, int dx_stride,
-                                                          float* __restrict__ dw, int B, int H, int W, int C, int f) {
-  extern __shared__ float sdw[];  // [k*k][C]
-  const int CV = C >> 3, k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f;
-  for (int i = threadIdx.x; i < k * k * C; i += 256) sdw[i] = 0.f;
-  __syncthreads();
-  // dw: walk the OUTPUT pixels once; each (oy,ox) touches exactly 2x2 (input pixel, tap) pairs
-  const long nout = (long)B * Ho * Wo * CV;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nout; idx += (long)gridDim.x * 256) {
-    const int cv = (int)(idx % CV);
-    long t = idx / CV;
-    const int ox = (int)(t % Wo); t /= Wo;
-    const int oy = (int)(t % Ho);
-    const int b = (int)(t / Ho);
-    const f16x8 g = *(const f16x8*)(dz + ((long)(b * Ho + oy) * Wo + ox) * dz_stride + cv * 8);
-    const int iy1 = (oy + p) / f, ky1 = (oy + p) - f * iy1;
-    const int ix1 = (ox + p) / f, kx1 = (ox + p) - f * ix1;
+// dw: one tap phase (ky1, kx1) = ((oy+p) % f, (ox+p) % f) per blockIdx.y.  All output pixels of a phase feed the same four
+// taps (ky1 + {0,f}, kx1 + {0,f}), so a thread (fixed 8-channel group) keeps its 4 x 8 partial sums in registers while it
+// walks the phase's pixels; partials are combined across the workgroup through LDS with plain stores (LDS float atomics
+// measured ~170 cycles per wave-instruction here) and leave as 4*C global atomics per workgroup.
+__global__ void __launch_bounds__(256) dwconvT_dw_kernel(const f16* __restrict__ x, int x_stride, const f16* __restrict__ dz,
+                                                         int dz_stride, float* __restrict__ dw, int B, int H, int W, int C,
+                                                         int f) {
+  extern __shared__ float part[];  // [S][4][C]
+  const int CV = C >> 3, S = 256 / CV, k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f;
+  const int cv = threadIdx.x % CV, sub = threadIdx.x / CV;
+  const int ky1 = blockIdx.y / f, kx1 = blockIdx.y % f;
+  float acc[4][8];
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-      const int iy = iy1 - dy, ky = ky1 + dy * f;
-      if (iy < 0 || iy >= H) continue;
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int dxx = 0; dxx < 2; ++dxx) {
-        const int ix = ix1 - dxx, kx = kx1 + dxx * f;
-        if (ix < 0 || ix >= W) continue;
-        const f16x8 xv = *(const f16x8*)(x + ((long)(b * H + iy) * W + ix) * x_stride + cv * 8);
-        float* acc = sdw + (ky * k + kx) * C + cv * 8;
+    for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+  const long npos = (long)B * (H + 1) * (W + 1);
+  if (sub < S) {
+    for (long pos = (long)blockIdx.x * S + sub; pos < npos; pos += (long)gridDim.x * S) {
+      const int ix1 = (int)(pos % (W + 1));
+      const long t2 = pos / (W + 1);
+      const int iy1 = (int)(t2 % (H + 1)), b = (int)(t2 / (H + 1));
+      const int oy = iy1 * f + ky1 - p, ox = ix1 * f + kx1 - p;
+      if (oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
+      const f16x8 g = *(const f16x8*)(dz + ((long)(b * Ho + oy) * Wo + ox) * dz_stride + cv * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(acc + e, (float)xv[e] * (float)g[e]);
+      for (int dy = 0; dy < 2; ++dy) {
+        const int iy = iy1 - dy;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int dxx = 0; dxx < 2; ++dxx) {
+          const int ix = ix1 - dxx;
+          if (ix < 0 || ix >= W) continue;
+          const f16x8 xv = *(const f16x8*)(x + ((long)(b * H + iy) * W + ix) * x_stride + cv * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[dy * 2 + dxx][e] += (float)xv[e] * (float)g[e];
+        }
       }
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part[(sub * 4 + t) * C + cv * 8 + e] = acc[t][e];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < k * k * C; i += 256)
-    if (sdw[i] != 0.f) atomicAdd(dw + i, sdw[i]);
-  // dx: gather the k x k output window of every input pixel
+  for (int i = threadIdx.x; i < 4 * C; i += 256) {
+    float sum = 0.f;
+    for (int s2 = 0; s2 < S; ++s2) sum += part[s2 * 4 * C + i];
+    const int t = i / C, c = i - t * C;
+    const int ky = ky1 + (t >> 1) * f, kx = kx1 + (t & 1) * f;
+    if (sum != 0.f) atomicAdd(dw + (long)(ky * k + kx) * C + c, sum);
+  }
+}
+
+// dx: gather the k x k output window of every input pixel
+__global__ void __launch_bounds__(256) dwconvT_dx_kernel(const f16* __restrict__ dz, int dz_stride, const float* __restrict__ w,
+                                                         f16* __restrict__ dx, int dx_stride, int B, int H, int W, int C, int f) {
+  const int CV = C >> 3, k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f;
   const long nin = (long)B * H * W * CV;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nin; idx += (long)gridDim.x * 256) {
     const int cv = (int)(idx % CV);
@@ -773,14 +793,17 @@ int launch_maxpool2x2_bwd(const f16* x, int x_stride, const f16* dz, int dz_stri
 
 int launch_dwconvT_bwd(const f16* x, int x_stride, const f16* dz, int dz_stride, const float* w, f16* dx, int dx_stride,
                        float* dw, int B, int H, int W, int C, int f, hipStream_t s) {
-  CTDET_CHECK(C % 8 == 0 && f % 2 == 0, "dwconvT_bwd: bad shape C=%d f=%d", C, f);
-  const size_t lds = (size_t)4 * f * f * C * sizeof(float);
-  CTDET_CHECK(lds <= 64 * 1024, "dwconvT_bwd: k*k*C=%d too large for the LDS accumulator", 4 * f * f * C);
-  long nb = ((long)B * H * f * W * f * (C / 8) + 256 * 8 - 1) / (256 * 8);
-  if (nb > 1024) nb = 1024;
+  CTDET_CHECK(C % 8 == 0 && f % 2 == 0 && C / 8 <= 256, "dwconvT_bwd: bad shape C=%d f=%d", C, f);
+  const int S = 256 / (C / 8);
+  const size_t lds = (size_t)S * 4 * C * sizeof(float);   // 32 KB for every C
+  long nb = ((long)B * (H + 1) * (W + 1) + S * 16 - 1) / (S * 16);
+  if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(dwconvT_bwd_kernel, dim3((unsigned)nb), dim3(256), lds, s, x, x_stride, dz, dz_stride, w, dx, dx_stride, dw,
-                     B, H, W, C, f);
+  hipLaunchKernelGGL(dwconvT_dw_kernel, dim3((unsigned)nb, (unsigned)(f * f)), dim3(256), lds, s, x, x_stride, dz, dz_stride,
+                     dw, B, H, W, C, f);
+  long nbx = ((long)B * H * W * (C / 8) + 255) / 256;
+  if (nbx > 4096) nbx = 4096;
+  hipLaunchKernelGGL(dwconvT_dx_kernel, dim3((unsigned)nbx), dim3(256), 0, s, dz, dz_stride, w, dx, dx_stride, B, H, W, C, f);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
