@@ -26,6 +26,8 @@ class SimpleTrainer:
                                            cfg.SOLVER.WARMUP_ITERS, cfg.SOLVER.WARMUP_METHOD)
         self.iter = 0
         self.last_losses = None
+        self.use_hip_graph = True
+        self._graphs = {}
 
     def run_step(self, data=None):
         assert self.model.training, "[SimpleTrainer] model was changed to eval mode!"
@@ -36,8 +38,62 @@ class SimpleTrainer:
         return self._finish_step(self.model(data))
 
     def run_step_tensors(self, images, boxes, classes, counts):
-        """device-resident batch (uint8 [B,3,H,W], boxes f32 [B,N,4], classes i64 [B,N], counts i32 [B])"""
-        return self._finish_step(self.model.train_batch_tensor(images, boxes, classes, counts))
+        """device-resident batch (uint8 [B,3,H,W], boxes f32 [B,N,4], classes i64 [B,N], counts i32 [B]).
+
+        Single-GPU runs replay the whole step (targets, forward, losses, backward, SGD) as ONE captured HIP graph from
+        the third call with a given batch shape on: the eager step issues ~2,700 launches and is bound by the host's
+        launch rate.  The LR schedule and the per-parameter version counters stay on the host.  Multi-GPU runs stay
+        eager (the bucketed all-reduce is launched from autograd hooks)."""
+        if not self.use_hip_graph or self.reducer.world > 1:
+            return self._finish_step(self.model.train_batch_tensor(images, boxes, classes, counts))
+        key = tuple((tuple(t.shape), t.dtype) for t in (images, boxes, classes, counts))
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = {"calls": 0, "graph": None}
+        g["calls"] += 1
+        if g["graph"] is None and g["calls"] <= 2 or g.get("failed"):
+            return self._finish_step(self.model.train_batch_tensor(images, boxes, classes, counts))
+        if g["graph"] is None:
+            self._capture(g, images, boxes, classes, counts)
+            if g.get("failed"):
+                return self._finish_step(self.model.train_batch_tensor(images, boxes, classes, counts))
+        for dst, src in zip(g["inputs"], (images, boxes, classes, counts)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        g["graph"].replay()
+        for p in self.optimizer.params:   # the captured SGD kernels wrote the parameters behind autograd's back
+            torch.autograd.graph.increment_version(p)
+        self.scheduler.step()
+        self.iter += 1
+        self.last_losses = g["losses"]
+        return self.last_losses
+
+    def _capture(self, g, images, boxes, classes, counts):
+        import gc
+        inputs = [t.clone() for t in (images, boxes, classes, counts)]
+        torch.cuda.synchronize()
+        gc.collect()
+        gc_on = gc.isenabled()
+        gc.disable()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss_dict = self.model.train_batch_tensor(*inputs)
+                losses = sum(loss_dict.values())
+                self.optimizer.zero_grad()
+                losses.backward()
+                self.optimizer.step()
+            g["graph"], g["inputs"] = graph, inputs
+            g["losses"] = {k: v.detach() for k, v in loss_dict.items()}
+            # the capture itself executed nothing: this call's step is the first replay
+        except Exception as e:  # capture is an optimisation: any op that cannot be captured keeps the eager path
+            import traceback
+            g["failed"] = repr(e)
+            g["traceback"] = traceback.format_exc()
+            torch.cuda.synchronize()
+        finally:
+            if gc_on:
+                gc.enable()
 
     def _finish_step(self, loss_dict):
         losses = sum(loss_dict.values())

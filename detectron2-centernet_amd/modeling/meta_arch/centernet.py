@@ -435,7 +435,11 @@ class CenterNet(nn.Module):
             a = a * C
         elif len(a) != C:
             a = a + [1] * (C - len(a))
-        return torch.tensor(a, dtype=torch.float32, device=self.device)
+        key = (tuple(a), str(self.device))
+        hit = self.__dict__.get("_alpha_cache")
+        if hit is None or hit[0] != key:   # built once: a host->device copy per step would also break graph capture
+            hit = self.__dict__["_alpha_cache"] = (key, torch.tensor(a, dtype=torch.float32, device=self.device))
+        return hit[1]
 
     def losses(self, outputs, targets):
         """centernet.py:191-212 on device tensors: outputs = (hm logits, wh, reg) NHWC f32; targets from

@@ -426,9 +426,13 @@ def maxpool2x2(x, out=None):
     return out
 
 
-def _dw_weight(weight, Cc, f):
+def _dw_weight(weight, Cc, f, fresh=False):
     """[C,1,2f,2f] -> f32 [2f,2f,C]; cached on the tensor object itself (an address-keyed cache would go stale
     when the allocator reuses a freed block)."""
+    if fresh:
+        # training: always re-derive from the live parameter -- a captured training step would otherwise replay with
+        # the copy made at capture time
+        return weight.detach().reshape(Cc, 2 * f, 2 * f).to(torch.float32).permute(1, 2, 0).contiguous()
     hit = getattr(weight, "_ctdet_dw", None)
     if hit is None or hit[0] != (weight.data_ptr(), weight._version):
         packed = weight.detach().reshape(Cc, 2 * f, 2 * f).to(torch.float32).permute(1, 2, 0).contiguous()
@@ -440,11 +444,11 @@ def _dw_weight(weight, Cc, f):
     return hit[1]
 
 
-def dwconvT_add(x, weight, f, skip=None, out=None):
+def dwconvT_add(x, weight, f, skip=None, out=None, fresh_weight=False):
     """ConvTranspose2d(C,C,2f,stride=f,padding=f//2,groups=C)(x) + skip; weight f32 [C,1,2f,2f] or [C,2f,2f]."""
     _require_cuda(x, weight, skip, out)
     B, H, W, Cc = x.shape
-    w = _dw_weight(weight, Cc, f)
+    w = _dw_weight(weight, Cc, f, fresh_weight)
     if out is None:
         out = torch.empty(B, H * f, W * f, Cc, dtype=x.dtype, device=x.device)
     rc = _lib.lib().ctdet_dwconvT_add(_ptr(x), _ptr(w), _ptr(skip), _ptr(out), dt_of(x), B, H, W, Cc, f,

@@ -85,7 +85,7 @@ def maxpool2x2_bwd(x, dz):
 
 def dwconvT_bwd(x, dz, weight, f):
     B, H, W, Cc = x.shape
-    w = ops._dw_weight(weight, Cc, f)
+    w = weight.detach().reshape(Cc, 2 * f, 2 * f).to(torch.float32).permute(1, 2, 0).contiguous()
     dx = torch.empty(B, H, W, Cc, dtype=torch.float16, device=x.device)
     dw = torch.zeros(2 * f, 2 * f, Cc, dtype=torch.float32, device=x.device)
     rc = _lib.lib().ctdet_dwconvT_bwd(_ptr(x), _nhwc_stride(x), _ptr(dz), _nhwc_stride(dz), _ptr(w), _ptr(dx),
@@ -213,7 +213,7 @@ class DwConvTAddFn(torch.autograd.Function):
     def forward(ctx, x, weight, skip, f):
         ctx.f = f
         ctx.save_for_backward(x, weight)
-        return ops.dwconvT_add(x, weight, f, skip=skip)
+        return ops.dwconvT_add(x, weight, f, skip=skip, fresh_weight=True)
 
     @staticmethod
     def backward(ctx, dz):

@@ -262,3 +262,39 @@ def test_full_training_step_matches_oracle(tmp_path, dev):
     # BatchNorm running statistics were updated like nn.BatchNorm2d(momentum=0.1) does
     bn = model.backbone.base.base_layer[1]
     assert int(bn.num_batches_tracked) == 1 and not torch.allclose(bn.running_mean.cpu(), sd0["backbone.base.base_layer.1.running_mean"])
+
+
+def test_training_step_graph_replay_matches_eager(tmp_path, dev):
+    """the single-GPU trainer replays the whole step as one captured HIP graph from the third call on: losses and the
+    momentum buffer must follow the eager trajectory (f32 atomics make both slightly non-deterministic, and a random-init
+    batch-statistics network amplifies that, so the comparison is statistical), the LR schedule must keep advancing and
+    live parameters -- not capture-time copies -- must be used: the parameters move by the same amount"""
+    from test_model_gpu import make_model
+    from detectron2_centernet_amd.engine.bench_train import synthetic_batch
+    from detectron2_centernet_amd.engine.train_loop import SimpleTrainer
+
+    res = {}
+    for mode in ("eager", "graph"):
+        model, cfg = make_model(tmp_path, "f16", seed=4)
+        cfg.SOLVER.IMS_PER_BATCH = 2
+        tr = SimpleTrainer(model, None, cfg)
+        tr.use_hip_graph = mode == "graph"
+        p0 = tr.optimizer.flat_param.clone()
+        batch = synthetic_batch(2, 128, 0, dev)
+        hist = []
+        for i in range(6):
+            l = tr.run_step_tensors(*batch)
+            hist.append(sum(float(v) for v in l.values()))
+        if mode == "graph":
+            g = next(iter(tr._graphs.values()))
+            assert g["graph"] is not None, g.get("failed")
+        res[mode] = (hist, (tr.optimizer.flat_param - p0).norm().item(), tr.optimizer.flat_mom.clone(), tr.optimizer.lr,
+                     tr.iter)
+    (he, de, me, lre, ite), (hg, dg, mg, lrg, itg) = res["eager"], res["graph"]
+    assert ite == itg == 6 and lre == lrg
+    for a, b in zip(he, hg):
+        assert abs(a - b) <= 2e-3 * abs(a), (he, hg)
+    assert de > 0 and abs(de - dg) <= 0.05 * de, (de, dg)          # six optimiser steps of the same size
+    assert abs(me.norm().item() - mg.norm().item()) <= 0.05 * me.norm().item()
+    cos = torch.nn.functional.cosine_similarity(me, mg, dim=0).item()
+    assert cos > 0.9, cos
