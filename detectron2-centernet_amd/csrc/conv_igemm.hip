@@ -1,22 +1,17 @@
-// Implicit-GEMM convolution for gfx950 (CDNA4), NHWC activations, KRSC weights.
-//
-// One kernel template covers every conv-shaped contraction of the CenterNet/DLA-34 path:
-//   * plain KxK / 1x1 convolutions (stride 1/2)         -- reference: torch.nn.Conv2d in
-//     detectron2/modeling/backbone/dla.py:48-55,79-81,132-133,213-214,253-255 and
-//     detectron2/modeling/meta_arch/centernet.py:115-121
-//   * DCNv2 main contraction (DEFORM=true): the A operand is produced by 4-corner bilinear
-//     sampling x mask instead of a shifted load          -- reference arithmetic:
-//     detectron2/layers/csrc/deformable/deform_conv_cuda_kernel.cu:666-699 (bilinear),
-//     :786-868 (im2col), deform_conv_cuda.cu:874-927 (GEMM + bias).  No `columns` buffer ever
-//     reaches HBM and there is no per-image loop: the batch is part of the GEMM M dimension.
-//
-// GEMM view:  D[cout][pixel] = sum_k W[cout][k] * A[pixel][k],  k = (r*S + s)*Cin + c.
-// MFMA: v_mfma_f32_16x16x32_f16, weights as the A operand, pixels as the B operand, so every
-// lane ends up with 4*TC *contiguous* output channels of one pixel (vector NHWC stores).
-// LDS tiles are [row][32 k] f16 (64-byte rows) with a 16-byte-slot XOR swizzle that makes the
-// ds_read_b128 fragment reads bank-conflict free (see swz()).  Global->LDS staging goes through
-// registers (the loader must zero-fill padding and, for DCNv2, blend four corners), double
-// buffered, one barrier per 32-deep K step.
+// Conv-shaped contractions of the CenterNet path for gfx950 (CDNA4): NHWC f16 activations, packed KRSC weights,
+// v_mfma_f32_16x16x32_f16 with the weights as the A operand and the pixels as the B operand
+// (D[cout][pixel] = sum_k W[cout][k] * A[pixel][k]), so a lane ends up with consecutive output channels of one pixel.
+// Kernels in this file (launch_conv_f16 picks one):
+//   conv3x3_halo_kernel   3x3/s1/p1, Cin % 32 == 0: input window of an 8x32 tile in LDS once per 32-channel chunk
+//   head_fused_kernel     CenterNet heads: 3x3 + ReLU + 1x1 per head, hidden map in registers
+//   conv_igemm_uk_kernel  1x1 / strided / Root (multi-source) convs: uniform-K im2col-on-the-fly tiles
+//   conv_igemm_dma_kernel generic fallback (odd channel counts, input dilation for strided input gradients)
+//   conv_win_kernel, conv_smallc_kernel   the 3/16-channel DLA base layers
+//   dcn_window_kernel     DCNv2 (deform_conv_cuda_kernel.cu:666-868 + deform_conv_cuda.cu:874-927): bilinear gathers from
+//                         an LDS window, blended straight into MFMA operand registers; no `columns` buffer, batch in M
+//   conv_direct_f32_kernel exact-f32 parity mode of all of the above
+// LDS tiles are [row][32 k] f16 (64-byte rows) with a 16-byte-slot XOR swizzle (swz()) that makes the ds_read_b128
+// fragment reads conflict free; global->LDS goes through LDS-DMA with counted vmcnt waits and one s_barrier per K step.
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -169,212 +164,6 @@ __device__ __forceinline__ void epilogue_tiles(const ConvArgs& a, int m, int cba
         *(f32x4*)(yp + 4) = v1;
       }
     }
-  }
-}
-
-// DCNv2 tiles are 8 x 16 pixel patches (when the map allows) instead of 128-pixel row strips: the bilinear-corner
-// gathers of neighbouring pixels/taps then overlap inside a ~23 KB window that stays in the 32 KB L1.
-__device__ __forceinline__ int dcn_pixel_of(const ConvArgs& a, int m) {
-  if ((a.Wo & 15) || (a.Ho & 7)) return m;
-  const int tiles_x = a.Wo >> 4, tiles_y = a.Ho >> 3;
-  const int t = m >> 7, l = m & 127;
-  const int tx = t % tiles_x, r = t / tiles_x;
-  const int ty = r % tiles_y, b = r / tiles_y;
-  return (b * a.Ho + ty * 8 + (l >> 4)) * a.Wo + tx * 16 + (l & 15);
-}
-
-template <int BP, int BC, int WP, int WC_, bool DEFORM, typename TOut>
-__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvArgs a) {
-  constexpr int TP = BP / WP / 16;   // 16-pixel MFMA tiles per wave
-  constexpr int TC = BC / WC_ / 16;  // 16-cout MFMA tiles per wave
-  constexpr int A_LD = BP / 64;      // pixel rows staged per thread per K step
-  constexpr int B_LD = (BC >= 64) ? BC / 64 : 1;
-  constexpr int STAGE = (BP + BC) * 64;
-  static_assert(WP * WC_ == 4, "4 waves per workgroup");
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wp = wave / WC_, wc = wave % WC_;
-  int m_tile, n_tile;
-  if (!tile_of_block((a.M + BP - 1) / BP, a.Cout_pad / BC, m_tile, n_tile)) return;
-  const int m0 = m_tile * BP, n0 = n_tile * BC;
-  const f16* __restrict__ x = (const f16*)a.x;
-  const f16* __restrict__ w = (const f16*)a.w;
-
-  // ---- loader coordinates: thread stages LDS rows lrow+64*i, 16-byte slot `slot` ----
-  const int lrow = tid >> 2, slot = tid & 3;
-  const int g = slot ^ swz(lrow);  // k-group (8 channels) this thread fetches every step
-  int a_pix[A_LD], a_hb[A_LD], a_wb[A_LD];
-  bool a_ok[A_LD];
-#pragma unroll
-  for (int i = 0; i < A_LD; ++i) {
-    const int mlin = m0 + lrow + 64 * i;
-    a_ok[i] = mlin < a.M;
-    const int mm = a_ok[i] ? (DEFORM ? dcn_pixel_of(a, mlin) : mlin) : 0;
-    const int wo = mm % a.Wo, t = mm / a.Wo;
-    const int ho = t % a.Ho, b = t / a.Ho;
-    a_pix[i] = b * a.H * a.W;
-    a_hb[i] = a_ok[i] ? ho * a.stride - a.pad : -(1 << 28);
-    a_wb[i] = wo * a.stride - a.pad;
-  }
-  // weight rows: LDS row L (tile-major inside a wave's cout block) <- packed cout row `cl`
-  long b_off[B_LD];
-#pragma unroll
-  for (int j = 0; j < B_LD; ++j) {
-    const int L = lrow + 64 * j;
-    const int Lw = L % (16 * TC), wv = L / (16 * TC);
-    const int tt = Lw >> 4, r = Lw & 15;
-    const int cl = wv * 16 * TC + cout_of<TC>(tt, r >> 2, r & 3);
-    b_off[j] = (long)(n0 + cl) * a.Kpad + g * 8;
-  }
-  const bool b_ld = lrow < BC;
-
-  // k-state of this thread's k-group: (tr, ts, c0)
-  int c0, tr, ts;
-  {
-    const int kc = g * 8, tap = kc / a.Cin;
-    c0 = kc - tap * a.Cin;
-    tr = tap / a.S;
-    ts = tap - tr * a.S;
-  }
-
-  DcnSample sp[DEFORM ? A_LD : 1];
-  auto setup_samples = [&]() {
-    if constexpr (DEFORM) {
-#pragma unroll
-      for (int i = 0; i < A_LD; ++i) {
-        const int mlin = m0 + lrow + 64 * i;
-        const int m = a_ok[i] ? dcn_pixel_of(a, mlin) : 0;
-        dcn_setup(a, a_ok[i], a_pix[i], a_hb[i], a_wb[i], tr, ts, a.om + (long)m * a.om_stride, sp[i]);
-      }
-    }
-  };
-  setup_samples();
-
-  f16x8 areg[DEFORM ? 1 : A_LD];
-  f16x8 creg[DEFORM ? A_LD : 1][4];
-  f16x8 breg[B_LD];
-  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
-  auto issue_loads = [&](int kt) {
-    if constexpr (!DEFORM) {
-      if (a.nsrc > 1) {
-        // concat-free Root: pick the source tensor holding channel kk of the virtual concat
-        const int kk = kt * 32 + g * 8;
-        const f16* src = (const f16*)a.xs[0];
-        int st = a.xs_stride[0], cb0 = 0;
-        if (kk >= a.xs_cend[0]) { src = (const f16*)a.xs[1]; st = a.xs_stride[1]; cb0 = a.xs_cend[0]; }
-        if (a.nsrc > 2 && kk >= a.xs_cend[1]) { src = (const f16*)a.xs[2]; st = a.xs_stride[2]; cb0 = a.xs_cend[1]; }
-        if (a.nsrc > 3 && kk >= a.xs_cend[2]) { src = (const f16*)a.xs[3]; st = a.xs_stride[3]; cb0 = a.xs_cend[2]; }
-        const bool kin = kk < a.Cin;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-          const long pix = a_pix[i] + a_hb[i] * a.W + a_wb[i];
-          areg[i] = (kin && a_ok[i]) ? *(const f16x8*)(src + pix * st + (kk - cb0)) : zero8;
-        }
-      } else
-#pragma unroll
-      for (int i = 0; i < A_LD; ++i) {
-        const int hi = a_hb[i] + tr * a.dil, wi = a_wb[i] + ts * a.dil;
-        const bool ok = (tr < a.R) && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-        areg[i] = ok ? *(const f16x8*)(x + (long)(a_pix[i] + hi * a.W + wi) * a.in_stride + c0) : zero8;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < A_LD; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          creg[i][q] = sp[i].off[q] >= 0 ? *(const f16x8*)(x + (long)sp[i].off[q] + c0) : zero8;
-    }
-#pragma unroll
-    for (int j = 0; j < B_LD; ++j) breg[j] = b_ld ? *(const f16x8*)(w + b_off[j] + kt * 32) : zero8;
-  };
-
-  auto store_stage = [&](int buf) {
-    char* base = smem + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      f16x8 v;
-      if constexpr (!DEFORM) {
-        v = areg[i];
-      } else {
-        // packed-f16 blend: 4 v_pk_mul/fma_f16 per corner instead of ~10 f32 ops per element; the operand is
-        // rounded to f16 for the MFMA anyway (measured end-to-end heatmap error stays ~1e-5, bar is 1e-3)
-        const f16 w0 = sp[i].wm[0], w1 = sp[i].wm[1], w2 = sp[i].wm[2], w3 = sp[i].wm[3];
-        const f16x8 w0v = {w0, w0, w0, w0, w0, w0, w0, w0}, w1v = {w1, w1, w1, w1, w1, w1, w1, w1};
-        const f16x8 w2v = {w2, w2, w2, w2, w2, w2, w2, w2}, w3v = {w3, w3, w3, w3, w3, w3, w3, w3};
-        v = creg[i][0] * w0v;
-        v = __builtin_elementwise_fma(creg[i][1], w1v, v);
-        v = __builtin_elementwise_fma(creg[i][2], w2v, v);
-        v = __builtin_elementwise_fma(creg[i][3], w3v, v);
-      }
-      *(f16x8*)(base + (lrow + 64 * i) * 64 + slot * 16) = v;
-    }
-    if (b_ld) {
-#pragma unroll
-      for (int j = 0; j < B_LD; ++j) *(f16x8*)(base + BP * 64 + (lrow + 64 * j) * 64 + slot * 16) = breg[j];
-    }
-  };
-
-  auto advance_k = [&]() {
-    c0 += 32;
-    bool moved = false;
-    while (c0 >= a.Cin) {
-      c0 -= a.Cin;
-      if (++ts == a.S) { ts = 0; ++tr; }
-      moved = true;
-    }
-    return moved;
-  };
-
-  f32x4 acc[TP][TC];
-#pragma unroll
-  for (int p = 0; p < TP; ++p)
-#pragma unroll
-    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int fr = lane & 15;
-  const int frag_off = fr * 64 + (((lane >> 4) ^ swz(fr)) << 4);
-  const int nk = a.Kpad / 32;
-
-  issue_loads(0);
-  store_stage(0);
-  __syncthreads();
-
-  int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) {
-      // advance the k-state (and, for DEFORM, the sampling geometry) to step kt+1 before prefetching it;
-      // the blend in store_stage() below then uses the same geometry the in-flight corner loads used.
-      const bool moved = advance_k();
-      if (DEFORM && moved) setup_samples();
-      issue_loads(kt + 1);
-    }
-    const char* base = smem + buf * STAGE;
-    f16x8 wf[TC];
-#pragma unroll
-    for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(base + BP * 64 + (wc * 16 * TC + 16 * c) * 64 + frag_off);
-#pragma unroll
-    for (int p = 0; p < TP; ++p) {
-      const f16x8 pf = *(const f16x8*)(base + (wp * 16 * TP + 16 * p) * 64 + frag_off);
-#pragma unroll
-      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf, acc[p][c], 0, 0, 0);
-    }
-    if (more) store_stage(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-
-  // ---- epilogue: lane holds couts [cb, cb+4*TC) of pixel m for every pixel tile ----
-  const int q = lane >> 4;
-  const int cb = n0 + wc * 16 * TC;
-#pragma unroll
-  for (int p = 0; p < TP; ++p) {
-    const int mlin = m0 + wp * 16 * TP + 16 * p + fr;
-    if (mlin >= a.M) continue;
-    const int m = DEFORM ? dcn_pixel_of(a, mlin) : mlin;
-    epilogue_tiles<TOut, TC>(a, m, cb, q, acc[p]);
   }
 }
 
@@ -845,7 +634,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const ConvArgs a) 
     constexpr int R_ = T / 3, S_ = T % 3, ST = T % 3, SL = (T + 2) % 3;
     // outstanding DMAs allowed while waiting for weights(kt): the younger weight tile (B_LD) and, right after a
     // halo prefetch was queued behind it (T == 1), those 6 as well
-    if (kt + 1 < nk) { if (T == 1) wait_vmcnt<B_LD + 6>(); else wait_vmcnt<B_LD>(); }
+    // (only when a prefetch WAS queued: in the last chunk the larger allowance would let the wait pass with
+    // weights(kt) itself still in flight -- wrong tiles under memory load, found by the full-size determinism test)
+    if (kt + 1 < nk) { if (T == 1 && chunk + 1 < nch) wait_vmcnt<B_LD + 6>(); else wait_vmcnt<B_LD>(); }
     else wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1003,7 +794,7 @@ __global__ void __launch_bounds__(256, 2) head_fused_kernel(const HeadArgs a) {
   auto kstep = [&](int kt, int chunk, auto tapc, auto hbc) {
     constexpr int T = decltype(tapc)::value, HB = decltype(hbc)::value;
     constexpr int R_ = T / 3, S_ = T % 3, ST = T % 3, SL = (T + 2) % 3;
-    if (kt + 1 < nk) { if (T == 1) wait_vmcnt<B_LD + 4>(); else wait_vmcnt<B_LD>(); }
+    if (kt + 1 < nk) { if (T == 1 && chunk + 1 < nch) wait_vmcnt<B_LD + 4>(); else wait_vmcnt<B_LD>(); }
     else wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1206,7 +997,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;   // edge tiles may be partial
   int m_tile, n_tile;
   if (!tile_of_block(a.B * tiles_y * tiles_x, a.Cout_pad / BC, m_tile, n_tile)) return;
   const int tx0 = (m_tile % tiles_x) * TW;
@@ -1271,12 +1062,13 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
   {
     const int gp = tid & 127, gh = tid >> 7;
     const int py = ty0 + (gp >> 4), pxx = tx0 + (gp & 15);
-    const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
+    const bool pin = py < a.H && pxx < a.W;      // pixel of a partial edge tile outside the map: contributes nothing
+    const float* omrow = a.om + ((long)(b * a.H + (pin ? py : 0)) * a.W + (pin ? pxx : 0)) * a.om_stride;
     float oh[5], ow[5], om_[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int t = 2 * i + gh;
-      const bool on = t < 9;
+      const bool on = t < 9 && pin;
       oh[i] = on ? omrow[2 * t] : 0.f; ow[i] = on ? omrow[2 * t + 1] : 0.f; om_[i] = on ? omrow[18 + t] : 0.f;
     }
 #pragma unroll
@@ -1289,7 +1081,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
         const float fh = floorf(h_im), fw = floorf(w_im);
         const int h_low = (int)fh, w_low = (int)fw;
         const float lh = h_im - fh, lw = w_im - fw, hh = 1.f - lh, hw = 1.f - lw;
-        const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W;
+        const bool valid = pin && h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W;
         const bool r0 = valid && h_low >= 0, r1 = valid && h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
         // corners outside the image contribute 0 (deform_conv_cuda_kernel.cu:259-266): zero their weights
         const float w0 = (r0 && c0) ? hh * hw * mk : 0.f, w1 = (r0 && c1) ? hh * lw * mk : 0.f;
@@ -1359,10 +1151,11 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
 #pragma unroll
     for (int p = 0; p < TP; ++p) {
       const int py = ty0 + prow, pxx = tx0 + 8 * p + pcol;
-      const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
+      const bool pin = py < a.H && pxx < a.W;
+      const float* omrow = a.om + ((long)(b * a.H + (pin ? py : 0)) * a.W + (pin ? pxx : 0)) * a.om_stride;
       const float h_im = (float)(py - 1 + tr) + omrow[2 * t], w_im = (float)(pxx - 1 + ts) + omrow[2 * t + 1];
       const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-      const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W;
+      const bool valid = pin && h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W;
       const bool r0 = valid && h_low >= 0, r1 = valid && h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
       const long o0 = ((long)h_low * a.W + w_low) * a.in_stride, o2 = o0 + (long)a.W * a.in_stride;
       const f16* base = ximg + chunk * 32 + q * 8;
@@ -1463,6 +1256,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
   // 16-byte stores
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
+    if (ty0 + prow >= a.H || tx0 + 8 * p + pcol >= a.W) continue;   // partial edge tile
     const long m = (long)(b * a.H + ty0 + prow) * a.W + tx0 + 8 * p + pcol;
 #pragma unroll
     for (int h = 0; h < TC / 2; ++h) {
@@ -1502,7 +1296,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
 
 template <int BC, int WP, int WC_, typename TOut>
 static int launch_dcn_window(const ConvArgs& a, hipStream_t s) {
-  const int nbx = a.B * (a.H / 8) * (a.W / 16), nby = a.Cout_pad / BC;
+  const int nbx = a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16), nby = a.Cout_pad / BC;
   dim3 grid(8 * ((nbx + 7) / 8) * nby);
   hipLaunchKernelGGL((dcn_window_kernel<BC, (BC > 64 ? 4 : 8), TOut>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
@@ -1792,14 +1586,6 @@ static inline int pick_bc(int cout) {
   return 32;
 }
 
-template <int BP, int BC, int WP, int WC_, bool DEFORM, typename TOut>
-static int launch_cfg(const ConvArgs& a, hipStream_t s) {
-  const int nbx = (a.M + BP - 1) / BP, nby = a.Cout_pad / BC;
-  dim3 grid(8 * ((nbx + 7) / 8) * nby);
-  hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC_, DEFORM, TOut>), grid, dim3(256), 0, s, a);
-  CTDET_LAUNCH_CHECK();
-  return 0;
-}
 
 template <int BP, int BC, int WP, int WC_, typename TOut>
 static int launch_dma(const ConvArgs& a, hipStream_t s) {
@@ -1844,21 +1630,15 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   CTDET_CHECK(a.in_dil >= 1 && (!deform || a.in_dil == 1), "conv: bad in_dil %d", a.in_dil);
   if (deform && a.korder == 1) {
     // chunk-major weights: LDS-window kernel (3x3/s1/p1, map divisible by the 8x16 tile)
-    CTDET_CHECK(a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Cin % 32 == 0 && a.H % 8 == 0 &&
-                    a.W % 16 == 0 && a.Kpad == a.K && a.om_stride % 4 == 0 && ((size_t)a.om & 15) == 0 && !a.res &&
+    CTDET_CHECK(a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Cin % 32 == 0 && a.Kpad == a.K && a.om_stride % 4 == 0 && ((size_t)a.om & 15) == 0 && !a.res &&
                     a.out_stride % 8 == 0 && ((size_t)a.y & 15) == 0,
                 "dcnv2(window): unsupported geometry");
     if (bc == 128) return launch_dcn_window<128, 2, 2, TOut>(a, s);
     if (bc == 64) return launch_dcn_window<64, 2, 2, TOut>(a, s);
     CTDET_CHECK(false, "dcnv2(window): unsupported Cout=%d", a.Cout);
   }
-  if (deform) {
-    CTDET_CHECK(a.Cin % 32 == 0 && a.korder == 0, "dcnv2: Cin=%d must be a multiple of 32, tap-major weights", a.Cin);
-    if (bc == 128) return launch_cfg<128, 128, 2, 2, true, TOut>(a, s);
-    if (bc == 64) return launch_cfg<128, 64, 2, 2, true, TOut>(a, s);
-    if (bc == 32) return launch_cfg<128, 32, 4, 1, true, TOut>(a, s);
-    CTDET_CHECK(false, "dcnv2: unsupported Cout=%d", a.Cout);
-  }
+  CTDET_CHECK(!deform, "dcnv2: the f16 path takes chunk-major weights (korder 1, Cin %% 32 == 0); got korder %d, Cin %d",
+              a.korder, a.Cin);
   // enough pixel tiles to fill 256 CUs with the big tile? otherwise use the 128-pixel variants
   const long tiles256 = ((long)a.M + 255) / 256 * (a.Cout_pad / bc);
   const bool big = tiles256 >= 512;

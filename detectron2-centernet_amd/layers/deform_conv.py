@@ -38,7 +38,7 @@ def modulated_deform_conv(input, offset, mask, weight, bias=None, stride=1, padd
     om = torch.zeros(B, Ho, Wo, ops.round_up(3 * kh * kw, 4), dtype=torch.float32, device=input.device)
     om[..., : 2 * kh * kw] = offset.permute(0, 2, 3, 1)
     om[..., 2 * kh * kw: 3 * kh * kw] = mask.permute(0, 2, 3, 1)
-    p = ops.PackedConv(weight, None, bias, stride=stride, pad=padding, dil=dilation, compute=compute, tap_major=True)
+    p = ops.PackedConv(weight, None, bias, stride=stride, pad=padding, dil=dilation, compute=compute)
     y = ops.dcnv2(x, om, p, mask_is_prob=True)
     return hipnn.to_nchw_view(y, weight.shape[0])
 
@@ -97,12 +97,7 @@ class DCN(nn.Module):
         """x NHWC -> act(bn(dcn(x))) NHWC; the offset/mask conv writes f32 so sampling coordinates keep full
         precision even in f16 mode."""
         om = hipnn.conv_module(x, self.conv_offset_mask, None, ACT_NONE, ctx=ctx, out_dtype=torch.float32)
-        # chunk-major weights select the LDS-window kernel (8x16 output tiles); other shapes gather from global
-        window = (ctx.compute == F16 and ops.DCN_WINDOW and self.kernel_size == (3, 3) and self.stride == 1
-                  and self.padding == 1 and self.dilation == 1 and self.in_channels % 32 == 0
-                  and x.shape[1] % 8 == 0 and x.shape[2] % 16 == 0)
-        p = hipnn.packed(self, "dcn_cm" if window else "dcn", ctx.compute, self.weight, bn, self.bias, self.stride,
-                         self.padding, self.dilation, tap_major=not window)
+        p = hipnn.packed(self, "dcn", ctx.compute, self.weight, bn, self.bias, self.stride, self.padding, self.dilation)
         return ops.dcnv2(x, om, p, act=act)
 
     def forward(self, x):

@@ -30,7 +30,7 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
     bc = _lib.lib().ctdet_conv_cout_tile(p.Cout_eff)
     o = "f16" if out_dt == F16 else "f32"
     if deform:
-        return f"dcn_window_kernel<128x{bc},{o}>" if p.korder == 1 else f"conv_igemm_kernel<128x{bc},dcn,{o}>"
+        return f"dcn_window_kernel<128x{bc},{o}>"
     H, W = (x_shape[1], x_shape[2]) if x_shape is not None else (0, 0)
     big = ((M + 255) // 256) * (p.Cout_pad // bc) >= 512
     bp = 256 if (big or bc == 16) else 128
@@ -285,7 +285,6 @@ def conv1x1_cat(xs, p, out=None, act=ACT_NONE, residual=None, out_dtype=None):
     return out
 
 
-DCN_WINDOW = os.environ.get("CTDET_NO_DCN_WINDOW", "0") != "1"
 HEADS_FUSED = os.environ.get("CTDET_NO_FUSED_HEADS", "0") != "1"
 
 

@@ -182,7 +182,7 @@ def test_dcnv2(ops, dev, case, mode):
     ref = (ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)).relu()
     comp = ops.F16 if mode == "f16" else ops.F32
     tdt = torch.float16 if mode == "f16" else torch.float32
-    pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=1, pad=1, compute=comp, tap_major=True)
+    pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=1, pad=1, compute=comp)
     om_d = torch.zeros(B, H, W, 32)
     om_d[..., :27] = nhwc(om)
     y = ops.dcnv2(nhwc(x).to(tdt).to(dev), om_d.to(dev), pc, act=ops.ACT_RELU)
@@ -193,8 +193,9 @@ def test_dcnv2(ops, dev, case, mode):
     assert err <= tol * max(1.0, ref.abs().max().item()), f"max err {err}"
 
 
-# LDS-window kernel (chunk-major weights): off_std 0/1/2 stay inside the +-4 px window margin (fast path), 6 and 12
-# push samples outside it so some / all workgroups take the gather-from-global path; both must agree with the oracle.
+# LDS-window kernel: off_std 0/1/2 stay inside the +-4 px window margin (fast path), 6 and 12 push samples outside it so
+# some / all waves take the gather-from-global path for those taps; both must agree with the oracle.  (test_dcnv2 above
+# covers maps the 8x16 tile does not divide: partial edge tiles.)
 DCN_WINDOW_CASES = [(2, 16, 32, 64, 64, 1.0), (1, 8, 16, 128, 64, 0.0), (2, 16, 16, 64, 64, 6.0),
                     (1, 8, 32, 256, 128, 2.0), (1, 24, 16, 128, 128, 3.0), (1, 8, 16, 512, 256, 12.0),
                     (1, 16, 48, 64, 40, 2.5)]
@@ -226,10 +227,6 @@ def test_dcnv2_window(ops, dev, case):
     got = nchw(y[..., :Cout].float().cpu())
     err = (got - ref).abs().max().item()
     assert err <= 6e-3 * max(1.0, ref.abs().max().item()), f"max err {err}"
-    # and against the gather-from-global kernel on the same operands (only the f32 accumulation order differs)
-    pt = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=1, pad=1, compute=ops.F16, tap_major=True)
-    y2 = ops.dcnv2(xd, om_d.to(dev), pt, act=ops.ACT_RELU)
-    assert (y.float() - y2.float()).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("tdt", [torch.float16, torch.float32])

@@ -29,7 +29,7 @@ dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 x = torch.randn(a.B, a.H, a.W, a.cin, generator=g).half().to(dev)
 w = (torch.randn(a.cout, a.cin, a.k, a.k, generator=g) / (a.cin * a.k * a.k) ** 0.5).to(dev)
-p = ops.PackedConv(w, None, None, stride=a.stride, pad=a.k // 2, compute=ops.F16, tap_major=a.tap_major or (a.dcn and not a.window))
+p = ops.PackedConv(w, None, None, stride=a.stride, pad=a.k // 2, compute=ops.F16, tap_major=a.tap_major and not a.dcn)
 od = torch.float32 if a.f32out else torch.float16
 if a.dcn:
     om = torch.randn(a.B, a.H, a.W, 28, generator=g)
