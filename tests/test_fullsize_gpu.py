@@ -115,3 +115,75 @@ def test_fullsize_dcn_window_matches_oracle_on_sampled_images():
         ref = O.dcnv2_forward(xb, omb[:, :18], torch.sigmoid(omb[:, 18:27]), w.half().float(), None, 1, 1, 1)
         err = (y[b] - ref.permute(0, 2, 3, 1)[0]).abs().max().item()
         assert err <= 6e-3 * max(1.0, ref.abs().max().item()), (b, err)
+
+
+# ---- training-side kernels at the size of the batch-16 training step (many rounds of workgroups per CU) ----
+def _close(got, ref, tol, what):
+    err = (got - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    assert err <= tol * scale, f"{what}: max err {err} (scale {scale})"
+
+
+@pytest.mark.parametrize("case", [(16, 128, 128, 64, 64, 3, 1, 1), (16, 256, 256, 32, 64, 3, 2, 1), (16, 64, 64, 128, 128, 3, 1, 1),
+                                  (16, 128, 128, 64, 256, 1, 1, 0)])
+def test_fullsize_wgrad_dgrad_match_torch(case):
+    import torch.nn.functional as F
+    from detectron2_centernet_amd import ops_train as ot
+    B, H, W, Cin, Cout, k, s, p = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).half().float().to(dev)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).half().float().to(dev)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = (torch.randn(B, Cout, Ho, Wo, generator=g) * 0.05).half().float().to(dev)
+    ref_dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=s, padding=p)
+    ref_dx = torch.nn.grad.conv2d_input(x.shape, w, dy, stride=s, padding=p)
+    xh, dyh = x.permute(0, 2, 3, 1).contiguous().half(), dy.permute(0, 2, 3, 1).contiguous().half()
+    dw = ot.conv_wgrad(xh, dyh, Cout, k, k, s, p).view(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    _close(dw, ref_dw, 3e-3, "dW")
+    dx = ot.conv_dgrad(dyh, w, s, p, (H, W))
+    _close(dx[..., :Cin].float().permute(0, 3, 1, 2), ref_dx, 3e-3, "dX")
+
+
+def test_fullsize_bn_train_fwd_bwd_match_torch():
+    import torch.nn.functional as F
+    from detectron2_centernet_amd import ops_train as ot
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    B, C, H, W = 16, 64, 128, 128
+    y = (torch.randn(B, C, H, W, generator=g) * 2 + 0.5).half().float().to(dev).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev).requires_grad_(True)
+    beta = torch.randn(C, generator=g).to(dev).requires_grad_(True)
+    ref = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5).relu()
+    dz = torch.randn(ref.shape, generator=g).half().float().to(dev)
+    ref.backward(dz)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    yh = y.detach().permute(0, 2, 3, 1).contiguous().half()
+    z, mean, invstd, scale = ot.bn_train_fwd(yh, gamma.detach(), beta.detach(), rm, rv, 1e-5, 0.1, relu=True)
+    _close(z.float().permute(0, 3, 1, 2), ref.detach(), 2e-3, "bn fwd")
+    dy, _, dgamma, dbeta = ot.bn_train_bwd(dz.permute(0, 2, 3, 1).contiguous().half(), z, yh, mean, invstd, scale, relu=True)
+    _close(dy.float().permute(0, 3, 1, 2), y.grad, 6e-3, "bn dy")
+    _close(dgamma, gamma.grad, 3e-3, "dgamma")
+    _close(dbeta, beta.grad, 3e-3, "dbeta")
+
+
+def test_fullsize_dcn_backward_scatter_window_vs_atomics():
+    """the LDS-window scatter kernel against the f32-atomics kernel on a full 16 x 128 x 128 x 64 layer"""
+    import os
+    from detectron2_centernet_amd import ops_train as ot
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    B, H, W, Cin = 16, 128, 128, 64
+    x = torch.randn(B, H, W, Cin, generator=g).half().to(dev)
+    dcol = (torch.randn(B, H, W, 9 * Cin, generator=g) * 0.1).half().to(dev)
+    om = torch.randn(B, H, W, 28, generator=g)
+    om[..., :18] *= 2.0
+    om = om.to(dev)
+    dx_w, dom_w = ot.dcn_col2im_coord(dcol, x, om)
+    os.environ["CTDET_NO_COL2IM_WINDOW"] = "1"
+    try:
+        dx_a, dom_a = ot.dcn_col2im_coord(dcol, x, om)
+    finally:
+        del os.environ["CTDET_NO_COL2IM_WINDOW"]
+    assert (dx_w - dx_a).abs().max().item() <= dx_a.abs().max().item() * 2.0 ** -14
+    assert (dom_w - dom_a).abs().max().item() <= dom_a.abs().max().item() * 2e-4
