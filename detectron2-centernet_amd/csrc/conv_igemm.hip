@@ -973,7 +973,8 @@ __device__ __forceinline__ u32x4 dcn_blend(const u32x4& v0, const u32x4& v1, con
   return r;
 }
 
-template <int BC, int NST, typename TOut>
+// PARTIAL: the map is not a multiple of the 8x16 tile (edge tiles carry pixels outside it)
+template <int BC, int NST, bool PARTIAL, typename TOut>
 __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
   constexpr int TH = 8, TW = 16, BP = 128, MG = 4;
   constexpr int WR = TH + 2 + 2 * MG, WCOLS = TW + 2 + 2 * MG;  // 18 x 26 window pixels
@@ -1062,7 +1063,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
   {
     const int gp = tid & 127, gh = tid >> 7;
     const int py = ty0 + (gp >> 4), pxx = tx0 + (gp & 15);
-    const bool pin = py < a.H && pxx < a.W;      // pixel of a partial edge tile outside the map: contributes nothing
+    const bool pin = !PARTIAL || (py < a.H && pxx < a.W);   // pixel of a partial edge tile outside the map: contributes nothing
     const float* omrow = a.om + ((long)(b * a.H + (pin ? py : 0)) * a.W + (pin ? pxx : 0)) * a.om_stride;
     float oh[5], ow[5], om_[5];
 #pragma unroll
@@ -1151,7 +1152,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
 #pragma unroll
     for (int p = 0; p < TP; ++p) {
       const int py = ty0 + prow, pxx = tx0 + 8 * p + pcol;
-      const bool pin = py < a.H && pxx < a.W;
+      const bool pin = !PARTIAL || (py < a.H && pxx < a.W);
       const float* omrow = a.om + ((long)(b * a.H + (pin ? py : 0)) * a.W + (pin ? pxx : 0)) * a.om_stride;
       const float h_im = (float)(py - 1 + tr) + omrow[2 * t], w_im = (float)(pxx - 1 + ts) + omrow[2 * t + 1];
       const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
@@ -1256,7 +1257,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
   // 16-byte stores
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
-    if (ty0 + prow >= a.H || tx0 + 8 * p + pcol >= a.W) continue;   // partial edge tile
+    if (PARTIAL && (ty0 + prow >= a.H || tx0 + 8 * p + pcol >= a.W)) continue;   // partial edge tile
     const long m = (long)(b * a.H + ty0 + prow) * a.W + tx0 + 8 * p + pcol;
 #pragma unroll
     for (int h = 0; h < TC / 2; ++h) {
@@ -1298,7 +1299,10 @@ template <int BC, int WP, int WC_, typename TOut>
 static int launch_dcn_window(const ConvArgs& a, hipStream_t s) {
   const int nbx = a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16), nby = a.Cout_pad / BC;
   dim3 grid(8 * ((nbx + 7) / 8) * nby);
-  hipLaunchKernelGGL((dcn_window_kernel<BC, (BC > 64 ? 4 : 8), TOut>), grid, dim3(256), 0, s, a);
+  if (a.H % 8 == 0 && a.W % 16 == 0)
+    hipLaunchKernelGGL((dcn_window_kernel<BC, (BC > 64 ? 4 : 8), false, TOut>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((dcn_window_kernel<BC, (BC > 64 ? 4 : 8), true, TOut>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
