@@ -116,16 +116,26 @@ __global__ void __launch_bounds__(256) dec_hist_kernel(DecArgs a, int level, int
   const uint32_t p0 = ws[ST_P0];
   const bool interior = p0 > 0 && p0 < 4095;
   const uint64_t pr = ((uint64_t)ws[ST_PR_HI] << 32) | ws[ST_PR_LO];
+  // run-length accumulation: a thread walks a pixel column, and real heat maps cluster (most values sit within a few
+  // fine bins around sigmoid(bias)), so consecutive peaks of a thread usually share a bin -- counting the run and issuing
+  // one LDS atomic per run removes most of the same-address serialisation
+  uint32_t run_bin = 0xFFFFFFFFu, run_cnt = 0;
+  auto count = [&](uint32_t bin) {
+    if (bin == run_bin) { ++run_cnt; return; }
+    if (run_cnt) atomicAdd(&lh[run_bin], run_cnt);
+    run_bin = bin; run_cnt = 1;
+  };
   for_each_peak(a, b, [&](uint32_t bits, uint32_t canon) {
     if (level == 0) {
-      if (!(dbg & 1)) atomicAdd(&lh[dec_d0(bits)], 1u);
+      if (!(dbg & 1)) count((uint32_t)dec_d0(bits));
     } else {
       if ((uint32_t)dec_d0(bits) != p0) return;
       const uint64_t r = dec_rest(bits, canon, interior);
       if (level > 1 && (r >> (60 - 12 * (level - 1))) != pr) return;
-      atomicAdd(&lh[(uint32_t)(r >> (60 - 12 * level)) & 0xFFFu], 1u);
+      count((uint32_t)(r >> (60 - 12 * level)) & 0xFFFu);
     }
   });
+  if (run_cnt) atomicAdd(&lh[run_bin], run_cnt);
   __syncthreads();
   uint32_t* gh = ws + DEC_ST_WORDS;
   if (dbg & 2) return;
