@@ -354,6 +354,32 @@ def main():
             f.write(f"backbone.{k} {tuple(r50.state_dict()[k].shape)}\n")
         for k in sorted(deconv.state_dict().keys()):
             f.write(f"deconv_layers.{k} {tuple(deconv.state_dict()[k].shape)}\n")
+    # ---------------- G10: ResNet-18 (BasicBlock, FrozenBN) res4 + deconv layers: the ctdet_res_18/34 configs ----------
+    torch.manual_seed(10)
+    stem18 = resnet.BasicStem(in_channels=3, out_channels=64, norm="FrozenBN")
+    stages18, cin, cout = [], 64, 64
+    for idx, nblk in enumerate([2, 2, 2]):
+        first_stride = 1 if idx == 0 else 2
+        stages18.append(resnet.ResNet.make_stage(block_class=resnet.BasicBlock, num_blocks=nblk,
+                                                 stride_per_block=[first_stride] + [1] * (nblk - 1), in_channels=cin,
+                                                 out_channels=cout, norm="FrozenBN"))
+        cin, cout = cout, cout * 2
+    r18 = resnet.ResNet(stem18, stages18, out_features=["res4"]).freeze(2)
+    deconv18 = cn.CenterNet._make_deconv_layer(None, 256, 2, [256, 256], [4, 4])
+    r18.eval(); deconv18.eval()
+    r18.load_state_dict(fill_state_dict(r18.state_dict(), seed=11))
+    deconv18.load_state_dict(fill_state_dict(deconv18.state_dict(), seed=12))
+    gg = torch.Generator().manual_seed(1000)
+    x = torch.randn(1, 3, 64, 96, generator=gg)
+    with torch.no_grad():
+        res4 = r18(x)["res4"]
+        up = deconv18(res4)
+    np.savez_compressed(os.path.join(HERE, "g10_resnet18.npz"), x=x.numpy(), res4=res4.numpy(), up=up.numpy())
+    with open(os.path.join(HERE, "g10_resnet18_state_dict_keys.txt"), "w") as f:
+        for k in sorted(r18.state_dict().keys()):
+            f.write(f"backbone.{k} {tuple(r18.state_dict()[k].shape)}\n")
+        for k in sorted(deconv18.state_dict().keys()):
+            f.write(f"deconv_layers.{k} {tuple(deconv18.state_dict()[k].shape)}\n")
     print("golden vectors written to", HERE)
 
 

@@ -170,3 +170,24 @@ def test_g9_resnet50_res4_and_deconv_match_reference():
     assert res4.shape == g["res4"].shape and up.shape == g["up"].shape
     assert np.abs(res4.numpy() - g["res4"]).max() <= 1e-5 * max(1.0, np.abs(g["res4"]).max())
     assert np.abs(up.numpy() - g["up"]).max() <= 1e-5 * max(1.0, np.abs(g["up"]).max())
+
+
+def test_g10_resnet18_res4_and_deconv_match_reference():
+    """the BasicBlock ResNet of the ctdet_res_18 / 34 configs (G10, from the reference's own modules)"""
+    from oracle import model_ref as MR
+
+    g = np.load(os.path.join(G, "g10_resnet18.npz"))
+    shapes = {}
+    for line in open(os.path.join(G, "g10_resnet18_state_dict_keys.txt")):
+        k, shp = line.split(" ", 1)
+        shapes[k] = tuple(int(v) for v in shp.strip().strip("()").split(",") if v.strip())
+    bb = {k[len("backbone."):]: torch.zeros(s) for k, s in shapes.items() if k.startswith("backbone.")}
+    dc = {k[len("deconv_layers."):]: torch.zeros(s) for k, s in shapes.items() if k.startswith("deconv_layers.")}
+    sd = {"backbone." + k: v for k, v in fill_state_dict(bb, seed=11).items()}
+    sd.update({"deconv_layers." + k: v for k, v in fill_state_dict(dc, seed=12).items()})
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        res4 = MR.resnet_features(sd, "backbone", x, blocks=(2, 2, 2), bottleneck=False)
+        up = MR.deconv_layers(sd, "deconv_layers", res4)
+    assert np.abs(res4.numpy() - g["res4"]).max() <= 1e-5 * max(1.0, np.abs(g["res4"]).max())
+    assert np.abs(up.numpy() - g["up"]).max() <= 1e-5 * max(1.0, np.abs(g["up"]).max())

@@ -90,7 +90,18 @@ def test_conv_transpose2d_dense(ops, dev, mode):
     assert (got - ref).abs().max() <= tol * max(1.0, ref.abs().max())
 
 
-def _make(tmp_path, precision):
+RES18_YAML = RES50_YAML.replace("""  CENTERNET:
+    FOCAL_LOSS_ALPHA: [1]
+""", """  CENTERNET:
+    FOCAL_LOSS_ALPHA: [1]
+    HEAD_CONV: 64
+  RESNETS:
+    DEPTH: 18
+    RES2_OUT_CHANNELS: 64
+""")
+
+
+def _make(tmp_path, precision, yaml_text=None):
     from detectron2_centernet_amd.config import get_cfg
     from detectron2_centernet_amd.data.catalog import register_synthetic
     from detectron2_centernet_amd.modeling import build_model
@@ -99,7 +110,7 @@ def _make(tmp_path, precision):
     from weights import fill_state_dict
 
     (tmp_path / "Base-CenterNet.yaml").write_text(BASE)
-    (tmp_path / "ctdet_res_50_1x.yaml").write_text(RES50_YAML)
+    (tmp_path / "ctdet_res_50_1x.yaml").write_text(yaml_text or RES50_YAML)
     cfg = get_cfg()
     cfg.merge_from_file(str(tmp_path / "ctdet_res_50_1x.yaml"))
     cfg.MODEL.CENTERNET.HIP_PRECISION = precision
@@ -144,3 +155,30 @@ def test_resnet50_centernet_eval_matches_oracle(tmp_path, dev, precision):
         bb, keep = O.detector_postprocess(bb, (96, 128), 96, 128)
         assert torch.equal(inst.scores.cpu(), ss[keep]) and torch.equal(inst.pred_classes.cpu(), cc[keep])
         assert torch.allclose(inst.pred_boxes.tensor.cpu(), bb[keep], atol=1e-4, rtol=1e-6)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_resnet18_centernet_eval_matches_oracle(tmp_path, dev, precision):
+    """`ctdet_res_18_1x.yaml`: BasicBlock ResNet-18, HEAD_CONV 64 (the unfused head path), deconv 256->256->256"""
+    model, cfg, sd = _make(tmp_path, precision, RES18_YAML)
+    keys = sorted(k for k in model.state_dict() if k.startswith(("backbone.", "deconv_layers.")))
+    import os
+    ref_keys = [l.split(" ")[0] for l in open(os.path.join(os.path.dirname(__file__), "golden",
+                                                           "g10_resnet18_state_dict_keys.txt"))]
+    assert keys == sorted(ref_keys)
+    g = torch.Generator().manual_seed(6)
+    img = torch.randint(0, 256, (2, 3, 80, 112), generator=g, dtype=torch.uint8)
+    model.score_threshold = 0.0
+    model([{"image": img[b]} for b in range(2)])
+    eng = next(iter(model._engines.values()))
+    hm, wh, reg = [t.float().cpu().permute(0, 3, 1, 2) for t in eng.out]
+    x, _ = O.preprocess([i for i in img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 16)
+    sdf = {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        y = MR.deconv_layers(sdf, "deconv_layers", MR.resnet_features(sdf, "backbone", x, blocks=(2, 2, 2), bottleneck=False))
+        z = MR.centernet_heads(MR.Net(sdf), y)
+    hm_ref = torch.clamp(torch.sigmoid(z["hm"]), 1e-4, 1 - 1e-4)
+    err = (hm - hm_ref).abs().max().item()
+    print(precision, "resnet18 heatmap err", err)
+    assert err <= (1e-5 if precision == "f32" else 1e-3)
+    assert (wh - z["wh"]).abs().max().item() <= (2e-4 if precision == "f32" else 2e-2) * max(1.0, z["wh"].abs().max().item())
