@@ -244,11 +244,14 @@ __global__ void __launch_bounds__(1024) dec_final_kernel(DecArgs a) {
   uint32_t n = ws[ST_NCAND];
   if (n > DEC_NCAND) n = DEC_NCAND;
   const int t = threadIdx.x;
-  for (int i = t; i < DEC_NCAND; i += 1024) keys[i] = (uint32_t)i < n ? cand[i] : 0ull;
+  // sort only as wide as needed: next power of two >= n (typically a few hundred candidates, not 4096)
+  int NS = 256;
+  while ((uint32_t)NS < n) NS <<= 1;
+  for (int i = t; i < NS; i += 1024) keys[i] = (uint32_t)i < n ? cand[i] : 0ull;
   __syncthreads();
-  for (int k = 2; k <= DEC_NCAND; k <<= 1) {
+  for (int k = 2; k <= NS; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = t; i < DEC_NCAND; i += 1024) {
+      for (int i = t; i < NS; i += 1024) {
         const int ixj = i ^ j;
         if (ixj > i) {
           const uint64_t x = keys[i], y = keys[ixj];
@@ -261,7 +264,7 @@ __global__ void __launch_bounds__(1024) dec_final_kernel(DecArgs a) {
   }
   const int HW = a.H * a.W;
   for (int k = t; k < a.K; k += 1024) {
-    const uint64_t key = keys[k];
+    const uint64_t key = k < NS ? keys[k] : 0ull;
     float score = 0.f; int cls = 0, ind = 0;
     if ((uint32_t)k < n) {
       score = __uint_as_float((uint32_t)(key >> 32));
