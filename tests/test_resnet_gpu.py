@@ -182,3 +182,28 @@ def test_resnet18_centernet_eval_matches_oracle(tmp_path, dev, precision):
     print(precision, "resnet18 heatmap err", err)
     assert err <= (1e-5 if precision == "f32" else 1e-3)
     assert (wh - z["wh"]).abs().max().item() <= (2e-4 if precision == "f32" else 2e-2) * max(1.0, z["wh"].abs().max().item())
+
+
+def test_resnet50_larger_batch_is_deterministic_and_matches_oracle(tmp_path, dev):
+    """8 x 384 x 512 through the ResNet-50 config: grids of several rounds of workgroups per CU for the kernels this path
+    adds (7x7 s2 stem on the generic LDS-DMA kernel, strided 1x1 / 3x3, input-dilated ConvTranspose); two runs are
+    bit-identical and image 0 / 7 agree with the CPU oracle"""
+    model, cfg, sd = _make(tmp_path, "f16")
+    g = torch.Generator().manual_seed(8)
+    img = torch.randint(0, 256, (8, 3, 384, 512), generator=g, dtype=torch.uint8).to(dev)
+    model.score_threshold = 0.0
+    model.infer_batch_tensor(img)
+    eng = next(iter(model._engines.values()))
+    first = [t.clone() for t in eng.out]
+    model.infer_batch_tensor(img)
+    for a, b in zip(first, eng.out):
+        assert torch.equal(a, b)
+    hm = first[0].float().cpu().permute(0, 3, 1, 2)
+    sdf = {k: v.float() for k, v in sd.items()}
+    for b in (0, 7):
+        x, _ = O.preprocess([img[b].cpu()], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 16)
+        with torch.no_grad():
+            z = MR.centernet_resnet_forward(sdf, x)
+        ref = torch.clamp(torch.sigmoid(z["hm"]), 1e-4, 1 - 1e-4)
+        err = (hm[b:b + 1] - ref).abs().max().item()
+        assert err <= 1e-3, (b, err)
