@@ -37,6 +37,8 @@ int launch_focal_loss(const float*, const float*, const float*, int, int, int, i
 int launch_reg_l1(const float*, int, const uint8_t*, const int64_t*, const float*, int, int, int, float, float*, float*,
                   int, hipStream_t);
 int launch_sgd(float*, const float*, float*, long, const float*, float, float, int, hipStream_t);
+int launch_sgd_runs(float*, const float*, float*, long, const long*, const int*, const float*, const float*, int, float, int,
+                    hipStream_t);
 
 struct WgradArgs {
   const f16* x; const f16* dy; float* dw;
@@ -349,6 +351,14 @@ int32_t ctdet_sgd_momentum(float* param, const float* grad, float* momentum_buf,
                            float momentum, float weight_decay, int32_t first_step, void* stream) {
   CTDET_CHECK(param && grad && momentum_buf && lr_dev, "sgd: null pointer");
   return launch_sgd(param, grad, momentum_buf, (long)n, lr_dev, momentum, weight_decay, first_step, (hipStream_t)stream);
+}
+
+int32_t ctdet_sgd_momentum_runs(float* param, const float* grad, float* momentum_buf, int64_t n, const int64_t* run_end,
+                                const int32_t* run_lr_index, const float* run_weight_decay, const float* lr_table,
+                                int32_t nruns, float momentum, int32_t first_step, void* stream) {
+  CTDET_CHECK(param && grad && momentum_buf && run_end && run_lr_index && run_weight_decay && lr_table, "sgd_runs: null pointer");
+  return launch_sgd_runs(param, grad, momentum_buf, (long)n, (const long*)run_end, run_lr_index, run_weight_decay, lr_table,
+                         nruns, momentum, first_step, (hipStream_t)stream);
 }
 
 }  // extern "C"

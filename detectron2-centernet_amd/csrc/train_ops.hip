@@ -307,6 +307,46 @@ __global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const f
   }
 }
 
+// the same update over a flat buffer cut into `nruns` consecutive runs with their own (lr, weight decay): run r covers
+// [run_end[r-1], run_end[r]); lr = lr_table[run_lr_index[r]] is read from device memory.  One launch instead of one per run
+// (DLA-34: 109 runs, weights / norm / bias parameters alternate in backward order).
+__global__ void __launch_bounds__(256) sgd_runs_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       long n, const long* __restrict__ run_end,
+                                                       const int* __restrict__ run_lr_index, const float* __restrict__ run_wd,
+                                                       const float* __restrict__ lr_table, int nruns, float mom, int first) {
+  long cur_end = -1;
+  float lr = 0.f, wd = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    if (i >= cur_end) {                      // first element, or crossed into a later run: binary search
+      int lo = 0, hi = nruns - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (run_end[mid] > i) hi = mid; else lo = mid + 1;
+      }
+      cur_end = run_end[lo];
+      lr = lr_table[run_lr_index[lo]];
+      wd = run_wd[lo];
+    }
+    float gi = g[i];
+    const float pi = p[i];
+    if (wd != 0.f) gi = gi + wd * pi;
+    const float bi = first ? gi : mom * m[i] + gi;
+    m[i] = bi;
+    p[i] = pi - lr * bi;
+  }
+}
+
+int launch_sgd_runs(float* p, const float* g, float* m, long n, const long* run_end, const int* run_lr_index,
+                    const float* run_wd, const float* lr_table, int nruns, float mom, int first, hipStream_t s) {
+  if (n == 0 || nruns == 0) return 0;
+  long nb = (n + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(sgd_runs_kernel, dim3((unsigned)nb), dim3(256), 0, s, p, g, m, n, run_end, run_lr_index, run_wd, lr_table,
+                     nruns, mom, first);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_sgd(float* p, const float* g, float* m, long n, const float* lr_dev, float mom, float wd, int first,
                hipStream_t s) {
   if (n == 0) return 0;

@@ -571,3 +571,14 @@ def sgd_momentum_(param, grad, buf, lr_dev, momentum, weight_decay, first_step):
     rc = _lib.lib().ctdet_sgd_momentum(_ptr(param), _ptr(grad), _ptr(buf), param.numel(), _ptr(lr_dev),
                                        float(momentum), float(weight_decay), int(bool(first_step)), _stream())
     _lib.check(rc, "ctdet_sgd_momentum")
+
+
+def sgd_momentum_runs_(param, grad, buf, run_end, run_lr_index, run_wd, lr_table, momentum, first_step):
+    """one launch over a flat buffer of consecutive hyper-parameter runs (see ctdet_sgd_momentum_runs)"""
+    _require_cuda(param, grad, buf, run_end, run_lr_index, run_wd, lr_table)
+    assert param.is_contiguous() and grad.is_contiguous() and buf.is_contiguous()
+    assert run_end.dtype == torch.int64 and run_lr_index.dtype == torch.int32
+    rc = _lib.lib().ctdet_sgd_momentum_runs(_ptr(param), _ptr(grad), _ptr(buf), param.numel(), _ptr(run_end),
+                                            _ptr(run_lr_index), _ptr(run_wd), _ptr(lr_table), run_end.numel(),
+                                            float(momentum), int(bool(first_step)), _stream())
+    _lib.check(rc, "ctdet_sgd_momentum_runs")

@@ -3,8 +3,8 @@
 Hyper-parameter grouping follows detectron2/solver/build.py:93-137: norm-layer parameters use WEIGHT_DECAY_NORM,
 `bias` parameters use BASE_LR*BIAS_LR_FACTOR and WEIGHT_DECAY_BIAS, everything else BASE_LR / WEIGHT_DECAY;
 momentum SOLVER.MOMENTUM, no Nesterov (defaults.py).  Design for MI355X: all parameters live in ONE contiguous f32
-buffer ordered by reverse registration (roughly the order backward produces gradients), so (i) one kernel launch per
-hyper-parameter group updates everything, (ii) the gradient buffer is directly the RCCL all-reduce operand, cut
+buffer ordered by reverse registration (roughly the order backward produces gradients), so (i) ONE kernel launch updates everything (per-run
+learning rate / weight decay tables in device memory), (ii) the gradient buffer is directly the RCCL all-reduce operand, cut
 into large contiguous buckets (engine/reducer.py).
 """
 import torch
@@ -62,14 +62,18 @@ class FlatSGD:
             self.offsets.append((off, n))
             off += n
         self.lr_factors = sorted({r[2] for r in self.runs})
-        self._lr_dev = {lf: torch.zeros(1, dtype=torch.float32, device=device) for lf in self.lr_factors}
+        # device-side tables for the one-launch update: run ends, weight decay, index into the lr table
+        self._lr_table = torch.zeros(len(self.lr_factors), dtype=torch.float32, device=device)
+        self._run_end = torch.tensor([r[1] for r in self.runs], dtype=torch.int64, device=device)
+        self._run_wd = torch.tensor([r[3] for r in self.runs], dtype=torch.float32, device=device)
+        self._run_lr_index = torch.tensor([self.lr_factors.index(r[2]) for r in self.runs], dtype=torch.int32, device=device)
         self._first = True
         self.set_lr_factor(1.0)
 
     def set_lr_factor(self, f):
         self._sched_factor = float(f)
-        for lf, t in self._lr_dev.items():
-            t.fill_(self.base_lr * lf * self._sched_factor)
+        for i, lf in enumerate(self.lr_factors):
+            self._lr_table[i:i + 1].fill_(self.base_lr * lf * self._sched_factor)
 
     @property
     def lr(self):
@@ -82,9 +86,8 @@ class FlatSGD:
                 p.grad = self.flat_grad[off:off + n].view_as(p.data)
 
     def step(self):
-        for a, b, lf, wd in self.runs:
-            ops.sgd_momentum_(self.flat_param[a:b], self.flat_grad[a:b], self.flat_mom[a:b], self._lr_dev[lf],
-                              self.momentum, wd, self._first)
+        ops.sgd_momentum_runs_(self.flat_param, self.flat_grad, self.flat_mom, self._run_end, self._run_lr_index,
+                               self._run_wd, self._lr_table, self.momentum, self._first)
         self._first = False
         for p in self.params:  # raw-pointer update: tell autograd / the packed-weight caches the values changed
             torch.autograd.graph.increment_version(p)

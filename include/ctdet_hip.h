@@ -169,6 +169,13 @@ int32_t ctdet_reg_l1_loss(const float* pred, int32_t pred_stride, const uint8_t*
 int32_t ctdet_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, const float* lr_dev,
                            float momentum, float weight_decay, int32_t first_step, void* stream);
 
+/* The same step over a flat buffer holding several parameter groups back to back: run r covers elements
+ * [run_end[r-1], run_end[r]) (device i64 array, ascending, run_end[nruns-1] == n) with weight decay run_weight_decay[r] and
+ * learning rate lr_table[run_lr_index[r]] (all device memory: the captured training graph stays valid across the schedule). */
+int32_t ctdet_sgd_momentum_runs(float* param, const float* grad, float* momentum_buf, int64_t n, const int64_t* run_end,
+                                const int32_t* run_lr_index, const float* run_weight_decay, const float* lr_table,
+                                int32_t nruns, float momentum, int32_t first_step, void* stream);
+
 /* ---- training-side entry points (f16 activations, f32 statistics and weight gradients) ------------------------
  * Input gradients of plain convs are ctdet_conv2d_fwd calls with transposed/flipped weights (in_dil for stride 2). */
 

@@ -429,6 +429,29 @@ def test_sgd_matches_torch(ops, dev):
     assert torch.allclose(pd.cpu(), pr.detach(), atol=1e-6, rtol=1e-6)
 
 
+def test_sgd_runs_matches_per_run_launches(ops, dev):
+    """one launch over a run table == one launch per run, bit for bit (runs of 1 element, odd lengths, two lr factors)"""
+    g = torch.Generator().manual_seed(43)
+    lens = [1, 255, 256, 257, 3, 70001, 1, 1, 4096, 9]
+    n = sum(lens)
+    ends = torch.tensor(lens).cumsum(0)
+    wds = [1e-4, 0.0, 1e-4, 0.0, 0.0, 1e-4, 0.0, 1e-4, 0.0, 1e-4]
+    lidx = [0, 1, 0, 0, 1, 0, 1, 1, 0, 0]
+    lrt = torch.tensor([0.01, 0.02], device=dev)
+    p0 = torch.randn(n, generator=g).to(dev)
+    pa, pb = p0.clone(), p0.clone()
+    ma, mb = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(3):
+        gr = torch.randn(n, generator=g).to(dev)
+        ops.sgd_momentum_runs_(pa, gr, ma, ends.to(dev), torch.tensor(lidx, dtype=torch.int32, device=dev),
+                               torch.tensor(wds, device=dev), lrt, 0.9, step == 0)
+        a = 0
+        for r, b in enumerate(ends.tolist()):
+            ops.sgd_momentum_(pb[a:b], gr[a:b], mb[a:b], lrt[lidx[r]:lidx[r] + 1], 0.9, wds[r], first_step=(step == 0))
+            a = b
+    assert torch.equal(pa, pb) and torch.equal(ma, mb)
+
+
 def test_cpu_tensors_are_rejected(ops):
     with pytest.raises(NotImplementedError):
         ops.maxpool2x2(torch.zeros(1, 4, 4, 8))
