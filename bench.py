@@ -131,7 +131,7 @@ def roofline_pass(model, images, passes=2):
             eng()
         ops.PROFILE_ON = False
         torch.cuda.synchronize()
-        for name, flops, e0, e1 in ops.PROFILE:
+        for name, flops, e0, e1, _bytes, _info in ops.PROFILE:
             a = agg.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0})
             a["ms"] += e0.elapsed_time(e1) / ops.PROFILE_REP
             a["flops"] += flops

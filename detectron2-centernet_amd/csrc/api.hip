@@ -188,6 +188,22 @@ int32_t ctdet_head_fused_fwd(const ctdet_head_desc* d, const void* x, const void
   return launch_head_fused(a, (hipStream_t)stream);
 }
 
+int32_t ctdet_dla_base_fwd(const ctdet_dla_base_desc* d, const void* images, const void* w_stem, const float* scale_stem,
+                           const float* bias_stem, const void* w_l0, const float* scale_l0, const float* bias_l0,
+                           const void* w_l1, const float* scale_l1, const float* bias_l1, void* out, void* stream) {
+  CTDET_CHECK(d && images && w_stem && scale_stem && bias_stem && w_l0 && scale_l0 && bias_l0 && w_l1 && scale_l1 && bias_l1 &&
+              out, "dla_base: null pointer");
+  BaseArgs a = {};
+  a.img = images; a.img_dtype = d->img_dtype; a.img_batch_stride = (long)d->img_batch_stride;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Hp = d->Hp; a.Wp = d->Wp;
+  for (int i = 0; i < 3; ++i) { a.mean[i] = d->mean[i]; a.stdv[i] = d->std[i]; }
+  a.w0 = w_stem; a.s0 = scale_stem; a.b0 = bias_stem;
+  a.w1 = w_l0; a.s1 = scale_l0; a.b1 = bias_l0;
+  a.w2 = w_l1; a.s2 = scale_l1; a.b2 = bias_l1;
+  a.y = out; a.out_stride = d->out_stride;
+  return launch_dla_base(a, (hipStream_t)stream);
+}
+
 int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
                          int32_t in_stride, int32_t out_stride, void* stream) {
   CTDET_CHECK(x && y, "maxpool2x2: null pointer");

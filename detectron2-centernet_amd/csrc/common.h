@@ -76,6 +76,23 @@ struct HeadArgs {
   float clamp_lo, clamp_hi;
 };
 
+// argument block of the fused DLA base kernel (dla_base.hip): normalisation + 7x7 stem + level0 + level1
+struct BaseArgs {
+  const void* img;        // [B,3,H,W] uint8 or f32 planar image batch
+  int img_dtype;          // CTDET_U8 / CTDET_F32
+  long img_batch_stride;  // elements between images
+  int B, H, W;            // image size
+  int Hp, Wp;             // network input size (image zero-padded bottom/right after normalisation)
+  float mean[3], stdv[3];
+  const void* w0;         // f16 [16][7*8*4]   stem, k = (r*8 + s)*4 + c (s = 7 and c = 3 zero)
+  const void* w1;         // f16 [16][160]     level0, k = (r*3 + s)*16 + c
+  const void* w2;         // f16 [32][160]     level1 (stride 2)
+  const float *s0, *b0, *s1, *b1, *s2, *b2;   // folded BatchNorm scale / bias per layer
+  void* y;                // f16 [B,Hp/2,Wp/2,out_stride]
+  int out_stride;
+};
+int launch_dla_base(const BaseArgs& a, hipStream_t s);
+
 // argument block of the batched decode (decode.hip)
 struct DecArgs {
   const float* heat; const float* wh; const float* reg;

@@ -211,6 +211,37 @@ class DLA(Backbone):
             y.append(x)
         return y
 
+    def base_fusable(self, ctx, Hp, Wp):
+        """the one-launch form of normalisation + base_layer + level0 + level1 (ops.dla_base_fused): DLA-34's 3->16->16->32
+        base, f16, BatchNorm in eval mode."""
+        return (ctx.compute == F16 and ops.dla_base_fused_ok(Hp, Wp) and len(self.level0) == 3 and len(self.level1) == 3
+                and self.channels[0] == 16 and self.channels[1] == 32 and not self.base_layer[1].training)
+
+    def _packed_base(self):
+        mods = [self.base_layer[0], self.base_layer[1], self.level0[0], self.level0[1], self.level1[0], self.level1[1]]
+        tensors = []
+        for conv, bn in zip(mods[0::2], mods[1::2]):
+            tensors += [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        ver = hipnn._versions(*tensors)
+        hit = self.__dict__.get("_ctdet_packed_base")
+        if hit is None or hit[0] != ver:
+            args = []
+            for conv, bn in zip(mods[0::2], mods[1::2]):
+                args += [conv.weight, hipnn.fold_bn(bn)]
+            hit = (ver, ops.PackedDlaBase(*args))
+            self.__dict__["_ctdet_packed_base"] = hit
+        return hit[1]
+
+    def hip_forward_images(self, images, mean, std, Hp, Wp, ctx):
+        """images: [B,3,H,W] uint8/f32 device batch (not normalised) -> the six level outputs; levels 0 and 1 are computed
+        inside the fused base kernel, level 0 is not materialised (None)."""
+        x = ops.dla_base_fused(images, mean, std, Hp, Wp, self._packed_base())
+        y = [None, x]
+        for i in range(2, 6):
+            x = getattr(self, "level{}".format(i)).hip_forward(x, ctx)
+            y.append(x)
+        return y
+
     def forward(self, x):
         ctx = hipnn.Ctx(F16 if x.dtype == torch.float16 else F32)
         return [hipnn.to_nchw_view(t) for t in self.hip_forward(hipnn.to_nhwc(x, ctx, pad_to=8), ctx)]
@@ -246,9 +277,13 @@ class DLA34(Backbone):
     def size_divisibility(self):
         return self.size_div
 
-    def hip_forward(self, x, ctx, prepadded=False):
-        """x: NHWC [B,H,W,8] normalised image -> list of NHWC maps; the last one is the [B,H/4,W/4,64] head input."""
-        x = self.base.hip_forward(x, ctx, prepadded)
+    def images_fusable(self, ctx, Hp, Wp):
+        return self.first_level >= 1 and self.base.base_fusable(ctx, Hp, Wp)
+
+    def hip_forward(self, x, ctx, prepadded=False, images=None):
+        """x: NHWC [B,H,W,8] normalised image -> list of NHWC maps; the last one is the [B,H/4,W/4,64] head input.
+        images = (batch, mean, std, Hp, Wp): start from the raw image batch instead (see DLA.hip_forward_images)."""
+        x = self.base.hip_forward_images(*images, ctx) if images is not None else self.base.hip_forward(x, ctx, prepadded)
         x = self.dla_up.hip_forward(x, ctx)
         # the reference clones these maps (dla.py:311-313) because IDAUp mutates in place; buffers here are
         # never written twice, so no copy is needed

@@ -60,8 +60,11 @@ class _EvalEngine:
         dev = model.device
         self.images = torch.zeros(B, 3, H, W, dtype=img_dtype, device=dev)
         self.img_params = torch.zeros(B, 4, dtype=torch.float32, device=dev)
-        # normalised input with a 3-pixel zero frame (the 7x7 stem's padding): cleared once, interior rewritten per call
-        self.xpad = torch.zeros(B, Hp + 6, Wp + 6, 8, dtype=model._ctx.dtype, device=dev)
+        # DLA-34: normalisation + base_layer + level0 + level1 run as one kernel straight from the image batch
+        self.fused_base = model.backbone_type != "resnet" and model.backbone.images_fusable(model._ctx, Hp, Wp)
+        # otherwise: normalised input with a 3-pixel zero frame (the 7x7 stem's padding), cleared once, interior rewritten
+        # per call
+        self.xpad = None if self.fused_base else torch.zeros(B, Hp + 6, Wp + 6, 8, dtype=model._ctx.dtype, device=dev)
         self.graph = None
         self.Hp, self.Wp = Hp, Wp
         self._run()                      # warm-up: packs weights, sizes the allocator
@@ -84,8 +87,12 @@ class _EvalEngine:
 
     def _run(self):
         m = self.model
-        x = ops.preprocess(self.images, m._mean_host, m._std_host, self.Hp, self.Wp, out=self.xpad, border=3)
-        self.out = m._network_outputs(x, apply_sigmoid=True, prepadded=True)
+        if self.fused_base:
+            self.out = m._network_outputs(None, apply_sigmoid=True,
+                                          images=(self.images, m._mean_host, m._std_host, self.Hp, self.Wp))
+        else:
+            x = ops.preprocess(self.images, m._mean_host, m._std_host, self.Hp, self.Wp, out=self.xpad, border=3)
+            self.out = m._network_outputs(x, apply_sigmoid=True, prepadded=True)
         hm, wh, reg = self.out
         self.dec = ops.decode(hm, wh, reg, m.topk_candidates, m.backbone.down_ratio)
         boxes, scores, classes, _ = self.dec
@@ -288,11 +295,11 @@ class CenterNet(nn.Module):
                 y = y[..., :up.out_channels]
         return y
 
-    def _network_outputs(self, x_nhwc, apply_sigmoid, prepadded=False):
+    def _network_outputs(self, x_nhwc, apply_sigmoid, prepadded=False, images=None):
         if self.backbone_type == "resnet":
             y = self._deconv_forward(self.backbone.hip_forward(x_nhwc, self._ctx, prepadded)["res4"])
         else:
-            y = self.backbone.hip_forward(x_nhwc, self._ctx, prepadded)[-1]
+            y = self.backbone.hip_forward(x_nhwc, self._ctx, prepadded, images=images)[-1]
         z = self._head_outputs(y, apply_sigmoid)
         hm = z["hm"]
         assert hm.shape[3] == self.num_classes or hm.shape[3] == ops.round_up(self.num_classes, 4)

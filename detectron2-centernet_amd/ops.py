@@ -56,6 +56,14 @@ class _Prof:
         if self.on:
             self.name = name if name is not None else _kernel_name(p, M, deform, out_dt, x_shape, nsrc)
             self.flops = flops if flops is not None else 2.0 * M * p.Cout * p.R * p.S * p.Cin_real
+            osz = 2 if out_dt == F16 else 4
+            if p is not None:   # algorithmic bytes: input once + output once (+ offsets/masks for the deformable conv)
+                isz = 2 if p.compute == F16 else 4
+                in_px = M * (p.stride * p.stride if not deform else 1)
+                self.bytes = in_px * p.Cin_real * isz + M * p.Cout * osz + (M * 27 * 4 if deform else 0) + p.w.numel() * isz
+                self.info = f"M={M} {p.Cin_real}->{p.Cout} k{p.R} s{p.stride}" + (" dcn" if deform else "") + (f" cat{nsrc}" if nsrc > 1 else "")
+            else:
+                self.bytes, self.info = 0.0, f"M={M}"
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
 
@@ -66,7 +74,7 @@ class _Prof:
         if self.on:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            PROFILE.append((self.name, self.flops, self.e0, e1))
+            PROFILE.append((self.name, self.flops, self.e0, e1, self.bytes, self.info))
 
 
 def _stream():
@@ -323,6 +331,53 @@ def preprocess(images, mean, std, Hp, Wp, out_dtype=torch.float16, out=None, par
     rc = _lib.lib().ctdet_preprocess(_ptr(images), dt_of(images), _ptr(out), dt_of(out), B, H, W, Hp, Wp,
                                      images.stride(0), m, s, _nhwc_stride(out), int(border), _stream())
     _lib.check(rc, "ctdet_preprocess")
+    return out
+
+
+class PackedDlaBase:
+    """operands of ctdet_dla_base_fwd: the 7x7 stem [16,3,7,7], level0 [16,16,3,3] and level1 [32,16,3,3] weights with
+    their folded BatchNorm (scale, bias) pairs."""
+
+    def __init__(self, w_stem, sb_stem, w_l0, sb_l0, w_l1, sb_l1):
+        assert tuple(w_stem.shape) == (16, 3, 7, 7) and tuple(w_l0.shape) == (16, 16, 3, 3) and tuple(w_l1.shape) == (32, 16, 3, 3)
+        dev = w_stem.device
+        # stem operand: k = (r*8 + s)*4 + c -- 4-channel pixels, kernel rows padded to 8 taps (one MFMA K step per row)
+        w4 = torch.zeros(16, 7, 8, 4, dtype=torch.float32, device=dev)
+        w4[:, :, :7, :3] = w_stem.detach().float().permute(0, 2, 3, 1)
+        self.w0 = w4.reshape(16, 224).to(torch.float16).contiguous()
+        self.p1 = PackedConv(w_l0, sb_l0[0], sb_l0[1], stride=1, pad=1, compute=F16)
+        self.p2 = PackedConv(w_l1, sb_l1[0], sb_l1[1], stride=2, pad=1, compute=F16)
+        assert self.p1.korder == 0 and self.p1.Kpad == 160 and self.p2.korder == 0 and self.p2.Kpad == 160
+        self.s0 = sb_stem[0].detach().float().contiguous()
+        self.b0 = sb_stem[1].detach().float().contiguous()
+
+
+BASE_FUSED = os.environ.get("CTDET_NO_FUSED_BASE", "0") != "1"
+
+
+def dla_base_fused_ok(Hp, Wp):
+    return BASE_FUSED and Hp % 16 == 0 and Wp % 32 == 0
+
+
+def dla_base_fused(images, mean, std, Hp, Wp, p, out=None):
+    """images [B,3,H,W] uint8/f32 on device -> level1 output of DLA (f16 NHWC [B,Hp/2,Wp/2,32]) in one launch:
+    normalisation, 7x7 stem, level0, level1 (stride 2), BatchNorm folded, ReLU after each."""
+    _require_cuda(images, out)
+    B, Cc, H, W = images.shape
+    assert Cc == 3 and images.stride(3) == 1 and images.stride(2) == W and images.stride(1) == H * W
+    if out is None:
+        out = torch.empty(B, Hp // 2, Wp // 2, 32, dtype=torch.float16, device=images.device)
+    assert out.dtype == torch.float16 and tuple(out.shape[:3]) == (B, Hp // 2, Wp // 2) and out.shape[3] >= 32
+    d = _lib.DlaBaseDesc()
+    d.B, d.H, d.W, d.Hp, d.Wp, d.img_dtype = B, H, W, Hp, Wp, dt_of(images)
+    d.img_batch_stride = images.stride(0)
+    for i in range(3):
+        d.mean[i], d.std[i] = float(mean[i]), float(std[i])
+    d.out_stride = _nhwc_stride(out)
+    rc = _lib.lib().ctdet_dla_base_fwd(C.byref(d), _ptr(images), _ptr(p.w0), _ptr(p.s0), _ptr(p.b0), _ptr(p.p1.w),
+                                       _ptr(p.p1.scale), _ptr(p.p1.bias), _ptr(p.p2.w), _ptr(p.p2.scale), _ptr(p.p2.bias),
+                                       _ptr(out), _stream())
+    _lib.check(rc, "ctdet_dla_base_fwd")
     return out
 
 

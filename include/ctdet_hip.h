@@ -95,6 +95,24 @@ typedef struct ctdet_head_desc {
 } ctdet_head_desc;
 int32_t ctdet_head_fused_fwd(const ctdet_head_desc* d, const void* x, const void* w1, const float* b1, void* stream);
 
+/* DLA base layers fused for inference: (x/255 - mean)/std (centernet.py:193-200) -> base_layer 7x7 3->16 -> level0 3x3
+ * 16->16 -> level1 3x3 stride 2 16->32, each + folded BatchNorm + ReLU (dla.py:204-215, called at dla.py:230-233 for
+ * levels 0-1).  images: [B,3,H,W] planar uint8 or f32 (img_dtype CTDET_U8 / CTDET_F32), zero-padded bottom/right to Hp x
+ * Wp after normalisation (ImageList.from_tensors); Hp % 16 == 0, Wp % 32 == 0.  Weights f16: w_stem [16][224] with
+ * k = (r*8 + s)*4 + c (tap column s = 7 and channel c = 3 zero), w_l0 [16][160] and w_l1 [32][160] with k = (r*3 + s)*16 + c
+ * (ctdet_pack_weights korder 0).  scale/bias: the folded BatchNorm of each layer, f32.  out: f16 NHWC
+ * [B,Hp/2,Wp/2,out_stride] (32 channels written).  The intermediate maps are rounded to f16 exactly where the layer-by-
+ * layer path rounds them. */
+typedef struct ctdet_dla_base_desc {
+  int32_t B, H, W, Hp, Wp, img_dtype;
+  int64_t img_batch_stride;   /* elements between images */
+  float mean[3], std[3];
+  int32_t out_stride;
+} ctdet_dla_base_desc;
+int32_t ctdet_dla_base_fwd(const ctdet_dla_base_desc* d, const void* images, const void* w_stem, const float* scale_stem,
+                           const float* bias_stem, const void* w_l0, const float* scale_l0, const float* bias_l0,
+                           const void* w_l1, const float* scale_l1, const float* bias_l1, void* out, void* stream);
+
 /* nn.MaxPool2d(2, stride=2) on NHWC (dla.py:128-129). */
 int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
                          int32_t in_stride, int32_t out_stride, void* stream);

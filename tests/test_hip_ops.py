@@ -133,6 +133,56 @@ def test_conv_window_small_channels(ops, dev, case):
     assert err < 3e-3 * max(1.0, ref.abs().max().item()), f"{name}: max err {err}"
 
 
+@pytest.mark.parametrize("case", [("u8_ragged", torch.uint8, 2, 50, 70, 64, 96), ("u8_full", torch.uint8, 3, 64, 64, 64, 64),
+                                  ("f32", torch.float32, 1, 32, 64, 32, 64), ("u8_tall", torch.uint8, 1, 130, 40, 144, 64)])
+def test_dla_base_fused(ops, dev, case):
+    """normalisation + 7x7 stem + level0 + level1 in one launch vs (a) torch with the maps rounded to f16 where the
+    layer-by-layer path rounds them and (b) that layer-by-layer HIP path itself; image smaller than the padded input,
+    tiles on every border, uint8 and f32 images"""
+    name, dt, B, H, W, Hp, Wp = case
+    g = torch.Generator().manual_seed(H + W)
+    img = torch.randint(0, 256, (B, 3, H, W), generator=g).to(dt)
+    mean, std = [103.5 / 255, 116.3 / 255, 123.7 / 255], [0.225, 0.224, 0.229]
+    ws = [h16(torch.randn(16, 3, 7, 7, generator=g) / 147 ** 0.5), h16(torch.randn(16, 16, 3, 3, generator=g) / 12),
+          h16(torch.randn(32, 16, 3, 3, generator=g) / 12)]
+    sb = [(torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3) for c in (16, 16, 32)]
+    x = (img.float() / 255 - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    x = h16(F.pad(x, (0, Wp - W, 0, Hp - H)))
+    ref = x
+    for w, (sc, bi), (st, pd) in zip(ws, sb, ((1, 3), (1, 1), (2, 1))):
+        ref = h16((F.conv2d(ref, w, None, st, pd) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1)).relu())
+    args = []
+    for w, (sc, bi) in zip(ws, sb):
+        args += [w.to(dev), (sc.to(dev), bi.to(dev))]
+    pb = ops.PackedDlaBase(*args)
+    y = ops.dla_base_fused(img.to(dev), mean, std, Hp, Wp, pb)
+    got = nchw(y.float().cpu())
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    assert err <= 3e-3 * max(1.0, ref.abs().max().item()), f"{name}: max err {err} vs torch"
+    # the layer-by-layer HIP path on the same operands: identical rounding points -> at most an f16 ulp or two apart
+    t = ops.preprocess(img.to(dev), mean, std, Hp, Wp)
+    p0 = ops.PackedConv(ws[0].to(dev), sb[0][0].to(dev), sb[0][1].to(dev), stride=1, pad=3, compute=ops.F16, cin_pad=8,
+                        tap_major=True)
+    t = ops.conv2d(t, p0, act=ops.ACT_RELU)
+    t = ops.conv2d(t, pb.p1, act=ops.ACT_RELU)
+    t = ops.conv2d(t, pb.p2, act=ops.ACT_RELU)
+    d = (t.float() - y.float()).abs().max().item()
+    assert d <= 4e-3 * max(1.0, ref.abs().max().item()), f"{name}: {d} vs the layer-by-layer path"
+    assert (t != y).float().mean().item() < 0.02
+
+
+def test_dla_base_fused_rejects_bad_shapes(ops, dev):
+    g = torch.Generator().manual_seed(1)
+    args = [torch.randn(16, 3, 7, 7, generator=g).to(dev), (torch.ones(16, device=dev), torch.zeros(16, device=dev)),
+            torch.randn(16, 16, 3, 3, generator=g).to(dev), (torch.ones(16, device=dev), torch.zeros(16, device=dev)),
+            torch.randn(32, 16, 3, 3, generator=g).to(dev), (torch.ones(32, device=dev), torch.zeros(32, device=dev))]
+    pb = ops.PackedDlaBase(*args)
+    img = torch.zeros(1, 3, 40, 40, dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError, match="multiple"):
+        ops.dla_base_fused(img, [0, 0, 0], [1, 1, 1], 40, 40, pb)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 32, 64, (80, 2, 2)), (1, 8, 16, 64, (5,)), (1, 24, 16, 128, (20, 2, 2, 7))])
 def test_heads_fused(ops, dev, case):
     """fused 3x3 + ReLU + 1x1 heads vs torch (f16 operands, f32 accumulation; the hidden map is rounded to f16 as in
