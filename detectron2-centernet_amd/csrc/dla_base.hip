@@ -19,6 +19,7 @@
 // Regions are walked as flat runs of 16 pixels (pixel index / region width by constant division), so odd region widths
 // waste only the tail of the last tile.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 constexpr int T1H = 8, T1W = 16;                   // level1 output tile
@@ -28,7 +29,9 @@ constexpr int INH = STH + 6, INW = STW + 6;          // input pixels under those
 constexpr int NIN = INH * INW, NST = STH * STW, NL0 = L0H * L0W;
 constexpr int IN_PAD = 8;                          // zeroed pixels behind the window: tap column 7 of the last row reads them
 constexpr int IN_ROUNDS = (NIN + IN_PAD + 255) / 256;
-constexpr int K0 = 7 * 32, K1 = 160;               // packed K of the stem / of the two 3x3 layers
+constexpr int K0 = 7 * 32, K1 = 160;
+constexpr int STP = (NST * 16 + 255) / 256 * 256, L0P = (NL0 * 16 + 255) / 256 * 256;   // plane strides: multiples of 256 B, so
+                                                                // the two planes of a pixel sit on the same LDS banks               // packed K of the stem / of the two 3x3 layers
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -39,152 +42,293 @@ __device__ __forceinline__ f16x8 lds_read16_align8(const char* p) {
   return __builtin_bit_cast(f16x8, v);
 }
 
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+
+// relu(acc * scale + bias) -> 4 f16 (round to nearest even like every other f16 store on the path, packed max after the
+// conversion); MASKED: zero when the pixel lies outside the map
+template <bool MASKED>
 __device__ __forceinline__ f16x4 bn_relu_f16(f32x4 acc, f32x4 sc, f32x4 bi, bool keep) {
-  f16x4 o;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float v = fmaxf(acc[j] * sc[j] + bi[j], 0.f);
-    o[j] = keep ? (f16)v : (f16)0.f;
-  }
+  const f32x4 v = acc * sc + bi;
+  f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  const f16x4 z = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+  o = __builtin_elementwise_max(o, z);
+  if constexpr (MASKED) o = keep ? o : z;
   return o;
+}
+
+// 4 bytes at any byte address
+__device__ __forceinline__ unsigned load_u32_unaligned(const void* p) {
+  typedef unsigned u32_a1 __attribute__((aligned(1)));
+  return *(const u32_a1*)p;
 }
 }  // namespace
 
 template <typename TIn>
-__global__ void __launch_bounds__(256, 2) dla_base_fused_kernel(const BaseArgs a) {
+__global__ void __launch_bounds__(256, 2) dla_base_fused_kernel(const BaseArgs a, int ntiles) {
   __shared__ __attribute__((aligned(16))) char inb[(NIN + IN_PAD) * 8];   // [pixel][4 ch] normalised input window
-  __shared__ __attribute__((aligned(16))) char stb[2 * NST * 16];         // [plane][pixel][8 ch] stem outputs
-  __shared__ __attribute__((aligned(16))) char l0b[2 * NL0 * 16];         // [plane][pixel][8 ch] level0 outputs
+  __shared__ __attribute__((aligned(16))) char stb[2 * STP];              // [plane][pixel][8 ch] stem outputs
+  __shared__ __attribute__((aligned(16))) char l0b[2 * L0P];              // [plane][pixel][8 ch] level0 outputs
+  __shared__ f16 lut[3 * 256];                                            // uint8 images: normalised value per (channel, byte)
+  __shared__ __attribute__((aligned(16))) float sbv[128];                 // scale/bias: stem 0/16, level0 32/48, level1 64/96
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, q = lane >> 4;
   const int H1 = a.Hp >> 1, W1 = a.Wp >> 1;
   const int tiles_x = W1 / T1W, tiles_y = H1 / T1H;
-  const int ox = (blockIdx.x % tiles_x) * T1W;
-  const int oy = ((blockIdx.x / tiles_x) % tiles_y) * T1H;
-  const int b = blockIdx.x / (tiles_x * tiles_y);
+  const long plane = (long)a.H * a.W;
+  constexpr bool BYTES = sizeof(TIn) == 1;
 
-  // ---- input window: (x / 255 - mean) / std in f32, the reference's operation order, rounded to f16; zero outside the image
-  // (the stem's padding and the batch padding up to Hp x Wp) ----
-  {
+  // (x / 255 - mean) / std in f32, the reference's operation order, rounded to f16.  A byte has 256 values: tabulate them
+  // once per workgroup instead of two f32 divisions per sample.
+  if constexpr (BYTES) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) lut[c * 256 + tid] = (f16)(((float)tid / 255.f - a.mean[c]) / a.stdv[c]);
+  }
+  // the window buffer's 4th channel and the pixels behind the window stay zero (the fast conversion path writes channels 0-2)
+  for (int i = tid; i < (NIN + IN_PAD) * 2; i += 256) ((unsigned*)inb)[i] = 0u;
+
+  // ---- the three layers' weight fragments, LDS tap offsets and BatchNorm vectors stay in registers across tiles ----
+  f16x8 wf0[7], wf1[5], wf2[5][2];
+  int kaddr1[5], kaddr2[5];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) wf0[r] = *(const f16x8*)((const f16*)a.w0 + fr * K0 + r * 32 + q * 8);
+#pragma unroll
+  for (int kt = 0; kt < 5; ++kt) {
+    wf1[kt] = *(const f16x8*)((const f16*)a.w1 + fr * K1 + kt * 32 + q * 8);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int cout = (fr >> 2) * 8 + c * 4 + (fr & 3);   // tile pair layout: tile c row r <-> cout (r/4)*8 + c*4 + r%4
+      wf2[kt][c] = *(const f16x8*)((const f16*)a.w2 + cout * K1 + kt * 32 + q * 8);
+    }
+    const int G = kt * 4 + q;
+    const int tap = (G >> 1) < 9 ? (G >> 1) : 0;           // K tail: zero weights, read tap 0
+    const int tr = tap / 3, ts = tap - tr * 3;
+    kaddr1[kt] = (G & 1) * STP + (tr * STW + ts) * 16;
+    kaddr2[kt] = (G & 1) * L0P + (tr * L0W + ts + 2 * fr) * 16;
+  }
+  // folded BatchNorm vectors: LDS (read back 16 bytes at a time in the epilogues; 32 VGPRs otherwise)
+  if (tid < 16) { sbv[tid] = a.s0[tid]; sbv[16 + tid] = a.b0[tid]; sbv[32 + tid] = a.s1[tid]; sbv[48 + tid] = a.b1[tid]; }
+  if (tid < 32) { sbv[64 + tid] = a.s2[tid]; sbv[96 + tid] = a.b2[tid]; }
+
+  // level0 walks its 17 x 33 region as flat runs of 16 pixels, 9 runs per wave: the lane's pixel in each run, as LDS byte
+  // offsets (read side: position in the 35-wide stem map; write side: position in the 33-wide level0 map; 0xffff = beyond
+  // the region), packed 2 x 16 bits.  Fixed for the whole launch.
+  unsigned l0pos[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int p = (wave * 9 + t) * 16 + fr;
+    const int pc = p < NL0 ? p : NL0 - 1;
+    const int py = pc / L0W, px = pc - py * L0W;
+    l0pos[t] = (unsigned)((py * STW + px) * 16) | ((p < NL0 ? (unsigned)(p * 16) : 0xffffu) << 16);
+  }
+
+  // ---- window fetch for the NEXT tile, issued while the current tile computes.  Nothing touches the registers before the
+  // conversion one tile later (a conditional load or an early pack would put an s_waitcnt vmcnt right behind each load).
+  // Interior tiles of byte images: a thread loads 4 consecutive bytes of one plane row (825 dwords per window, 4 per
+  // thread).  Other tiles, and f32 images: one sample per load at clamped coordinates, validity kept as a bit mask. ----
+  constexpr int FAST_PER_ROW = (INW + 3) / 4;                    // 11 dwords cover the 41 pixels of a window row
+  constexpr int FAST_N = 3 * INH * FAST_PER_ROW;                 // 825
+  constexpr int FAST_ROUNDS = (FAST_N + 255) / 256;              // 4
+  // (byte images, border tiles: the three channels of a pixel packed into one register -- that path waits for its loads)
+  constexpr int RAWC = BYTES ? 1 : 3;
+  unsigned raw[IN_ROUNDS * RAWC];
+  unsigned okmask = 0;
+  bool raw_fast = false;
+  auto tile_origin = [&](int tile, int& ox, int& oy, int& b) {
+    ox = (tile % tiles_x) * T1W;
+    oy = ((tile / tiles_x) % tiles_y) * T1H;
+    b = tile / (tiles_x * tiles_y);
+  };
+  auto fetch = [&](int tile) {
+    int ox, oy, b;
+    tile_origin(tile, ox, oy, b);
     const TIn* img = (const TIn*)a.img + (long)b * a.img_batch_stride;
-    const long plane = (long)a.H * a.W;
     const int y0 = 2 * oy - 5, x0 = 2 * ox - 5;
-    float v[IN_ROUNDS][3];
+    // every byte the fast path touches lies inside the image rows (it reads 3 bytes past the window's last column)
+    raw_fast = BYTES && y0 >= 0 && y0 + INH <= a.H && x0 >= 0 && x0 + 4 * FAST_PER_ROW <= a.W;
+    if (raw_fast) {
 #pragma unroll
-    for (int i = 0; i < IN_ROUNDS; ++i) {
-      const int pid = tid + 256 * i;
-      const int wr = pid / INW, wc = pid - wr * INW;
-      const int Y = y0 + wr, X = x0 + wc;
-      v[i][0] = v[i][1] = v[i][2] = 0.f;
-      if (pid < NIN && Y >= 0 && Y < a.H && X >= 0 && X < a.W) {
-        const TIn* p = img + (long)Y * a.W + X;
-        v[i][0] = ((float)p[0] / 255.f - a.mean[0]) / a.stdv[0];
-        v[i][1] = ((float)p[plane] / 255.f - a.mean[1]) / a.stdv[1];
-        v[i][2] = ((float)p[2 * plane] / 255.f - a.mean[2]) / a.stdv[2];
+      for (int i = 0; i < FAST_ROUNDS; ++i) {
+        const int e = min(tid + 256 * i, FAST_N - 1);
+        const int c = e / (INH * FAST_PER_ROW), rem = e - c * (INH * FAST_PER_ROW);
+        const int wr = rem / FAST_PER_ROW, g = rem - wr * FAST_PER_ROW;
+        raw[i] = load_u32_unaligned((const char*)img + c * plane + (long)(y0 + wr) * a.W + x0 + 4 * g);
+      }
+    } else {
+      okmask = 0;
+#pragma unroll
+      for (int i = 0; i < IN_ROUNDS; ++i) {
+        const int pid = tid + 256 * i;
+        const int wr = pid / INW, wc = pid - wr * INW;
+        const int Y = y0 + wr, X = x0 + wc;
+        const bool ok = pid < NIN && Y >= 0 && Y < a.H && X >= 0 && X < a.W;
+        const int Yc = Y < 0 ? 0 : (Y >= a.H ? a.H - 1 : Y), Xc = X < 0 ? 0 : (X >= a.W ? a.W - 1 : X);
+        const TIn* p = img + (long)Yc * a.W + Xc;
+        if constexpr (BYTES) {
+          raw[i] = (unsigned)p[0] | ((unsigned)p[plane] << 8) | ((unsigned)p[2 * plane] << 16);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) raw[i * 3 + c] = __builtin_bit_cast(unsigned, p[c * plane]);
+        }
+        okmask |= ok ? 1u << i : 0u;
       }
     }
+  };
+  auto convert = [&]() {
+    if (raw_fast) {
 #pragma unroll
-    for (int i = 0; i < IN_ROUNDS; ++i) {
-      const int pid = tid + 256 * i;
-      if (pid < NIN + IN_PAD) {
-        const f16x4 o = {(f16)v[i][0], (f16)v[i][1], (f16)v[i][2], (f16)0.f};
-        *(f16x4*)(inb + pid * 8) = o;
+      for (int i = 0; i < FAST_ROUNDS; ++i) {
+        const int e = tid + 256 * i;
+        const int c = e / (INH * FAST_PER_ROW), rem = e - c * (INH * FAST_PER_ROW);
+        const int wr = rem / FAST_PER_ROW, g = rem - wr * FAST_PER_ROW;
+        char* dst = inb + (wr * INW + 4 * g) * 8 + c * 2;
+        const int npx = e < FAST_N ? (g == FAST_PER_ROW - 1 ? INW - 4 * (FAST_PER_ROW - 1) : 4) : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < npx) *(f16*)(dst + k * 8) = lut[c * 256 + ((raw[i] >> (8 * k)) & 255u)];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < IN_ROUNDS; ++i) {
+        const int pid = tid + 256 * i;
+        if (pid < NIN) {
+          const bool ok = okmask & (1u << i);
+          f16x4 o = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            f16 v;
+            if constexpr (BYTES) v = lut[c * 256 + ((raw[i] >> (8 * c)) & 255u)];
+            else v = (f16)((__builtin_bit_cast(float, raw[i * 3 + c]) / 255.f - a.mean[c]) / a.stdv[c]);
+            o[c] = ok ? v : (f16)0.f;
+          }
+          *(f16x4*)(inb + pid * 8) = o;
+        }
       }
     }
-  }
-  __syncthreads();
+  };
 
-  // ---- stem: 7x7, 3 -> 16 ----
-  {
-    f16x8 wf[7];
-    const f16* wr = (const f16*)a.w0 + fr * K0 + q * 8;
+  // ---- the three conv phases of one tile; MASKED: the tile touches the border of the Hp x Wp map, so stem / level0 outputs
+  // outside it are forced to zero (they are the next layer's zero padding) ----
+  auto compute = [&](auto masked_c, int ox, int oy, int b) {
+    constexpr bool MASKED = decltype(masked_c)::value;
+    // stem: 7x7, 3 -> 16.  Wave w owns stem rows [5w, 5w+5) (the last wave 4) in three 16-column strips (the third overlaps
+    // the second: columns 19..34; both write the same values).  A strip's 11 window rows are read once -- output row i,
+    // kernel row r uses fragment i + r -- and its five accumulator chains are independent.
+    {
+      const int sy0 = 2 * oy - 2, sx0 = 2 * ox - 2;
+      const int r0 = wave * 5;
+      const bool five = wave < 3;
+      const f32x4 sc = *(const f32x4*)(sbv + q * 4), bi = *(const f32x4*)(sbv + 16 + q * 4);
 #pragma unroll
-    for (int r = 0; r < 7; ++r) wf[r] = *(const f16x8*)(wr + r * 32);
-    const f32x4 sc = *(const f32x4*)(a.s0 + q * 4), bi = *(const f32x4*)(a.b0 + q * 4);
-    const int sy0 = 2 * oy - 2, sx0 = 2 * ox - 2;
-    for (int t = wave; t < (NST + 15) / 16; t += 4) {
-      const int p = t * 16 + fr;
-      const int pc = p < NST ? p : NST - 1;
-      const int py = pc / STW, px = pc - py * STW;
-      const char* base = inb + (py * INW + px) * 8 + q * 16;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int strip = 0; strip < 3; ++strip) {
+        const int px = (strip == 0 ? 0 : strip == 1 ? 16 : STW - 16) + fr;
+        const char* base = inb + (r0 * INW + px) * 8 + q * 16;
+        f16x8 f[11];
 #pragma unroll
-      for (int r = 0; r < 7; ++r)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[r], lds_read16_align8(base + r * INW * 8), acc, 0, 0, 0);
-      const int Y = sy0 + py, X = sx0 + px;
-      const bool inside = Y >= 0 && Y < a.Hp && X >= 0 && X < a.Wp;   // outside: level0's zero padding
-      const f16x4 o = bn_relu_f16(acc, sc, bi, inside);
-      if (p < NST) *(f16x4*)(stb + (q >> 1) * (NST * 16) + p * 16 + (q & 1) * 8) = o;
+        for (int j = 0; j < 10; ++j) f[j] = lds_read16_align8(base + j * INW * 8);
+        f[10] = lds_read16_align8(base + (five ? 10 : 9) * INW * 8);
+        f32x4 acc[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
+          for (int i = 0; i < 5; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[r], f[i + r], acc[i], 0, 0, 0);
+        const int X = sx0 + px;
+        const bool xin = X >= 0 && X < a.Wp;
+        char* wbase = stb + (q >> 1) * STP + (r0 * STW + px) * 16 + (q & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const int Y = sy0 + r0 + i;
+          const f16x4 o = bn_relu_f16<MASKED>(acc[i], sc, bi, xin && Y >= 0 && Y < a.Hp);
+          if (i < 4 || five) *(f16x4*)(wbase + i * STW * 16) = o;   // the last wave has four rows
+        }
+      }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 
-  // ---- level0: 3x3, 16 -> 16 ----
-  {
-    f16x8 wf[5];
-    const f16* wr = (const f16*)a.w1 + fr * K1 + q * 8;
-    int kaddr[5];
+    // level0: 3x3, 16 -> 16: 36 flat runs of 16 pixels, 9 per wave, three at a time (fifteen fragment reads in flight, three
+    // independent accumulator chains)
+    {
+      const int ly0 = 2 * oy - 1, lx0 = 2 * ox - 1;
+      const f32x4 sc = *(const f32x4*)(sbv + 32 + q * 4), bi = *(const f32x4*)(sbv + 48 + q * 4);
 #pragma unroll
-    for (int kt = 0; kt < 5; ++kt) {
-      wf[kt] = *(const f16x8*)(wr + kt * 32);
-      const int G = kt * 4 + q;
-      const int tap = (G >> 1) < 9 ? (G >> 1) : 0;     // K tail: zero weights, read tap 0
-      const int tr = tap / 3, ts = tap - tr * 3;
-      kaddr[kt] = (G & 1) * (NST * 16) + (tr * STW + ts) * 16;
+      for (int it = 0; it < 3; ++it) {
+        f16x8 f[3][5];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const char* base = stb + (l0pos[it * 3 + u] & 0xffffu);
+#pragma unroll
+          for (int kt = 0; kt < 5; ++kt) f[u][kt] = *(const f16x8*)(base + kaddr1[kt]);
+        }
+        f32x4 acc[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+          for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[kt], f[u][kt], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const unsigned wofs = l0pos[it * 3 + u] >> 16;
+          bool inside = true;
+          if constexpr (MASKED) {
+            const int p = (int)(wofs >> 4), py = p / L0W, px = p - py * L0W;
+            const int Y = ly0 + py, X = lx0 + px;
+            inside = Y >= 0 && Y < a.Hp && X >= 0 && X < a.Wp;
+          }
+          const f16x4 o = bn_relu_f16<MASKED>(acc[u], sc, bi, inside);
+          if (wofs != 0xffffu) *(f16x4*)(l0b + (q >> 1) * L0P + wofs + (q & 1) * 8) = o;
+        }
+      }
     }
-    const f32x4 sc = *(const f32x4*)(a.s1 + q * 4), bi = *(const f32x4*)(a.b1 + q * 4);
-    const int ly0 = 2 * oy - 1, lx0 = 2 * ox - 1;
-    for (int t = wave; t < (NL0 + 15) / 16; t += 4) {
-      const int p = t * 16 + fr;
-      const int pc = p < NL0 ? p : NL0 - 1;
-      const int py = pc / L0W, px = pc - py * L0W;
-      const char* base = stb + (py * STW + px) * 16;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    // level1: 3x3 stride 2, 16 -> 32; lane = (pixel column fr, 8 consecutive couts q*8..q*8+7); rows wave and wave+4
+    {
+      f16x8 pf[2][5];
+#pragma unroll
+      for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt) pf[rw][kt] = *(const f16x8*)(l0b + (2 * (wave + 4 * rw) * L0W) * 16 + kaddr2[kt]);
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int rw = 0; rw < 2; ++rw) acc[rw][0] = acc[rw][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kt = 0; kt < 5; ++kt)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kt], *(const f16x8*)(base + kaddr[kt]), acc, 0, 0, 0);
-      const int Y = ly0 + py, X = lx0 + px;
-      const bool inside = Y >= 0 && Y < a.Hp && X >= 0 && X < a.Wp;   // outside: level1's zero padding
-      const f16x4 o = bn_relu_f16(acc, sc, bi, inside);
-      if (p < NL0) *(f16x4*)(l0b + (q >> 1) * (NL0 * 16) + p * 16 + (q & 1) * 8) = o;
+#pragma unroll
+        for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            acc[rw][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf2[kt][c], pf[rw][kt], acc[rw][c], 0, 0, 0);
+      f16* yp = (f16*)a.y + ((long)(b * H1 + oy + wave) * W1 + ox + fr) * a.out_stride + q * 8;
+#pragma unroll
+      for (int rw = 0; rw < 2; ++rw) {
+        const f16x4 o0 = bn_relu_f16<false>(acc[rw][0], *(const f32x4*)(sbv + 64 + q * 8), *(const f32x4*)(sbv + 96 + q * 8), true);
+        const f16x4 o1 = bn_relu_f16<false>(acc[rw][1], *(const f32x4*)(sbv + 68 + q * 8), *(const f32x4*)(sbv + 100 + q * 8), true);
+        const f16x8 o = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+        *(f16x8*)(yp + (long)rw * 4 * W1 * a.out_stride) = o;
+      }
     }
-  }
-  __syncthreads();
+  };
 
-  // ---- level1: 3x3 stride 2, 16 -> 32; lane = (pixel column fr, 8 consecutive couts q*8..q*8+7) ----
-  {
-    f16x8 wf[5][2];
-    int kaddr[5];
-#pragma unroll
-    for (int kt = 0; kt < 5; ++kt) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int cout = (fr >> 2) * 8 + c * 4 + (fr & 3);   // tile pair layout: tile c row r <-> cout (r/4)*8 + c*4 + r%4
-        wf[kt][c] = *(const f16x8*)((const f16*)a.w2 + cout * K1 + kt * 32 + q * 8);
-      }
-      const int G = kt * 4 + q;
-      const int tap = (G >> 1) < 9 ? (G >> 1) : 0;
-      const int tr = tap / 3, ts = tap - tr * 3;
-      kaddr[kt] = (G & 1) * (NL0 * 16) + (tr * L0W + ts + 2 * fr) * 16;
-    }
-    const f32x4 sc0 = *(const f32x4*)(a.s2 + q * 8), sc1 = *(const f32x4*)(a.s2 + q * 8 + 4);
-    const f32x4 bi0 = *(const f32x4*)(a.b2 + q * 8), bi1 = *(const f32x4*)(a.b2 + q * 8 + 4);
-    for (int row = wave; row < T1H; row += 4) {
-      const char* base = l0b + (2 * row * L0W) * 16;
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kt = 0; kt < 5; ++kt) {
-        const f16x8 pf = *(const f16x8*)(base + kaddr[kt]);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kt][0], pf, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kt][1], pf, acc1, 0, 0, 0);
-      }
-      const f16x4 o0 = bn_relu_f16(acc0, sc0, bi0, true), o1 = bn_relu_f16(acc1, sc1, bi1, true);
-      const f16x8 o = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
-      f16* yp = (f16*)a.y + ((long)(b * H1 + oy + row) * W1 + ox + fr) * a.out_stride + q * 8;
-      *(f16x8*)yp = o;
-    }
+  // weights have landed before the first window fetch is issued: the waitcnt pass then never waits for them inside the tile
+  // loop (vmcnt counts in order, so a wait for a weight register would also drain the younger window loads)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  __syncthreads();                                   // lut, sbv, cleared inb
+  for (; tile < ntiles; tile += gridDim.x) {
+    int ox, oy, b;
+    tile_origin(tile, ox, oy, b);
+    convert();                                       // inb was last read in the previous tile's stem phase, two barriers ago
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    // stem outputs of this tile span rows 2oy-2 .. 2oy+16 and columns 2ox-2 .. 2ox+32 of the Hp x Wp map
+    const bool interior = oy > 0 && 2 * oy + 16 < a.Hp && ox > 0 && 2 * ox + 32 < a.Wp;
+    if (interior) compute(std::false_type{}, ox, oy, b);
+    else compute(std::true_type{}, ox, oy, b);
   }
 }
 
@@ -194,13 +338,24 @@ int launch_dla_base(const BaseArgs& a, hipStream_t s) {
   CTDET_CHECK(a.H <= a.Hp && a.W <= a.Wp && a.H > 0 && a.W > 0, "dla_base: image %dx%d larger than padded %dx%d", a.H, a.W,
               a.Hp, a.Wp);
   CTDET_CHECK(a.out_stride >= 32 && a.out_stride % 8 == 0 && (((size_t)a.y) & 15) == 0, "dla_base: output rows must be 16-byte aligned");
-  const long blocks = (long)a.B * (a.Hp / (2 * T1H)) * (a.Wp / (2 * T1W));
-  if (blocks == 0) return 0;
-  CTDET_CHECK(blocks < (1L << 31), "dla_base: too many tiles");
+  const long tiles = (long)a.B * (a.Hp / (2 * T1H)) * (a.Wp / (2 * T1W));
+  if (tiles == 0) return 0;
+  CTDET_CHECK(tiles < (1L << 31), "dla_base: too many tiles");
+  // persistent workgroups: 2 per CU, each walks tiles blockIdx.x, + gridDim.x, ... with its weights in
+  // registers and the next tile's image window in flight
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const long want = 2L * ncu;
+  const unsigned blocks = (unsigned)(tiles < want ? tiles : want);
   if (a.img_dtype == CTDET_U8)
-    hipLaunchKernelGGL((dla_base_fused_kernel<uint8_t>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((dla_base_fused_kernel<uint8_t>), dim3(blocks), dim3(256), 0, s, a, (int)tiles);
   else if (a.img_dtype == CTDET_F32)
-    hipLaunchKernelGGL((dla_base_fused_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((dla_base_fused_kernel<float>), dim3(blocks), dim3(256), 0, s, a, (int)tiles);
   else
     CTDET_CHECK(false, "dla_base: image dtype %d (want u8 or f32)", a.img_dtype);
   CTDET_LAUNCH_CHECK();

@@ -134,7 +134,10 @@ def test_conv_window_small_channels(ops, dev, case):
 
 
 @pytest.mark.parametrize("case", [("u8_ragged", torch.uint8, 2, 50, 70, 64, 96), ("u8_full", torch.uint8, 3, 64, 64, 64, 64),
-                                  ("f32", torch.float32, 1, 32, 64, 32, 64), ("u8_tall", torch.uint8, 1, 130, 40, 144, 64)])
+                                  ("f32", torch.float32, 1, 32, 64, 32, 64), ("u8_tall", torch.uint8, 1, 130, 40, 144, 64),
+                                  ("u8_interior", torch.uint8, 2, 128, 160, 128, 160),
+                                  ("u8_interior_ragged", torch.uint8, 1, 121, 150, 128, 160),
+                                  ("f32_interior", torch.float32, 1, 96, 128, 96, 128)])
 def test_dla_base_fused(ops, dev, case):
     """normalisation + 7x7 stem + level0 + level1 in one launch vs (a) torch with the maps rounded to f16 where the
     layer-by-layer path rounds them and (b) that layer-by-layer HIP path itself; image smaller than the padded input,
