@@ -232,10 +232,13 @@ class DLA(Backbone):
             self.__dict__["_ctdet_packed_base"] = hit
         return hit[1]
 
-    def hip_forward_images(self, images, mean, std, Hp, Wp, ctx):
-        """images: [B,3,H,W] uint8/f32 device batch (not normalised) -> the six level outputs; levels 0 and 1 are computed
-        inside the fused base kernel, level 0 is not materialised (None)."""
-        x = ops.dla_base_fused(images, mean, std, Hp, Wp, self._packed_base())
+    def base_level1(self, images, mean, std, Hp, Wp, out=None):
+        """images: [B,3,H,W] uint8/f32 device batch (not normalised) -> level1 output [B,Hp/2,Wp/2,32] f16 NHWC, computed by
+        the fused base kernel (normalisation, base_layer, level0, level1); level 0 is never materialised."""
+        return ops.dla_base_fused(images, mean, std, Hp, Wp, self._packed_base(), out=out)
+
+    def hip_forward_level1(self, x, ctx):
+        """the six level outputs given level1's (levels 0 is None)"""
         y = [None, x]
         for i in range(2, 6):
             x = getattr(self, "level{}".format(i)).hip_forward(x, ctx)
@@ -280,10 +283,10 @@ class DLA34(Backbone):
     def images_fusable(self, ctx, Hp, Wp):
         return self.first_level >= 1 and self.base.base_fusable(ctx, Hp, Wp)
 
-    def hip_forward(self, x, ctx, prepadded=False, images=None):
+    def hip_forward(self, x, ctx, prepadded=False, level1=None):
         """x: NHWC [B,H,W,8] normalised image -> list of NHWC maps; the last one is the [B,H/4,W/4,64] head input.
-        images = (batch, mean, std, Hp, Wp): start from the raw image batch instead (see DLA.hip_forward_images)."""
-        x = self.base.hip_forward_images(*images, ctx) if images is not None else self.base.hip_forward(x, ctx, prepadded)
+        level1: start from DLA.base_level1's output instead of the normalised image."""
+        x = self.base.hip_forward_level1(level1, ctx) if level1 is not None else self.base.hip_forward(x, ctx, prepadded)
         x = self.dla_up.hip_forward(x, ctx)
         # the reference clones these maps (dla.py:311-313) because IDAUp mutates in place; buffers here are
         # never written twice, so no copy is needed
