@@ -185,6 +185,83 @@ __global__ void __launch_bounds__(256) dwconvT_add_kernel(const T* __restrict__ 
   *(V*)(y + opix * out_stride + cv * N) = r;
 }
 
+// the same, for the shapes DLA-34 uses (f = 2, 4, 8; C / N a power of two).  A thread owns one (output column, channel
+// vector) and walks DW_ROWS output rows of one kernel-row phase (oy, oy + f, oy + 2f, ...): those rows use the same four
+// taps, so the weights are loaded once into registers, and consecutive rows of a phase share an input row, so each output
+// costs two input loads, the skip load and the store.  The generic kernel above issues 13 loads per 16 output bytes (8 of
+// them weights) plus five runtime integer divisions and reaches 3.2 TB/s.
+constexpr int DW_ROWS = 8;
+template <typename T, int F>
+__global__ void __launch_bounds__(256) dwconvT_add_rows_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                               const T* __restrict__ skip, T* __restrict__ y, int H, int W,
+                                                               int C, int cv_shift, int nchunk, int in_stride,
+                                                               int skip_stride, int out_stride) {
+  using V = typename Vec<T>::type;
+  constexpr int N = Vec<T>::N;
+  constexpr int K = 2 * F, P = F / 2;
+  const int Ho = H * F, Wo = W * F;
+  const int phase = blockIdx.y % F;
+  const int chunk = (blockIdx.y / F) % nchunk;
+  const int b = blockIdx.y / (F * nchunk);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (Wo << cv_shift)) return;
+  const int cv = i & ((1 << cv_shift) - 1), ox = i >> cv_shift;
+  const int ky1 = (phase + P) % F, iyo = (phase + P) / F;   // output row (j*F + phase) reads input rows j + iyo, j + iyo - 1
+  const int ix1 = (ox + P) / F, kx1 = (ox + P) - F * ix1;
+  const bool c1 = ix1 < W, c0 = ix1 >= 1;                   // ix1 >= 0 and ix1 - 1 < W always hold
+  // taps [dy][dx]: kernel row ky1 + dy*F, kernel column kx1 + dx*F
+  float wt[2][2][N];
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+      for (int e4 = 0; e4 < N; e4 += 4) {
+        const f32x4 wv = *(const f32x4*)(w + ((long)(ky1 + dy * F) * K + kx1 + dx * F) * C + cv * N + e4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wt[dy][dx][e4 + e] = wv[e];
+      }
+  V zero;
+#pragma unroll
+  for (int e = 0; e < N; ++e) zero[e] = (T)0.f;
+  const T* xb = x + (long)b * H * W * in_stride + cv * N;
+  auto load_row = [&](int iy, V& v1, V& v0) {               // input row iy, columns ix1 and ix1 - 1 (zero outside)
+    const bool rin = iy >= 0 && iy < H;
+    const T* xr = xb + (long)iy * W * in_stride;
+    v1 = (rin && c1) ? *(const V*)(xr + (long)ix1 * in_stride) : zero;
+    v0 = (rin && c0) ? *(const V*)(xr + (long)(ix1 - 1) * in_stride) : zero;
+  };
+  const int j0 = chunk * DW_ROWS;
+  V lo1, lo0, hi1, hi0;                                      // rows iy - 1 (dy = 1) and iy (dy = 0)
+  load_row(j0 + iyo - 1, lo1, lo0);
+#pragma unroll
+  for (int r = 0; r < DW_ROWS; ++r) {
+    const int j = j0 + r, oy = j * F + phase;
+    if (oy >= Ho) break;
+    load_row(j + iyo, hi1, hi0);
+    float acc[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      acc[e] = (float)hi1[e] * wt[0][0][e];
+      acc[e] = fmaf((float)hi0[e], wt[0][1][e], acc[e]);
+      acc[e] = fmaf((float)lo1[e], wt[1][0][e], acc[e]);
+      acc[e] = fmaf((float)lo0[e], wt[1][1][e], acc[e]);
+    }
+    const long opix = (long)(b * Ho + oy) * Wo + ox;
+    V o;
+    if (skip) {
+      const V sv = *(const V*)(skip + opix * skip_stride + cv * N);
+#pragma unroll
+      for (int e = 0; e < N; ++e) o[e] = (T)(acc[e] + (float)sv[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < N; ++e) o[e] = (T)acc[e];
+    }
+    *(V*)(y + opix * out_stride + cv * N) = o;
+    lo1 = hi1; lo0 = hi0;
+  }
+}
+
 static inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
 
 int launch_preprocess(const void* img, int img_dtype, void* out, int out_dtype, int B, int H, int W, int Hp, int Wp,
@@ -263,6 +340,22 @@ int launch_dwconvT_add(const void* x, const float* w, const void* skip, void* y,
               "dwconvT: channels must be multiples of %d", N);
   const long total = (long)B * H * f * W * f * (C / N);
   if (total == 0) return 0;
+  const int CV = C / N;
+  const int nchunk = (H + DW_ROWS - 1) / DW_ROWS;           // a block walks DW_ROWS output rows of one phase
+  const long gy = (long)B * nchunk * f;
+  if ((f == 2 || f == 4 || f == 8) && (CV & (CV - 1)) == 0 && gy <= 65535 && (dtype == CTDET_F16 || dtype == CTDET_F32)) {
+    int sh = 0;
+    while ((1 << sh) < CV) ++sh;
+    const dim3 grid(nblk((long)W * f * CV), (unsigned)gy);
+#define DW(T, F_)                                                                                                        \
+  hipLaunchKernelGGL((dwconvT_add_rows_kernel<T, F_>), grid, dim3(256), 0, s, (const T*)x, w, (const T*)skip, (T*)y, H, W, C, \
+                     sh, nchunk, in_stride, skip_stride, out_stride)
+    if (dtype == CTDET_F16) { if (f == 2) DW(f16, 2); else if (f == 4) DW(f16, 4); else DW(f16, 8); }
+    else { if (f == 2) DW(float, 2); else if (f == 4) DW(float, 4); else DW(float, 8); }
+#undef DW
+    CTDET_LAUNCH_CHECK();
+    return 0;
+  }
   if (dtype == CTDET_F16)
     hipLaunchKernelGGL((dwconvT_add_kernel<f16>), dim3(nblk(total)), dim3(256), 0, s, (const f16*)x, w, (const f16*)skip,
                        (f16*)y, B, H, W, C, f, in_stride, skip_stride, out_stride);

@@ -288,13 +288,17 @@ def test_maxpool_and_dwconvT(ops, dev, tdt):
     x = h16(torch.randn(2, 64, 12, 16, generator=g))
     y = ops.maxpool2x2(nhwc(x).to(tdt).to(dev))
     assert torch.equal(nchw(y.float().cpu()), F.max_pool2d(x, 2, 2))
-    for f in (2, 4):
-        w = torch.rand(64, 1, 2 * f, 2 * f, generator=g)
-        skip = h16(torch.randn(2, 64, 12 * f, 16 * f, generator=g))
-        ref = F.conv_transpose2d(x, w, None, stride=f, padding=f // 2, groups=64) + skip
-        out = ops.dwconvT_add(nhwc(x).to(tdt).to(dev), w.to(dev), f, skip=nhwc(skip).to(tdt).to(dev))
-        tol = 2e-3 if tdt == torch.float16 else 1e-5
-        assert (nchw(out.float().cpu()) - ref).abs().max() < tol * ref.abs().max()
+    tol = 2e-3 if tdt == torch.float16 else 1e-5
+    # C = 64: the row-mapped kernel (f = 2, 4, 8, channel vectors a power of two); C = 24: the generic one
+    for Cc, f in ((64, 2), (64, 4), (64, 8), (24, 2), (24, 4)):
+        xc = x[:, :Cc]
+        w = torch.rand(Cc, 1, 2 * f, 2 * f, generator=g)
+        skip = h16(torch.randn(2, Cc, 12 * f, 16 * f, generator=g))
+        up = F.conv_transpose2d(xc, w, None, stride=f, padding=f // 2, groups=Cc)
+        out = ops.dwconvT_add(nhwc(xc).to(tdt).to(dev), w.to(dev), f, skip=nhwc(skip).to(tdt).to(dev))
+        assert (nchw(out.float().cpu()) - (up + skip)).abs().max() < tol * (up + skip).abs().max(), (Cc, f)
+        out = ops.dwconvT_add(nhwc(xc).to(tdt).to(dev), w.to(dev), f)
+        assert (nchw(out.float().cpu()) - up).abs().max() < tol * up.abs().max(), (Cc, f, "no skip")
 
 
 def test_preprocess(ops, dev):
