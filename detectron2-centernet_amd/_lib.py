@@ -32,7 +32,7 @@ SIGNATURES = {
     "ctdet_dcnv2_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ctdet_preprocess": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp]),
     "ctdet_head_fused_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp]),
-    "ctdet_dla_base_fwd": (_i32, [_vp] * 13),
+    "ctdet_dla_base_fwd": (_i32, [_vp] * 14),
     "ctdet_maxpool2x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_maxpool3x3s2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_pack_weights": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -90,7 +90,7 @@ class DlaBaseDesc(C.Structure):
     """mirrors ctdet_dla_base_desc"""
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Hp", C.c_int32), ("Wp", C.c_int32),
                 ("img_dtype", C.c_int32), ("img_batch_stride", C.c_int64), ("mean", C.c_float * 3), ("std", C.c_float * 3),
-                ("out_stride", C.c_int32)]
+                ("out_stride", C.c_int32), ("pool_stride", C.c_int32)]
 
 
 class HeadDesc(C.Structure):

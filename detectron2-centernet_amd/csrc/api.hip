@@ -190,7 +190,8 @@ int32_t ctdet_head_fused_fwd(const ctdet_head_desc* d, const void* x, const void
 
 int32_t ctdet_dla_base_fwd(const ctdet_dla_base_desc* d, const void* images, const void* w_stem, const float* scale_stem,
                            const float* bias_stem, const void* w_l0, const float* scale_l0, const float* bias_l0,
-                           const void* w_l1, const float* scale_l1, const float* bias_l1, void* out, void* stream) {
+                           const void* w_l1, const float* scale_l1, const float* bias_l1, void* out, void* pooled,
+                           void* stream) {
   CTDET_CHECK(d && images && w_stem && scale_stem && bias_stem && w_l0 && scale_l0 && bias_l0 && w_l1 && scale_l1 && bias_l1 &&
               out, "dla_base: null pointer");
   BaseArgs a = {};
@@ -201,6 +202,7 @@ int32_t ctdet_dla_base_fwd(const ctdet_dla_base_desc* d, const void* images, con
   a.w1 = w_l0; a.s1 = scale_l0; a.b1 = bias_l0;
   a.w2 = w_l1; a.s2 = scale_l1; a.b2 = bias_l1;
   a.y = out; a.out_stride = d->out_stride;
+  a.pool = pooled; a.pool_stride = d->pool_stride;
   return launch_dla_base(a, (hipStream_t)stream);
 }
 

@@ -90,6 +90,8 @@ struct BaseArgs {
   const float *s0, *b0, *s1, *b1, *s2, *b2;   // folded BatchNorm scale / bias per layer
   void* y;                // f16 [B,Hp/2,Wp/2,out_stride]
   int out_stride;
+  void* pool;             // optional f16 [B,Hp/4,Wp/4,pool_stride]: 2x2 max-pool of y
+  int pool_stride;
 };
 int launch_dla_base(const BaseArgs& a, hipStream_t s);
 

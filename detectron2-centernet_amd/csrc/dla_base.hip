@@ -285,13 +285,15 @@ __global__ void __launch_bounds__(256, 2) dla_base_fused_kernel(const BaseArgs a
     }
     __syncthreads();
 
-    // level1: 3x3 stride 2, 16 -> 32; lane = (pixel column fr, 8 consecutive couts q*8..q*8+7); rows wave and wave+4
+    // level1: 3x3 stride 2, 16 -> 32; lane = (pixel column fr, 8 consecutive couts q*8..q*8+7); rows 2*wave and 2*wave+1,
+    // so the 2x2 max-pool of the tile (Tree.downsample of level2, dla.py:128-129) is one packed max across the wave's two
+    // rows and one with the neighbouring lane
     {
       f16x8 pf[2][5];
 #pragma unroll
       for (int rw = 0; rw < 2; ++rw)
 #pragma unroll
-        for (int kt = 0; kt < 5; ++kt) pf[rw][kt] = *(const f16x8*)(l0b + (2 * (wave + 4 * rw) * L0W) * 16 + kaddr2[kt]);
+        for (int kt = 0; kt < 5; ++kt) pf[rw][kt] = *(const f16x8*)(l0b + (2 * (2 * wave + rw) * L0W) * 16 + kaddr2[kt]);
       f32x4 acc[2][2];
 #pragma unroll
       for (int rw = 0; rw < 2; ++rw) acc[rw][0] = acc[rw][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -302,13 +304,25 @@ __global__ void __launch_bounds__(256, 2) dla_base_fused_kernel(const BaseArgs a
 #pragma unroll
           for (int c = 0; c < 2; ++c)
             acc[rw][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf2[kt][c], pf[rw][kt], acc[rw][c], 0, 0, 0);
-      f16* yp = (f16*)a.y + ((long)(b * H1 + oy + wave) * W1 + ox + fr) * a.out_stride + q * 8;
+      f16* yp = (f16*)a.y + ((long)(b * H1 + oy + 2 * wave) * W1 + ox + fr) * a.out_stride + q * 8;
+      f16x8 o[2];
 #pragma unroll
       for (int rw = 0; rw < 2; ++rw) {
         const f16x4 o0 = bn_relu_f16<false>(acc[rw][0], *(const f32x4*)(sbv + 64 + q * 8), *(const f32x4*)(sbv + 96 + q * 8), true);
         const f16x4 o1 = bn_relu_f16<false>(acc[rw][1], *(const f32x4*)(sbv + 68 + q * 8), *(const f32x4*)(sbv + 100 + q * 8), true);
-        const f16x8 o = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
-        *(f16x8*)(yp + (long)rw * 4 * W1 * a.out_stride) = o;
+        o[rw] = (f16x8){o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+        *(f16x8*)(yp + (long)rw * W1 * a.out_stride) = o[rw];
+      }
+      if (a.pool) {
+        const f16x8 v = __builtin_elementwise_max(o[0], o[1]);
+        u32x4 vb = __builtin_bit_cast(u32x4, v), nb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)   // the pixel column fr ^ 1: quad_perm [1,0,3,2]
+          nb[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)vb[e], 0xB1, 0xF, 0xF, true);
+        const f16x8 m = __builtin_elementwise_max(v, __builtin_bit_cast(f16x8, nb));
+        if (!(fr & 1))
+          *(f16x8*)((f16*)a.pool + ((long)(b * (H1 >> 1) + (oy >> 1) + wave) * (W1 >> 1) + ((ox + fr) >> 1)) * a.pool_stride +
+                    q * 8) = m;
       }
     }
   };
@@ -338,6 +352,8 @@ int launch_dla_base(const BaseArgs& a, hipStream_t s) {
   CTDET_CHECK(a.H <= a.Hp && a.W <= a.Wp && a.H > 0 && a.W > 0, "dla_base: image %dx%d larger than padded %dx%d", a.H, a.W,
               a.Hp, a.Wp);
   CTDET_CHECK(a.out_stride >= 32 && a.out_stride % 8 == 0 && (((size_t)a.y) & 15) == 0, "dla_base: output rows must be 16-byte aligned");
+  CTDET_CHECK(!a.pool || (a.pool_stride >= 32 && a.pool_stride % 8 == 0 && (((size_t)a.pool) & 15) == 0),
+              "dla_base: pooled output rows must be 16-byte aligned");
   const long tiles = (long)a.B * (a.Hp / (2 * T1H)) * (a.Wp / (2 * T1W));
   if (tiles == 0) return 0;
   CTDET_CHECK(tiles < (1L << 31), "dla_base: too many tiles");

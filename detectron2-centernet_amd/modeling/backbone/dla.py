@@ -100,9 +100,11 @@ class Tree(nn.Module):
                 nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, bias=False),
                 nn.BatchNorm2d(out_channels, momentum=BN_MOMENTUM))
 
-    def hip_forward(self, x, ctx, residual=None, children=None):
+    def hip_forward(self, x, ctx, residual=None, children=None, bottom=None):
+        """bottom: the down-sampled input when the caller already has it (the fused base kernel emits level1's pool)"""
         children = [] if children is None else children
-        bottom = ops.maxpool2x2(x) if self.downsample else x
+        if bottom is None:
+            bottom = ops.maxpool2x2(x) if self.downsample else x
         residual = hipnn.conv_module(bottom, self.project[0], self.project[1], ACT_NONE, ctx=ctx) if self.project \
             else bottom
         if self.level_root:
@@ -232,16 +234,18 @@ class DLA(Backbone):
             self.__dict__["_ctdet_packed_base"] = hit
         return hit[1]
 
-    def base_level1(self, images, mean, std, Hp, Wp, out=None):
+    def base_level1(self, images, mean, std, Hp, Wp, out=None, pooled=None):
         """images: [B,3,H,W] uint8/f32 device batch (not normalised) -> level1 output [B,Hp/2,Wp/2,32] f16 NHWC, computed by
-        the fused base kernel (normalisation, base_layer, level0, level1); level 0 is never materialised."""
-        return ops.dla_base_fused(images, mean, std, Hp, Wp, self._packed_base(), out=out)
+        the fused base kernel (normalisation, base_layer, level0, level1); level 0 is never materialised.  pooled: optional
+        [B,Hp/4,Wp/4,32] buffer for the 2x2 max-pool of the output (level2's down-sampled input)."""
+        return ops.dla_base_fused(images, mean, std, Hp, Wp, self._packed_base(), out=out, pooled=pooled)
 
-    def hip_forward_level1(self, x, ctx):
-        """the six level outputs given level1's (levels 0 is None)"""
+    def hip_forward_level1(self, x, ctx, pooled=None):
+        """the six level outputs given level1's (level 0 is None); pooled: MaxPool2d(2) of x when already computed"""
         y = [None, x]
         for i in range(2, 6):
-            x = getattr(self, "level{}".format(i)).hip_forward(x, ctx)
+            lvl = getattr(self, "level{}".format(i))
+            x = lvl.hip_forward(x, ctx, bottom=pooled if i == 2 and lvl.downsample else None)
             y.append(x)
         return y
 
@@ -285,8 +289,11 @@ class DLA34(Backbone):
 
     def hip_forward(self, x, ctx, prepadded=False, level1=None):
         """x: NHWC [B,H,W,8] normalised image -> list of NHWC maps; the last one is the [B,H/4,W/4,64] head input.
-        level1: start from DLA.base_level1's output instead of the normalised image."""
-        x = self.base.hip_forward_level1(level1, ctx) if level1 is not None else self.base.hip_forward(x, ctx, prepadded)
+        level1 = (map, pooled map or None): start from DLA.base_level1's outputs instead of the normalised image."""
+        if level1 is not None:   # (level1 output, its 2x2 max-pool or None)
+            x = self.base.hip_forward_level1(level1[0], ctx, pooled=level1[1])
+        else:
+            x = self.base.hip_forward(x, ctx, prepadded)
         x = self.dla_up.hip_forward(x, ctx)
         # the reference clones these maps (dla.py:311-313) because IDAUp mutates in place; buffers here are
         # never written twice, so no copy is needed

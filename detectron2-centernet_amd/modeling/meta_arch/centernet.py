@@ -68,6 +68,7 @@ class _EvalEngine:
         # the base kernel runs outside the captured graph and reads the caller's image batch in place (no staging copy);
         # the graph starts from its output
         self.l1 = torch.empty(B, Hp // 2, Wp // 2, 32, dtype=torch.float16, device=dev) if self.fused_base else None
+        self.l1p = torch.empty(B, Hp // 4, Wp // 4, 32, dtype=torch.float16, device=dev) if self.fused_base else None
         self.graph = None
         self.Hp, self.Wp = Hp, Wp
         if self.fused_base:
@@ -92,12 +93,12 @@ class _EvalEngine:
 
     def _base(self, images):
         m = self.model
-        m.backbone.base.base_level1(images, m._mean_host, m._std_host, self.Hp, self.Wp, out=self.l1)
+        m.backbone.base.base_level1(images, m._mean_host, m._std_host, self.Hp, self.Wp, out=self.l1, pooled=self.l1p)
 
     def _run(self):
         m = self.model
         if self.fused_base:
-            self.out = m._network_outputs(None, apply_sigmoid=True, level1=self.l1)
+            self.out = m._network_outputs(None, apply_sigmoid=True, level1=(self.l1, self.l1p))
         else:
             x = ops.preprocess(self.images, m._mean_host, m._std_host, self.Hp, self.Wp, out=self.xpad, border=3)
             self.out = m._network_outputs(x, apply_sigmoid=True, prepadded=True)

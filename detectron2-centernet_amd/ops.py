@@ -359,10 +359,11 @@ def dla_base_fused_ok(Hp, Wp):
     return BASE_FUSED and Hp % 16 == 0 and Wp % 32 == 0
 
 
-def dla_base_fused(images, mean, std, Hp, Wp, p, out=None):
+def dla_base_fused(images, mean, std, Hp, Wp, p, out=None, pooled=None):
     """images [B,3,H,W] uint8/f32 on device -> level1 output of DLA (f16 NHWC [B,Hp/2,Wp/2,32]) in one launch:
-    normalisation, 7x7 stem, level0, level1 (stride 2), BatchNorm folded, ReLU after each."""
-    _require_cuda(images, out)
+    normalisation, 7x7 stem, level0, level1 (stride 2), BatchNorm folded, ReLU after each.  pooled: optional f16
+    [B,Hp/4,Wp/4,>=32] buffer that receives MaxPool2d(2) of the output (what level2's Tree starts with)."""
+    _require_cuda(images, out, pooled)
     B, Cc, H, W = images.shape
     assert Cc == 3 and images.stride(3) == 1 and images.stride(2) == W and images.stride(1) == H * W
     if out is None:
@@ -374,10 +375,21 @@ def dla_base_fused(images, mean, std, Hp, Wp, p, out=None):
     for i in range(3):
         d.mean[i], d.std[i] = float(mean[i]), float(std[i])
     d.out_stride = _nhwc_stride(out)
-    rc = _lib.lib().ctdet_dla_base_fwd(C.byref(d), _ptr(images), _ptr(p.w0), _ptr(p.s0), _ptr(p.b0), _ptr(p.p1.w),
-                                       _ptr(p.p1.scale), _ptr(p.p1.bias), _ptr(p.p2.w), _ptr(p.p2.scale), _ptr(p.p2.bias),
-                                       _ptr(out), _stream())
+    if pooled is not None:
+        assert pooled.dtype == torch.float16 and tuple(pooled.shape[:3]) == (B, Hp // 4, Wp // 4) and pooled.shape[3] >= 32
+        d.pool_stride = _nhwc_stride(pooled)
+    px = B * Hp * Wp
+    prof = _Prof(None, px, False, F16, name="dla_base_fused_kernel<u8|f32 -> 32ch,f16>",
+                 flops=2.0 * (px * 16 * 147 + px * 16 * 144 + (px // 4) * 32 * 144))
+    for _ in range(prof.reps()):
+        rc = _lib.lib().ctdet_dla_base_fwd(C.byref(d), _ptr(images), _ptr(p.w0), _ptr(p.s0), _ptr(p.b0), _ptr(p.p1.w),
+                                           _ptr(p.p1.scale), _ptr(p.p1.bias), _ptr(p.p2.w), _ptr(p.p2.scale),
+                                           _ptr(p.p2.bias), _ptr(out), _ptr(pooled), _stream())
     _lib.check(rc, "ctdet_dla_base_fwd")
+    if prof.on:
+        prof.bytes = images.numel() * images.element_size() + (px // 4) * 32 * 2
+        prof.info = f"M={px} 3->16->16->32 fused"
+    prof.done()
     return out
 
 

@@ -101,17 +101,20 @@ int32_t ctdet_head_fused_fwd(const ctdet_head_desc* d, const void* x, const void
  * Wp after normalisation (ImageList.from_tensors); Hp % 16 == 0, Wp % 32 == 0.  Weights f16: w_stem [16][224] with
  * k = (r*8 + s)*4 + c (tap column s = 7 and channel c = 3 zero), w_l0 [16][160] and w_l1 [32][160] with k = (r*3 + s)*16 + c
  * (ctdet_pack_weights korder 0).  scale/bias: the folded BatchNorm of each layer, f32.  out: f16 NHWC
- * [B,Hp/2,Wp/2,out_stride] (32 channels written).  The intermediate maps are rounded to f16 exactly where the layer-by-
- * layer path rounds them. */
+ * [B,Hp/2,Wp/2,out_stride] (32 channels written).  pooled (may be NULL): f16 NHWC [B,Hp/4,Wp/4,pool_stride], the
+ * MaxPool2d(2) of `out` that level2's Tree starts with (dla.py:128-129, 139).  The intermediate maps are rounded to f16
+ * exactly where the layer-by-layer path rounds them. */
 typedef struct ctdet_dla_base_desc {
   int32_t B, H, W, Hp, Wp, img_dtype;
   int64_t img_batch_stride;   /* elements between images */
   float mean[3], std[3];
   int32_t out_stride;
+  int32_t pool_stride;        /* pixel stride of `pooled` (elements); ignored when pooled is NULL */
 } ctdet_dla_base_desc;
 int32_t ctdet_dla_base_fwd(const ctdet_dla_base_desc* d, const void* images, const void* w_stem, const float* scale_stem,
                            const float* bias_stem, const void* w_l0, const float* scale_l0, const float* bias_l0,
-                           const void* w_l1, const float* scale_l1, const float* bias_l1, void* out, void* stream);
+                           const void* w_l1, const float* scale_l1, const float* bias_l1, void* out, void* pooled,
+                           void* stream);
 
 /* nn.MaxPool2d(2, stride=2) on NHWC (dla.py:128-129). */
 int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,

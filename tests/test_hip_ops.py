@@ -158,7 +158,10 @@ def test_dla_base_fused(ops, dev, case):
     for w, (sc, bi) in zip(ws, sb):
         args += [w.to(dev), (sc.to(dev), bi.to(dev))]
     pb = ops.PackedDlaBase(*args)
-    y = ops.dla_base_fused(img.to(dev), mean, std, Hp, Wp, pb)
+    pooled = torch.empty(B, Hp // 4, Wp // 4, 32, dtype=torch.float16, device=dev)
+    y = ops.dla_base_fused(img.to(dev), mean, std, Hp, Wp, pb, pooled=pooled)
+    assert torch.equal(pooled, ops.maxpool2x2(y)), f"{name}: fused 2x2 max-pool"
+    assert torch.equal(y, ops.dla_base_fused(img.to(dev), mean, std, Hp, Wp, pb)), f"{name}: with / without the pooled output"
     got = nchw(y.float().cpu())
     assert got.shape == ref.shape
     err = (got - ref).abs().max().item()
