@@ -146,8 +146,8 @@ def roofline_pass(model, images, passes=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--task", default="infer", choices=["infer", "train"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64 infer / 16 train)")
     ap.add_argument("--size", type=int, default=512)

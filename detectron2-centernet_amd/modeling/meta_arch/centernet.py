@@ -104,9 +104,14 @@ class _EvalEngine:
             self.out = m._network_outputs(x, apply_sigmoid=True, prepadded=True)
         hm, wh, reg = self.out
         self.dec = ops.decode(hm, wh, reg, m.topk_candidates, m.backbone.down_ratio)
+
+    def _post(self):
+        """threshold / rescale / clip / compact into FRESH output tensors: runs after the captured part, outside the graph, so
+        a step's results stay valid while later steps replay (no snapshot copies)"""
+        m = self.model
         boxes, scores, classes, _ = self.dec
         max_det = min(m.max_detections_per_image, m.topk_candidates)
-        self.final = ops.postprocess(boxes, scores, classes, max_det, m.score_threshold, self.img_params)
+        return ops.postprocess(boxes, scores, classes, max_det, m.score_threshold, self.img_params)
 
     def __call__(self, images=None):
         """one eval step on `images` ([B,3,H,W] device batch of the engine's shape and dtype, contiguous) or, when None, on
@@ -119,7 +124,7 @@ class _EvalEngine:
             self.graph.replay()
         else:
             self._run()
-        return self.final
+        return self._post()
 
 
 @META_ARCH_REGISTRY.register()
@@ -380,10 +385,8 @@ class CenterNet(nn.Module):
                                   dtype=torch.float32)
             eng.img_params.copy_(params, non_blocking=False)
             eng._params_key = pkey
-        boxes, scores, classes, counts = eng(images)
-        # snapshot on the launch stream: the next replay may overwrite the engine's output buffers
-        h = _EvalHandle(boxes.clone(), scores.clone(), classes.clone(), counts, out_sizes)
-        return h
+        boxes, scores, classes, counts = eng(images)   # fresh tensors per step (the engine's post-processing allocates them)
+        return _EvalHandle(boxes, scores, classes, counts, out_sizes)
 
     def _forward_eval_ragged(self, batched_inputs, imgs, sizes, Hp, Wp):
         """images of different sizes: per-image preprocess launches into the zero-padded batch, eager launches."""
