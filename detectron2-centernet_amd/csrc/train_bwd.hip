@@ -196,15 +196,16 @@ __device__ __forceinline__ f16x4 lds_tr_read(const f16* p) {
 
 #define WG_BN 64
 #define WG_BK 128
+#define WG_BM 64            // pixels per K-loop step (two MFMA K slabs of 32)
 #define WG_LDA (WG_BK + 8)  // row padding (elements) to spread banks
 #define WG_LDY (WG_BN + 8)
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) f16 sA[32 * WG_LDA];
-  __shared__ __attribute__((aligned(16))) f16 sY[32 * WG_LDY];
+  __shared__ __attribute__((aligned(16))) f16 sA[WG_BM * WG_LDA];
+  __shared__ __attribute__((aligned(16))) f16 sY[WG_BM * WG_LDY];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k0 = blockIdx.x * WG_BK, n0 = blockIdx.y * WG_BN;
   const int wn = wave >> 1, wk = wave & 1;  // wave tile: 32 couts x 64 k
-  const int m_per = ((a.M + a.msplit - 1) / a.msplit + 31) / 32 * 32;
+  const int m_per = ((a.M + a.msplit - 1) / a.msplit + WG_BM - 1) / WG_BM * WG_BM;
   const int m_begin = blockIdx.z * m_per;
   const int m_end = m_begin + m_per < a.M ? m_begin + m_per : a.M;
 
@@ -214,9 +215,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // loaders: A tile 32 rows x 128 k = 512 16-byte groups (2 per thread); dY tile 32 x 64 = 256 groups (1 per thread)
-  const int a_row = tid >> 4, a_kg = tid & 15;      // rows a_row, a_row+16 ; k-group a_kg (8 channels)
-  const int y_row = tid >> 3, y_ng = tid & 7;
+  // loaders: A tile 64 rows x 128 k = 1024 16-byte groups (4 per thread); dY tile 64 x 64 = 512 groups (2 per thread)
+  const int a_row = tid >> 4, a_kg = tid & 15;      // rows a_row + 16 i ; k-group a_kg (8 channels)
+  const int y_row = tid >> 3, y_ng = tid & 7;       // rows y_row + 32 i
   const int kk = k0 + a_kg * 8;
   const bool k_ok = kk < a.K;
   const int tap = k_ok ? kk / a.Cin : 0;
@@ -225,49 +226,61 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
   const bool n_ok = n0 + y_ng * 8 < a.Cout;
 
   const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
-  for (int mb = m_begin; mb < m_end; mb += 32) {
-    f16x8 av[2], yv;
-    const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  f16x8 av[4], yv[2];
+  const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  // the 64-pixel slab `mb` of both operands into registers (unconditional loads from clamped addresses + select, so the
+  // loads of the next slab stay in flight behind the MFMAs of the current one)
+  auto fetch = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + a_row + 16 * i;
+      const int mc = m < m_end ? m : m_end - 1;
+      const int wo = mc % a.Wo, t = mc / a.Wo;
+      const int ho = t % a.Ho, b = t / a.Ho;
+      const int hi = ho * a.stride - a.pad + tr * a.dil, wi = wo * a.stride - a.pad + ts * a.dil;
+      const bool ok = m < m_end && k_ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+      const f16x8 v = *(const f16x8*)(ok ? a.x + ((long)(b * a.H + hi) * a.W + wi) * a.in_stride + c0 : a.x);
+      av[i] = ok ? v : z8;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int m = mb + a_row + 16 * i;
-      av[i] = z8;
-      if (m < m_end && k_ok) {
-        const int wo = m % a.Wo, t = m / a.Wo;
-        const int ho = t % a.Ho, b = t / a.Ho;
-        const int hi = ho * a.stride - a.pad + tr * a.dil, wi = wo * a.stride - a.pad + ts * a.dil;
-        if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W)
-          av[i] = *(const f16x8*)(a.x + ((long)(b * a.H + hi) * a.W + wi) * a.in_stride + c0);
-      }
+      const int m = mb + y_row + 32 * i;
+      const bool ok = m < m_end && n_ok;
+      const f16x8 v = *(const f16x8*)(ok ? a.dy + (long)m * a.dy_stride + n0 + y_ng * 8 : a.dy);
+      yv[i] = ok ? v : z8;
     }
-    {
-      const int m = mb + y_row;
-      yv = (m < m_end && n_ok) ? *(const f16x8*)(a.dy + (long)m * a.dy_stride + n0 + y_ng * 8) : z8;
-    }
+  };
+  if (m_begin < m_end) fetch(m_begin);
+  for (int mb = m_begin; mb < m_end; mb += WG_BM) {
     __syncthreads();  // previous iteration's fragment reads are done
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *(f16x8*)(sA + (a_row + 16 * i) * WG_LDA + a_kg * 8) = av[i];
-    *(f16x8*)(sY + y_row * WG_LDY + y_ng * 8) = yv;
+    for (int i = 0; i < 4; ++i) *(f16x8*)(sA + (a_row + 16 * i) * WG_LDA + a_kg * 8) = av[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(f16x8*)(sY + (y_row + 32 * i) * WG_LDY + y_ng * 8) = yv[i];
     __syncthreads();
-    // fragments: lane group grp covers pixels 8*grp .. 8*grp+7 (two 4-row blocks); lane 4q+p addresses
-    // row q, columns 4p..4p+3 of a 4x16 block and receives column li of its 4 rows
-    f16x8 fy[2], fa[4];
+    if (mb + WG_BM < m_end) fetch(mb + WG_BM);
+    // fragments: lane group grp covers pixels 8*grp .. 8*grp+7 of a 32-pixel K slab (two 4-row blocks); lane 4q+p
+    // addresses row q, columns 4p..4p+3 of a 4x16 block and receives column li of its 4 rows
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const f16* base = sY + (8 * grp + q) * WG_LDY + wn * 32 + i * 16 + 4 * p;
-      const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * WG_LDY);
-      fy[i] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    for (int h = 0; h < WG_BM / 32; ++h) {
+      f16x8 fy[2], fa[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f16* base = sY + (32 * h + 8 * grp + q) * WG_LDY + wn * 32 + i * 16 + 4 * p;
+        const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * WG_LDY);
+        fy[i] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f16* base = sA + (32 * h + 8 * grp + q) * WG_LDA + wk * 64 + j * 16 + 4 * p;
+        const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * WG_LDA);
+        fa[j] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[i], fa[j], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f16* base = sA + (8 * grp + q) * WG_LDA + wk * 64 + j * 16 + 4 * p;
-      const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * WG_LDA);
-      fa[j] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[i], fa[j], acc[i][j], 0, 0, 0);
   }
   // D[row = cout][col = k]: lane holds rows 4*(lane>>4)+reg, col lane&15
 #pragma unroll
@@ -769,7 +782,7 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
   CTDET_CHECK(a.Cin % 8 == 0 && a.in_stride % 8 == 0 && a.dy_stride % 8 == 0 && a.Cout % 8 == 0,
               "wgrad: channel counts / strides must be multiples of 8 (Cin=%d Cout=%d)", a.Cin, a.Cout);
   const int gx = (a.K + WG_BK - 1) / WG_BK, gy = (a.Cout + WG_BN - 1) / WG_BN;
-  int split = 2048 / (gx * gy);
+  int split = 1024 / (gx * gy);   // ~4 workgroups per CU: fewer, longer pixel ranges (the atomic epilogue is per workgroup)
   if (split < 1) split = 1;
   const int max_split = (a.M + 255) / 256;
   if (split > max_split) split = max_split;
