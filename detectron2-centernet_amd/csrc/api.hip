@@ -43,12 +43,13 @@ int launch_sgd_runs(float*, const float*, float*, long, const long*, const int*,
 struct WgradArgs {
   const f16* x; const f16* dy; float* dw;
   int B, H, W, Cin, in_stride, Cout, Ho, Wo, dy_stride, R, S, stride, pad, dil, K, M, msplit;
+  float scale;
 };
 size_t chan_reduce_workspace_bytes(int C);
 int launch_bn_train_fwd(const f16*, int, const f16*, int, f16*, int, int, int, const float*, const float*, float, float,
                         float*, float*, float*, float*, float*, float*, void*, int, hipStream_t);
 int launch_bn_train_bwd(const f16*, int, const f16*, int, const f16*, int, const float*, const float*, const float*, int,
-                        int, int, f16*, int, f16*, int, float*, float*, void*, hipStream_t);
+                        int, int, f16*, int, f16*, int, float*, float*, float, void*, hipStream_t);
 int launch_conv_wgrad(const WgradArgs&, hipStream_t);
 int launch_maxpool2x2_bwd(const f16*, int, const f16*, int, f16*, int, int, int, int, int, hipStream_t);
 int launch_dwconvT_bwd(const f16*, int, const f16*, int, const float*, f16*, int, float*, int, int, int, int, int,
@@ -317,22 +318,22 @@ int32_t ctdet_bn_train_fwd(const void* y, int32_t y_stride, const void* res, int
 int32_t ctdet_bn_train_bwd(const void* dz, int32_t dz_stride, const void* z, int32_t z_stride, const void* y,
                            int32_t y_stride, const float* mean, const float* invstd, const float* scale, int32_t M,
                            int32_t C, int32_t relu, void* dy, int32_t dy_stride, void* dres, int32_t dres_stride,
-                           float* dgamma, float* dbeta, void* workspace, void* stream) {
+                           float* dgamma, float* dbeta, float grad_mult, void* workspace, void* stream) {
   CTDET_CHECK(dz && dy && dgamma && dbeta && workspace, "bn_train_bwd: null pointer");
   CTDET_CHECK(!relu || z, "bn_train_bwd: relu backward needs z");
   CTDET_CHECK(!y || (mean && invstd && scale), "bn_train_bwd: statistics missing");
   return launch_bn_train_bwd((const f16*)dz, dz_stride, (const f16*)z, z_stride, (const f16*)y, y_stride, mean, invstd,
-                             scale, M, C, relu, (f16*)dy, dy_stride, (f16*)dres, dres_stride, dgamma, dbeta, workspace,
-                             (hipStream_t)stream);
+                             scale, M, C, relu, (f16*)dy, dy_stride, (f16*)dres, dres_stride, dgamma, dbeta, grad_mult,
+                             workspace, (hipStream_t)stream);
 }
 
-int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy, float* dw, void* stream) {
+int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy, float* dw, float scale, void* stream) {
   CTDET_CHECK(d && x && dy && dw, "conv_wgrad: null pointer");
   WgradArgs a;
   a.x = (const f16*)x; a.dy = (const f16*)dy; a.dw = dw;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_stride = d->in_stride; a.Cout = d->Cout; a.Ho = d->Ho;
   a.Wo = d->Wo; a.dy_stride = d->out_stride; a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
-  a.K = d->R * d->S * d->Cin; a.M = d->B * d->Ho * d->Wo; a.msplit = 1;
+  a.K = d->R * d->S * d->Cin; a.M = d->B * d->Ho * d->Wo; a.msplit = 1; a.scale = scale;
   if (a.M == 0) return 0;
   return launch_conv_wgrad(a, (hipStream_t)stream);
 }

@@ -112,8 +112,12 @@ __global__ void __launch_bounds__(256) chan_finalize_kernel(const float* __restr
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
   } else {
-    out0[c] = (float)s0;
-    out1[c] = (float)s1;
+    // the apply kernel needs the plain sums (scale / shift double as their slots); the parameter gradients leave scaled
+    // (eps carries the multiplier in this mode: 1 / (loss scale * world size))
+    scale[c] = (float)s0;
+    shift[c] = (float)s1;
+    out0[c] = (float)s0 * eps;
+    out1[c] = (float)s1 * eps;
   }
 }
 
@@ -187,6 +191,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const f16* __restrict
 struct WgradArgs {
   const f16* x; const f16* dy; float* dw;
   int B, H, W, Cin, in_stride, Cout, Ho, Wo, dy_stride, R, S, stride, pad, dil, K, M, msplit;
+  float scale;   // multiplier applied to every partial sum before it is added to dw
 };
 
 __device__ __forceinline__ f16x4 lds_tr_read(const f16* p) {
@@ -292,7 +297,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 32 + i * 16 + 4 * (lane >> 4) + r;
-        if (n < a.Cout) atomicAdd(a.dw + (long)n * a.K + kcol, acc[i][j][r]);
+        if (n < a.Cout) atomicAdd(a.dw + (long)n * a.K + kcol, acc[i][j][r] * a.scale);
       }
     }
 }
@@ -731,7 +736,8 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
 // ------------------------------------------------------------------------------------------------
 static inline unsigned nblk256(long n) { return (unsigned)((n + 255) / 256); }
 
-size_t chan_reduce_workspace_bytes(int C) { return (size_t)1024 * 2 * C * sizeof(float); }
+// 1024 block partials of (sum0, sum1) per channel + the two finalized sums the BN backward apply pass reads
+size_t chan_reduce_workspace_bytes(int C) { return (size_t)(1024 * 2 + 2) * C * sizeof(float); }
 
 static int chan_blocks(int M, int C) {
   const int rows = 256 / (C / 8);
@@ -760,19 +766,21 @@ int launch_bn_train_fwd(const f16* y, int y_stride, const f16* res, int res_stri
 
 int launch_bn_train_bwd(const f16* dz, int dz_stride, const f16* z, int z_stride, const f16* y, int y_stride,
                         const float* mean, const float* invstd, const float* scale, int M, int C, int relu, f16* dy,
-                        int dy_stride, f16* dres, int dres_stride, float* dgamma, float* dbeta, void* workspace,
-                        hipStream_t s) {
+                        int dy_stride, f16* dres, int dres_stride, float* dgamma, float* dbeta, float grad_mult,
+                        void* workspace, hipStream_t s) {
   CTDET_CHECK(C % 8 == 0 && C / 8 <= 256, "bn_bwd: unsupported channel count %d", C);
   ChanRedArgs a = {};
   a.y = y; a.y_stride = y_stride; a.dz = dz; a.dz_stride = dz_stride; a.z = z; a.z_stride = z_stride;
   a.mean = mean; a.invstd = invstd; a.M = M; a.C = C; a.mode = 1; a.relu = relu; a.partial = (float*)workspace;
   const int nb = chan_blocks(M, C);
   hipLaunchKernelGGL(chan_reduce_kernel, dim3(nb), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(chan_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)workspace, nb, C, M, 1, 0.f,
-                     0.f, (const float*)nullptr, (const float*)nullptr, dbeta, dgamma, (float*)nullptr, (float*)nullptr,
+  float* sums = (float*)workspace + (size_t)1024 * 2 * C;   // [2][C]: sum g, sum g*xhat
+  hipLaunchKernelGGL(chan_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)workspace, nb, C, M, 1,
+                     grad_mult, 0.f, (const float*)nullptr, (const float*)nullptr, dbeta, dgamma, sums, sums + C,
                      (float*)nullptr, (float*)nullptr);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk256((long)M * (C / 8))), dim3(256), 0, s, dz, dz_stride, z, z_stride, y,
-                     y_stride, mean, invstd, scale, dbeta, dgamma, dy, dy_stride, dres, dres_stride, (long)M, C, relu);
+                     y_stride, mean, invstd, scale, (const float*)sums, (const float*)(sums + C), dy, dy_stride, dres,
+                     dres_stride, (long)M, C, relu);
   CTDET_LAUNCH_CHECK();
   return 0;
 }

@@ -25,6 +25,44 @@ def set_world_size(world):
     PARAM_GRAD_MULT = 1.0 / (GRAD_SCALE * max(1, int(world)))
 
 
+class ZeroArena:
+    """One f32 buffer that is cleared with a single fill at the start of a training step and handed out in slices to the
+    kernels that accumulate with atomics (the weight gradients): ~80 fills per step become one.  A slice lives until the
+    next `begin_step()`; autograd has added it into the parameter's .grad long before."""
+
+    def __init__(self, numel, device):
+        self.buf = torch.zeros(int(numel), dtype=torch.float32, device=device)
+        self.used = self.high = 0
+
+    def begin_step(self):
+        if self.high:
+            self.buf[:self.high].zero_()
+        self.used = 0
+
+    def take(self, numel):
+        n = (int(numel) + 63) // 64 * 64          # 256-byte granules
+        if self.used + n > self.buf.numel():
+            return None
+        t = self.buf[self.used:self.used + numel]
+        self.used += n
+        self.high = max(self.high, self.used)
+        return t
+
+
+ARENA = None   # set by the trainer (engine/train_loop.py); None: every accumulator is its own torch.zeros
+
+
+def _zeros_f32(shape, device):
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if ARENA is not None and ARENA.buf.device == device:
+        t = ARENA.take(n)
+        if t is not None:
+            return t.view(*shape)
+    return torch.zeros(*shape, dtype=torch.float32, device=device)
+
+
 def _ws(Cc, device):
     return torch.empty(_lib.lib().ctdet_chan_workspace_bytes(Cc) // 4, dtype=torch.float32, device=device)
 
@@ -43,24 +81,26 @@ def bn_train_fwd(y, gamma, beta, running_mean, running_var, eps, momentum, res=N
     return z, mean, invstd, scale
 
 
-def bn_train_bwd(dz, z, y, mean, invstd, scale, relu=True, want_dres=False):
+def bn_train_bwd(dz, z, y, mean, invstd, scale, relu=True, want_dres=False, grad_mult=None):
+    """dgamma / dbeta come back multiplied by grad_mult (default: PARAM_GRAD_MULT, what every parameter gradient carries)"""
     B, H, W, Cc = dz.shape
     dev = dz.device
     dy = torch.empty(B, H, W, Cc, dtype=torch.float16, device=dev)
     dres = torch.empty(B, H, W, Cc, dtype=torch.float16, device=dev) if want_dres else None
-    dgamma = torch.zeros(Cc, dtype=torch.float32, device=dev)
-    dbeta = torch.zeros(Cc, dtype=torch.float32, device=dev)
+    dgb = torch.empty(2, Cc, dtype=torch.float32, device=dev)   # written, not accumulated
+    dgamma, dbeta = dgb[0], dgb[1]
+    gm = PARAM_GRAD_MULT if grad_mult is None else grad_mult
     rc = _lib.lib().ctdet_bn_train_bwd(_ptr(dz), _nhwc_stride(dz), _ptr(z), _nhwc_stride(z) if z is not None else 0,
                                        _ptr(y), _nhwc_stride(y) if y is not None else 0, _ptr(mean), _ptr(invstd),
                                        _ptr(scale), B * H * W, Cc, int(relu), _ptr(dy), _nhwc_stride(dy), _ptr(dres),
                                        _nhwc_stride(dres) if dres is not None else 0, _ptr(dgamma), _ptr(dbeta),
-                                       _ptr(_ws(Cc, dev)), _stream())
+                                       float(gm), _ptr(_ws(Cc, dev)), _stream())
     _lib.check(rc, "ctdet_bn_train_bwd")
     return dy, dres, dgamma, dbeta
 
 
-def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1):
-    """dW f32 [Cout, R*S*Cin] (tap-major) for y = conv(x, W); x, dy f16 NHWC."""
+def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1, scale=None):
+    """scale * dW, f32 [Cout, R*S*Cin] (tap-major) for y = conv(x, W); x, dy f16 NHWC.  scale defaults to PARAM_GRAD_MULT."""
     B, H, W, Cin = x.shape
     _, Ho, Wo, Cd = dy.shape
     assert Cd >= Cout
@@ -68,8 +108,9 @@ def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1):
     d.B, d.H, d.W, d.Cin, d.in_stride = B, H, W, Cin, _nhwc_stride(x)
     d.Cout, d.Ho, d.Wo, d.out_stride = Cout, Ho, Wo, _nhwc_stride(dy)
     d.R, d.S, d.stride, d.pad, d.dil = R, S, stride, pad, dil
-    dw = torch.zeros(Cout, R * S * Cin, dtype=torch.float32, device=x.device)
-    rc = _lib.lib().ctdet_conv_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _stream())
+    dw = _zeros_f32((Cout, R * S * Cin), x.device)
+    rc = _lib.lib().ctdet_conv_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
+                                     float(PARAM_GRAD_MULT if scale is None else scale), _stream())
     _lib.check(rc, "ctdet_conv_wgrad")
     return dw
 
@@ -131,8 +172,7 @@ def conv_dgrad(dy, weight, stride, pad, in_hw):
 
 
 def _wgrad_to_oihw(dw, Cout, Cin_real, Cin_used, R, S):
-    g = dw.view(Cout, R, S, Cin_used)[..., :Cin_real].permute(0, 3, 1, 2)
-    return g * PARAM_GRAD_MULT
+    return dw.view(Cout, R, S, Cin_used)[..., :Cin_real].permute(0, 3, 1, 2)   # already scaled by the kernel; a view
 
 
 # ------------------------------------------------------------------------------------------ autograd Functions
@@ -159,7 +199,7 @@ class ConvFn(torch.autograd.Function):
         dbias = None
         if relu or has_bias:
             dy, _, _, db = bn_train_bwd(dy, _pad_c(y) if relu else None, None, None, None, None, relu=relu)
-            dbias = db[:Cout] * PARAM_GRAD_MULT if has_bias else None
+            dbias = db[:Cout] if has_bias else None
         dw = conv_wgrad(x, dy, Cw, R, S, stride, pad)[:Cout]
         dwt = _wgrad_to_oihw(dw, Cout, Cin, x.shape[3], R, S)
         dx = None
@@ -192,8 +232,7 @@ class BNActFn(torch.autograd.Function):
         y, z, mean, invstd, scale = ctx.saved_tensors
         dy, dres, dgamma, dbeta = bn_train_bwd(dz.contiguous(), z, y, mean, invstd, scale, relu=ctx.relu,
                                                want_dres=ctx.has_res)
-        s = PARAM_GRAD_MULT
-        return dy, dgamma * s, dbeta * s, dres, None, None, None, None, None
+        return dy, dgamma, dbeta, dres, None, None, None, None, None
 
 
 class MaxPoolFn(torch.autograd.Function):
@@ -245,10 +284,10 @@ class DCNFn(torch.autograd.Function):
         wmat = weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
         _, _, _, dbias = bn_train_bwd(dy, None, None, None, None, None, relu=False)
         dw = conv_wgrad(col, dy, Cout, 1, 1, 1, 0)                       # [Cout, 9*Cin]
-        dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2) * PARAM_GRAD_MULT
+        dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
         dcol = conv_dgrad(dy, wmat, 1, 0, x.shape[1:3])                  # [M, 9*Cin]
         dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om)
-        return dx32.half(), dom, dwt, dbias * PARAM_GRAD_MULT
+        return dx32.half(), dom, dwt, dbias
 
 
 class FocalLossFn(torch.autograd.Function):

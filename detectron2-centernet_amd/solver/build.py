@@ -69,6 +69,12 @@ class FlatSGD:
         self._run_lr_index = torch.tensor([self.lr_factors.index(r[2]) for r in self.runs], dtype=torch.int32, device=device)
         self._first = True
         self.set_lr_factor(1.0)
+        # zero-initialised scratch for the atomically accumulated weight gradients (ops_train.ZeroArena): a little larger
+        # than the parameter count (channel padding), cleared together with the gradient buffer
+        self._arena = None
+        if torch.device(device).type == "cuda":
+            from .. import ops_train
+            self._arena = ops_train.ARENA = ops_train.ZeroArena(int(total * 1.25) + (1 << 20), torch.device(device))
 
     def set_lr_factor(self, f):
         self._sched_factor = float(f)
@@ -81,6 +87,8 @@ class FlatSGD:
 
     def zero_grad(self):
         self.flat_grad.zero_()
+        if self._arena is not None:       # the weight-gradient accumulators of this backward pass: one fill for all of them
+            self._arena.begin_step()
         for p, (off, n) in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 p.grad = self.flat_grad[off:off + n].view_as(p.data)

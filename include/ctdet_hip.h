@@ -210,14 +210,16 @@ int32_t ctdet_bn_train_fwd(const void* y, int32_t y_stride, const void* res, int
                            float* save_invstd, float* scale, float* shift, void* workspace, int32_t relu, void* stream);
 /* backward of the above: g = dz*(z>0) if relu; dgamma = sum g*xhat, dbeta = sum g,
  * dy = scale*(g - dbeta/M - xhat*dgamma/M); dres (optional) = g.  With y == NULL it is the backward of
- * "bias + activation" (dy = g, dbeta = bias gradient, dgamma untouched semantics: 0). */
+ * "bias + activation" (dy = g, dbeta = bias gradient, dgamma untouched semantics: 0).  dgamma / dbeta are written (not
+ * accumulated) multiplied by grad_mult -- the 1 / (loss scale * world size) every parameter gradient carries; dy uses
+ * the plain sums. */
 int32_t ctdet_bn_train_bwd(const void* dz, int32_t dz_stride, const void* z, int32_t z_stride, const void* y,
                            int32_t y_stride, const float* mean, const float* invstd, const float* scale, int32_t M,
                            int32_t C, int32_t relu, void* dy, int32_t dy_stride, void* dres, int32_t dres_stride,
-                           float* dgamma, float* dbeta, void* workspace, void* stream);
-/* weight gradient of a conv: dw f32 [Cout][R*S*Cin] (tap-major k) += sum over pixels; dw must be zeroed by the
- * caller.  Geometry from the descriptor (out_stride = pixel stride of dy). */
-int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy, float* dw, void* stream);
+                           float* dgamma, float* dbeta, float grad_mult, void* workspace, void* stream);
+/* weight gradient of a conv: dw f32 [Cout][R*S*Cin] (tap-major k) += scale * sum over pixels; dw must be zeroed by
+ * the caller.  Geometry from the descriptor (out_stride = pixel stride of dy). */
+int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy, float* dw, float scale, void* stream);
 int32_t ctdet_maxpool2x2_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, void* dx,
                              int32_t dx_stride, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 /* depthwise ConvTranspose2d backward: dx f16, dw f32 [2f][2f][C] (+=, zeroed by the caller); w as in the forward */

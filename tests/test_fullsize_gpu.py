@@ -139,7 +139,7 @@ def test_fullsize_wgrad_dgrad_match_torch(case):
     ref_dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=s, padding=p)
     ref_dx = torch.nn.grad.conv2d_input(x.shape, w, dy, stride=s, padding=p)
     xh, dyh = x.permute(0, 2, 3, 1).contiguous().half(), dy.permute(0, 2, 3, 1).contiguous().half()
-    dw = ot.conv_wgrad(xh, dyh, Cout, k, k, s, p).view(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    dw = ot.conv_wgrad(xh, dyh, Cout, k, k, s, p, scale=1.0).view(Cout, k, k, Cin).permute(0, 3, 1, 2)
     _close(dw, ref_dw, 3e-3, "dW")
     dx = ot.conv_dgrad(dyh, w, s, p, (H, W))
     _close(dx[..., :Cin].float().permute(0, 3, 1, 2), ref_dx, 3e-3, "dX")
@@ -161,7 +161,8 @@ def test_fullsize_bn_train_fwd_bwd_match_torch():
     yh = y.detach().permute(0, 2, 3, 1).contiguous().half()
     z, mean, invstd, scale = ot.bn_train_fwd(yh, gamma.detach(), beta.detach(), rm, rv, 1e-5, 0.1, relu=True)
     _close(z.float().permute(0, 3, 1, 2), ref.detach(), 2e-3, "bn fwd")
-    dy, _, dgamma, dbeta = ot.bn_train_bwd(dz.permute(0, 2, 3, 1).contiguous().half(), z, yh, mean, invstd, scale, relu=True)
+    dy, _, dgamma, dbeta = ot.bn_train_bwd(dz.permute(0, 2, 3, 1).contiguous().half(), z, yh, mean, invstd, scale, relu=True,
+                                           grad_mult=1.0)
     _close(dy.float().permute(0, 3, 1, 2), y.grad, 6e-3, "bn dy")
     _close(dgamma, gamma.grad, 3e-3, "dgamma")
     _close(dbeta, beta.grad, 3e-3, "dbeta")

@@ -63,7 +63,7 @@ def test_bn_train_fwd_bwd(T, dev, C, res, relu):
     close(rm_d.cpu(), rm, 1e-4, "running_mean")
     close(rv_d.cpu(), rv, 1e-4, "running_var")
     dy, dres, dgamma, dbeta = ot.bn_train_bwd(nhwc(dz).half().to(dev), z, nhwc(y.detach()).half().to(dev), mean, invstd,
-                                              scale, relu=relu, want_dres=res)
+                                              scale, relu=relu, want_dres=res, grad_mult=1.0)
     close(nchw(dy.float().cpu()), y.grad, 6e-3, "bn dy")
     close(dgamma.cpu(), gamma.grad, 3e-3, "dgamma")
     close(dbeta.cpu(), beta.grad, 3e-3, "dbeta")
@@ -86,7 +86,7 @@ def test_conv_wgrad_and_dgrad(T, dev, case):
     y = F.conv2d(x, w, None, s, p)
     dy = h16(torch.randn(y.shape, generator=g))
     y.backward(dy)
-    dw = ot.conv_wgrad(nhwc(x.detach()).half().to(dev), nhwc(dy).half().to(dev), Cout, k, k, s, p)
+    dw = ot.conv_wgrad(nhwc(x.detach()).half().to(dev), nhwc(dy).half().to(dev), Cout, k, k, s, p, scale=1.0)
     got = dw.view(Cout, k, k, Cin).permute(0, 3, 1, 2).cpu()
     close(got, w.grad, 2e-3, "dW")
     dx = ot.conv_dgrad(nhwc(dy).half().to(dev), w.detach().to(dev), s, p, (H, W))
