@@ -1,5 +1,5 @@
-from .boxes import Boxes
+from .boxes import Boxes, BoxMode
 from .image_list import ImageList
 from .instances import Instances
 
-__all__ = ["Boxes", "ImageList", "Instances"]
+__all__ = ["Boxes", "BoxMode", "ImageList", "Instances"]

@@ -5,6 +5,32 @@ from typing import List, Tuple
 import torch
 
 
+class BoxMode:
+    """the two absolute box encodings the CenterNet data path meets (structures/boxes.py:18-129): COCO json stores XYWH,
+    everything downstream is XYXY"""
+    XYXY_ABS = 0
+    XYWH_ABS = 1
+
+    @staticmethod
+    def convert(box, from_mode, to_mode):
+        import numpy as np
+        if from_mode == to_mode:
+            return box
+        single = isinstance(box, (list, tuple))
+        arr = np.array(box, dtype=np.float64).reshape(-1, 4) if not isinstance(box, torch.Tensor) else box.clone().reshape(-1, 4)
+        if from_mode == BoxMode.XYWH_ABS and to_mode == BoxMode.XYXY_ABS:
+            arr[:, 2] += arr[:, 0]
+            arr[:, 3] += arr[:, 1]
+        elif from_mode == BoxMode.XYXY_ABS and to_mode == BoxMode.XYWH_ABS:
+            arr[:, 2] -= arr[:, 0]
+            arr[:, 3] -= arr[:, 1]
+        else:
+            raise NotImplementedError(f"BoxMode conversion {from_mode} -> {to_mode}")
+        if single:
+            return type(box)(arr.flatten().tolist())
+        return arr if not isinstance(box, np.ndarray) or box.ndim == 2 else arr.reshape(box.shape)
+
+
 class Boxes:
     def __init__(self, tensor):
         device = tensor.device if isinstance(tensor, torch.Tensor) else torch.device("cpu")
