@@ -1,9 +1,6 @@
 """Training sampler and a minimal batched loader (reference: data/samplers/distributed_sampler.py:12-55 TrainingSampler,
-data/build.py:270-355 build_detection_train_loader / per-GPU batch size).  The loader is a plain generator over mapped
-samples (optionally through a thread pool): the GPU path takes `list[dict]` batches of unequal image sizes as they come."""
+data/build.py:270-355 build_detection_train_loader / per-GPU batch size).  The GPU path takes `list[dict]` batches of unequal image sizes as they come."""
 import itertools
-from concurrent.futures import ThreadPoolExecutor
-
 import torch
 
 from .catalog import DatasetCatalog
@@ -37,8 +34,35 @@ def filter_images_with_only_crowd_annotations(dataset_dicts):
     return [d for d in dataset_dicts if valid(d.get("annotations", []))]
 
 
+class _MapDataset(torch.utils.data.Dataset):
+    def __init__(self, dicts, mapper):
+        self.dicts, self.mapper = dicts, mapper
+
+    def __len__(self):
+        return len(self.dicts)
+
+    def __getitem__(self, i):
+        return self.mapper(self.dicts[i])
+
+
+def _trivial_batch_collator(batch):
+    return batch
+
+
+def _worker_init_reset_seed(worker_id):
+    """every worker process gets its own numpy / python RNG stream (data/build.py worker_init_reset_seed)"""
+    import random
+
+    import numpy as np
+    seed = (torch.initial_seed() + worker_id) % 2 ** 31
+    np.random.seed(seed)
+    random.seed(seed)
+
+
 def build_detection_train_loader(cfg, mapper=None, rank=0, world_size=1, seed=0, num_workers=None):
-    """yields lists of `IMS_PER_BATCH // world_size` mapped samples forever"""
+    """iterator over lists of `IMS_PER_BATCH // world_size` mapped samples, forever (data/build.py:300-355): a
+    torch DataLoader with worker PROCESSES (the mapper is numpy / PIL code under the GIL), infinite TrainingSampler, batches
+    kept as lists -- images in a batch have different sizes"""
     names = cfg.DATASETS.TRAIN
     dicts = list(itertools.chain.from_iterable(DatasetCatalog.get(n) for n in names))
     if cfg.DATALOADER.FILTER_EMPTY_ANNOTATIONS and dicts and "annotations" in dicts[0]:
@@ -48,19 +72,10 @@ def build_detection_train_loader(cfg, mapper=None, rank=0, world_size=1, seed=0,
     assert total % world_size == 0, f"IMS_PER_BATCH ({total}) must be divisible by the number of workers ({world_size})"
     per_gpu = total // world_size
     mapper = mapper if mapper is not None else TrafficLightDatasetMapper(cfg, True)
-    sampler = iter(TrainingSampler(len(dicts), seed=seed, rank=rank, world_size=world_size))
+    sampler = TrainingSampler(len(dicts), seed=seed, rank=rank, world_size=world_size)
     workers = cfg.DATALOADER.NUM_WORKERS if num_workers is None else num_workers
-
-    def gen():
-        pool = ThreadPoolExecutor(workers) if workers > 0 else None
-        try:
-            while True:
-                idx = [next(sampler) for _ in range(per_gpu)]
-                if pool is not None:
-                    yield list(pool.map(lambda i: mapper(dicts[i]), idx))
-                else:
-                    yield [mapper(dicts[i]) for i in idx]
-        finally:
-            if pool is not None:
-                pool.shutdown(wait=False)
-    return gen()
+    batch_sampler = torch.utils.data.BatchSampler(sampler, per_gpu, drop_last=True)
+    loader = torch.utils.data.DataLoader(_MapDataset(dicts, mapper), batch_sampler=batch_sampler, num_workers=workers,
+                                         collate_fn=_trivial_batch_collator,
+                                         worker_init_fn=_worker_init_reset_seed if workers > 0 else None)
+    return iter(loader)

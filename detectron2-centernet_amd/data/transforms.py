@@ -76,6 +76,16 @@ class BlendTransform(Transform):
 
     def apply_image(self, img, interp=None):
         if img.dtype == np.uint8:
+            src = np.asarray(self.src_image)
+            if src.size in (1, img.shape[-1]) and img.ndim == 3:
+                # per-channel affine map of a byte: tabulate the 256 results with the very expression below (same dtypes,
+                # same rounding) and look the pixels up -- 5 float passes over the image become one gather
+                ramp = np.arange(256, dtype=np.uint8).reshape(256, 1).repeat(img.shape[-1], 1)
+                lut = np.clip(self.src_weight * src.reshape(-1) + self.dst_weight * ramp.astype(np.float32), 0, 255).astype(np.uint8)
+                if img.shape[-1] == 3:     # PIL applies a 3 x 256 table to an RGB image in C
+                    pil = Image.fromarray(np.ascontiguousarray(img)).point(lut.T.reshape(-1).tolist())
+                    return np.asarray(pil)
+                return np.stack([np.take(lut[:, c], img[..., c]) for c in range(img.shape[-1])], axis=-1)
             out = self.src_weight * self.src_image + self.dst_weight * img.astype(np.float32)
             return np.clip(out, 0, 255).astype(np.uint8)
         return self.src_weight * self.src_image + self.dst_weight * img
@@ -197,7 +207,9 @@ class RandomSaturation(_RandomIntensity):
     def get_transform(self, image):
         assert image.shape[-1] == 3, "RandomSaturation only works on RGB images"
         w = np.random.uniform(self.intensity_min, self.intensity_max)
-        grayscale = image.dot([0.299, 0.587, 0.114])[:, :, np.newaxis]
+        # image.dot([0.299, 0.587, 0.114]) in the reference: the same float64 sum channel by channel (numpy's generic
+        # uint8 x float64 dot is 6x slower)
+        grayscale = (image[..., 0] * 0.299 + image[..., 1] * 0.587 + image[..., 2] * 0.114)[:, :, np.newaxis]
         return BlendTransform(src_image=grayscale, src_weight=1 - w, dst_weight=w)
 
 
