@@ -30,6 +30,7 @@ class BucketedReducer:
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        self.enabled = True   # False while a training step is captured / replayed as a graph: see reduce_all()
         if self.world > 1:
             for i, p in enumerate(optimizer.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -38,6 +39,8 @@ class BucketedReducer:
         b = self.bucket_of[i]
 
         def hook(param):
+            if not self.enabled:
+                return
             self._ready[b] += 1
             if self._ready[b] == self.buckets[b][2] and not self._launched[b]:
                 self._launch(b)
@@ -65,6 +68,17 @@ class BucketedReducer:
         for h in self._handles:
             h.wait()
         self._handles = []
+
+    def reduce_all(self):
+        """all buckets, back to back, after a backward pass that ran without the hooks (the captured-graph step: forward +
+        backward replay as one HIP graph, the exchange and the SGD launch follow it; the hooks only exist while autograd
+        runs eagerly)"""
+        if self.world == 1:
+            return
+        handles = [dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                   for s, e, _ in self.buckets]
+        for h in handles:
+            h.wait()
 
     def broadcast_parameters(self, buffers=()):
         """DDP's initial synchronisation: rank 0's parameters (and BN buffers) to everyone."""
