@@ -27,7 +27,9 @@ class SimpleTrainer:
         self.iter = 0
         self.last_losses = None
         import os
-        self.use_hip_graph = os.environ.get("CTDET_TRAIN_GRAPH", "1") != "0"
+        mode = os.environ.get("CTDET_TRAIN_GRAPH", "1")
+        self.use_hip_graph = mode != "0"
+        self.graph_ddp = mode == "ddp"
         self._graphs = {}
 
     def run_step(self, data=None):
@@ -42,13 +44,14 @@ class SimpleTrainer:
         """device-resident batch (uint8 [B,3,H,W], boxes f32 [B,N,4], classes i64 [B,N], counts i32 [B]).
 
         From the third call with a given batch shape on, the step replays as ONE captured HIP graph: the eager step issues
-        ~2,300 launches and is bound by the host's launch rate.  Single GPU: targets, forward, losses, backward and the SGD
-        launch are all in the graph.  Data parallel: the graph ends after backward; the bucketed all-reduce of the flat
-        gradient buffer and the SGD launch follow it eagerly (the exchange is then not overlapped with backward -- 79 MB
-        over xGMI, ~1 ms, against ~15 ms of host launch time saved).  The LR schedule and the per-parameter version
-        counters stay on the host.  CTDET_TRAIN_GRAPH=0 keeps every step eager (all-reduce from autograd hooks)."""
+        ~2,300 launches, which a slow host cannot keep up with.  Single GPU: targets, forward, losses, backward and the SGD
+        launch are all in the graph.  Data parallel: eager by default, the bucketed all-reduce launched from autograd hooks
+        so that it overlaps backward (on the GPU box's host an eager step costs the same 29 ms as the replay; measured).
+        CTDET_TRAIN_GRAPH=ddp replays forward + backward as a graph there too and runs the all-reduce of the flat gradient
+        buffer and the SGD launch after it (no overlap).  The LR schedule and the per-parameter version counters stay on
+        the host.  CTDET_TRAIN_GRAPH=0 keeps every step eager."""
         multi = self.reducer.world > 1
-        if not self.use_hip_graph:
+        if not self.use_hip_graph or (multi and not self.graph_ddp):
             return self._finish_step(self.model.train_batch_tensor(images, boxes, classes, counts))
         key = tuple((tuple(t.shape), t.dtype) for t in (images, boxes, classes, counts))
         g = self._graphs.get(key)
