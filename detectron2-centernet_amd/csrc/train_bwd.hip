@@ -192,6 +192,7 @@ struct WgradArgs {
   const f16* x; const f16* dy; float* dw;
   int B, H, W, Cin, in_stride, Cout, Ho, Wo, dy_stride, R, S, stride, pad, dil, K, M, msplit;
   float scale;   // multiplier applied to every partial sum before it is added to dw
+  int lw, lh;    // log2(Wo), log2(Ho) when both are powers of two, else -1
 };
 
 __device__ __forceinline__ f16x4 lds_tr_read(const f16* p) {
@@ -240,8 +241,17 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int m = mb + a_row + 16 * i;
       const int mc = m < m_end ? m : m_end - 1;
-      const int wo = mc % a.Wo, t = mc / a.Wo;
-      const int ho = t % a.Ho, b = t / a.Ho;
+      int wo, ho, b;
+      if (a.lw >= 0) {          // power-of-two maps (every DLA-34 level at 512^2): shifts instead of four divisions per row
+        wo = mc & (a.Wo - 1);
+        ho = (mc >> a.lw) & (a.Ho - 1);
+        b = mc >> (a.lw + a.lh);
+      } else {
+        wo = mc % a.Wo;
+        const int t = mc / a.Wo;
+        ho = t % a.Ho;
+        b = t / a.Ho;
+      }
       const int hi = ho * a.stride - a.pad + tr * a.dil, wi = wo * a.stride - a.pad + ts * a.dil;
       const bool ok = m < m_end && k_ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
       const f16x8 v = *(const f16x8*)(ok ? a.x + ((long)(b * a.H + hi) * a.W + wi) * a.in_stride + c0 : a.x);
@@ -796,6 +806,12 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
   a.msplit = split;
+  a.lw = a.lh = -1;
+  if ((a.Wo & (a.Wo - 1)) == 0 && (a.Ho & (a.Ho - 1)) == 0) {
+    a.lw = a.lh = 0;
+    while ((1 << a.lw) < a.Wo) ++a.lw;
+    while ((1 << a.lh) < a.Ho) ++a.lh;
+  }
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, gy, split), dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
