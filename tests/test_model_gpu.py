@@ -220,3 +220,39 @@ def test_cpu_device_is_rejected(tmp_path):
     model = build_model(cfg).eval()
     with pytest.raises(NotImplementedError):
         model([{"image": images(1, 64, 64)[0]}])
+
+
+def test_export_split_matches_forward(dev):
+    """export/meta_modeling.CenterNetModel: convert_inputs -> inference({images, im_info} -> {hm, wh, reg}) ->
+    convert_outputs gives what model.forward gives (reference: export/meta_modeling.py:151-201)"""
+    import bench
+    from detectron2_centernet_amd.export import CenterNetModel
+    model, cfg = bench.build_model("f16", dev, seed=4)
+    model.eval()
+    model.score_threshold = 0.0
+    for name, m in model.named_modules():          # boxes of non-degenerate size
+        if name == "wh":
+            list(m.children())[-1].bias.data.fill_(3.0)
+    g = torch.Generator().manual_seed(9)
+    batch = [{"image": torch.randint(0, 256, (3, 96, 128), generator=g, dtype=torch.uint8), "height": 192, "width": 256},
+             {"image": torch.randint(0, 256, (3, 80, 100), generator=g, dtype=torch.uint8)}]
+    em = CenterNetModel(cfg, model)
+    assert em.get_input_names() == ["images", "im_info"] and em.get_output_names() == ["hm", "wh", "reg"]
+    inputs = em.convert_inputs(batch)
+    assert tuple(inputs["images"].shape) == (2, 3, 96, 128) and inputs["im_info"].tolist() == [[96, 128], [80, 100]]
+    res = em.inference(inputs)
+    assert tuple(res["hm"].shape) == (2, 80, 24, 32) and tuple(res["wh"].shape) == (2, 2, 24, 32)
+    assert res["hm"].min() >= 1e-4 and res["hm"].max() <= 1 - 1e-4
+    out = em.convert_outputs(batch, inputs, res)
+    with torch.no_grad():
+        ref = model(batch)
+    assert len(out) == 2 and len(out[0]["instances"]) > 0
+    for a, b in zip(out, ref):
+        ia, ib = a["instances"], b["instances"]
+        assert ia.image_size == ib.image_size and len(ia) == len(ib)
+        assert torch.allclose(ia.pred_boxes.tensor, ib.pred_boxes.tensor, atol=1e-3)
+        assert torch.equal(ia.pred_classes, ib.pred_classes) and torch.allclose(ia.scores, ib.scores)
+    # a caller-made normalised NCHW batch (no NHWC side buffer) goes through the same kernels
+    res2 = em.inference({"images": inputs["images"].clone(), "im_info": inputs["im_info"]})
+    assert torch.allclose(res2["hm"].float(), res["hm"].float(), atol=1e-6)
+
