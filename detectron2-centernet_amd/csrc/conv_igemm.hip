@@ -974,7 +974,12 @@ __device__ __forceinline__ u32x4 dcn_blend(const u32x4& v0, const u32x4& v1, con
 }
 
 // PARTIAL: the map is not a multiple of the 8x16 tile (edge tiles carry pixels outside it)
-template <int BC, int NST, bool PARTIAL, typename TOut>
+// MIXED selects how a tap is served when some lane of the wave samples outside the window.  false (default): the whole wave
+// gathers that tap from global memory, re-deriving the coordinates from the offsets.  true (CTDET_DCN_MIXED=1): the geometry
+// stage stores the image coordinates of such samples and only those lanes go to global memory, the rest keep reading the
+// window -- 10 % / 35 % faster at offset sigma 2 / 4 px, 5 % slower when (almost) nothing leaves the window, which is the
+// regime of the benchmark's weights; a separate instantiation so that the default kernel's code is untouched.
+template <int BC, int NST, bool PARTIAL, typename TOut, bool MIXED = false>
 __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
   constexpr int TH = 8, TW = 16, BP = 128, MG = 4;
   constexpr int WR = TH + 2 + 2 * MG, WCOLS = TW + 2 + 2 * MG;  // 18 x 26 window pixels
@@ -1098,7 +1103,14 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
         wv.x = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
         wv.y = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
         *(uint2*)(geow + (t * BP + gp) * 8) = wv;
-        *(unsigned*)(geoo + (t * BP + gp) * 4) = off | ((unsigned)(wr & 1) << 16) | (oow ? 0x80000000u : 0u);
+        if constexpr (MIXED) {
+          // out-of-window sample (bit 31): the image coordinates of corner 0, biased by one (h_low, w_low >= -1 in a valid
+          // sample), instead of a window offset
+          *(unsigned*)(geoo + (t * BP + gp) * 4) =
+              oow ? (0x80000000u | ((unsigned)(h_low + 1) << 12) | (unsigned)(w_low + 1)) : (off | ((unsigned)(wr & 1) << 16));
+        } else {
+          *(unsigned*)(geoo + (t * BP + gp) * 4) = off | ((unsigned)(wr & 1) << 16) | (oow ? 0x80000000u : 0u);
+        }
       }
     }
   }
@@ -1118,7 +1130,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
       const uint2 wv = *(const uint2*)(geow + (t * BP + px) * 8);
       const unsigned o = *(const unsigned*)(geoo + (t * BP + px) * 4);
       gw01[p][t] = wv.x; gw23[p][t] = wv.y;
-      gofs[p][t] = (o & 0xFFFFu) + ((q ^ (2 * ((o >> 16) & 1u))) << 4);
+      gofs[p][t] = (MIXED && (o >> 31)) ? (unsigned)(q << 4) : (o & 0xFFFFu) + ((q ^ (2 * ((o >> 16) & 1u))) << 4);
       oow_bits |= (o >> 31) << t;
     }
   // taps for which some lane of this wave samples outside the window take the global-gather path (wave-uniform)
@@ -1148,6 +1160,29 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
   // Corner coordinates are recomputed from the offsets with the arithmetic of the staging pass; corners outside
   // the image read the zero page, their weights are 0 as well.
   auto gather_global = [&](int t, int chunk, f16x8 (&pf)[TP]) {
+    if constexpr (MIXED) {
+#pragma unroll
+      for (int p = 0; p < TP; ++p) {
+        const int px = prow * 16 + 8 * p + pcol;
+        const unsigned o = *(const unsigned*)(geoo + (t * BP + px) * 4);
+        const bool out = o >> 31;
+        const int h_low = (int)((o >> 12) & 0xFFFu) - 1, w_low = (int)(o & 0xFFFu) - 1;
+        const bool r0 = out && h_low >= 0, r1 = out && h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
+        const int o0 = (h_low * a.W + w_low) * a.in_stride, o2 = o0 + a.W * a.in_stride;
+        const f16* base = ximg + chunk * 32 + q * 8;
+        const u32x4 g0 = *(gp16)((r0 && c0) ? base + o0 : zero);      // lanes inside the window: the zero page
+        const u32x4 g1 = *(gp16)((r0 && c1) ? base + o0 + a.in_stride : zero);
+        const u32x4 g2 = *(gp16)((r1 && c0) ? base + o2 : zero);
+        const u32x4 g3 = *(gp16)((r1 && c1) ? base + o2 + a.in_stride : zero);
+        const char* c0p = win + gofs[p][t];
+        const char* c2p = win + (gofs[p][t] ^ 32u) + WCOLS * 64;
+        const u32x4 l0 = *(const u32x4*)(c0p), l1 = *(const u32x4*)(c0p + 64);
+        const u32x4 l2 = *(const u32x4*)(c2p), l3 = *(const u32x4*)(c2p + 64);
+        pf[p] = __builtin_bit_cast(f16x8, dcn_blend(out ? g0 : l0, out ? g1 : l1, out ? g2 : l2, out ? g3 : l3, gw01[p][t],
+                                                    gw23[p][t]));
+      }
+      return;
+    }
     const int tr = t / 3, ts = t % 3;
 #pragma unroll
     for (int p = 0; p < TP; ++p) {
@@ -1299,7 +1334,11 @@ template <int BC, int WP, int WC_, typename TOut>
 static int launch_dcn_window(const ConvArgs& a, hipStream_t s) {
   const int nbx = a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16), nby = a.Cout_pad / BC;
   dim3 grid(8 * ((nbx + 7) / 8) * nby);
-  if (a.H % 8 == 0 && a.W % 16 == 0)
+  const char* mx = getenv("CTDET_DCN_MIXED");     // read per launch: tests flip it
+  const bool mixed = mx && atoi(mx) != 0;
+  if (mixed && a.H % 8 == 0 && a.W % 16 == 0 && a.H <= 4094 && a.W <= 4094)
+    hipLaunchKernelGGL((dcn_window_kernel<BC, (BC > 64 ? 4 : 8), false, TOut, true>), grid, dim3(256), 0, s, a);
+  else if (a.H % 8 == 0 && a.W % 16 == 0)
     hipLaunchKernelGGL((dcn_window_kernel<BC, (BC > 64 ? 4 : 8), false, TOut>), grid, dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((dcn_window_kernel<BC, (BC > 64 ? 4 : 8), true, TOut>), grid, dim3(256), 0, s, a);

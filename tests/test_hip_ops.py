@@ -257,8 +257,14 @@ DCN_WINDOW_CASES = [(2, 16, 32, 64, 64, 1.0), (1, 8, 16, 128, 64, 0.0), (2, 16, 
                     (1, 16, 48, 64, 40, 2.5)]
 
 
+@pytest.mark.parametrize("mixed", [False, True])
 @pytest.mark.parametrize("case", DCN_WINDOW_CASES)
-def test_dcnv2_window(ops, dev, case):
+def test_dcnv2_window(ops, dev, case, mixed, monkeypatch):
+    """mixed: the CTDET_DCN_MIXED=1 instantiation (only the lanes that left the window gather from global memory)"""
+    if mixed:
+        monkeypatch.setenv("CTDET_DCN_MIXED", "1")
+    else:
+        monkeypatch.delenv("CTDET_DCN_MIXED", raising=False)
     B, H, W, Cin, Cout, off_std = case
     g = torch.Generator().manual_seed(Cin + Cout + H + 1)
     x = h16(torch.randn(B, Cin, H, W, generator=g))
