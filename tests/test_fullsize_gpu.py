@@ -74,7 +74,7 @@ def test_fullsize_replay_is_bit_exact_and_batch_independent(setup):
 # was invisible at the small test sizes).  Full BASELINE-sized layers against torch's own convolution on the GPU.
 @pytest.mark.parametrize("case", [(64, 128, 128, 64, 64, False), (64, 128, 128, 64, 27, True), (64, 64, 64, 128, 128, False),
                                   (64, 32, 32, 256, 256, False), (32, 128, 128, 64, 768, False),
-                                  (64, 128, 128, 32, 64, False)])
+                                  (64, 128, 128, 32, 64, False), (64, 16, 16, 512, 512, False), (64, 16, 16, 512, 27, True)])
 def test_fullsize_conv3x3_matches_torch(case):
     import torch.nn.functional as F
     from detectron2_centernet_amd import ops

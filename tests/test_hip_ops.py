@@ -47,6 +47,10 @@ CONV_CASES = [
     (1, 10, 10, 64, 27, 3, 1, 1, False, False),
     (5, 40, 40, 64, 64, 3, 1, 1, False, True),   # > 512 tiles -> 256-pixel tile variant
     (4, 64, 64, 128, 128, 3, 1, 1, True, True),
+    # 16-pixel-wide maps (DLA-34's 512-channel level at 512^2 input)
+    (4, 16, 16, 128, 128, 3, 1, 1, True, True),
+    (2, 8, 16, 512, 27, 3, 1, 1, False, False),
+    (6, 24, 16, 64, 40, 3, 1, 1, False, True),
 ]
 
 
