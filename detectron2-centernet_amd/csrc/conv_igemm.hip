@@ -1676,9 +1676,12 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
     CTDET_CHECK(a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Cin % 32 == 0 && a.Kpad == a.K && a.om_stride % 4 == 0 && ((size_t)a.om & 15) == 0 && !a.res &&
                     a.out_stride % 8 == 0 && ((size_t)a.y & 15) == 0,
                 "dcnv2(window): unsupported geometry");
-    if (bc == 128) return launch_dcn_window<128, 2, 2, TOut>(a, s);
-    if (bc == 64) return launch_dcn_window<64, 2, 2, TOut>(a, s);
-    CTDET_CHECK(false, "dcnv2(window): unsupported Cout=%d", a.Cout);
+    // 64- or 128-cout tiles whatever Cout is: the packed rows are padded to a multiple of 64 (zero rows; nothing beyond
+    // Cout is stored)
+    CTDET_CHECK(a.Cout_pad % 64 == 0, "dcnv2(window): weight rows must be padded to a multiple of 64 (Cout=%d, packed %d)",
+                a.Cout, a.Cout_pad);
+    if (a.Cout > 64 && a.Cout_pad % 128 == 0) return launch_dcn_window<128, 2, 2, TOut>(a, s);
+    return launch_dcn_window<64, 2, 2, TOut>(a, s);
   }
   CTDET_CHECK(!deform, "dcnv2: the f16 path takes chunk-major weights (korder 1, Cin %% 32 == 0); got korder %d, Cin %d",
               a.korder, a.Cin);

@@ -97,7 +97,8 @@ class DCN(nn.Module):
         """x NHWC -> act(bn(dcn(x))) NHWC; the offset/mask conv writes f32 so sampling coordinates keep full
         precision even in f16 mode."""
         om = hipnn.conv_module(x, self.conv_offset_mask, None, ACT_NONE, ctx=ctx, out_dtype=torch.float32)
-        p = hipnn.packed(self, "dcn", ctx.compute, self.weight, bn, self.bias, self.stride, self.padding, self.dilation)
+        p = hipnn.packed(self, "dcn", ctx.compute, self.weight, bn, self.bias, self.stride, self.padding, self.dilation,
+                         cout_align=64 if ctx.compute == F16 else None)
         return ops.dcnv2(x, om, p, act=act)
 
     def forward(self, x):

@@ -33,7 +33,7 @@ def fold_bn(bn, conv_bias=None):
 
 
 def packed(owner, key, compute, weight, bn=None, conv_bias=None, stride=1, pad=0, dil=1, cin_pad=None,
-           tap_major=False):
+           tap_major=False, cout_align=None):
     """PackedConv for (weight, folded bn, bias), cached on `owner` and rebuilt when any tensor changed."""
     cache = owner.__dict__.setdefault("_ctdet_packed", {})
     tensors = [weight, conv_bias]
@@ -50,7 +50,7 @@ def packed(owner, key, compute, weight, bn=None, conv_bias=None, stride=1, pad=0
     else:
         scale, bias = None, (conv_bias.detach().float() if conv_bias is not None else None)
     p = ops.PackedConv(weight, scale, bias, stride=stride, pad=pad, dil=dil, compute=compute, cin_pad=cin_pad,
-                       tap_major=tap_major)
+                       tap_major=tap_major, cout_align=cout_align)
     cache[(key, compute)] = (ver, p)
     return p
 

@@ -131,9 +131,10 @@ class PackedConv:
     """
 
     def __init__(self, weight, scale=None, bias=None, stride=1, pad=0, dil=1, compute=F16, cin_pad=None,
-                 tap_major=False, transposed=False):
+                 tap_major=False, transposed=False, cout_align=None):
         """transposed: pack the input-gradient operand of `weight` (rows = its input channels, taps flipped) -- the
-        conv that maps dY to dX; f16 only."""
+        conv that maps dY to dX; f16 only.  cout_align: pad the packed rows to a multiple of this (the DCNv2 window kernel
+        works on 64-cout tiles whatever Cout is)."""
         _require_cuda(weight)
         if transposed:
             assert compute == F16 and scale is None and bias is None
@@ -155,7 +156,7 @@ class PackedConv:
             # one packing kernel instead of the torch chain below
             if self.Cin % 8:
                 raise ValueError(f"f16 path needs Cin % 8 == 0 (got {self.Cin}); pass cin_pad")
-            tile = _lib.lib().ctdet_conv_cout_tile(self.Cout_eff)
+            tile = max(_lib.lib().ctdet_conv_cout_tile(self.Cout_eff), cout_align or 1)
             self.Kpad = round_up(K, 32)
             self.Cout_pad = round_up(self.Cout_eff, tile)
             wp = torch.empty(self.Cout_pad, self.Kpad, dtype=torch.float16, device=dev)
@@ -179,7 +180,7 @@ class PackedConv:
         if compute == F16:
             if self.Cin % 8:
                 raise ValueError(f"f16 path needs Cin % 8 == 0 (got {self.Cin}); pass cin_pad")
-            tile = _lib.lib().ctdet_conv_cout_tile(self.Cout_eff)
+            tile = max(_lib.lib().ctdet_conv_cout_tile(self.Cout_eff), cout_align or 1)
             self.Kpad = round_up(K, 32)
             self.Cout_pad = round_up(self.Cout_eff, tile)
             wp = torch.zeros(self.Cout_pad, self.Kpad, dtype=torch.float16, device=dev)
@@ -301,6 +302,15 @@ def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_pro
     with mask_is_prob the 9 mask channels already went through sigmoid."""
     _require_cuda(x, offset_mask, out)
     assert dt_of(x) == p.compute and offset_mask.dtype == torch.float32
+    if p.compute == F16 and p.Cout_pad % 64:
+        raise ValueError(f"dcnv2 (f16) works on 64-cout tiles: pack the weights with PackedConv(..., cout_align=64) "
+                         f"(Cout={p.Cout}, packed rows {p.Cout_pad})")
+    if out is None and p.compute == F16 and p.Cout_eff % 8:
+        # the window kernel stores 16 bytes at a time: give the buffer a pixel stride that is a multiple of 8 channels and
+        # hand back the view of the real ones
+        B, H, W, _ = x.shape
+        dt = out_dtype if out_dtype is not None else torch.float16
+        out = torch.empty(B, H, W, round_up(p.Cout_eff, 8), dtype=dt, device=x.device)[..., :p.Cout_eff]
     out = _alloc_out(x, p, out, out_dtype)
     assert tuple(offset_mask.shape[:3]) == tuple(out.shape[:3])
     d = p.desc(x, out, act, None)

@@ -85,6 +85,71 @@ def test_conv2d(ops, dev, case, mode):
     assert err <= tol * max(1.0, ref.abs().max().item()), f"max err {err}"
 
 
+def test_conv2d_random_shapes(ops, dev):
+    """seeded sweep over shapes the fixed cases do not hit: every dispatch branch (halo / uniform-K / generic DMA / small-channel
+    kernels, 128- and 256-pixel tiles, ragged maps, padded couts) must agree with torch"""
+    rng = np.random.RandomState(20261004)
+    for it in range(48):
+        k = int(rng.choice([1, 3, 3]))
+        stride = int(rng.choice([1, 1, 2]))
+        Cin = int(rng.choice([8, 16, 24, 32, 64, 96, 128, 160]))
+        Cout = int(rng.choice([3, 4, 16, 27, 32, 40, 64, 80, 128, 132]))
+        B = int(rng.randint(1, 4))
+        H, W = int(rng.randint(3, 41)), int(rng.randint(3, 41))
+        if rng.rand() < 0.3:                       # tile-divisible maps: the halo-resident kernel's domain
+            H, W = 8 * int(rng.randint(1, 4)), 32 * int(rng.randint(1, 3))
+        use_res, relu = bool(rng.rand() < 0.4), bool(rng.rand() < 0.6)
+        g = torch.Generator().manual_seed(1000 + it)
+        x = h16(torch.randn(B, Cin, H, W, generator=g))
+        w = h16(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+        scale = torch.rand(Cout, generator=g) + 0.5
+        bias = torch.randn(Cout, generator=g)
+        ref = F.conv2d(x, w, None, stride, k // 2) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+        pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=stride, pad=k // 2, compute=ops.F16)
+        res_d = None
+        if use_res:
+            res = h16(torch.randn(ref.shape, generator=g))
+            ref = ref + res
+            res_d = torch.zeros(ref.shape[0], ref.shape[2], ref.shape[3], pc.Cout_eff, dtype=torch.float16)
+            res_d[..., :Cout] = nhwc(res).half()
+            res_d = res_d.to(dev)
+        if relu:
+            ref = ref.relu()
+        y = ops.conv2d(nhwc(x).half().to(dev), pc, act=ops.ACT_RELU if relu else ops.ACT_NONE, residual=res_d)
+        got = nchw(y[..., :Cout].float().cpu())
+        assert got.shape == ref.shape, (it, got.shape, ref.shape)
+        err = (got - ref).abs().max().item()
+        assert err < 4e-3 * max(1.0, ref.abs().max().item()), \
+            f"case {it}: B{B} {H}x{W} {Cin}->{Cout} k{k} s{stride} res={use_res} relu={relu}: max err {err}"
+
+
+def test_dcnv2_random_shapes(ops, dev):
+    """seeded sweep for the DCNv2 window kernel: partial edge tiles, 64- and 128-cout tiles, padded couts, offsets from inside
+    to far outside the LDS window"""
+    rng = np.random.RandomState(7)
+    for it in range(16):
+        Cin = int(rng.choice([32, 64, 128]))
+        Cout = int(rng.choice([8, 40, 64, 128, 132, 200]))
+        B, H, W = int(rng.randint(1, 3)), int(rng.randint(3, 30)), int(rng.randint(3, 40))
+        off_std = float(rng.choice([0.0, 0.7, 2.0, 5.0, 9.0]))
+        g = torch.Generator().manual_seed(500 + it)
+        x = h16(torch.randn(B, Cin, H, W, generator=g))
+        w = h16(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+        om = torch.randn(B, 27, H, W, generator=g)
+        om[:, :18] *= off_std
+        ref = O.dcnv2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, None, 1, 1, 1).relu()
+        pc = ops.PackedConv(w.to(dev), None, None, stride=1, pad=1, compute=ops.F16, cout_align=64)
+        om_d = torch.zeros(B, H, W, 28)
+        om_d[..., :27] = nhwc(om)
+        y = ops.dcnv2(nhwc(x).half().to(dev), om_d.to(dev), pc, act=ops.ACT_RELU)
+        err = (nchw(y[..., :Cout].float().cpu()) - ref).abs().max().item()
+        assert err <= 6e-3 * max(1.0, ref.abs().max().item()), f"case {it}: B{B} {H}x{W} {Cin}->{Cout} std {off_std}: {err}"
+    # weights packed for an ordinary conv of a narrow layer (16-row tile) are refused with a message that says what to do
+    narrow = ops.PackedConv(torch.randn(8, 32, 3, 3).to(dev), None, None, stride=1, pad=1, compute=ops.F16)
+    with pytest.raises(ValueError, match="cout_align=64"):
+        ops.dcnv2(torch.zeros(1, 8, 16, 32, dtype=torch.float16, device=dev), torch.zeros(1, 8, 16, 28, device=dev), narrow)
+
+
 def test_conv_f16_f32_output_and_slices(ops, dev):
     """f32 output from the f16 MFMA kernel, reading a channel slice and writing into a slice of a wider buffer."""
     g = torch.Generator().manual_seed(3)
