@@ -414,6 +414,60 @@ def test_decode_matches_oracle(ops, dev, shape):
     assert torch.allclose(b.cpu(), rb, atol=1e-4, rtol=1e-6)
 
 
+def test_decode_random_shapes(ops, dev):
+    """seeded sweep: odd map sizes (partial 16x16 tiles), class counts from 4 to 92, K from 1 to 300, narrow-band and wide
+    heat maps -- scores / classes / peak indices bit-exact with the oracle"""
+    rng = np.random.RandomState(11)
+    for it in range(14):
+        B = int(rng.randint(1, 4))
+        C = 4 * int(rng.randint(1, 24))
+        H, W = int(rng.randint(5, 70)), int(rng.randint(5, 70))
+        K = int(rng.choice([1, 7, 100, 300]))
+        g = torch.Generator().manual_seed(300 + it)
+        spread = float(rng.choice([0.02, 0.5, 1.5]))        # 0.02: nearly constant map, every value in a few fine bins
+        heat = torch.clamp(torch.sigmoid(torch.randn(B, C, H, W, generator=g) * spread - 2.19), 1e-4, 1 - 1e-4)
+        wh = torch.rand(B, 2, H, W, generator=g) * 20
+        reg = torch.rand(B, 2, H, W, generator=g)
+        if K > C * H * W:
+            continue
+        rb, rs, rc, ri = O.ctdet_decode(heat, wh, reg, down_ratio=4, K=K)
+        whreg = torch.cat([nhwc(wh), nhwc(reg)], dim=3).to(dev)
+        b, sc, c, i = ops.decode(nhwc(heat).contiguous().to(dev), whreg[..., 0:2], whreg[..., 2:4], K, 4.0, check_status=True)
+        tag = f"case {it}: B{B} C{C} {H}x{W} K{K} spread {spread}"
+        assert torch.equal(sc.cpu(), rs), tag + ": scores"
+        assert torch.equal(c.cpu(), rc), tag + ": classes"
+        assert torch.equal(i.cpu().long(), ri), tag + ": peak indices"
+        assert torch.allclose(b.cpu(), rb, atol=1e-4, rtol=1e-6), tag + ": boxes"
+
+
+def test_heads_fused_random_shapes(ops, dev):
+    """seeded sweep for the fused heads: class counts 1..91, 32..256 input channels (other map sizes take the layer-by-layer
+    heads in the model, see CenterNet._head_outputs)"""
+    rng = np.random.RandomState(23)
+    for it in range(8):
+        B, H, W = int(rng.randint(1, 3)), 8 * int(rng.randint(1, 5)), 16 * int(rng.randint(1, 4))   # the kernel's domain:
+        Cin = int(rng.choice([32, 64, 128, 256]))                                                    # maps of 8x16 tiles
+        couts = (int(rng.choice([1, 3, 20, 80, 91])), 2, 2)
+        g = torch.Generator().manual_seed(800 + it)
+        x = h16(torch.randn(B, Cin, H, W, generator=g))
+        w1 = [h16(torch.randn(256, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5) for _ in couts]
+        b1 = [torch.randn(256, generator=g) * 0.3 for _ in couts]
+        w2 = [h16(torch.randn(c, 256, 1, 1, generator=g) / 16) for c in couts]
+        b2 = [torch.randn(c, generator=g) for c in couts]
+        acts = [ops.ACT_SIGMOID_CLAMP, ops.ACT_NONE, ops.ACT_NONE]
+        ph = ops.PackedHeads([w.to(dev) for w in w1], [b.to(dev) for b in b1], [w.to(dev) for w in w2],
+                             [b.to(dev) for b in b2], acts)
+        outs = ops.heads_fused(nhwc(x).half().to(dev), ph, clamp=(1e-4, 1 - 1e-4))
+        for i, c in enumerate(couts):
+            hid = h16(F.conv2d(x, w1[i], b1[i], 1, 1).relu())
+            ref = F.conv2d(hid, w2[i], b2[i])
+            if i == 0:
+                ref = torch.clamp(torch.sigmoid(ref), 1e-4, 1 - 1e-4)
+            got = nchw(outs[i][..., :c].cpu())
+            err = (got - ref).abs().max().item()
+            assert err <= 3e-3 * max(1.0, ref.abs().max().item()), f"case {it} head {i}: B{B} {H}x{W} Cin{Cin} cout{c}: {err}"
+
+
 def test_decode_plateau_and_sparse(ops, dev):
     """plateaus: `hmax == heat` keeps every plateau cell; ties resolve by flat NCHW index ascending.
     sparse: fewer than K positive peaks -> remaining slots have score 0."""

@@ -93,6 +93,50 @@ def test_conv_wgrad_and_dgrad(T, dev, case):
     close(nchw(dx.float().cpu()), x.grad, 3e-3, "dX")
 
 
+def test_wgrad_dgrad_bn_random_shapes(T, dev):
+    """seeded sweep: weight / input gradients and the BatchNorm backward on shapes the fixed cases miss (odd maps, power-of-two
+    maps that take the shift-based index path, stride 2 with odd sizes, channel counts whose 8-channel vector count is not a
+    power of two -> the generic BN apply kernel)"""
+    import numpy as np
+    ops, ot = T
+    rng = np.random.RandomState(99)
+    for it in range(16):
+        k = int(rng.choice([1, 3]))
+        s_ = int(rng.choice([1, 1, 2]))
+        Cin, Cout = int(rng.choice([8, 16, 32, 64, 136])), int(rng.choice([8, 24, 64, 72, 128]))
+        B = int(rng.randint(1, 4))
+        H, W = (int(rng.randint(4, 30)), int(rng.randint(4, 30))) if rng.rand() < 0.6 else (int(rng.choice([8, 16, 32])),) * 2
+        g = torch.Generator().manual_seed(700 + it)
+        x = h16(torch.randn(B, Cin, H, W, generator=g)).requires_grad_(True)
+        w = h16(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).requires_grad_(True)
+        y = F.conv2d(x, w, None, s_, k // 2)
+        dy = h16(torch.randn(y.shape, generator=g))
+        y.backward(dy)
+        tag = f"case {it}: B{B} {H}x{W} {Cin}->{Cout} k{k} s{s_}"
+        dw = ot.conv_wgrad(nhwc(x.detach()).half().to(dev), nhwc(dy).half().to(dev), Cout, k, k, s_, k // 2, scale=1.0)
+        close(dw.view(Cout, k, k, Cin).permute(0, 3, 1, 2).cpu(), w.grad, 3e-3, tag + " dW")
+        dx = ot.conv_dgrad(nhwc(dy).half().to(dev), w.detach().to(dev), s_, k // 2, (H, W))
+        close(nchw(dx.float().cpu()), x.grad, 4e-3, tag + " dX")
+    for it, C in enumerate([8, 24, 40, 64, 72, 256]):
+        g = torch.Generator().manual_seed(900 + it)
+        Bn, H, W = 2, 7 + it, 9
+        yb = h16(torch.randn(Bn, C, H, W, generator=g) * 2 + 0.5).requires_grad_(True)
+        gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+        beta = torch.randn(C, generator=g).requires_grad_(True)
+        ref = F.batch_norm(yb, torch.zeros(C), torch.ones(C), gamma, beta, True, 0.1, 1e-5).relu()
+        dz = h16(torch.randn(ref.shape, generator=g))
+        ref.backward(dz)
+        rm_d, rv_d = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        z, mean, invstd, scale = ot.bn_train_fwd(nhwc(yb.detach()).half().to(dev), gamma.detach().to(dev), beta.detach().to(dev),
+                                                 rm_d, rv_d, 1e-5, 0.1, relu=True)
+        close(nchw(z.float().cpu()), ref.detach(), 2e-3, f"C{C} bn fwd")
+        dyb, _, dgamma, dbeta = ot.bn_train_bwd(nhwc(dz).half().to(dev), z, nhwc(yb.detach()).half().to(dev), mean, invstd, scale,
+                                                relu=True, grad_mult=1.0)
+        close(nchw(dyb.float().cpu()), yb.grad, 8e-3, f"C{C} bn dy")
+        close(dgamma.cpu(), gamma.grad, 4e-3, f"C{C} dgamma")
+        close(dbeta.cpu(), beta.grad, 4e-3, f"C{C} dbeta")
+
+
 def test_maxpool_and_dwconvT_bwd(T, dev):
     ops, ot = T
     g = torch.Generator().manual_seed(5)
