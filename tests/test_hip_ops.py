@@ -150,6 +150,56 @@ def test_dcnv2_random_shapes(ops, dev):
         ops.dcnv2(torch.zeros(1, 8, 16, 32, dtype=torch.float16, device=dev), torch.zeros(1, 8, 16, 28, device=dev), narrow)
 
 
+def test_conv1x1_cat_random_splits(ops, dev):
+    """Root (dla.py:86-94) reads its children in place: 1..4 sources with channel counts that are / are not multiples of 32,
+    odd maps, with and without residual"""
+    rng = np.random.RandomState(31)
+    for it in range(12):
+        n = int(rng.randint(1, 5))
+        cins = [int(rng.choice([8, 16, 24, 32, 64, 128])) for _ in range(n)]
+        Cout = int(rng.choice([16, 40, 64, 128, 256]))
+        B, H, W = int(rng.randint(1, 3)), int(rng.randint(3, 24)), int(rng.randint(3, 24))
+        g = torch.Generator().manual_seed(600 + it)
+        xs = [h16(torch.randn(B, c, H, W, generator=g)) for c in cins]
+        w = h16(torch.randn(Cout, sum(cins), 1, 1, generator=g) / sum(cins) ** 0.5)
+        scale, bias = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+        ref = (F.conv2d(torch.cat(xs, 1), w) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)).relu()
+        pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), compute=ops.F16)
+        y = ops.conv1x1_cat([nhwc(x).half().to(dev) for x in xs], pc, act=ops.ACT_RELU)
+        err = (nchw(y[..., :Cout].float().cpu()) - ref).abs().max().item()
+        assert err < 4e-3 * max(1.0, ref.abs().max().item()), f"case {it}: {cins}->{Cout} {H}x{W}: {err}"
+
+
+def test_dla_base_fused_random_sizes(ops, dev):
+    """seeded sweep of the fused base kernel: image smaller than / equal to the padded size, tall and wide maps, 1..3 images,
+    byte and f32 images, against torch with f16-rounded intermediate maps; the pooled output equals maxpool2x2 of the main one"""
+    rng = np.random.RandomState(41)
+    mean, std = [0.408, 0.447, 0.470], [0.289, 0.274, 0.278]
+    g = torch.Generator().manual_seed(77)
+    ws = [h16(torch.randn(16, 3, 7, 7, generator=g) / 147 ** 0.5), h16(torch.randn(16, 16, 3, 3, generator=g) / 12),
+          h16(torch.randn(32, 16, 3, 3, generator=g) / 12)]
+    sb = [(torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3) for c in (16, 16, 32)]
+    args = []
+    for w, (sc, bi) in zip(ws, sb):
+        args += [w.to(dev), (sc.to(dev), bi.to(dev))]
+    pb = ops.PackedDlaBase(*args)
+    for it in range(8):
+        Hp, Wp = 16 * int(rng.randint(1, 12)), 32 * int(rng.randint(1, 7))
+        H, W = Hp - int(rng.randint(0, 16)), Wp - int(rng.randint(0, 32))
+        B = int(rng.randint(1, 4))
+        dt = torch.uint8 if rng.rand() < 0.7 else torch.float32
+        img = torch.randint(0, 256, (B, 3, H, W), generator=g).to(dt)
+        x = (img.float() / 255 - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+        ref = h16(F.pad(x, (0, Wp - W, 0, Hp - H)))
+        for w, (sc, bi), (st, pd) in zip(ws, sb, ((1, 3), (1, 1), (2, 1))):
+            ref = h16((F.conv2d(ref, w, None, st, pd) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1)).relu())
+        pooled = torch.empty(B, Hp // 4, Wp // 4, 32, dtype=torch.float16, device=dev)
+        y = ops.dla_base_fused(img.to(dev), mean, std, Hp, Wp, pb, pooled=pooled)
+        err = (nchw(y.float().cpu()) - ref).abs().max().item()
+        assert err <= 3e-3 * max(1.0, ref.abs().max().item()), f"case {it}: B{B} {H}x{W} in {Hp}x{Wp} {dt}: {err}"
+        assert torch.equal(pooled, ops.maxpool2x2(y)), f"case {it}: pooled output"
+
+
 def test_conv_f16_f32_output_and_slices(ops, dev):
     """f32 output from the f16 MFMA kernel, reading a channel slice and writing into a slice of a wider buffer."""
     g = torch.Generator().manual_seed(3)
