@@ -342,3 +342,39 @@ def test_training_step_graph_replay_matches_eager(tmp_path, dev):
     assert abs(me.norm().item() - mg.norm().item()) <= 0.05 * me.norm().item()
     cos = torch.nn.functional.cosine_similarity(me, mg, dim=0).item()
     assert cos > 0.7, cos   # two eager runs of this chaotic toy problem differ by about as much (observed 0.85-0.97)
+
+
+def test_trainer_on_ragged_list_batches(tmp_path, dev):
+    """the reference's run_step(data) contract: a list of dataset-mapper dicts with images of unequal, non-/32 sizes and
+    `Instances` targets -- padding, targets, forward, backward (every HIP autograd node on odd map sizes), SGD; losses are
+    finite, the parameters move and the hm loss falls over a few (warm-up) steps on a fixed batch"""
+    from test_model_gpu import make_model
+    from detectron2_centernet_amd.engine.train_loop import SimpleTrainer
+    from detectron2_centernet_amd.structures import Boxes, Instances
+
+    model, cfg = make_model(tmp_path, "f16", seed=6)
+    cfg.SOLVER.IMS_PER_BATCH = 3
+    cfg.SOLVER.BASE_LR = 2e-3
+    tr = SimpleTrainer(model, None, cfg)
+    g = torch.Generator().manual_seed(12)
+    batch = []
+    for (h, w) in ((150, 200), (97, 131), (160, 96)):
+        inst = Instances((h, w))
+        n = 5
+        x0 = torch.rand(n, generator=g) * (w - 40)
+        y0 = torch.rand(n, generator=g) * (h - 40)
+        inst.gt_boxes = Boxes(torch.stack([x0, y0, x0 + 8 + torch.rand(n, generator=g) * 30, y0 + 8 + torch.rand(n, generator=g) * 30], 1))
+        inst.gt_classes = torch.randint(0, 80, (n,), generator=g)
+        batch.append({"image": torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8), "instances": inst,
+                      "height": h, "width": w})
+    p0 = tr.optimizer.flat_param.clone()
+    hist = []
+    for _ in range(8):
+        losses = tr.run_step(batch)
+        assert set(losses) == {"hm_loss", "wh_loss", "off_loss"}
+        hist.append({k: float(v) for k, v in losses.items()})
+        assert all(torch.isfinite(torch.tensor(list(hist[-1].values()))))
+    assert torch.isfinite(tr.optimizer.flat_param).all() and torch.isfinite(tr.optimizer.flat_grad).all()
+    assert (tr.optimizer.flat_param - p0).abs().max() > 0
+    assert hist[-1]["hm_loss"] < 0.98 * hist[0]["hm_loss"], hist      # warm-up learning rates: a few per cent in 8 steps
+
