@@ -52,6 +52,7 @@ SIGNATURES = {
     "ctdet_bn_train_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32,
                                    _vp, _vp, _f32, _vp, _vp]),
     "ctdet_conv_wgrad": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _f32, _vp]),
+    "ctdet_depth_to_space2": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_maxpool2x2_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_dwconvT_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_dcn_cols": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),

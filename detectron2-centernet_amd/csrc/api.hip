@@ -53,6 +53,7 @@ int launch_bn_train_bwd(const f16*, int, const f16*, int, const f16*, int, const
                         int, int, f16*, int, f16*, int, float*, float*, float, void*, hipStream_t);
 int launch_conv_wgrad(const WgradArgs&, hipStream_t);
 int launch_maxpool2x2_bwd(const f16*, int, const f16*, int, f16*, int, int, int, int, int, hipStream_t);
+int launch_depth_to_space2(const f16*, int, f16*, int, int, int, int, int, int, int, hipStream_t);
 int launch_dwconvT_bwd(const f16*, int, const f16*, int, const float*, f16*, int, float*, int, int, int, int, int,
                        hipStream_t);
 int launch_dcn_cols(const f16*, int, const float*, int, f16*, int, int, int, int, hipStream_t);
@@ -337,6 +338,12 @@ int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy
   a.K = d->R * d->S * d->Cin; a.M = d->B * d->Ho * d->Wo; a.msplit = 1; a.scale = scale;
   if (a.M == 0) return 0;
   return launch_conv_wgrad(a, (hipStream_t)stream);
+}
+
+int32_t ctdet_depth_to_space2(const void* src, int32_t src_stride, void* dst, int32_t dst_stride, int32_t B, int32_t H,
+                              int32_t W, int32_t C, int32_t Hs, int32_t Ws, void* stream) {
+  CTDET_CHECK(src && dst, "depth_to_space2: null pointer");
+  return launch_depth_to_space2((const f16*)src, src_stride, (f16*)dst, dst_stride, B, H, W, C, Hs, Ws, (hipStream_t)stream);
 }
 
 int32_t ctdet_maxpool2x2_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, void* dx,

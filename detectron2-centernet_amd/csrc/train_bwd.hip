@@ -877,6 +877,40 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// depth-to-space for the input gradient of a stride-2 3x3 convolution.  dx of such a conv splits into four output phases
+// (row parity, column parity) that use 1, 2, 2 and 4 of the 9 taps; ops_train.conv_dgrad computes all four as ONE 2x2
+// convolution over dY with 4*C output channels (16 tap-products per output quad instead of the 36 of the zero-stuffed
+// form) and this kernel interleaves them:  dst[b, y, x, c] = src[b, (y+1)/2, (x+1)/2, ((y&1)*2 + (x&1))*C + c].
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) depth_to_space2_kernel(const f16* __restrict__ src, int src_stride, f16* __restrict__ dst,
+                                                              int dst_stride, int B, int H, int W, int C, int Hs, int Ws) {
+  const int CV = C >> 3;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * H * W * CV) return;
+  const int cv = (int)(idx % CV);
+  long t = idx / CV;
+  const int x = (int)(t % W); t /= W;
+  const int y = (int)(t % H);
+  const int b = (int)(t / H);
+  const int phase = (y & 1) * 2 + (x & 1);
+  const long sp = ((long)b * Hs + ((y + 1) >> 1)) * Ws + ((x + 1) >> 1);
+  *(f16x8*)(dst + ((long)(b * H + y) * W + x) * dst_stride + cv * 8) = *(const f16x8*)(src + sp * src_stride + phase * C + cv * 8);
+}
+
+int launch_depth_to_space2(const f16* src, int src_stride, f16* dst, int dst_stride, int B, int H, int W, int C, int Hs, int Ws,
+                           hipStream_t s) {
+  CTDET_CHECK(C % 8 == 0 && src_stride % 8 == 0 && dst_stride % 8 == 0 && src_stride >= 4 * C,
+              "depth_to_space2: C=%d / strides must be multiples of 8, src_stride >= 4*C", C);
+  CTDET_CHECK(Hs >= (H + 1) / 2 + ((H & 1) ? 0 : 1) && Ws >= (W + 1) / 2 + ((W & 1) ? 0 : 1), "depth_to_space2: source map %dx%d too small for %dx%d", Hs, Ws, H, W);
+  const long total = (long)B * H * W * (C / 8);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(depth_to_space2_kernel, dim3(nblk256(total)), dim3(256), 0, s, src, src_stride, dst, dst_stride, B, H, W, C,
+                     Hs, Ws);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_maxpool2x2_bwd(const f16* x, int x_stride, const f16* dz, int dz_stride, f16* dx, int dx_stride, int B, int H,
                           int W, int C, hipStream_t s) {
   CTDET_CHECK(C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool_bwd: bad shape");

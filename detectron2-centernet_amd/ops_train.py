@@ -158,10 +158,55 @@ def _fwd_pack(weight, stride, pad, cin_pad=None, bias=None):
     return ops.PackedConv(weight, None, bias, stride=stride, pad=pad, compute=F16, cin_pad=cin_pad)
 
 
+_PHASE_TAPS = {}
+
+
+def _phase_tap_index(device):
+    """index into the 9 taps (+ a zero tap at 9) of the [phase (row parity, col parity)][a][b] 2x2 kernels: a row of
+    parity 0 is fed by kernel row 1 of dY row i only, a row of parity 1 by kernel row 2 of dY row i (a = 0) and kernel row 0
+    of dY row i + 1 (a = 1); columns alike"""
+    t = _PHASE_TAPS.get(device)
+    if t is None:
+        rmap = {(0, 0): -1, (0, 1): 1, (1, 0): 2, (1, 1): 0}
+        idx = []
+        for ph in range(2):
+            for pw in range(2):
+                for a in range(2):
+                    for b in range(2):
+                        r, s_ = rmap[(ph, a)], rmap[(pw, b)]
+                        idx.append(9 if r < 0 or s_ < 0 else r * 3 + s_)
+        t = _PHASE_TAPS[device] = torch.tensor(idx, dtype=torch.int64, device=device)
+    return t
+
+
+def _conv_dgrad_s2_phases(dy, weight, in_hw):
+    """input gradient of a 3x3 / stride 2 / pad 1 conv without zero-stuffing: one 2x2 conv over dy to the four output phases
+    (4*Cin channels), then ctdet_depth_to_space2"""
+    Cout, Cin, _, _ = weight.shape
+    B, Ho, Wo, Cd = dy.shape
+    H, W = in_hw
+    Cp = (Cin + 7) // 8 * 8
+    w9 = weight.detach().reshape(Cout, Cin, 9)
+    if Cd != Cout:
+        w9 = torch.nn.functional.pad(w9, (0, 0, 0, 0, 0, Cd - Cout))
+    w10 = torch.nn.functional.pad(w9, (0, 1, 0, Cp - Cin))                         # zero tap, channel padding -> [Cd, Cp, 10]
+    wd = w10.index_select(2, _phase_tap_index(dy.device)).view(Cd, Cp, 4, 2, 2)     # [co, ci, phase, a, b]
+    wd = wd.permute(2, 1, 0, 3, 4).reshape(4 * Cp, Cd, 2, 2).contiguous()
+    p = ops.PackedConv(wd, None, None, stride=1, pad=1, compute=F16)
+    ph = ops.conv2d(dy, p)                                                           # [B, Ho+1, Wo+1, 4*Cp]
+    dx = torch.empty(B, H, W, Cp, dtype=torch.float16, device=dy.device)
+    rc = _lib.lib().ctdet_depth_to_space2(_ptr(ph), _nhwc_stride(ph), _ptr(dx), _nhwc_stride(dx), B, H, W, Cp, ph.shape[1],
+                                          ph.shape[2], _stream())
+    _lib.check(rc, "ctdet_depth_to_space2")
+    return dx if Cp == Cin else dx[..., :Cin]
+
+
 def conv_dgrad(dy, weight, stride, pad, in_hw):
     """dx of y = conv(x, weight): a conv over dy with the taps flipped and in/out channels swapped;
-    stride > 1 reads dy as zero-stuffed (in_dil)."""
+    3x3 / stride 2 / pad 1 goes through the four-phase form, other strides read dy as zero-stuffed (in_dil)."""
     Cout, Cin, R, S = weight.shape
+    if stride == 2 and R == 3 and S == 3 and pad == 1 and dy.shape[3] % 8 == 0:
+        return _conv_dgrad_s2_phases(dy, weight, in_hw)
     p = ops.PackedConv(weight.detach(), None, None, stride=1, pad=R - 1 - pad, compute=F16, tap_major=stride > 1,
                        transposed=True)
     p.in_dil = stride

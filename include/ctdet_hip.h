@@ -220,6 +220,11 @@ int32_t ctdet_bn_train_bwd(const void* dz, int32_t dz_stride, const void* z, int
 /* weight gradient of a conv: dw f32 [Cout][R*S*Cin] (tap-major k) += scale * sum over pixels; dw must be zeroed by
  * the caller.  Geometry from the descriptor (out_stride = pixel stride of dy). */
 int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy, float* dw, float scale, void* stream);
+/* Interleave of the four output phases of a stride-2 3x3 conv's input gradient (f16 NHWC):
+ * dst[b,y,x,c] = src[b,(y+1)/2,(x+1)/2,((y&1)*2+(x&1))*C + c]; src is the [B,Hs,Ws,>=4C] result of the 2x2 "phase" conv
+ * over dY (ops_train.conv_dgrad), dst the [B,H,W,C] gradient (C % 8 == 0). */
+int32_t ctdet_depth_to_space2(const void* src, int32_t src_stride, void* dst, int32_t dst_stride, int32_t B, int32_t H,
+                              int32_t W, int32_t C, int32_t Hs, int32_t Ws, void* stream);
 int32_t ctdet_maxpool2x2_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, void* dx,
                              int32_t dx_stride, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 /* depthwise ConvTranspose2d backward: dx f16, dw f32 [2f][2f][C] (+=, zeroed by the caller); w as in the forward */
