@@ -86,6 +86,10 @@ def build_model(precision, device, seed=0):
         if name.endswith("conv_offset_mask"):
             m.weight.data.copy_((torch.randn(m.weight.shape, generator=g) * (0.5 / (m.weight.shape[1] * 9) ** 0.5)).to(device))
             m.bias.data.copy_((torch.randn(m.bias.shape, generator=g) * 0.5).to(device))
+    # the reference initialises the wh head to ~0 (centernet.py fill_fc_weights): every decoded box would have zero size and be
+    # dropped as empty, and the step would end with no detections to post-process.  A constant wh bias gives 12-pixel boxes, so
+    # each image yields its full 100 detections (threshold 0.05 < the ~0.1 scores of the -2.19 hm bias).
+    model.wh[-1].bias.data.fill_(3.0)
     return model, cfg
 
 
@@ -230,7 +234,8 @@ def main():
             "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": f"DLA-34 CenterNet eval forward+decode, {B}x3x{args.size}x{args.size} uint8 per GPU, "
-                                   "80 classes, K=100, random-init weights, DCN offsets ~N(0,1px)",
+                                   "80 classes, K=100, random-init weights, DCN offsets ~N(0,1px), "
+                                   f"{sum(len(o['instances']) for o in out) / max(1, len(out)):.0f} detections per image post-processed",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"replicas x{world}"},
         }
         if rank == 0 and not args.no_roofline:
