@@ -1,58 +1,64 @@
-"""The CenterNet project's dataset mapper (reference: projects/CenterNet/center_net/dataset_mapper.py:17-175):
-read the image, ResizeShortestEdge, four colour augmentations applied with probability 0.15 each (training), boxes through
-the same transforms, `Instances(gt_boxes, gt_classes)` with empty boxes removed.  Output contract: the dataset dict plus
-"image" (uint8 CHW tensor in INPUT.FORMAT order) and, in training, "instances"; "annotations" removed."""
+"""The CenterNet project's dataset mapper.  Contract (reference: projects/CenterNet/center_net/dataset_mapper.py:17-175):
+input one Detectron2 dataset dict; output a copy with "image" (uint8 CHW tensor, channel order INPUT.FORMAT) and, when
+training, "instances" (gt_boxes XYXY in the resized image, gt_classes int64; crowd and empty boxes removed); the
+"annotations" list is consumed.  Pipeline: read -> ResizeShortestEdge -> four colour jitters, each applied with probability
+0.15 (training only) -> boxes through the same transform list."""
 import copy
 
 import numpy as np
 import torch
 
-from . import detection_utils as utils
+from . import detection_utils as du
 from . import transforms as T
+
+# colour jitters of the training pipeline (:36-43 of the reference mapper): (augmentation, constructor arguments)
+_COLOUR_JITTER = ((T.RandomContrast, (0.8, 1.2)), (T.RandomBrightness, (0.8, 1.2)), (T.RandomSaturation, (0.8, 1.2)),
+                  (T.RandomLighting, (0.8,)))
+_JITTER_PROB = 0.15
 
 
 def bulb_traffic_light_augmentation(cfg, is_train):
+    """resize rule from INPUT.{MIN,MAX}_SIZE_{TRAIN,TEST}; training adds the colour jitters"""
+    inp = cfg.INPUT
     if is_train:
-        min_size, max_size, sample_style = cfg.INPUT.MIN_SIZE_TRAIN, cfg.INPUT.MAX_SIZE_TRAIN, cfg.INPUT.MIN_SIZE_TRAIN_SAMPLING
+        sizes, longest, style = inp.MIN_SIZE_TRAIN, inp.MAX_SIZE_TRAIN, inp.MIN_SIZE_TRAIN_SAMPLING
+        if style == "range" and len(sizes) != 2:
+            raise AssertionError("more than 2 ({}) min_size(s) are provided for ranges".format(len(sizes)))
     else:
-        min_size, max_size, sample_style = cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST, "choice"
-    if sample_style == "range":
-        assert len(min_size) == 2, "more than 2 ({}) min_size(s) are provided for ranges".format(len(min_size))
-    augmentation = [T.ResizeShortestEdge(min_size, max_size, sample_style)]
+        sizes, longest, style = inp.MIN_SIZE_TEST, inp.MAX_SIZE_TEST, "choice"
+    pipeline = [T.ResizeShortestEdge(sizes, longest, style)]
     if is_train:
-        augmentation.extend([
-            T.RandomApply(T.RandomContrast(intensity_min=0.8, intensity_max=1.2), prob=0.15),
-            T.RandomApply(T.RandomBrightness(intensity_min=0.8, intensity_max=1.2), prob=0.15),
-            T.RandomApply(T.RandomSaturation(intensity_min=0.8, intensity_max=1.2), prob=0.15),
-            T.RandomApply(T.RandomLighting(0.8), prob=0.15),
-        ])
-    return augmentation
+        pipeline += [T.RandomApply(aug(*args), prob=_JITTER_PROB) for aug, args in _COLOUR_JITTER]
+    return pipeline
 
 
 class TrafficLightDatasetMapper:
     def __init__(self, cfg, is_train=True):
-        self.augmentation = bulb_traffic_light_augmentation(cfg, is_train)
+        unsupported = [k for k in ("MASK_ON", "KEYPOINT_ON", "LOAD_PROPOSALS") if getattr(cfg.MODEL, k, False)]
+        if unsupported:
+            raise NotImplementedError(f"MODEL.{unsupported[0]}: masks / keypoints / proposals are not part of the CenterNet path")
         crop = getattr(cfg.INPUT, "CROP", None)
-        if crop is not None and getattr(crop, "ENABLED", False) and is_train:
+        if is_train and crop is not None and getattr(crop, "ENABLED", False):
             raise NotImplementedError("INPUT.CROP is off in the CenterNet configs and not built")
-        self.img_format = cfg.INPUT.FORMAT
-        if cfg.MODEL.MASK_ON or cfg.MODEL.KEYPOINT_ON or cfg.MODEL.LOAD_PROPOSALS:
-            raise NotImplementedError("masks / keypoints / proposals are not part of the CenterNet path")
         self.is_train = is_train
+        self.img_format = cfg.INPUT.FORMAT
+        self.augmentation = bulb_traffic_light_augmentation(cfg, is_train)
+
+    def _image(self, record):
+        pixels = du.read_image(record["file_name"], format=self.img_format)
+        du.check_image_size(record, pixels)
+        return T.apply_augmentations(self.augmentation, pixels)
+
+    @staticmethod
+    def _targets(annotations, transforms, hw):
+        kept = [du.transform_instance_annotations(a, transforms, hw) for a in annotations if not a.get("iscrowd", 0)]
+        return du.filter_empty_instances(du.annotations_to_instances(kept, hw))
 
     def __call__(self, dataset_dict):
-        dataset_dict = copy.deepcopy(dataset_dict)
-        image = utils.read_image(dataset_dict["file_name"], format=self.img_format)
-        utils.check_image_size(dataset_dict, image)
-        image, transforms = T.apply_augmentations(self.augmentation, image)
-        image_shape = image.shape[:2]
-        dataset_dict["image"] = torch.as_tensor(np.ascontiguousarray(image.transpose(2, 0, 1)))
-        if not self.is_train:
-            dataset_dict.pop("annotations", None)
-            return dataset_dict
-        if "annotations" in dataset_dict:
-            annos = [utils.transform_instance_annotations(obj, transforms, image_shape)
-                     for obj in dataset_dict.pop("annotations") if obj.get("iscrowd", 0) == 0]
-            instances = utils.annotations_to_instances(annos, image_shape)
-            dataset_dict["instances"] = utils.filter_empty_instances(instances)
-        return dataset_dict
+        record = copy.deepcopy(dataset_dict)       # the caller's dict (shared by every epoch) is never modified
+        pixels, transforms = self._image(record)
+        record["image"] = torch.as_tensor(np.ascontiguousarray(pixels.transpose(2, 0, 1)))
+        annotations = record.pop("annotations", None)
+        if self.is_train and annotations is not None:
+            record["instances"] = self._targets(annotations, transforms, pixels.shape[:2])
+        return record
