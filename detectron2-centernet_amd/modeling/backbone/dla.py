@@ -25,29 +25,32 @@ from .build import BACKBONE_REGISTRY
 BN_MOMENTUM = 0.1
 
 
+def _conv3x3(cin, cout, stride=1, dilation=1):
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+
+
+def _bn(channels):
+    return nn.BatchNorm2d(channels, momentum=BN_MOMENTUM)
+
+
 def fill_up_weights(up):
-    """bilinear-interpolation initialiser of the depthwise up-convolution (dla.py:33-42)."""
+    """bilinear-interpolation initialiser of the depthwise up-convolution (dla.py:33-42): every channel gets the outer
+    product of the 1-D tent profile 1 - |i/f - c|."""
     w = up.weight.data
-    f = math.ceil(w.size(2) / 2)
+    k = w.size(2)
+    f = math.ceil(k / 2)
     c = (2 * f - 1 - f % 2) / (2.0 * f)
-    for i in range(w.size(2)):
-        for j in range(w.size(3)):
-            w[0, 0, i, j] = (1 - math.fabs(i / f - c)) * (1 - math.fabs(j / f - c))
-    for ch in range(1, w.size(0)):
-        w[ch, 0, :, :] = w[0, 0, :, :]
+    tent = torch.tensor([1 - math.fabs(i / f - c) for i in range(k)], dtype=w.dtype, device=w.device)
+    w.copy_((tent[:, None] * tent[None, :]).expand_as(w))
 
 
 class DLABasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, dilation=1):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=dilation, bias=False,
-                               dilation=dilation)
-        self.bn1 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
-        self.relu = nn.ReLU(inplace=True)
-        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=dilation, bias=False,
-                               dilation=dilation)
-        self.bn2 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
         self.stride = stride
+        self.conv1, self.bn1 = _conv3x3(inplanes, planes, stride, dilation), _bn(planes)
+        self.conv2, self.bn2 = _conv3x3(planes, planes, 1, dilation), _bn(planes)
+        self.relu = nn.ReLU(inplace=True)
 
     def hip_forward(self, x, ctx, residual=None):
         if residual is None:
@@ -59,10 +62,10 @@ class DLABasicBlock(nn.Module):
 class Root(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, residual):
         super().__init__()
-        self.conv = nn.Conv2d(in_channels, out_channels, 1, stride=1, bias=False, padding=(kernel_size - 1) // 2)
-        self.bn = nn.BatchNorm2d(out_channels, momentum=BN_MOMENTUM)
-        self.relu = nn.ReLU(inplace=True)
         self.residual = residual
+        self.conv = nn.Conv2d(in_channels, out_channels, 1, stride=1, padding=(kernel_size - 1) // 2, bias=False)
+        self.bn = _bn(out_channels)
+        self.relu = nn.ReLU(inplace=True)
 
     def hip_forward(self, xs, ctx):
         p = hipnn.packed(self.conv, "conv", ctx.compute, self.conv.weight, self.bn, None, 1, 0, 1)
@@ -70,35 +73,29 @@ class Root(nn.Module):
 
 
 class Tree(nn.Module):
+    """recursive aggregation node (dla.py:97-150): tree1 / tree2 are blocks at the leaves and Trees above; the leaf level owns
+    the Root whose input width collects 2*out (+ in when level_root) (+ out per enclosing level)"""
+
     def __init__(self, levels, block, in_channels, out_channels, stride=1, level_root=False, root_dim=0,
                  root_kernel_size=1, dilation=1, root_residual=False):
         super().__init__()
-        if root_dim == 0:
-            root_dim = 2 * out_channels
-        if level_root:
-            root_dim += in_channels
+        self.levels, self.level_root = levels, level_root
+        root_dim = (root_dim or 2 * out_channels) + (in_channels if level_root else 0)
+        self.root_dim = root_dim
         if levels == 1:
             self.tree1 = block(in_channels, out_channels, stride, dilation=dilation)
             self.tree2 = block(out_channels, out_channels, 1, dilation=dilation)
-        else:
-            self.tree1 = Tree(levels - 1, block, in_channels, out_channels, stride, root_dim=0,
-                              root_kernel_size=root_kernel_size, dilation=dilation, root_residual=root_residual)
-            self.tree2 = Tree(levels - 1, block, out_channels, out_channels, root_dim=root_dim + out_channels,
-                              root_kernel_size=root_kernel_size, dilation=dilation, root_residual=root_residual)
-        if levels == 1:
             self.root = Root(root_dim, out_channels, root_kernel_size, root_residual)
-        self.level_root = level_root
-        self.root_dim = root_dim
-        self.downsample = None
+        else:
+            sub = dict(root_kernel_size=root_kernel_size, dilation=dilation, root_residual=root_residual)
+            self.tree1 = Tree(levels - 1, block, in_channels, out_channels, stride, root_dim=0, **sub)
+            self.tree2 = Tree(levels - 1, block, out_channels, out_channels, root_dim=root_dim + out_channels, **sub)
+        assert stride in (1, 2), "HIP max-pool kernel is 2x2/2 (the only one DLA-34 uses)"
+        self.downsample = nn.MaxPool2d(stride, stride=stride) if stride > 1 else None
         self.project = None
-        self.levels = levels
-        if stride > 1:
-            assert stride == 2, "HIP max-pool kernel is 2x2/2 (the only one DLA-34 uses)"
-            self.downsample = nn.MaxPool2d(stride, stride=stride)
         if in_channels != out_channels:
-            self.project = nn.Sequential(
-                nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, bias=False),
-                nn.BatchNorm2d(out_channels, momentum=BN_MOMENTUM))
+            self.project = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, bias=False),
+                                         _bn(out_channels))
 
     def hip_forward(self, x, ctx, residual=None, children=None, bottom=None):
         """bottom: the down-sampled input when the caller already has it (the fused base kernel emits level1's pool)"""
@@ -119,18 +116,23 @@ class Tree(nn.Module):
 
 
 class IDAUp(nn.Module):
+    """per extra input i: proj_i (DCN c_i -> o), up_i (depthwise bilinear-initialised ConvTranspose, factor f_i), node_i
+    (DCN o -> o)  (dla.py:152-170)"""
+
     def __init__(self, o, channels, up_f):
         super().__init__()
-        for i in range(1, len(channels)):
-            c = channels[i]
-            f = int(up_f[i])
-            proj = DeformConvV2(c, o)
-            node = DeformConvV2(o, o)
-            up = nn.ConvTranspose2d(o, o, f * 2, stride=f, padding=f // 2, output_padding=0, groups=o, bias=False)
+        for i, (c, f) in enumerate(zip(channels, up_f)):
+            if i == 0:
+                continue
+            f = int(f)
+            # construction order proj, node, up (the order in which the reference draws their random initial values),
+            # registration order proj, up, node (the order of its state-dict keys)
+            proj, node = DeformConvV2(c, o), DeformConvV2(o, o)
+            up = nn.ConvTranspose2d(o, o, 2 * f, stride=f, padding=f // 2, output_padding=0, groups=o, bias=False)
             fill_up_weights(up)
-            setattr(self, "proj_" + str(i), proj)
-            setattr(self, "up_" + str(i), up)
-            setattr(self, "node_" + str(i), node)
+            self.add_module(f"proj_{i}", proj)
+            self.add_module(f"up_{i}", up)
+            self.add_module(f"node_{i}", node)
 
     def hip_forward(self, layers, startp, endp, ctx):
         for i in range(startp + 1, endp):
@@ -144,20 +146,20 @@ class IDAUp(nn.Module):
 
 
 class DLAUp(nn.Module):
+    """ida_0 .. ida_{n-2}, coarsest level first: ida_i merges everything from level n-2-i upwards at that level's resolution
+    (dla.py:180-196)"""
+
     def __init__(self, startp, channels, scales, in_channels=None):
         super().__init__()
-        self.startp = startp
-        if in_channels is None:
-            in_channels = channels
-        self.channels = channels
-        channels = list(channels)
-        in_channels = list(in_channels)
-        scales = np.array(scales, dtype=int)
-        for i in range(len(channels) - 1):
-            j = -i - 2
-            setattr(self, "ida_{}".format(i), IDAUp(channels[j], in_channels[j:], scales[j:] // scales[j]))
-            scales[j + 1:] = scales[j]
-            in_channels[j + 1:] = [channels[j] for _ in channels[j + 1:]]
+        self.startp, self.channels = startp, channels
+        outs = list(channels)
+        ins = list(channels if in_channels is None else in_channels)
+        scale = np.array(scales, dtype=int)
+        for i in range(len(outs) - 1):
+            j = len(outs) - 2 - i
+            self.add_module(f"ida_{i}", IDAUp(outs[j], ins[j:], scale[j:] // scale[j]))
+            scale[j + 1:] = scale[j]
+            ins[j + 1:] = [outs[j]] * (len(outs) - j - 1)
 
     def hip_forward(self, layers, ctx):
         layers = list(layers)
@@ -172,27 +174,21 @@ class DLAUp(nn.Module):
 class DLA(Backbone):
     def __init__(self, levels, channels, num_classes=1000, block=DLABasicBlock, residual_root=False):
         super().__init__()
-        self.channels = channels
-        self.num_classes = num_classes
-        self.base_layer = nn.Sequential(
-            nn.Conv2d(3, channels[0], kernel_size=7, stride=1, padding=3, bias=False),
-            nn.BatchNorm2d(channels[0], momentum=BN_MOMENTUM), nn.ReLU(inplace=True))
+        self.channels, self.num_classes = channels, num_classes
+        self.base_layer = nn.Sequential(nn.Conv2d(3, channels[0], kernel_size=7, stride=1, padding=3, bias=False),
+                                        _bn(channels[0]), nn.ReLU(inplace=True))
         self.level0 = self._make_conv_level(channels[0], channels[0], levels[0])
         self.level1 = self._make_conv_level(channels[0], channels[1], levels[1], stride=2)
-        self.level2 = Tree(levels[2], block, channels[1], channels[2], 2, level_root=False, root_residual=residual_root)
-        self.level3 = Tree(levels[3], block, channels[2], channels[3], 2, level_root=True, root_residual=residual_root)
-        self.level4 = Tree(levels[4], block, channels[3], channels[4], 2, level_root=True, root_residual=residual_root)
-        self.level5 = Tree(levels[5], block, channels[4], channels[5], 2, level_root=True, root_residual=residual_root)
+        for lvl in range(2, 6):     # aggregation trees, each halving the resolution; from level3 on the Root also takes the
+            self.add_module(f"level{lvl}", Tree(levels[lvl], block, channels[lvl - 1], channels[lvl], 2,   # pooled input
+                                                level_root=lvl > 2, root_residual=residual_root))
 
     def _make_conv_level(self, inplanes, planes, convs, stride=1, dilation=1):
-        modules = []
+        layers = []
         for i in range(convs):
-            modules.extend([
-                nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride if i == 0 else 1, padding=dilation, bias=False,
-                          dilation=dilation),
-                nn.BatchNorm2d(planes, momentum=BN_MOMENTUM), nn.ReLU(inplace=True)])
-            inplanes = planes
-        return nn.Sequential(*modules)
+            layers += [_conv3x3(inplanes if i == 0 else planes, planes, stride if i == 0 else 1, dilation), _bn(planes),
+                       nn.ReLU(inplace=True)]
+        return nn.Sequential(*layers)
 
     @staticmethod
     def _conv_level_forward(seq, x, ctx, cin_pad=None, prepadded=False):
