@@ -1,7 +1,10 @@
-"""detectron2/layers/shape_spec.py:1-20."""
-from collections import namedtuple
+"""Shape descriptor handed to backbone factories (`f(cfg, input_shape)`); same four optional fields, keyword or positional,
+immutable and tuple-like, as the reference's ShapeSpec (detectron2/layers/shape_spec.py)."""
+from typing import NamedTuple, Optional
 
 
-class ShapeSpec(namedtuple("_ShapeSpec", ["channels", "height", "width", "stride"])):
-    def __new__(cls, channels=None, height=None, width=None, stride=None):
-        return super().__new__(cls, channels, height, width, stride)
+class ShapeSpec(NamedTuple):
+    channels: Optional[int] = None
+    height: Optional[int] = None
+    width: Optional[int] = None
+    stride: Optional[int] = None

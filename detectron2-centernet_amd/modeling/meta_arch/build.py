@@ -1,4 +1,5 @@
-"""detectron2/modeling/meta_arch/build.py:6-23."""
+"""Meta-architecture registry (`MODEL.META_ARCHITECTURE` -> class called with cfg); contract of
+detectron2/modeling/meta_arch/build.py:6-23."""
 import torch
 
 from ...utils.registry import Registry
@@ -7,7 +8,6 @@ META_ARCH_REGISTRY = Registry("META_ARCH")
 
 
 def build_model(cfg):
-    """Builds `cfg.MODEL.META_ARCHITECTURE` and moves it to `cfg.MODEL.DEVICE` (does not load weights)."""
-    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
-    model.to(torch.device(cfg.MODEL.DEVICE))
-    return model
+    """instantiate the configured meta-architecture on `cfg.MODEL.DEVICE`; weights are whatever the constructor made"""
+    arch = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
+    return arch(cfg).to(torch.device(cfg.MODEL.DEVICE))
