@@ -855,8 +855,181 @@ int launch_bn_train_bwd(const f16* dz, int dz_stride, const f16* z, int z_stride
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 weight gradient, window form (maps divisible by 8x32, Cin % 32 == 0).  The generic kernel above
+// gathers every tap's pixels separately (nine reads of the input through L2) and ends in 8192 f32 atomics per workgroup on
+// ~1000 workgroups.  Here a workgroup owns 32 couts x 32 cin x all 9 taps and walks 8x32-pixel tiles: per tile the dY rows
+// (256 x 32) and the (8+2) x (32+2) input window of its 32 channels go to LDS once and the taps read the window at shifted
+// rows.  A wave takes two tile rows (two K slabs of 32 pixels), keeps its dY fragments for all nine taps and loads each of
+// its four window rows' fragments once (row v serves tap row v of the first tile row and v-1 of the second): 56 transposing
+// LDS reads for 72 MFMAs.  Partial sums: the four waves are added through LDS, then one f32 atomic per element at the end
+// of the workgroup's tile range -- one workgroup per CU, so a 64->64 layer ends in 2.4 M atomics instead of 8.4 M.
+// Measured on the batch-16 step (rocprofv3, us per launch, generic -> window): 64->64 @128^2 68 -> 55, 128->128 @64^2
+// 63 -> 44, 256->256 @32^2 58 -> 40, head 64->256 @128^2 179 -> 142, offset convs (Cout 27) 68/43/26 -> 37/27/20.
+// ------------------------------------------------------------------------------------------------
+#define WW_LD 40   // LDS row pitch in f16 elements (32 channels + 8 pad: 80 bytes, spreads the transposing reads over banks)
+__global__ void __launch_bounds__(256, 2) conv_wgrad_win_kernel(const WgradArgs a) {
+  constexpr int TH = 8, TW = 32, WC = TW + 2, NWIN = (TH + 2) * WC;   // 340 window pixels
+  __shared__ __attribute__((aligned(16))) f16 sm[(TH * TW + NWIN) * WW_LD];   // 47680 B; the first 36864 B hold the f32 sums at the end
+  f16* const sY = sm;
+  f16* const sX = sm + TH * TW * WW_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH, ntiles = a.B * tiles_y * tiles_x;
+  const int per = (ntiles + gridDim.z - 1) / gridDim.z;
+  const int t_begin = blockIdx.z * per, t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
+
+  f32x4 acc[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Operand pieces of 16 bytes, piece = tid + 256*i: dY 256 pixels x 4 cout groups (i < 4), window 340 pixels x 4 cin groups
+  // (i < 6).  The channel group is tid & 3 for every piece; the pixel of a piece inside the tile / window does not depend on
+  // the tile, so its offset and its border flags (first / last window row / column, past the window) are computed once.
+  // Loads are unconditional from a selected 32-bit byte offset (0 when the pixel is outside the image) and the zeroing
+  // happens when the registers go to LDS one tile later: nothing in the loop waits on a load it has just issued.
+  const int g = tid & 3, pix = tid >> 2;
+  const bool n_ok = n0 + g * 8 < a.Cout;
+  const unsigned y_first = (unsigned)((((pix >> 5) * a.W + (pix & 31)) * a.dy_stride + n0 + g * 8) * 2);
+  const unsigned y_step = (unsigned)(2 * a.W * a.dy_stride * 2);      // 64 pixels of the tile = two rows further down
+  int woff[6];
+  unsigned wflags = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int wpx = pix + 64 * i, wr = wpx / WC, wc = wpx - wr * WC;
+    woff[i] = wr * a.W + wc;
+    const unsigned f = (wr == 0 ? 1u : 0u) | (wr == TH + 1 ? 2u : 0u) | (wc == 0 ? 4u : 0u) | (wc == WC - 1 ? 8u : 0u) |
+                       (wpx >= NWIN ? 16u : 0u);
+    wflags |= f << (5 * i);
+  }
+  const char* const xbase = (const char*)(a.x + c0 + g * 8);
+  const char* const ybase = (const char*)a.dy;
+  const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  f16x8 yv[4], xv[6];
+  unsigned okbits = 0;
+  auto fetch = [&](int tile) {
+    const int txi = tile % tiles_x, tq = tile / tiles_x, tyi = tq % tiles_y, b = tq / tiles_y;
+    const int tx0 = txi * TW, ty0 = tyi * TH;
+    const unsigned edge = (tyi == 0 ? 1u : 0u) | (tyi == tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) | (txi == tiles_x - 1 ? 8u : 0u);
+    const unsigned bad = wflags & (edge * 0x02108421u | 0x21084210u);
+    const int tile_pix = (b * a.H + ty0 - 1) * a.W + tx0 - 1;
+    const unsigned ytile = (unsigned)(((b * a.H + ty0) * a.W + tx0) * a.dy_stride * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned off = n_ok ? ytile + y_first + y_step * i : 0u;
+      yv[i] = *(const f16x8*)(ybase + off);
+    }
+    okbits = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const bool ok = ((bad >> (5 * i)) & 31u) == 0u;
+      const unsigned off = ok ? (unsigned)((tile_pix + woff[i]) * a.in_stride * 2) : 0u;
+      xv[i] = *(const f16x8*)(xbase + off);
+      okbits |= ok ? 1u << i : 0u;
+    }
+  };
+  const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  if (t_begin < t_end) fetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();   // the previous tile's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f16x8*)(sY + (pix + 64 * i) * WW_LD + g * 8) = n_ok ? yv[i] : z8;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (pix + 64 * i < NWIN) *(f16x8*)(sX + (pix + 64 * i) * WW_LD + g * 8) = (okbits >> i) & 1u ? xv[i] : z8;
+    __syncthreads();
+    if (tile + 1 < t_end) fetch(tile + 1);
+    // dY fragments of this wave's two tile rows (K slabs of 32 pixels), both cout tiles: kept for all nine taps
+    f16x8 fy[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f16* base = sY + ((2 * wave + h) * TW + 8 * grp + q) * WW_LD + i * 16 + 4 * p;
+        const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * WW_LD);
+        fy[h][i] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    // window rows 2*wave .. 2*wave+3: row v serves tap row v of tile row 0 and tap row v-1 of tile row 1
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int ts = 0; ts < 3; ++ts) {
+        f16x8 fx[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f16* base = sX + ((2 * wave + v) * WC + ts + 8 * grp + q) * WW_LD + j * 16 + 4 * p;
+          const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * WW_LD);
+          fx[j] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int tr = v - h;
+          if (tr < 0 || tr > 2) continue;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[tr * 3 + ts][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[h][i], fx[j], acc[tr * 3 + ts][i][j], 0, 0, 0);
+        }
+      }
+  }
+  // The four waves hold partial sums of the same 32 x 32 x 9 block with the same lane -> element mapping.  f32 atomics to
+  // L2 are what this kernel's fixed cost is made of, so the waves are summed through LDS first (wave 3 stores, 2 / 1 / 0
+  // add their registers in turn -- no LDS atomics needed) and one atomic per element leaves the workgroup.
+  float* const red = (float*)sm;    // [36 tiles][4 r][64 lanes]
+  __syncthreads();
+#pragma unroll
+  for (int w = 3; w >= 0; --w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* slot = red + (((t * 2 + i) * 2 + j) * 4 + r) * 64 + lane;
+              *slot = w == 3 ? acc[t][i][j][r] : *slot + acc[t][i][j][r];
+            }
+    }
+    __syncthreads();
+  }
+  // D[row = cout][col = cin]: lane held rows 4*(lane>>4)+r, column lane&15; k = tap*Cin + c (tap-major dW)
+  for (int e = tid; e < 36 * 256; e += 256) {
+    const int tile = e >> 8, t = tile >> 2, i = (tile >> 1) & 1, j = tile & 1, r = (e >> 6) & 3, ln = e & 63;
+    const int n = n0 + i * 16 + 4 * (ln >> 4) + r;
+    if (n < a.Cout) atomicAdd(a.dw + (long)n * a.K + t * a.Cin + c0 + j * 16 + (ln & 15), red[e] * a.scale);
+  }
+}
+
 int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
   WgradArgs a = a0;
+  if (a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Cin % 32 == 0 && a.H % 8 == 0 && a.W % 32 == 0 &&
+      a.Ho == a.H && a.Wo == a.W && a.in_stride % 8 == 0 && a.dy_stride % 8 == 0 &&
+      (long)a.B * a.H * a.W * (a.in_stride > a.dy_stride ? a.in_stride : a.dy_stride) * 2 < (1L << 31) && !getenv("CTDET_NO_WGRAD_WINDOW")) {
+    const int gx = a.Cin / 32, gy = (a.Cout + 31) / 32;
+    const int ntiles = a.B * (a.H / 8) * (a.W / 32);
+    // one workgroup per CU: the f32 atomics of the epilogue (9216 per workgroup) are the fixed cost, and a second
+    // co-resident workgroup does not speed the tile loop up (measured: 256 / 384 / 512 workgroups -> 25.0 / 25.1 / 25.3 ms steps)
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+      ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    int split = ncu / (gx * gy);
+    if (split < 1) split = 1;
+    if (split > ntiles) split = ntiles;
+    hipLaunchKernelGGL(conv_wgrad_win_kernel, dim3(gx, gy, split), dim3(256), 0, s, a);
+    CTDET_LAUNCH_CHECK();
+    return 0;
+  }
   CTDET_CHECK(a.Cin % 8 == 0 && a.in_stride % 8 == 0 && a.dy_stride % 8 == 0 && a.Cout % 8 == 0,
               "wgrad: channel counts / strides must be multiples of 8 (Cin=%d Cout=%d)", a.Cin, a.Cout);
   const int gx = (a.K + WG_BK - 1) / WG_BK, gy = (a.Cout + WG_BN - 1) / WG_BN;
