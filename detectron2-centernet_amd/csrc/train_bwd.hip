@@ -1007,22 +1007,175 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_win_kernel(const WgradArgs 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Window-form weight gradient for the narrow layers at full resolution: KS x KS / stride 1 / pad KS/2 with 8 or 16 input
+// channels and at most 16 couts -- DLA's 7x7 stem (3 -> 16, input padded to 8 channels) and level0 (16 -> 16), both on
+// 512^2 maps.  The generic kernel reads the input once per tap (49 x 67 MB for the stem).  Here the (8+KS-1) x (32+KS-1)
+// window of an 8x32-pixel tile sits in LDS as [pixel][CIN] with no padding, so that a 16-column MFMA operand is simply 16
+// consecutive halves starting at a pixel: one tap of 16 channels, or two horizontally adjacent taps of 8 (row pitch of the
+// transposing read = one pixel, rows overlap).  D = dY^T (16 couts x 32 pixels) x window (32 pixels x 16 columns); a wave
+// owns two tile rows and loads each window row's operand once for both.  The odd tap of a 7-wide row pairs with a column
+// that does not exist; those eight D columns are dropped in the epilogue.  Epilogue as in conv_wgrad_win_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int KS, int CIN>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_narrow_kernel(const WgradArgs a) {
+  constexpr int TH = 8, TW = 32, PADK = KS / 2, WR = TH + KS - 1, WCOL = TW + KS - 1, NWIN = WR * WCOL;
+  constexpr int SUB = CIN / 8;                             // 16-byte pieces per pixel
+  constexpr int NROUND = (NWIN * SUB + 255) / 256;
+  constexpr int NP = CIN == 8 ? (KS + 1) / 2 : KS;         // column tiles per kernel row
+  constexpr int NT = KS * NP;
+  constexpr int LDY = 24;                                  // dY row pitch: 16 couts + 8 pad
+  constexpr int Y_ELEMS = TH * TW * LDY, X_ELEMS = (NWIN + 8) * CIN;
+  constexpr int SM_BYTES = (X_ELEMS + Y_ELEMS) * 2 > NT * 1024 ? (X_ELEMS + Y_ELEMS) * 2 : NT * 1024;
+  static_assert(NROUND <= 6, "border flags are 5 bits per round in one word");
+  __shared__ __attribute__((aligned(16))) unsigned char smraw[SM_BYTES];
+  f16* const sY = (f16*)smraw;
+  f16* const sX = sY + Y_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH, ntiles = a.B * tiles_y * tiles_x;
+  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int t_begin = blockIdx.x * per, t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // 16-byte pieces, piece = tid + 256*i: dY 256 pixels x 2 cout groups (i < 2); window NWIN pixels x SUB channel groups
+  const int yg = tid & 1, ypix = tid >> 1;
+  const bool n_ok = yg * 8 < a.Cout;
+  const unsigned y_first = (unsigned)((((ypix >> 5) * a.W + (ypix & 31)) * a.dy_stride + yg * 8) * 2);
+  const unsigned y_step = (unsigned)(4 * a.W * a.dy_stride * 2);     // 128 pixels of the tile = four rows further down
+  const int sub = SUB == 2 ? tid & 1 : 0, wpix = SUB == 2 ? tid >> 1 : tid;
+  constexpr int WSTEP = 256 / SUB;
+  int woff[NROUND];
+  unsigned wflags = 0, rep = 0, beyond = 0;
+#pragma unroll
+  for (int i = 0; i < NROUND; ++i) {
+    const int wpx = wpix + WSTEP * i, wr = wpx / WCOL, wc = wpx - wr * WCOL;
+    woff[i] = wr * a.W + wc;
+    const unsigned f = (wr < PADK ? 1u : 0u) | (wr >= TH + PADK ? 2u : 0u) | (wc < PADK ? 4u : 0u) | (wc >= TW + PADK ? 8u : 0u) |
+                       (wpx >= NWIN ? 16u : 0u);
+    wflags |= f << (5 * i);
+    rep |= 1u << (5 * i);
+    beyond |= 16u << (5 * i);
+  }
+  const char* const xbase = (const char*)(a.x + sub * 8);
+  const char* const ybase = (const char*)a.dy;
+  const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  f16x8 yv[2], xv[NROUND];
+  unsigned okbits = 0;
+  auto fetch = [&](int tile) {
+    const int txi = tile % tiles_x, tq = tile / tiles_x, tyi = tq % tiles_y, b = tq / tiles_y;
+    const int tx0 = txi * TW, ty0 = tyi * TH;
+    const unsigned edge = (tyi == 0 ? 1u : 0u) | (tyi == tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) | (txi == tiles_x - 1 ? 8u : 0u);
+    const unsigned bad = wflags & (edge * rep | beyond);
+    const int tile_pix = (b * a.H + ty0 - PADK) * a.W + tx0 - PADK;
+    const unsigned ytile = (unsigned)(((b * a.H + ty0) * a.W + tx0) * a.dy_stride * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned off = n_ok ? ytile + y_first + y_step * i : 0u;
+      yv[i] = *(const f16x8*)(ybase + off);
+    }
+    okbits = 0;
+#pragma unroll
+    for (int i = 0; i < NROUND; ++i) {
+      const bool ok = ((bad >> (5 * i)) & 31u) == 0u;
+      const unsigned off = ok ? (unsigned)((tile_pix + woff[i]) * a.in_stride * 2) : 0u;
+      xv[i] = *(const f16x8*)(xbase + off);
+      okbits |= ok ? 1u << i : 0u;
+    }
+  };
+  const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  if (t_begin < t_end) fetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();   // the previous tile's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(f16x8*)(sY + (ypix + 128 * i) * LDY + yg * 8) = n_ok ? yv[i] : z8;
+#pragma unroll
+    for (int i = 0; i < NROUND; ++i)
+      if (wpix + WSTEP * i < NWIN) *(f16x8*)(sX + (wpix + WSTEP * i) * CIN + sub * 8) = (okbits >> i) & 1u ? xv[i] : z8;
+    __syncthreads();
+    if (tile + 1 < t_end) fetch(tile + 1);
+    f16x8 fy[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f16* base = sY + ((2 * wave + h) * TW + 8 * grp + q) * LDY + 4 * p;
+      const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * LDY);
+      fy[h] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+    // window rows 2*wave .. 2*wave+KS: row v serves tap row v of the first tile row and v-1 of the second
+#pragma unroll
+    for (int v = 0; v <= KS; ++v)
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) {
+        const int s0 = CIN == 8 ? 2 * pr : pr;
+        const f16* base = sX + ((2 * wave + v) * WCOL + s0 + 8 * grp + q) * CIN + 4 * p;
+        const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * CIN);
+        const f16x8 fx = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int tr = v - h;
+          if (tr < 0 || tr >= KS) continue;
+          acc[tr * NP + pr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[h], fx, acc[tr * NP + pr], 0, 0, 0);
+        }
+      }
+  }
+  float* const red = (float*)smraw;    // [NT tiles][4 r][64 lanes]
+  __syncthreads();
+#pragma unroll
+  for (int w = 3; w >= 0; --w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* slot = red + (t * 4 + r) * 64 + lane;
+          *slot = w == 3 ? acc[t][r] : *slot + acc[t][r];
+        }
+    }
+    __syncthreads();
+  }
+  // D[row = cout][col]: lane held rows 4*(lane>>4)+r, column lane&15 = (tap parity, channel) or channel; k = tap*CIN + c
+  for (int e = tid; e < NT * 256; e += 256) {
+    const int t = e >> 8, r = (e >> 6) & 3, ln = e & 63, col = ln & 15;
+    const int n = 4 * (ln >> 4) + r, tr = t / NP, pr = t - tr * NP;
+    const int ts = CIN == 8 ? 2 * pr + (col >> 3) : pr, c = CIN == 8 ? col & 7 : col;
+    if (n < a.Cout && ts < KS) atomicAdd(a.dw + (long)n * a.K + (tr * KS + ts) * CIN + c, red[e] * a.scale);
+  }
+}
+
+static int device_cu_count() {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return ncu;
+}
+
 int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
   WgradArgs a = a0;
-  if (a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Cin % 32 == 0 && a.H % 8 == 0 && a.W % 32 == 0 &&
-      a.Ho == a.H && a.Wo == a.W && a.in_stride % 8 == 0 && a.dy_stride % 8 == 0 &&
-      (long)a.B * a.H * a.W * (a.in_stride > a.dy_stride ? a.in_stride : a.dy_stride) * 2 < (1L << 31) && !getenv("CTDET_NO_WGRAD_WINDOW")) {
+  const bool window_ok = a.stride == 1 && a.dil == 1 && a.R == a.S && a.pad == a.R / 2 && a.H % 8 == 0 && a.W % 32 == 0 &&
+                         a.Ho == a.H && a.Wo == a.W && a.in_stride % 8 == 0 && a.dy_stride % 8 == 0 &&
+                         (long)a.B * a.H * a.W * (a.in_stride > a.dy_stride ? a.in_stride : a.dy_stride) * 2 < (1L << 31) &&
+                         !getenv("CTDET_NO_WGRAD_WINDOW");
+  if (window_ok && a.Cout <= 16 && ((a.R == 7 && a.Cin == 8) || (a.R == 3 && a.Cin == 16))) {
+    const int ntiles = a.B * (a.H / 8) * (a.W / 32);
+    int blocks = device_cu_count();   // 1x / 2x / 4x CUs measured the same within noise; fewest atomics wins
+    if (blocks > ntiles) blocks = ntiles;
+    if (a.R == 7) hipLaunchKernelGGL((conv_wgrad_narrow_kernel<7, 8>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_narrow_kernel<3, 16>), dim3(blocks), dim3(256), 0, s, a);
+    CTDET_LAUNCH_CHECK();
+    return 0;
+  }
+  if (window_ok && a.R == 3 && a.Cin % 32 == 0) {
     const int gx = a.Cin / 32, gy = (a.Cout + 31) / 32;
     const int ntiles = a.B * (a.H / 8) * (a.W / 32);
     // one workgroup per CU: the f32 atomics of the epilogue (9216 per workgroup) are the fixed cost, and a second
     // co-resident workgroup does not speed the tile loop up (measured: 256 / 384 / 512 workgroups -> 25.0 / 25.1 / 25.3 ms steps)
-    static int ncu = 0;
-    if (!ncu) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
-      ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int ncu = device_cu_count();
     int split = ncu / (gx * gy);
     if (split < 1) split = 1;
     if (split > ntiles) split = ntiles;

@@ -125,7 +125,8 @@ def _close(got, ref, tol, what):
 
 
 @pytest.mark.parametrize("case", [(16, 128, 128, 64, 64, 3, 1, 1), (16, 256, 256, 32, 64, 3, 2, 1), (16, 64, 64, 128, 128, 3, 1, 1),
-                                  (16, 128, 128, 64, 256, 1, 1, 0)])
+                                  (16, 128, 128, 64, 256, 1, 1, 0),
+                                  (4, 512, 512, 8, 16, 7, 1, 3), (4, 512, 512, 16, 16, 3, 1, 1)])
 def test_fullsize_wgrad_dgrad_match_torch(case):
     import torch.nn.functional as F
     from detectron2_centernet_amd import ops_train as ot

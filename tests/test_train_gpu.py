@@ -75,7 +75,9 @@ WG_CASES = [(2, 12, 14, 64, 64, 3, 1, 1), (1, 16, 16, 32, 64, 3, 2, 1), (2, 9, 9
             (1, 8, 8, 256, 64, 1, 1, 0), (2, 20, 20, 16, 32, 3, 2, 1), (1, 16, 24, 8, 16, 7, 1, 3),
             (2, 6, 6, 576, 64, 1, 1, 0),
             # window-form weight gradient (3x3 / stride 1, maps divisible by 8x32, Cin % 32 == 0); Cout 24 / 40: partial cout tiles
-            (2, 8, 32, 64, 64, 3, 1, 1), (1, 16, 64, 32, 24, 3, 1, 1), (3, 24, 32, 96, 40, 3, 1, 1)]
+            (2, 8, 32, 64, 64, 3, 1, 1), (1, 16, 64, 32, 24, 3, 1, 1), (3, 24, 32, 96, 40, 3, 1, 1),
+            # narrow window form: 7x7 on 8 input channels (the stem) and 3x3 16 -> 16 (level0), one and several tiles per image
+            (1, 8, 32, 8, 16, 7, 1, 3), (2, 24, 64, 8, 16, 7, 1, 3), (2, 16, 64, 16, 16, 3, 1, 1), (3, 8, 32, 16, 8, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("case", WG_CASES)
