@@ -308,24 +308,24 @@ class DwConvTAddFn(torch.autograd.Function):
 
 
 class DCNFn(torch.autograd.Function):
-    """modulated deformable conv (3x3/s1/p1) for training: columns are materialised once (as the reference does,
-    deform_conv_cuda.cu:874-917) so forward, dW and d(columns) are plain 1x1 contractions on the MFMA kernels."""
+    """modulated deformable conv (3x3/s1/p1) for training.  Forward: the fused sampling + MFMA kernel of the inference path
+    (no column tensor).  Backward: the columns are materialised once there (as the reference does for both directions,
+    deform_conv_cuda.cu:874-917) so dW and d(columns) are plain 1x1 contractions on the MFMA kernels; nothing of size
+    9*Cin per pixel lives between forward and backward."""
 
     @staticmethod
     def forward(ctx, x, om, weight, bias):
-        Cout, Cin = weight.shape[:2]
-        col = dcn_cols(x, om)
-        wmat = weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)  # tap-major columns
-        p = ops.PackedConv(wmat, None, bias, compute=F16)
-        y = ops.conv2d(col, p)
-        ctx.save_for_backward(x, om, weight, col)
+        p = ops.PackedConv(weight.detach(), None, bias, stride=1, pad=1, compute=F16, cout_align=64)
+        y = ops.dcnv2(x, om, p)
+        ctx.save_for_backward(x, om, weight)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, om, weight, col = ctx.saved_tensors
+        x, om, weight = ctx.saved_tensors
         Cout, Cin = weight.shape[:2]
         dy = dy.contiguous()
+        col = dcn_cols(x, om)
         wmat = weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
         _, _, _, dbias = bn_train_bwd(dy, None, None, None, None, None, relu=False)
         dw = conv_wgrad(col, dy, Cout, 1, 1, 1, 0)                       # [Cout, 9*Cin]
