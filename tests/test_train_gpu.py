@@ -77,7 +77,9 @@ WG_CASES = [(2, 12, 14, 64, 64, 3, 1, 1), (1, 16, 16, 32, 64, 3, 2, 1), (2, 9, 9
             # window-form weight gradient (3x3 / stride 1, maps divisible by 8x32, Cin % 32 == 0); Cout 24 / 40: partial cout tiles
             (2, 8, 32, 64, 64, 3, 1, 1), (1, 16, 64, 32, 24, 3, 1, 1), (3, 24, 32, 96, 40, 3, 1, 1),
             # narrow window form: 7x7 on 8 input channels (the stem) and 3x3 16 -> 16 (level0), one and several tiles per image
-            (1, 8, 32, 8, 16, 7, 1, 3), (2, 24, 64, 8, 16, 7, 1, 3), (2, 16, 64, 16, 16, 3, 1, 1), (3, 8, 32, 16, 8, 3, 1, 1)]
+            (1, 8, 32, 8, 16, 7, 1, 3), (2, 24, 64, 8, 16, 7, 1, 3), (2, 16, 64, 16, 16, 3, 1, 1), (3, 8, 32, 16, 8, 3, 1, 1),
+            # three tiles across (W = 96), five down: interior tiles with no border at all
+            (1, 40, 96, 32, 32, 3, 1, 1), (1, 40, 96, 8, 16, 7, 1, 3), (1, 40, 96, 16, 16, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("case", WG_CASES)
@@ -95,6 +97,24 @@ def test_conv_wgrad_and_dgrad(T, dev, case):
     close(got, w.grad, 2e-3, "dW")
     dx = ot.conv_dgrad(nhwc(dy).half().to(dev), w.detach().to(dev), s, p, (H, W))
     close(nchw(dx.float().cpu()), x.grad, 3e-3, "dX")
+
+
+@pytest.mark.parametrize("case", [(2, 16, 64, 64, 48, 3, 1), (2, 16, 32, 8, 16, 7, 3), (1, 8, 64, 16, 16, 3, 1), (2, 9, 20, 32, 16, 3, 1)])
+def test_conv_wgrad_reads_channel_slices(T, dev, case):
+    """x and dy handed over as channel slices of wider NHWC buffers (pixel stride > channel count), as the DLA tree does
+    with its concatenation buffers: window, narrow and generic weight-gradient kernels"""
+    ops, ot = T
+    B, H, W, Cin, Cout, k, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = h16(torch.randn(B, Cin, H, W, generator=g))
+    dy = h16(torch.randn(B, Cout, H, W, generator=g))
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, stride=1, padding=p)
+    xw = torch.randn(B, H, W, Cin + 16, generator=g).half().to(dev)
+    dw_ = torch.randn(B, H, W, Cout + 8, generator=g).half().to(dev)
+    xw[..., 8:8 + Cin] = nhwc(x).half().to(dev)
+    dw_[..., :Cout] = nhwc(dy).half().to(dev)
+    got = ot.conv_wgrad(xw[..., 8:8 + Cin], dw_[..., :Cout], Cout, k, k, 1, p, scale=1.0)
+    close(got.view(Cout, k, k, Cin).permute(0, 3, 1, 2).cpu(), ref, 2e-3, "dW from slices")
 
 
 def test_wgrad_dgrad_bn_random_shapes(T, dev):
