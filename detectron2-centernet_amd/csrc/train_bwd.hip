@@ -259,10 +259,15 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
   __shared__ __attribute__((aligned(16))) f16 sA[WG_BM * WG_LDA];
   __shared__ __attribute__((aligned(16))) f16 sY[WG_BM * WG_LDY];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k0 = blockIdx.x * WG_BK, n0 = blockIdx.y * WG_BN;
+  // 1-D grid; the gx*gy workgroups of one pixel range get ids 8 apart = the same XCD / L2 (see conv_wgrad_win_kernel)
+  const int gx = (a.K + WG_BK - 1) / WG_BK, gy = (a.Cout + WG_BN - 1) / WG_BN, nxy = gx * gy;
+  int xy, bz;
+  if ((a.msplit & 7) == 0) { const int slot = blockIdx.x >> 3; bz = (slot / nxy) * 8 + (blockIdx.x & 7); xy = slot % nxy; }
+  else { xy = blockIdx.x % nxy; bz = blockIdx.x / nxy; }
+  const int k0 = (xy % gx) * WG_BK, n0 = (xy / gx) * WG_BN;
   const int wn = wave >> 1, wk = wave & 1;  // wave tile: 32 couts x 64 k
   const int m_per = ((a.M + a.msplit - 1) / a.msplit + WG_BM - 1) / WG_BM * WG_BM;
-  const int m_begin = blockIdx.z * m_per;
+  const int m_begin = bz * m_per;
   const int m_end = m_begin + m_per < a.M ? m_begin + m_per : a.M;
 
   f32x4 acc[2][4];
@@ -874,10 +879,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_win_kernel(const WgradArgs 
   f16* const sY = sm;
   f16* const sX = sm + TH * TW * WW_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  // 1-D grid of gx*gy*split workgroups.  Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2):
+  // the gx*gy workgroups that walk the SAME pixel range (all channel tiles of it) are given ids 8 apart, so that they share
+  // an XCD and its L2 serves their common dY / input tiles -- the kernel is bound by operand traffic.
+  const int gx = a.Cin / 32, gy = (a.Cout + 31) / 32, nxy = gx * gy, split = a.msplit;
+  int xy, bz;
+  if ((split & 7) == 0) { const int slot = blockIdx.x >> 3; bz = (slot / nxy) * 8 + (blockIdx.x & 7); xy = slot % nxy; }
+  else { xy = blockIdx.x % nxy; bz = blockIdx.x / nxy; }
+  const int c0 = (xy % gx) * 32, n0 = (xy / gx) * 32;
   const int tiles_x = a.W / TW, tiles_y = a.H / TH, ntiles = a.B * tiles_y * tiles_x;
-  const int per = (ntiles + gridDim.z - 1) / gridDim.z;
-  const int t_begin = blockIdx.z * per, t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
+  const int per = (ntiles + split - 1) / split;
+  const int t_begin = bz * per, t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
 
   f32x4 acc[9][2][2];
 #pragma unroll
@@ -1179,7 +1191,8 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
     int split = ncu / (gx * gy);
     if (split < 1) split = 1;
     if (split > ntiles) split = ntiles;
-    hipLaunchKernelGGL(conv_wgrad_win_kernel, dim3(gx, gy, split), dim3(256), 0, s, a);
+    a.msplit = split;
+    hipLaunchKernelGGL(conv_wgrad_win_kernel, dim3(gx * gy * split), dim3(256), 0, s, a);
     CTDET_LAUNCH_CHECK();
     return 0;
   }
@@ -1198,7 +1211,7 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
     while ((1 << a.lw) < a.Wo) ++a.lw;
     while ((1 << a.lh) < a.Ho) ++a.lh;
   }
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, gy, split), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx * gy * split), dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
