@@ -46,7 +46,41 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(ChanRedArgs a) {
     for (int e = 0; e < 8; ++e) { mu[e] = a.mean[cv * 8 + e]; is[e] = a.invstd[cv * 8 + e]; }
   }
   if (rl < rows_per_pass) {
-    for (long m = (long)blockIdx.x * rows_per_pass + rl; m < a.M; m += (long)gridDim.x * rows_per_pass) {
+    const long step = (long)gridDim.x * rows_per_pass;
+    long m = (long)blockIdx.x * rows_per_pass + rl;
+    if (a.mode == 0) {
+      // four rows in flight per thread: with one 16-byte load outstanding per thread the pass ran at ~2 TB/s (latency x
+      // occupancy), the mid-sized maps at a quarter of that
+      for (; m + 3 * step < a.M; m += 4 * step) {
+        f16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const f16x8*)(a.y + (m + u * step) * a.y_stride + cv * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e]; s0[e] += f; s1[e] += f * f; }
+      }
+    } else {
+      for (; m + step < a.M; m += 2 * step) {      // two rows of the (up to) three tensors in flight
+        f16x8 g[2], zz[2], yy[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          g[u] = *(const f16x8*)(a.dz + (m + u * step) * a.dz_stride + cv * 8);
+          zz[u] = g[u]; yy[u] = g[u];
+          if (a.relu) zz[u] = *(const f16x8*)(a.z + (m + u * step) * a.z_stride + cv * 8);
+          if (a.y) yy[u] = *(const f16x8*)(a.y + (m + u * step) * a.y_stride + cv * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float gf = (a.relu && !((float)zz[u][e] > 0.f)) ? 0.f : (float)g[u][e];
+            s0[e] += gf;
+            if (a.y) s1[e] += gf * (((float)yy[u][e] - mu[e]) * is[e]);
+          }
+      }
+    }
+    for (; m < a.M; m += step) {
       if (a.mode == 0) {
         const f16x8 v = *(const f16x8*)(a.y + m * a.y_stride + cv * 8);
 #pragma unroll
@@ -68,19 +102,31 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(ChanRedArgs a) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s0[e]; red[1][threadIdx.x][e] = s1[e]; }
   __syncthreads();
+  // tree over the row lanes of a channel vector (fixed order => deterministic): with few channels (C = 8 ... 32: 256 ... 64
+  // row lanes) one thread summing them all was most of the kernel's time on the small maps
+  for (int n = rows_per_pass; n > 1;) {
+    const int half = (n + 1) >> 1;
+    if (rl + half < n) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[0][threadIdx.x][e] += red[0][threadIdx.x + half * CV][e];
+        red[1][threadIdx.x][e] += red[1][threadIdx.x + half * CV][e];
+      }
+    }
+    __syncthreads();
+    n = half;
+  }
   if (rl == 0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float t0 = 0.f, t1 = 0.f;
-      for (int r = 0; r < rows_per_pass; ++r) { t0 += red[0][r * CV + cv][e]; t1 += red[1][r * CV + cv][e]; }
-      a.partial[((long)blockIdx.x * 2 + 0) * a.C + cv * 8 + e] = t0;
-      a.partial[((long)blockIdx.x * 2 + 1) * a.C + cv * 8 + e] = t1;
+      a.partial[((long)blockIdx.x * 2 + 0) * a.C + cv * 8 + e] = red[0][cv][e];
+      a.partial[((long)blockIdx.x * 2 + 1) * a.C + cv * 8 + e] = red[1][cv][e];
     }
   }
 }
 
 // mode 0: mean/invstd/scale/shift (+ running stats);  mode 1: out0 = sum g (dbeta / dbias), out1 = sum g*xhat (dgamma)
-// one wave per channel: lanes stride over the block partials, fixed-order f64 shuffle reduction (deterministic)
+// threads stride over the block partials, fixed-order f64 shuffle + LDS reduction (deterministic)
 __global__ void __launch_bounds__(256) chan_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, int M,
                                                             int mode, float eps, float momentum,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -88,14 +134,20 @@ __global__ void __launch_bounds__(256) chan_finalize_kernel(const float* __restr
                                                             float* __restrict__ scale, float* __restrict__ shift,
                                                             float* __restrict__ running_mean,
                                                             float* __restrict__ running_var) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
+  // one workgroup per channel (the kernel sits on the step's dependency chain 146 times: with one wave per channel and 16
+  // serial loads per lane it took 6 us)
+  __shared__ double sh[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x;
   double s0 = 0, s1 = 0;
-  for (int b = lane; b < nblocks; b += 64) { s0 += partial[((long)b * 2 + 0) * C + c]; s1 += partial[((long)b * 2 + 1) * C + c]; }
+  for (int b = threadIdx.x; b < nblocks; b += 256) { s0 += partial[((long)b * 2 + 0) * C + c]; s1 += partial[((long)b * 2 + 1) * C + c]; }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_down(s0, o, 64); s1 += __shfl_down(s1, o, 64); }
-  if (lane != 0) return;
+  if (lane == 0) { sh[0][wave] = s0; sh[1][wave] = s1; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  s0 = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+  s1 = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
   if (mode == 0) {
     const double mean = s0 / M;
     double var = s1 / M - mean * mean;
@@ -206,14 +258,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_rows_kernel(const f16* __res
       mu[e] = mean[c]; is[e] = invstd[c]; sc[e] = scale[c]; a0[e] = s0[c] * invM; a1[e] = s1[c] * invM;
     }
   }
-#pragma unroll
-  for (int r = 0; r < BN_ROWS; ++r) {
-    const long m = m0 + (long)r * ppb;
-    if (m >= M) break;
-    const f16x8 g = *(const f16x8*)(dz + m * dz_stride + cv * 8);
-    f16x8 zz = g, yy = g;
-    if (relu) zz = *(const f16x8*)(z + m * z_stride + cv * 8);
-    if (y) yy = *(const f16x8*)(y + m * y_stride + cv * 8);
+  auto finish = [&](long m, const f16x8& g, const f16x8& zz, const f16x8& yy) {
     f16x8 o, gr;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -228,6 +273,34 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_rows_kernel(const f16* __res
     }
     *(f16x8*)(dy + m * dy_stride + cv * 8) = o;
     if (dres) *(f16x8*)(dres + m * dres_stride + cv * 8) = gr;
+  };
+  if (m0 + (long)(BN_ROWS - 1) * ppb < M) {
+    // whole range in bounds: four rows of the three tensors in flight before the first use (a loop with a bounds `break`
+    // keeps one row's loads outstanding per thread and runs at latency x occupancy)
+#pragma unroll
+    for (int r0 = 0; r0 < BN_ROWS; r0 += 4) {
+      f16x8 g[4], zz[4], yy[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long m = m0 + (long)(r0 + u) * ppb;
+        g[u] = *(const f16x8*)(dz + m * dz_stride + cv * 8);
+        zz[u] = g[u]; yy[u] = g[u];
+        if (relu) zz[u] = *(const f16x8*)(z + m * z_stride + cv * 8);
+        if (y) yy[u] = *(const f16x8*)(y + m * y_stride + cv * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) finish(m0 + (long)(r0 + u) * ppb, g[u], zz[u], yy[u]);
+    }
+    return;
+  }
+  for (int r = 0; r < BN_ROWS; ++r) {
+    const long m = m0 + (long)r * ppb;
+    if (m >= M) break;
+    const f16x8 g = *(const f16x8*)(dz + m * dz_stride + cv * 8);
+    f16x8 zz = g, yy = g;
+    if (relu) zz = *(const f16x8*)(z + m * z_stride + cv * 8);
+    if (y) yy = *(const f16x8*)(y + m * y_stride + cv * 8);
+    finish(m, g, zz, yy);
   }
 }
 
@@ -821,7 +894,7 @@ int launch_bn_train_fwd(const f16* y, int y_stride, const f16* res, int res_stri
   a.y = y; a.y_stride = y_stride; a.M = M; a.C = C; a.mode = 0; a.partial = (float*)workspace;
   const int nb = chan_blocks(M, C);
   hipLaunchKernelGGL(chan_reduce_kernel, dim3(nb), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(chan_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)workspace, nb, C, M, 0, eps,
+  hipLaunchKernelGGL(chan_finalize_kernel, dim3(C), dim3(256), 0, s, (const float*)workspace, nb, C, M, 0, eps,
                      momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
   hipLaunchKernelGGL(affine_act_kernel, dim3(nblk256((long)M * (C / 8))), dim3(256), 0, s, y, y_stride, scale, shift, res,
                      res_stride, z, z_stride, (long)M, C, relu);
@@ -840,7 +913,7 @@ int launch_bn_train_bwd(const f16* dz, int dz_stride, const f16* z, int z_stride
   const int nb = chan_blocks(M, C);
   hipLaunchKernelGGL(chan_reduce_kernel, dim3(nb), dim3(256), 0, s, a);
   float* sums = (float*)workspace + (size_t)1024 * 2 * C;   // [2][C]: sum g, sum g*xhat
-  hipLaunchKernelGGL(chan_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)workspace, nb, C, M, 1,
+  hipLaunchKernelGGL(chan_finalize_kernel, dim3(C), dim3(256), 0, s, (const float*)workspace, nb, C, M, 1,
                      grad_mult, 0.f, (const float*)nullptr, (const float*)nullptr, dbeta, dgamma, sums, sums + C,
                      (float*)nullptr, (float*)nullptr);
   const int CV = C / 8;

@@ -314,33 +314,59 @@ __global__ void __launch_bounds__(256) sgd_runs_kernel(float* __restrict__ p, co
                                                        long n, const long* __restrict__ run_end,
                                                        const int* __restrict__ run_lr_index, const float* __restrict__ run_wd,
                                                        const float* __restrict__ lr_table, int nruns, float mom, int first) {
+  // A workgroup owns a contiguous range and a thread walks it in steps of 1024 elements, four at a time: a thread stays
+  // inside one run for many iterations, so the run lookup (a binary search over dependent global loads) is rare.  With a
+  // grid-wide stride every iteration landed in another run and searched again (204 us for 18.6 M parameters).
+  const long per = (((n + gridDim.x - 1) / gridDim.x) + 1023) & ~1023L;
+  const long beg = (long)blockIdx.x * per, end = beg + per < n ? beg + per : n;
   long cur_end = -1;
   float lr = 0.f, wd = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    if (i >= cur_end) {                      // first element, or crossed into a later run: binary search
-      int lo = 0, hi = nruns - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (run_end[mid] > i) hi = mid; else lo = mid + 1;
-      }
-      cur_end = run_end[lo];
-      lr = lr_table[run_lr_index[lo]];
-      wd = run_wd[lo];
+  auto lookup = [&](long i) {
+    int lo = 0, hi = nruns - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (run_end[mid] > i) hi = mid; else lo = mid + 1;
     }
-    float gi = g[i];
-    const float pi = p[i];
-    if (wd != 0.f) gi = gi + wd * pi;
-    const float bi = first ? gi : mom * m[i] + gi;
-    m[i] = bi;
-    p[i] = pi - lr * bi;
+    cur_end = run_end[lo];
+    lr = lr_table[run_lr_index[lo]];
+    wd = run_wd[lo];
+  };
+  for (long i = beg + (long)threadIdx.x * 4; i < end; i += 1024) {
+    if (i >= cur_end) lookup(i);
+    if (i + 4 <= cur_end && i + 4 <= end) {
+      const float4 gv = *(const float4*)(g + i), pv = *(const float4*)(p + i);
+      float4 mv = {0.f, 0.f, 0.f, 0.f};
+      if (!first) mv = *(const float4*)(m + i);
+      const float ge[4] = {gv.x, gv.y, gv.z, gv.w}, pe[4] = {pv.x, pv.y, pv.z, pv.w}, me[4] = {mv.x, mv.y, mv.z, mv.w};
+      float bo[4], po[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float gi = ge[k];
+        if (wd != 0.f) gi = gi + wd * pe[k];
+        bo[k] = first ? gi : mom * me[k] + gi;
+        po[k] = pe[k] - lr * bo[k];
+      }
+      *(float4*)(m + i) = make_float4(bo[0], bo[1], bo[2], bo[3]);
+      *(float4*)(p + i) = make_float4(po[0], po[1], po[2], po[3]);
+    } else {
+      for (long j = i; j < i + 4 && j < end; ++j) {
+        if (j >= cur_end) lookup(j);
+        float gi = g[j];
+        const float pi = p[j];
+        if (wd != 0.f) gi = gi + wd * pi;
+        const float bi = first ? gi : mom * m[j] + gi;
+        m[j] = bi;
+        p[j] = pi - lr * bi;
+      }
+    }
   }
 }
 
 int launch_sgd_runs(float* p, const float* g, float* m, long n, const long* run_end, const int* run_lr_index,
                     const float* run_wd, const float* lr_table, int nruns, float mom, int first, hipStream_t s) {
   if (n == 0 || nruns == 0) return 0;
-  long nb = (n + 255) / 256;
-  if (nb > 8192) nb = 8192;
+  long nb = (n + 1023) / 1024;
+  if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(sgd_runs_kernel, dim3((unsigned)nb), dim3(256), 0, s, p, g, m, n, run_end, run_lr_index, run_wd, lr_table,
                      nruns, mom, first);
   CTDET_LAUNCH_CHECK();
