@@ -1,0 +1,436 @@
+// f32 mode of the conv-shaped contractions (the reference's own arithmetic: fp32 in, fp32 accumulate) on the gfx950
+// f32 matrix pipe: v_mfma_f32_16x16x4_f32 is bit-for-bit a k-ordered f32 fmaf chain at the f32 vector peak
+// (157 TFLOP/s), so this path keeps reference precision while the contraction runs on MFMA.
+//   conv_f32_mfma_kernel   implicit GEMM of any plain conv / Root (multi-source 1x1) / input-dilated conv:
+//                          D[cout][pixel] = sum_k W[cout][k] * im2col(x)[pixel][k], k tap-major; 16-k LDS tiles
+//                          ([row][16 f32] = the same 64-byte swizzled rows as the f16 kernels), LDS-DMA 3-stage ring
+//   dcn_f32_mfma_kernel    DCNv2 (deform_conv_cuda_kernel.cu:666-868 + deform_conv_cuda.cu:874-927): the four bilinear
+//                          corners of a (pixel, tap, 4 channels) are gathered as float4s, blended in f32 exactly as the
+//                          reference's im2col does (val = sum wt_q * v_q; val * mask) and written to the LDS tile the MFMAs
+//                          read -- no `columns` buffer
+//   conv_direct_f32_kernel one thread per (pixel, cout): shapes the vector paths cannot take (Cin or strides not
+//                          multiples of 4 floats)
+// Weights: f32 [Cout_pad][Kpad], k = (r*S + s)*Cin + c, Kpad = roundup(K, 16), zero padded.
+#include "conv_common.h"
+
+template <int BP, int BC, int WP, int WC_>
+__global__ void __launch_bounds__(256) conv_f32_mfma_kernel(const ConvArgs a) {
+  constexpr int KS = 16, EPV = 4;            // k per LDS row (64 bytes), elements per 16-byte vector
+  constexpr int TP = BP / WP / 16;
+  constexpr int TC = BC / WC_ / 16;
+  constexpr int A_LD = BP / 64;
+  constexpr int BCL = BC < 64 ? 64 : BC;
+  constexpr int B_LD = BCL / 64;
+  constexpr int NLOAD = A_LD + B_LD;
+  constexpr int STAGE = (BP + BCL) * 64;
+  constexpr int NST = 3;
+  static_assert(WP * WC_ == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave / WC_, wc = wave % WC_;
+  int m_tile, n_tile;
+  if (!tile_of_block((a.M + BP - 1) / BP, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int m0 = m_tile * BP, n0 = n_tile * BC;
+  const float* __restrict__ x = (const float*)a.x;
+  const float* __restrict__ w = (const float*)a.w;
+  const float* zero = (const float*)g_zero_page;   // opaque: one v_cndmask + ONE DMA per staged row (see conv_igemm.hip)
+  asm volatile("" : "+v"(zero));
+
+  const int lrow = tid >> 2, slot = tid & 3;
+  const int g = slot ^ swz(lrow);
+  int rb[A_LD], rhb[A_LD], rwb[A_LD];
+  unsigned long long tapmask[A_LD];
+  long rowm[A_LD];
+  const int idl = a.in_dil;
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = m0 + lrow + 64 * i;
+    const bool ok = m < a.M;
+    const int mm = ok ? m : 0;
+    const int wo = mm % a.Wo, t = mm / a.Wo;
+    const int ho = t % a.Ho, b = t / a.Ho;
+    const int hb = ho * a.stride - a.pad, wb = wo * a.stride - a.pad;
+    rb[i] = b; rhb[i] = hb; rwb[i] = wb;
+    rowm[i] = ok ? (long)m : -1;
+    unsigned long long mk = 0;
+    if (ok)
+      for (int r = 0; r < a.R; ++r)
+        for (int s2 = 0; s2 < a.S; ++s2) {
+          const int hn = hb + r * a.dil, wn = wb + s2 * a.dil;  // position in the (zero-stuffed) input
+          if (hn >= 0 && wn >= 0 && hn % idl == 0 && wn % idl == 0 && hn / idl < a.H && wn / idl < a.W)
+            mk |= 1ull << (r * a.S + s2);
+        }
+    tapmask[i] = mk;
+  }
+  long b_off[B_LD];
+  bool b_ok[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int L = lrow + 64 * j;
+    const int Lw = L % (16 * TC), wv = L / (16 * TC);
+    const int tt = Lw >> 4, r = Lw & 15;
+    const int cl = wv * 16 * TC + cout_of<TC>(tt, r >> 2, r & 3);
+    b_ok[j] = L < BC;
+    b_off[j] = (long)(n0 + (b_ok[j] ? cl : 0)) * a.Kpad + g * EPV;
+  }
+
+  // per-lane k state (tap-major k): this lane's 4 channels of the current K step sit in tap (tr, ts) at channel c0
+  int c0, tr, ts;
+  {
+    const int kc = g * EPV, tap = kc / a.Cin;
+    c0 = kc - tap * a.Cin;
+    tr = tap / a.S;
+    ts = tap - tr * a.S;
+  }
+  auto advance_k = [&]() {
+    c0 += KS;
+    while (c0 >= a.Cin) {
+      c0 -= a.Cin;
+      if (++ts == a.S) { ts = 0; ++tr; }
+    }
+  };
+
+  auto issue = [&](int kt, int stage) {
+    char* sb = smem + stage * STAGE + wave * 1024;
+    if (a.nsrc > 1) {
+      const int kk = kt * KS + g * EPV;
+      const float* src = (const float*)a.xs[0];
+      int st = a.xs_stride[0], cb0 = 0;
+      if (kk >= a.xs_cend[0]) { src = (const float*)a.xs[1]; st = a.xs_stride[1]; cb0 = a.xs_cend[0]; }
+      if (a.nsrc > 2 && kk >= a.xs_cend[1]) { src = (const float*)a.xs[2]; st = a.xs_stride[2]; cb0 = a.xs_cend[1]; }
+      if (a.nsrc > 3 && kk >= a.xs_cend[2]) { src = (const float*)a.xs[3]; st = a.xs_stride[3]; cb0 = a.xs_cend[2]; }
+      const bool kin = kk < a.Cin;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i)
+        dma16((kin && rowm[i] >= 0) ? src + rowm[i] * st + (kk - cb0) : zero, sb + i * 4096);
+    } else {
+      const int tap = tr * a.S + ts;
+      const bool kin = tr < a.R && c0 < a.Cin;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        const int hi = (rhb[i] + tr * a.dil) / idl, wi = (rwb[i] + ts * a.dil) / idl;
+        dma16((kin && ((tapmask[i] >> tap) & 1ull)) ? x + ((long)(rb[i] * a.H + hi) * a.W + wi) * a.in_stride + c0 : zero,
+              sb + i * 4096);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) dma16(b_ok[j] ? w + b_off[j] + kt * KS : zero, sb + BP * 64 + j * 4096);
+  };
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15;
+  const int frag_off = fr * 64 + (((lane >> 4) ^ swz(fr)) << 4);
+  const int nk = a.Kpad / KS;
+
+  issue(0, 0);
+  advance_k();
+  if (nk > 1) { issue(1, 1); advance_k(); }
+
+  int st_c = 0, st_l = 2;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) { issue(kt + 2, st_l); advance_k(); }
+    const char* base = smem + st_c * STAGE;
+    // a lane's 16 bytes = k {4q .. 4q+3} of its row (q = lane / 16): element e of both fragments is the operand of the
+    // e-th 16x16x4 MFMA of this K step (its k index lane/16 then stands for k = 4q + e on both sides)
+    f32x4 wf[TC], pf[TP];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f32x4*)(base + BP * 64 + (wc * 16 * TC + 16 * c) * 64 + frag_off);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) pf[p] = *(const f32x4*)(base + (wp * 16 * TP + 16 * p) * 64 + frag_off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int p = 0; p < TP; ++p)
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], pf[p][e], acc[p][c], 0, 0, 0);
+    st_c = st_c == NST - 1 ? 0 : st_c + 1;
+    st_l = st_l == NST - 1 ? 0 : st_l + 1;
+  }
+
+  const int q = lane >> 4;
+  const int cb = n0 + wc * 16 * TC;
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int m = m0 + wp * 16 * TP + 16 * p + fr;
+    if (m >= a.M) continue;
+    epilogue_tiles<float, TC>(a, m, cb, q, acc[p]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// DCNv2, f32: Cin % 16 == 0, so the 16 k of a K step belong to one tap; the sampling geometry of a (pixel, tap) is
+// recomputed when the tap changes (every Cin/16 steps) and kept in registers.  Per K step a thread gathers the four
+// corners of its (row, 4 channels) for the NEXT step before the MFMAs of the current one, blends after them and
+// writes the blended float4 where the LDS-DMA of the plain kernel would have put it; weights stream by LDS-DMA.
+// ------------------------------------------------------------------------------------------
+template <int BP, int BC, int WP, int WC_>
+__global__ void __launch_bounds__(256) dcn_f32_mfma_kernel(const ConvArgs a) {
+  constexpr int KS = 16, EPV = 4;
+  constexpr int TP = BP / WP / 16;
+  constexpr int TC = BC / WC_ / 16;
+  constexpr int A_LD = BP / 64;
+  constexpr int BCL = BC < 64 ? 64 : BC;
+  constexpr int B_LD = BCL / 64;
+  constexpr int ASTAGE = BP * 64, WSTAGE = BCL * 64;
+  static_assert(WP * WC_ == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) char smem[2 * ASTAGE + 2 * WSTAGE];
+  char* const smA = smem;
+  char* const smW = smem + 2 * ASTAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave / WC_, wc = wave % WC_;
+  int m_tile, n_tile;
+  if (!tile_of_block((a.M + BP - 1) / BP, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int m0 = m_tile * BP, n0 = n_tile * BC;
+  const float* __restrict__ x = (const float*)a.x;
+  const float* __restrict__ w = (const float*)a.w;
+  const float* zero = (const float*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+
+  const int lrow = tid >> 2, slot = tid & 3;
+  const int g = slot ^ swz(lrow);
+  bool rok[A_LD];
+  int rpix[A_LD], rhb[A_LD], rwb[A_LD];
+  const float* omrow[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = m0 + lrow + 64 * i;
+    rok[i] = m < a.M;
+    const int mm = rok[i] ? m : 0;
+    const int wo = mm % a.Wo, t = mm / a.Wo;
+    const int ho = t % a.Ho, b = t / a.Ho;
+    rpix[i] = b * a.H * a.W;
+    rhb[i] = ho * a.stride - a.pad;
+    rwb[i] = wo * a.stride - a.pad;
+    omrow[i] = a.om + (long)mm * a.om_stride;
+  }
+  long b_off[B_LD];
+  bool b_ok[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int L = lrow + 64 * j;
+    const int Lw = L % (16 * TC), wv = L / (16 * TC);
+    const int tt = Lw >> 4, r = Lw & 15;
+    const int cl = wv * 16 * TC + cout_of<TC>(tt, r >> 2, r & 3);
+    b_ok[j] = L < BC;
+    b_off[j] = (long)(n0 + (b_ok[j] ? cl : 0)) * a.Kpad + g * EPV;
+  }
+
+  int goff[A_LD][4];
+  float gwt[A_LD][4], gmask[A_LD];
+  auto geometry = [&](int tap) {
+    const int tr = tap / a.S, ts = tap - tr * a.S;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      DcnSample sp;
+      dcn_setup(a, rok[i], rpix[i], rhb[i], rwb[i], tr, ts, omrow[i], sp);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { goff[i][q] = sp.off[q]; gwt[i][q] = sp.wt[q]; }
+      gmask[i] = sp.mask;
+    }
+  };
+  f32x4 cv[A_LD][4];
+  auto gather = [&](int c) {   // corners of channels c .. c+3 (this lane's k group of the step)
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        cv[i][q] = goff[i][q] >= 0 ? *(const f32x4*)(x + (long)goff[i][q] + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto blend_store = [&](char* stage) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float val = gwt[i][0] * cv[i][0][j] + gwt[i][1] * cv[i][1][j] + gwt[i][2] * cv[i][2][j] + gwt[i][3] * cv[i][3][j];
+        v[j] = val * gmask[i];
+      }
+      *(f32x4*)(stage + i * 4096 + tid * 16) = v;
+    }
+  };
+  auto issue_w = [&](int kt, char* stage) {
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) dma16(b_ok[j] ? w + b_off[j] + kt * KS : zero, stage + wave * 1024 + j * 4096);
+  };
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15;
+  const int frag_off = fr * 64 + (((lane >> 4) ^ swz(fr)) << 4);
+  const int nk = a.K / KS;          // K = R*S*Cin, Cin % 16 == 0
+  const int spt = a.Cin / KS;       // K steps per tap
+
+  int tap = 0, cstep = 0;           // tap / channel step of the K step whose corners are gathered next
+  geometry(0);
+  gather(g * EPV);
+  issue_w(0, smW);
+  blend_store(smA);
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<0>();
+    __syncthreads();
+    const bool more = kt + 1 < nk;
+    if (more) {
+      issue_w(kt + 1, smW + ((kt + 1) & 1) * WSTAGE);
+      if (++cstep == spt) { cstep = 0; ++tap; geometry(tap); }
+      gather(cstep * KS + g * EPV);
+    }
+    const char* bA = smA + (kt & 1) * ASTAGE;
+    const char* bW = smW + (kt & 1) * WSTAGE;
+    f32x4 wf[TC], pf[TP];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f32x4*)(bW + (wc * 16 * TC + 16 * c) * 64 + frag_off);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) pf[p] = *(const f32x4*)(bA + (wp * 16 * TP + 16 * p) * 64 + frag_off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int p = 0; p < TP; ++p)
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], pf[p][e], acc[p][c], 0, 0, 0);
+    if (more) blend_store(smA + ((kt + 1) & 1) * ASTAGE);
+  }
+
+  const int q = lane >> 4;
+  const int cb = n0 + wc * 16 * TC;
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int m = m0 + wp * 16 * TP + 16 * p + fr;
+    if (m >= a.M) continue;
+    epilogue_tiles<float, TC>(a, m, cb, q, acc[p]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Direct form: one thread per (pixel, cout), f32 FMA chain in k order (any Cin / stride).
+// ------------------------------------------------------------------------------------------
+template <bool DEFORM>
+__global__ void __launch_bounds__(256) conv_direct_f32_kernel(const ConvArgs a) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int CP = (a.Cout + 3) & ~3;
+  if (idx >= (long)a.M * CP) return;
+  const int n = (int)(idx % CP);
+  const int m = (int)(idx / CP);
+  if (n >= a.Cout) return;
+  const float* __restrict__ x = (const float*)a.x;
+  const float* __restrict__ w = (const float*)a.w + (long)n * a.Kpad;
+  const int wo = m % a.Wo, t = m / a.Wo;
+  const int ho = t % a.Ho, b = t / a.Ho;
+  const int pix_base = b * a.H * a.W;
+  const int hb = ho * a.stride - a.pad, wb = wo * a.stride - a.pad;
+  const int idl = a.in_dil;
+  float acc = 0.f;
+  for (int tr = 0; tr < a.R; ++tr)
+    for (int ts = 0; ts < a.S; ++ts) {
+      const float* wk = w + (tr * a.S + ts) * a.Cin;
+      if constexpr (!DEFORM) {
+        const int hn = hb + tr * a.dil, wn = wb + ts * a.dil;
+        if (hn < 0 || wn < 0 || hn % idl || wn % idl) continue;
+        const int hi = hn / idl, wi = wn / idl;
+        if (hi >= a.H || wi >= a.W) continue;
+        if (a.nsrc > 1) {
+          int c = 0;
+          for (int j = 0; j < a.nsrc; ++j) {
+            const float* xp = (const float*)a.xs[j] + (long)m * a.xs_stride[j] - c;
+            for (; c < a.xs_cend[j]; ++c) acc = fmaf(xp[c], wk[c], acc);
+          }
+          continue;
+        }
+        const float* xp = x + (long)(pix_base + hi * a.W + wi) * a.in_stride;
+        for (int c = 0; c < a.Cin; ++c) acc = fmaf(xp[c], wk[c], acc);
+      } else {
+        DcnSample sp;
+        dcn_setup(a, true, pix_base, hb, wb, tr, ts, a.om + (long)m * a.om_stride, sp);
+        for (int c = 0; c < a.Cin; ++c) {
+          const float v1 = sp.off[0] >= 0 ? x[(long)sp.off[0] + c] : 0.f;
+          const float v2 = sp.off[1] >= 0 ? x[(long)sp.off[1] + c] : 0.f;
+          const float v3 = sp.off[2] >= 0 ? x[(long)sp.off[2] + c] : 0.f;
+          const float v4 = sp.off[3] >= 0 ? x[(long)sp.off[3] + c] : 0.f;
+          const float val = sp.wt[0] * v1 + sp.wt[1] * v2 + sp.wt[2] * v3 + sp.wt[3] * v4;
+          acc = fmaf(val * sp.mask, wk[c], acc);
+        }
+      }
+    }
+  float v = acc;
+  if (a.scale) v *= a.scale[n];
+  if (a.bias) v += a.bias[n];
+  if (a.res) v += ((const float*)a.res)[(long)m * a.res_stride + n];
+  if (a.act == CTDET_ACT_RELU) v = fmaxf(v, 0.f);
+  else if (a.act == CTDET_ACT_SIGMOID_CLAMP) v = fminf(fmaxf(ctdet_sigmoid_exact(v), a.clamp_lo), a.clamp_hi);
+  ((float*)a.y)[(long)m * a.out_stride + n] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
+
+static bool f32_vector_ok(const ConvArgs& a, int bc) {
+  if (a.Cin % 4 || a.in_stride % 4 || a.Kpad % 16 || a.Kpad < a.K || a.Cout_pad % bc || a.Cout_pad < a.Cout) return false;
+  if (a.Cout % 4 || a.out_stride % 4 || !aligned16(a.y) || !aligned16(a.w)) return false;
+  if (a.res && (a.res_stride % 4 || !aligned16(a.res))) return false;
+  if (a.R * a.S > 64) return false;
+  if (a.nsrc > 1) {
+    for (int j = 0; j < a.nsrc; ++j)
+      if (a.xs_cend[j] % 4 || a.xs_stride[j] % 4 || !aligned16(a.xs[j])) return false;
+    return true;
+  }
+  return aligned16(a.x);
+}
+
+template <int BP, int BC, int WP, int WC_>
+static int launch_f32_mfma(const ConvArgs& a, bool deform, hipStream_t s) {
+  const int nbx = (a.M + BP - 1) / BP, nby = a.Cout_pad / BC;
+  dim3 grid(8 * ((nbx + 7) / 8) * nby);
+  if (deform)
+    hipLaunchKernelGGL((dcn_f32_mfma_kernel<BP, BC, WP, WC_>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_f32_mfma_kernel<BP, BC, WP, WC_>), grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s) {
+  CTDET_CHECK((long)a.B * a.H * a.W * a.in_stride < (1L << 31), "conv: input too large for 32-bit element offsets");
+  CTDET_CHECK(a.in_dil >= 1 && (!deform || a.in_dil == 1), "conv: bad in_dil %d", a.in_dil);
+  CTDET_CHECK(a.Kpad >= a.K && a.Cout_pad >= a.Cout, "conv(f32): packed weights [%d][%d] too small for Cout=%d K=%d",
+              a.Cout_pad, a.Kpad, a.Cout, a.K);
+  const int bc = pick_bc(a.Cout);
+  const bool vec = f32_vector_ok(a, bc) && (!deform || (a.Cin % 16 == 0 && a.nsrc <= 1));
+  if (vec) {
+    const bool big = ((long)a.M + 255) / 256 * (a.Cout_pad / bc) >= 512;
+    switch (bc) {
+      case 16: return launch_f32_mfma<256, 16, 4, 1>(a, deform, s);
+      case 32: return big ? launch_f32_mfma<256, 32, 4, 1>(a, deform, s) : launch_f32_mfma<128, 32, 4, 1>(a, deform, s);
+      case 64: return big ? launch_f32_mfma<256, 64, 4, 1>(a, deform, s) : launch_f32_mfma<128, 64, 2, 2>(a, deform, s);
+      case 128: return big ? launch_f32_mfma<256, 128, 2, 2>(a, deform, s) : launch_f32_mfma<128, 128, 2, 2>(a, deform, s);
+    }
+  }
+  const int CP = (a.Cout + 3) & ~3;
+  const long total = (long)a.M * CP;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (deform)
+    hipLaunchKernelGGL((conv_direct_f32_kernel<true>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_direct_f32_kernel<false>), grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}

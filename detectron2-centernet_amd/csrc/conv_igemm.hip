@@ -9,188 +9,14 @@
 //   conv_win_kernel, conv_smallc_kernel   the 3/16-channel DLA base layers
 //   dcn_window_kernel     DCNv2 (deform_conv_cuda_kernel.cu:666-868 + deform_conv_cuda.cu:874-927): bilinear gathers from
 //                         an LDS window, blended straight into MFMA operand registers; no `columns` buffer, batch in M
-//   conv_direct_f32_kernel exact-f32 parity mode of all of the above
+//   (the f32 mode of all of the above lives in conv_f32.hip)
 // LDS tiles are [row][32 k] f16 (64-byte rows) with a 16-byte-slot XOR swizzle (swz()) that makes the ds_read_b128
 // fragment reads conflict free; global->LDS goes through LDS-DMA with counted vmcnt waits and one s_barrier per K step.
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
 
-// slot permutation for 64-byte LDS rows read as 16-row fragments by ds_read_b128:
-// rows r and r+4 share banks, so the 4 rows {r, r+4, r+8, r+12} get distinct slot XORs.
-__device__ __forceinline__ int swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
-
-// XCD-aware tile mapping (1-D grid of 8*mchunk*nby workgroups).  Workgroups are dealt round-robin over the 8
-// XCDs, each with a private L2: XCD x gets the contiguous pixel-tile range [x*mchunk, (x+1)*mchunk) and walks it
-// with the cout tile innermost, so workgroups that share an input tile (other cout tiles) or halo rows
-// (neighbouring pixel tiles) run on the same L2 close in time.  Placement only affects speed, never results.
-__device__ __forceinline__ bool tile_of_block(int nbx, int nby, int& m_tile, int& n_tile) {
-  const int lin = blockIdx.x;
-  const int xcd = lin & 7, sq = lin >> 3;
-  const int mchunk = (nbx + 7) >> 3;
-  n_tile = sq % nby;
-  const int m_local = sq / nby;
-  m_tile = xcd * mchunk + m_local;
-  return m_local < mchunk && m_tile < nbx;
-}
-
-struct DcnSample {
-  int off[4];    // element offsets of the 4 corner pixels (already * in_stride), -1 = contributes 0
-  float wt[4];   // bilinear weights
-  float mask;    // sigmoid(mask logit)
-  f16 wm[4];     // f16(wt[q] * mask): the MFMA path blends in packed f16 (v_pk_fma_f16)
-};
-
-// Sampling geometry of one (pixel, tap); follows deform_conv_cuda_kernel.cu:836-861 and :666-699.
-__device__ __forceinline__ void dcn_setup(const ConvArgs& a, bool row_ok, int pix_base, int hb, int wb,
-                                          int tr, int ts, const float* omrow, DcnSample& sp) {
-  sp.off[0] = sp.off[1] = sp.off[2] = sp.off[3] = -1;
-  sp.wt[0] = sp.wt[1] = sp.wt[2] = sp.wt[3] = 0.f;
-  sp.wm[0] = sp.wm[1] = sp.wm[2] = sp.wm[3] = (f16)0.f;
-  sp.mask = 0.f;
-  if (!row_ok || tr >= a.R) return;
-  const int tap = tr * a.S + ts;
-  const float oh = omrow[2 * tap], ow = omrow[2 * tap + 1];
-  const float mraw = omrow[2 * a.R * a.S + tap];
-  sp.mask = a.mask_is_prob ? mraw : ctdet_sigmoid_exact(mraw);
-  const float h_im = (float)(hb + tr * a.dil) + oh;
-  const float w_im = (float)(wb + ts * a.dil) + ow;
-  if (!(h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W)) return;
-  const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-  const int h_high = h_low + 1, w_high = w_low + 1;
-  const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-  const float hh = 1.f - lh, hw = 1.f - lw;
-  sp.wt[0] = hh * hw; sp.wt[1] = hh * lw; sp.wt[2] = lh * hw; sp.wt[3] = lh * lw;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) sp.wm[q] = (f16)(sp.wt[q] * sp.mask);
-  if (h_low >= 0 && w_low >= 0) sp.off[0] = (pix_base + h_low * a.W + w_low) * a.in_stride;
-  if (h_low >= 0 && w_high <= a.W - 1) sp.off[1] = (pix_base + h_low * a.W + w_high) * a.in_stride;
-  if (h_high <= a.H - 1 && w_low >= 0) sp.off[2] = (pix_base + h_high * a.W + w_low) * a.in_stride;
-  if (h_high <= a.H - 1 && w_high <= a.W - 1) sp.off[3] = (pix_base + h_high * a.W + w_high) * a.in_stride;
-}
-
-template <typename TOut>
-__device__ __forceinline__ void epilogue_store4(const ConvArgs& a, int m, int c, f32x4 v) {
-  // c is a multiple of 4; Cout is a multiple of 4 (host guarantees), so a group is all-in or all-out
-  if (c >= a.Cout) return;
-  if (a.scale) { const f32x4 s = *(const f32x4*)(a.scale + c); v = v * s; }
-  if (a.bias) { const f32x4 b = *(const f32x4*)(a.bias + c); v = v + b; }
-  if (a.res) {
-    const TOut* rp = (const TOut*)a.res + (long)m * a.res_stride + c;
-    if constexpr (sizeof(TOut) == 2) {
-      const f16x4 r = *(const f16x4*)rp;
-      v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
-    } else {
-      v = v + *(const f32x4*)rp;
-    }
-  }
-  if (a.act == CTDET_ACT_RELU) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-  } else if (a.act == CTDET_ACT_SIGMOID_CLAMP) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(ctdet_sigmoid_exact(v[j]), a.clamp_lo), a.clamp_hi);
-  }
-  TOut* yp = (TOut*)a.y + (long)m * a.out_stride + c;
-  if constexpr (sizeof(TOut) == 2) {
-    f16x4 o; o[0] = (f16)v[0]; o[1] = (f16)v[1]; o[2] = (f16)v[2]; o[3] = (f16)v[3];
-    *(f16x4*)yp = o;
-  } else {
-    *(f32x4*)yp = v;
-  }
-}
-
-// Cout (relative to the wave's first one) held in accumulator element i of cout tile c by the lanes of quad-group q
-// (q = lane / 16).  Tiles pair up: a lane owns 8 consecutive couts per pair, so one 16-byte store per lane lets the
-// four q-lanes of a pixel write 64 contiguous bytes (whole 32-byte sectors; the 8-byte pieces of the unpaired layout
-// left every sector to be completed by four separate store instructions, and the store tail of a tile cost as much
-// as a dozen K steps).  The weight loaders place LDS row (tile tt, row r) = cout_of(tt, r / 4, r % 4) to match.
-template <int TC>
-__device__ __forceinline__ constexpr int cout_of(int c, int q, int i) {
-  if (TC % 2 == 0) return (c >> 1) * 32 + q * 8 + (c & 1) * 4 + i;
-  return 4 * TC * q + 4 * c + i;
-}
-
-// scale/bias/residual/activation + store of the TC accumulator tiles one lane holds for output pixel m;
-// cbase = first cout of the wave.
-template <typename TOut, int TC>
-__device__ __forceinline__ void epilogue_tiles(const ConvArgs& a, int m, int cbase, int q, const f32x4 (&acc)[TC]) {
-  if constexpr (TC % 2 != 0) {
-#pragma unroll
-    for (int c = 0; c < TC; ++c) epilogue_store4<TOut>(a, m, cbase + cout_of<TC>(c, q, 0), acc[c]);
-  } else {
-    constexpr int VEC = 16 / sizeof(TOut);  // elements per 16-byte store
-    const bool wide = (a.out_stride % VEC) == 0 && (((size_t)a.y) & 15) == 0 &&
-                      (!a.res || ((a.res_stride % VEC) == 0 && (((size_t)a.res) & 15) == 0));
-#pragma unroll
-    for (int h = 0; h < TC / 2; ++h) {
-      const int c0 = cbase + h * 32 + q * 8;
-      if (!wide || c0 + 8 > a.Cout) {
-        epilogue_store4<TOut>(a, m, c0, acc[2 * h]);
-        epilogue_store4<TOut>(a, m, c0 + 4, acc[2 * h + 1]);
-        continue;
-      }
-      f32x4 v0 = acc[2 * h], v1 = acc[2 * h + 1];
-      if (a.scale) { v0 = v0 * *(const f32x4*)(a.scale + c0); v1 = v1 * *(const f32x4*)(a.scale + c0 + 4); }
-      if (a.bias) { v0 = v0 + *(const f32x4*)(a.bias + c0); v1 = v1 + *(const f32x4*)(a.bias + c0 + 4); }
-      if (a.res) {
-        const TOut* rp = (const TOut*)a.res + (long)m * a.res_stride + c0;
-        if constexpr (sizeof(TOut) == 2) {
-          const f16x8 r = *(const f16x8*)rp;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { v0[j] += (float)r[j]; v1[j] += (float)r[4 + j]; }
-        } else {
-          v0 = v0 + *(const f32x4*)rp; v1 = v1 + *(const f32x4*)(rp + 4);
-        }
-      }
-      if (a.act == CTDET_ACT_RELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); }
-      } else if (a.act == CTDET_ACT_SIGMOID_CLAMP) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v0[j] = fminf(fmaxf(ctdet_sigmoid_exact(v0[j]), a.clamp_lo), a.clamp_hi);
-          v1[j] = fminf(fmaxf(ctdet_sigmoid_exact(v1[j]), a.clamp_lo), a.clamp_hi);
-        }
-      }
-      TOut* yp = (TOut*)a.y + (long)m * a.out_stride + c0;
-      if constexpr (sizeof(TOut) == 2) {
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { o[j] = (f16)v0[j]; o[4 + j] = (f16)v1[j]; }
-        *(f16x8*)yp = o;
-      } else {
-        *(f32x4*)yp = v0;
-        *(f32x4*)(yp + 4) = v1;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// LDS-DMA variant for plain convolutions (everything except the DCNv2 sampler): tiles go HBM/L2 -> LDS
-// with global_load_lds_dwordx4 (no staging registers, no ds_write), 3-stage LDS ring, loads two K steps
-// ahead kept in flight across the barrier with a counted s_waitcnt vmcnt (never 0 in the main loop),
-// one raw s_barrier per K step.  Padding / K-tail / rows beyond M read a 16-byte zero page instead of
-// being zero-filled in registers.  The LDS image is the same swizzled [row][32 k] layout as above: the
-// DMA writes lane-linear (wave base + lane*16), so the swizzle lives in which k-group a lane *fetches*.
-// ------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// One 16-byte-per-lane global->LDS DMA (global_load_lds_dwordx4: LDS address = M0 + lane*16).  Issued through inline
-// asm on purpose: the compiler's waitcnt pass treats every LDS read as possibly aliasing every outstanding
-// __builtin_amdgcn_global_load_lds and puts s_waitcnt vmcnt(0) in front of it, which serialises the multi-stage
-// rings below.  All consumers here order DMA -> LDS read themselves (wait_vmcnt<N>() + s_barrier before the first
-// read of a stage, lgkmcnt(0) + s_barrier before a stage is overwritten).
-__device__ __forceinline__ void dma16(const void* g, char* lds_wave_base) {
-  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory", "m0");
-}
+#include "conv_common.h"
 
 template <int BP, int BC, int WP, int WC_, typename TOut>
 __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(const ConvArgs a) {
@@ -1560,74 +1386,8 @@ static int launch_win(const ConvArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Exact-f32 direct form (parity mode): one thread per (pixel, cout), f32 FMA chain in k order.
-// Weights packed [Kpad][Cout_pad] f32.  Used to pin the algorithm against the oracle at 1e-5;
-// the f16 MFMA kernels above are the throughput path.
-// ------------------------------------------------------------------------------------------
-template <bool DEFORM>
-__global__ void __launch_bounds__(256) conv_direct_f32_kernel(const ConvArgs a) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const int CP = (a.Cout + 3) & ~3;
-  if (idx >= (long)a.M * CP) return;
-  const int n = (int)(idx % CP);
-  const int m = (int)(idx / CP);
-  if (n >= a.Cout) return;
-  const float* __restrict__ x = (const float*)a.x;
-  const float* __restrict__ w = (const float*)a.w;
-  const int wo = m % a.Wo, t = m / a.Wo;
-  const int ho = t % a.Ho, b = t / a.Ho;
-  const int pix_base = b * a.H * a.W;
-  const int hb = ho * a.stride - a.pad, wb = wo * a.stride - a.pad;
-  float acc = 0.f;
-  for (int tr = 0; tr < a.R; ++tr)
-    for (int ts = 0; ts < a.S; ++ts) {
-      const float* wk = w + (long)((tr * a.S + ts) * a.Cin) * a.Cout_pad + n;
-      if constexpr (!DEFORM) {
-        const int hi = hb + tr * a.dil, wi = wb + ts * a.dil;
-        if (hi < 0 || hi >= a.H || wi < 0 || wi >= a.W) continue;
-        if (a.nsrc > 1) {
-          int c = 0;
-          for (int j = 0; j < a.nsrc; ++j) {
-            const float* xp = (const float*)a.xs[j] + (long)m * a.xs_stride[j] - c;
-            for (; c < a.xs_cend[j]; ++c) acc = fmaf(xp[c], wk[(long)c * a.Cout_pad], acc);
-          }
-          continue;
-        }
-        const float* xp = x + (long)(pix_base + hi * a.W + wi) * a.in_stride;
-        for (int c = 0; c < a.Cin; ++c) acc = fmaf(xp[c], wk[(long)c * a.Cout_pad], acc);
-      } else {
-        DcnSample sp;
-        dcn_setup(a, true, pix_base, hb, wb, tr, ts, a.om + (long)m * a.om_stride, sp);
-        for (int c = 0; c < a.Cin; ++c) {
-          const float v1 = sp.off[0] >= 0 ? x[(long)sp.off[0] + c] : 0.f;
-          const float v2 = sp.off[1] >= 0 ? x[(long)sp.off[1] + c] : 0.f;
-          const float v3 = sp.off[2] >= 0 ? x[(long)sp.off[2] + c] : 0.f;
-          const float v4 = sp.off[3] >= 0 ? x[(long)sp.off[3] + c] : 0.f;
-          const float val = sp.wt[0] * v1 + sp.wt[1] * v2 + sp.wt[2] * v3 + sp.wt[3] * v4;
-          acc = fmaf(val * sp.mask, wk[(long)c * a.Cout_pad], acc);
-        }
-      }
-    }
-  float v = acc;
-  if (a.scale) v *= a.scale[n];
-  if (a.bias) v += a.bias[n];
-  if (a.res) v += ((const float*)a.res)[(long)m * a.res_stride + n];
-  if (a.act == CTDET_ACT_RELU) v = fmaxf(v, 0.f);
-  else if (a.act == CTDET_ACT_SIGMOID_CLAMP) v = fminf(fmaxf(ctdet_sigmoid_exact(v), a.clamp_lo), a.clamp_hi);
-  ((float*)a.y)[(long)m * a.out_stride + n] = v;
-}
-
-// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-static inline int pick_bc(int cout) {
-  if (cout <= 16) return 16;
-  if (cout <= 32) return 32;
-  if (cout <= 64) return 64;
-  if (cout % 128 == 0) return 128;
-  if (cout % 64 == 0) return 64;
-  return 32;
-}
 
 
 template <int BP, int BC, int WP, int WC_, typename TOut>
@@ -1739,18 +1499,4 @@ int launch_conv_f16(const ConvArgs& a, int out_dtype, bool deform, hipStream_t s
   if (out_dtype == CTDET_F16) return launch_conv_f16_t<f16>(a, deform, s);
   if (out_dtype == CTDET_F32) return launch_conv_f16_t<float>(a, deform, s);
   CTDET_CHECK(false, "conv: bad out dtype %d", out_dtype);
-}
-
-int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s) {
-  CTDET_CHECK(a.in_dil == 1, "conv(f32): input dilation is only implemented on the f16 path");
-  CTDET_CHECK((long)a.B * a.H * a.W * a.in_stride < (1L << 31), "conv: input too large for 32-bit element offsets");
-  const int CP = (a.Cout + 3) & ~3;
-  const long total = (long)a.M * CP;
-  dim3 grid((unsigned)((total + 255) / 256));
-  if (deform)
-    hipLaunchKernelGGL((conv_direct_f32_kernel<true>), grid, dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((conv_direct_f32_kernel<false>), grid, dim3(256), 0, s, a);
-  CTDET_LAUNCH_CHECK();
-  return 0;
 }

@@ -25,9 +25,12 @@ PROFILE_REP = 5   # each profiled launch is issued this many times back to back 
 
 def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
     """mirrors the kernel selection of launch_conv_f16_t() in csrc/conv_igemm.hip"""
-    if p.compute != F16:
-        return "conv_direct_f32<dcn>" if deform else "conv_direct_f32<conv>"
     bc = _lib.lib().ctdet_conv_cout_tile(p.Cout_eff)
+    if p.compute != F16:
+        bp = 256 if ((M + 255) // 256) * (p.Cout_pad // bc) >= 512 else 128
+        if bc == 16:
+            bp = 256
+        return f"{'dcn' if deform else 'conv'}_f32_mfma_kernel<{bp}x{bc}>"
     o = "f16" if out_dt == F16 else "f32"
     if deform:
         return f"dcn_window_kernel<128x{bc},{o}>"
@@ -186,10 +189,12 @@ class PackedConv:
             wp = torch.zeros(self.Cout_pad, self.Kpad, dtype=torch.float16, device=dev)
             wp[:Cout, :K] = w.to(torch.float16)
         else:
-            self.Kpad = K
-            self.Cout_pad = self.Cout_eff
-            wp = torch.zeros(self.Kpad, self.Cout_pad, dtype=torch.float32, device=dev)
-            wp[:K, :Cout] = w.t()
+            # f32 MFMA path: the same [row = cout][k] image as the f16 operand, 16 k per LDS row
+            tile = max(_lib.lib().ctdet_conv_cout_tile(self.Cout_eff), cout_align or 1)
+            self.Kpad = round_up(K, 16)
+            self.Cout_pad = round_up(self.Cout_eff, tile)
+            wp = torch.zeros(self.Cout_pad, self.Kpad, dtype=torch.float32, device=dev)
+            wp[:Cout, :K] = w
         self.w = wp.contiguous()
 
         self.scale = self._pad_vec(scale, 1.0, dev)
@@ -468,8 +473,8 @@ def maxpool3x3s2(x, out=None):
 
 def conv_transpose2d(x, weight, scale, bias, stride, padding, compute, act=ACT_NONE, cache=None):
     """Dense nn.ConvTranspose2d (weight [Cin, Cout, k, k], output_padding 0) + per-channel scale/bias + act on NHWC:
-    a stride-1 convolution with the flipped kernel over the zero-stuffed input (pad k-1-p).  The f16 kernels read
-    the input as zero-stuffed in place (`in_dil`); the exact-f32 mode materialises the stuffed tensor."""
+    a stride-1 convolution with the flipped kernel over the zero-stuffed input (pad k-1-p); the kernels read the
+    input as zero-stuffed in place (`in_dil`)."""
     _require_cuda(x, weight)
     Cin, Cout, k, k2 = weight.shape
     assert k == k2 and x.shape[3] == Cin
@@ -482,13 +487,8 @@ def conv_transpose2d(x, weight, scale, bias, stride, padding, compute, act=ACT_N
     B, H, W, _ = x.shape
     Ho, Wo = (H - 1) * stride - 2 * padding + k, (W - 1) * stride - 2 * padding + k
     out = torch.empty(B, Ho, Wo, p.Cout_eff, dtype=x.dtype, device=x.device)
-    if compute == F16:
-        p.in_dil = stride
-        return conv2d(x, p, out=out, act=act)
-    xd = torch.zeros(B, (H - 1) * stride + 1, (W - 1) * stride + 1, Cin, dtype=x.dtype, device=x.device)
-    xd[:, ::stride, ::stride] = x
-    p.in_dil = 1
-    return conv2d(xd, p, out=out, act=act)
+    p.in_dil = stride
+    return conv2d(x, p, out=out, act=act)
 
 
 def maxpool2x2(x, out=None):

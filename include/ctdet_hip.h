@@ -26,8 +26,9 @@ enum ctdet_act { CTDET_AC_NONE = 0, CTDET_AC_RELU = 1, CTDET_AC_SIGMOID_CLAMP = 
  * compute_dtype F16: x is f16 NHWC, weights f16 packed [Cout_pad][Kpad], k ordered per `korder`,
  *   Kpad = roundup(R*S*Cin, 32), Cout_pad = roundup(Cout, tile) with tile = ctdet_conv_cout_tile(Cout);
  *   MFMA f16 x f16 -> f32 accumulate; y is out_dtype (f16 or f32).
- * compute_dtype F32: x, y f32, weights f32 packed [Kpad][Cout_pad] (any Kpad >= K, Cout_pad >= Cout);
- *   exact f32 FMA chain (parity mode). */
+ * compute_dtype F32 (the reference's own arithmetic): x, y f32, weights f32 packed [Cout_pad][Kpad], k tap-major,
+ *   Kpad = roundup(R*S*Cin, 16), Cout_pad = roundup(Cout, tile); v_mfma_f32_16x16x4_f32 (bit-for-bit a k-ordered
+ *   f32 fma chain) when Cin and the pixel strides are multiples of 4, a scalar f32 chain otherwise. */
 typedef struct ctdet_conv_desc {
   int32_t B, H, W, Cin, in_stride;
   int32_t Cout, Ho, Wo, out_stride;

@@ -1,0 +1,135 @@
+"""f32 mode (the reference's own arithmetic) on the f32 matrix pipe: conv_f32_mfma_kernel / dcn_f32_mfma_kernel /
+the scalar fallback, through the C ABI, against torch's fp32 convolution and the DCNv2 oracle.
+
+Tolerance: 1e-5 of the output scale (f32 sums in a different order; north_star allows 1e-3 on fp32 values).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ctdet_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import detectron2_centernet_amd.ops as ops
+
+    return ops
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def test_conv_f32_random_shapes(ops, dev):
+    """every tile of the f32 MFMA kernel (16..128 couts, 128/256-pixel tiles), Cin below / not dividing the 16-k step,
+    strides, dilation, ragged maps, residual; Cin % 4 != 0 takes the scalar kernel"""
+    rng = np.random.RandomState(2026)
+    for it in range(40):
+        k = int(rng.choice([1, 3, 3, 7]))
+        stride = int(rng.choice([1, 1, 2]))
+        dil = int(rng.choice([1, 1, 2])) if k == 3 else 1
+        Cin = int(rng.choice([3, 4, 6, 8, 12, 16, 20, 32, 64, 96, 128]))
+        Cout = int(rng.choice([2, 4, 16, 27, 32, 40, 64, 80, 128, 132, 256]))
+        B = int(rng.randint(1, 4))
+        H, W = int(rng.randint(5, 45)), int(rng.randint(5, 45))
+        if it % 5 == 0:
+            B, H, W = 5, 56, 64     # enough pixel tiles for the 256-pixel variants
+        use_res, relu = bool(rng.rand() < 0.4), bool(rng.rand() < 0.6)
+        pad = dil * (k // 2)
+        g = torch.Generator().manual_seed(3000 + it)
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        scale = torch.rand(Cout, generator=g) + 0.5
+        bias = torch.randn(Cout, generator=g)
+        ref = F.conv2d(x, w, None, stride, pad, dil) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+        pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=stride, pad=pad, dil=dil, compute=ops.F32)
+        res_d = None
+        if use_res:
+            res = torch.randn(ref.shape, generator=g)
+            ref = ref + res
+            res_d = torch.zeros(ref.shape[0], ref.shape[2], ref.shape[3], pc.Cout_eff)
+            res_d[..., :Cout] = nhwc(res)
+            res_d = res_d.to(dev)
+        if relu:
+            ref = ref.relu()
+        y = ops.conv2d(nhwc(x).to(dev), pc, act=ops.ACT_RELU if relu else ops.ACT_NONE, residual=res_d)
+        got = nchw(y[..., :Cout].cpu())
+        assert got.shape == ref.shape
+        err = (got - ref).abs().max().item()
+        assert err < TOL * max(1.0, ref.abs().max().item()), \
+            f"case {it}: B{B} {H}x{W} {Cin}->{Cout} k{k} s{stride} d{dil} res={use_res}: max err {err}"
+
+
+def test_conv_f32_slices_and_cat(ops, dev):
+    """channel-slice input / output views and Root's multi-source 1x1 (dla.py:86-94) in f32"""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 96, 12, 20, generator=g)
+    w = torch.randn(32, 64, 3, 3, generator=g) / 24
+    ref = F.conv2d(x[:, 16:80], w, None, 1, 1)
+    pc = ops.PackedConv(w.to(dev), None, None, stride=1, pad=1, compute=ops.F32)
+    out = torch.zeros(2, 12, 20, 48, device=dev)
+    ops.conv2d(nhwc(x).to(dev)[..., 16:80], pc, out=out[..., 8:40])
+    assert (nchw(out[..., 8:40].cpu()) - ref).abs().max() < TOL * ref.abs().max()
+    assert out[..., :8].abs().max() == 0 and out[..., 40:].abs().max() == 0
+    rng = np.random.RandomState(9)
+    for it in range(8):
+        n = int(rng.randint(1, 5))
+        cins = [int(rng.choice([4, 8, 12, 16, 32, 64])) for _ in range(n)]
+        Cout = int(rng.choice([16, 40, 64, 128]))
+        B, H, W = int(rng.randint(1, 3)), int(rng.randint(3, 24)), int(rng.randint(3, 24))
+        xs = [torch.randn(B, c, H, W, generator=g) for c in cins]
+        w = torch.randn(Cout, sum(cins), 1, 1, generator=g) / sum(cins) ** 0.5
+        ref = F.conv2d(torch.cat(xs, 1), w).relu()
+        pc = ops.PackedConv(w.to(dev), None, None, compute=ops.F32)
+        y = ops.conv1x1_cat([nhwc(t).to(dev) for t in xs], pc, act=ops.ACT_RELU)
+        err = (nchw(y[..., :Cout].cpu()) - ref).abs().max().item()
+        assert err < TOL * max(1.0, ref.abs().max().item()), f"cat case {it}: {cins}->{Cout}: {err}"
+
+
+def test_conv_transpose_f32(ops, dev):
+    """dense ConvTranspose2d 4x4 s2 p1 (centernet.py:268-293) in f32: the input is read as zero-stuffed in place"""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 32, 9, 11, generator=g)
+    w = torch.randn(32, 24, 4, 4, generator=g) / 16
+    ref = F.conv_transpose2d(x, w, None, stride=2, padding=1)
+    y = ops.conv_transpose2d(nhwc(x).to(dev), w.to(dev), None, None, 2, 1, ops.F32)
+    assert (nchw(y[..., :24].cpu()) - ref).abs().max() < TOL * ref.abs().max()
+
+
+def test_dcnv2_f32_random_shapes(ops, dev):
+    """DCNv2 on the f32 matrix pipe vs the oracle (deform_conv_cuda_kernel.cu:666-868 restated): partial tiles, every cout
+    tile, offsets from zero to far outside the image, exact-integer and border coordinates; Cin % 16 != 0 -> scalar kernel"""
+    rng = np.random.RandomState(77)
+    for it in range(14):
+        Cin = int(rng.choice([16, 32, 64, 128, 24]))
+        Cout = int(rng.choice([8, 16, 40, 64, 128, 132]))
+        B, H, W = int(rng.randint(1, 3)), int(rng.randint(3, 30)), int(rng.randint(3, 40))
+        if it % 6 == 0:
+            B, H, W = 6, 48, 64
+        off_std = float(rng.choice([0.0, 0.7, 2.0, 5.0, 30.0]))
+        g = torch.Generator().manual_seed(700 + it)
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+        om = torch.randn(B, 27, H, W, generator=g)
+        om[:, :18] *= off_std
+        om[:, 0, 0, 0] = -0.0
+        om[:, 1, 0, 0] = -1.0
+        om[:, 2, -1, -1] = 1.0
+        om[:, 3, 1, 1] = 0.5
+        bias = torch.randn(Cout, generator=g)
+        ref = O.dcnv2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, bias, 1, 1, 1).relu()
+        pc = ops.PackedConv(w.to(dev), None, bias.to(dev), stride=1, pad=1, compute=ops.F32)
+        om_d = torch.zeros(B, H, W, 28)
+        om_d[..., :27] = nhwc(om)
+        y = ops.dcnv2(nhwc(x).to(dev), om_d.to(dev), pc, act=ops.ACT_RELU)
+        err = (nchw(y[..., :Cout].cpu()) - ref).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), f"case {it}: B{B} {H}x{W} {Cin}->{Cout} std {off_std}: {err}"
