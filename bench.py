@@ -10,9 +10,13 @@ torch.distributed.run, one rank per GPU) every rank runs the same per-GPU batch 
 (weak scaling, no data-path collective for inference); the timed region is bracketed by barrier +
 torch.cuda.synchronize and the maximum over ranks is reported.
 
-Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel (measured live with
-HIP events around every launch of that kernel in an instrumented eager pass) and the CPU baseline (the
-oracle's port of the reference arithmetic timed on this host's cores, bounded sample).
+Prints ONE JSON line (rank 0): the f16 inference throughput (`value`), the roofline of the dominant kernel
+(measured live with HIP events around every launch in an instrumented eager pass, plus the decode's HBM rate),
+the CPU baseline (the oracle's port of the reference arithmetic timed on this host's cores, bounded sample),
+`accuracy` (this dtype's heat-map error and top-K agreement against the fp32 oracle on the CPU sample), `f32`
+(the same workload at the reference's own precision on the f32 matrix pipe, with its roofline against 157.3
+TFLOP/s and its accuracy) and `train` (BASELINE.json's training half: bs 16 per GPU, whole step, data parallel
+over RCCL when N > 1, with its dominant kernel's roofline and a CPU train-step baseline).
 """
 import argparse
 import json
@@ -60,7 +64,7 @@ VERSION: 2
 """
 
 
-def build_model(precision, device, seed=0):
+def build_model(precision, device, seed=0, calibrate=True):
     import tempfile
 
     from detectron2_centernet_amd.config import get_cfg
@@ -90,7 +94,45 @@ def build_model(precision, device, seed=0):
     # dropped as empty, and the step would end with no detections to post-process.  A constant wh bias gives 12-pixel boxes, so
     # each image yields its full 100 detections (threshold 0.05 < the ~0.1 scores of the -2.19 hm bias).
     model.wh[-1].bias.data.fill_(3.0)
+    if calibrate and torch.device(device).type == "cuda":
+        if precision == "f16":
+            calibrate_batchnorm(model, seed)
+        else:   # the calibration pass runs on the f16 training kernels: take the statistics from an f16 twin (same seed)
+            twin, _ = build_model("f16", device, seed, calibrate=True)
+            model.load_state_dict(twin.state_dict())
     return model, cfg
+
+
+def calibrate_batchnorm(model, seed=0, n_images=4, size=512):
+    """A random-init DLA-34 in eval mode (running_mean 0 / running_var 1) lets the activations collapse layer by layer: the
+    head inputs end up ~1e-6 and the heat map is a constant, on which neither an error figure nor a top-K comparison means
+    anything.  One training-mode forward with momentum 1 sets every BatchNorm's running statistics to the batch statistics
+    of synthetic images, which is what a trained network's look like: O(1) activations at every layer, heat-map logits
+    spread around the -2.19 bias.  Deterministic in `seed` up to f32 reduction order; every consumer (f16 / f32 engines,
+    the CPU oracle) reads the resulting state dict."""
+    from detectron2_centernet_amd import ops
+    from detectron2_centernet_amd.engine import train_step as TS
+
+    if model.backbone_type != "dla34" or model._ctx.compute != ops.F16:
+        return
+    g = torch.Generator().manual_seed(4321 + seed)
+    imgs = torch.randint(0, 256, (n_images, 3, size, size), generator=g, dtype=torch.uint8).to(model.device)
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    saved = [m.momentum for m in bns]
+    was_training = model.training
+    model.train()
+    for m in bns:
+        m.momentum = 1.0
+    try:
+        with torch.no_grad():
+            x = ops.preprocess(imgs, model._mean_host, model._std_host, size, size, out_dtype=model._ctx.dtype)
+            TS.heads(model, TS.dla34(model.backbone, x)[-1])
+    finally:
+        for m, mom in zip(bns, saved):
+            m.momentum = mom
+            m.num_batches_tracked.zero_()
+        model.train(was_training)
+    torch.cuda.synchronize()
 
 
 def synthetic_images(B, size, rank, device):
@@ -98,24 +140,109 @@ def synthetic_images(B, size, rank, device):
     return torch.randint(0, 256, (B, 3, size, size), generator=g, dtype=torch.uint8).to(device)
 
 
-def cpu_baseline(model, cfg, size, n_images=2, reps=3):
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_sample_images(size, n_images=2):
+    g = torch.Generator().manual_seed(99)
+    return [torch.randint(0, 256, (3, size, size), generator=g, dtype=torch.uint8) for _ in range(n_images)]
+
+
+def cpu_baseline(model, cfg, size, n_images=2, warm=2, reps=5, budget_s=40.0):
     """the oracle (CPU port of the reference arithmetic: torch-CPU convs + the DCNv2 restatement + decode) on a
-    bounded sample: BASELINE.json configs[0] = 2 synthetic 512x512 images, forward + decode."""
+    bounded sample: BASELINE.json configs[0] = 2 synthetic 512x512 images, forward + decode; `warm` untimed runs,
+    then up to `reps` timed ones (fewer if `budget_s` of CPU time is used up first; at least 3).
+    Returns (record, oracle outputs of the sample) -- the outputs feed the `accuracy` records."""
     from oracle import model_ref as MR
 
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    g = torch.Generator().manual_seed(99)
-    imgs = [torch.randint(0, 256, (3, size, size), generator=g, dtype=torch.uint8) for _ in range(n_images)]
-    times = []
+    imgs = cpu_sample_images(size, n_images)
+    times, out = [], None
+    t_start = time.perf_counter()
     with torch.no_grad():
-        for _ in range(reps):
+        for i in range(warm + reps):
             t0 = time.perf_counter()
-            MR.centernet_inference(sd, imgs, cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+            out = MR.centernet_inference(sd, imgs, cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, thresh=0.0)
+            if i >= warm:
+                times.append(time.perf_counter() - t0)
+            if len(times) >= 3 and time.perf_counter() - t_start > budget_s:
+                break
+    times.sort()
+    med = times[len(times) // 2]
+    rec = {"value": n_images / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+           "cpu": _cpu_model(), "nproc": os.cpu_count(),
+           "sample": f"{n_images} synthetic {size}x{size} images, forward+decode, {warm} warm-up runs, median of {len(times)} timed"}
+    return rec, out
+
+
+def cpu_train_baseline(model, cfg, size, n_images=1, warm=1, reps=2, budget_s=30.0):
+    """CPU train step of the oracle port (targets + forward in train mode + losses + autograd backward; no optimizer
+    update) on a bounded sample of the bs-16 workload: `n_images` images per step."""
+    from oracle import ctdet_oracle as O
+    from oracle import model_ref as MR
+    from detectron2_centernet_amd.data.catalog import synthetic_sample
+
+    sd0 = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    smp = [synthetic_sample(i, size=size, num_classes=80, max_boxes=32) for i in range(n_images)]
+    x, _ = O.preprocess([d["image"] for d in smp], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 32)
+    times = []
+    t_start = time.perf_counter()
+    for i in range(warm + reps):
+        t0 = time.perf_counter()
+        sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+              for k, v in sd0.items()}
+        targets = [O.gen_heatmap(d["boxes"], d["classes"], size // 4, size // 4, 80) for d in smp]
+        z = MR.centernet_forward(sd, x, training=True)
+        sum(MR.centernet_losses(z, targets, [1.0]).values()).backward()
+        if i >= warm:
             times.append(time.perf_counter() - t0)
+        if len(times) >= 1 and time.perf_counter() - t_start > budget_s:
+            break
     times.sort()
     med = times[len(times) // 2]
     return {"value": n_images / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_images} synthetic {size}x{size} images, forward+decode, median of {reps} (first run included)"}
+            "cpu": _cpu_model(), "nproc": os.cpu_count(),
+            "sample": f"train step (targets+fwd+loss+bwd) on {n_images} synthetic {size}x{size} images (of the 16 per step), "
+                      f"{warm} warm-up, median of {len(times)} timed"}
+
+
+def accuracy_vs_oracle(model, imgs, oracle_out, K=100):
+    """the HIP engine on the cpu_baseline sample against the fp32 oracle's outputs for the same images and weights:
+    post-sigmoid heat-map error and agreement of the top-K (class, position) lists (north_star: within 1e-3 on fp32 heat
+    maps, bit-exact peak indices / top-K)."""
+    from oracle import ctdet_oracle as O
+
+    _res, hm_ref, z = oracle_out
+    thr, model.score_threshold = model.score_threshold, 0.0
+    try:
+        with torch.no_grad():
+            model([{"image": im} for im in imgs])
+    finally:
+        model.score_threshold = thr
+    B, _, H, W = len(imgs), 3, imgs[0].shape[1], imgs[0].shape[2]
+    eng = model._engines[(B, H, W, H, W, torch.uint8)]
+    hm = eng.out[0].float().cpu().permute(0, 3, 1, 2)
+    _b, sc, cl, ind = [t.cpu() for t in eng.dec]
+    _rb, rs, rc, ri = O.ctdet_decode(hm_ref, z["wh"], z["reg"], down_ratio=4, K=K)
+    same = (cl == rc) & (ind.long() == ri)
+    got = [set(zip(cl[b].tolist(), ind[b].tolist())) for b in range(B)]
+    ref = [set(zip(rc[b].tolist(), ri[b].tolist())) for b in range(B)]
+    return {
+        "sample": f"{B} images of the cpu_baseline sample, K={K}, vs the fp32 oracle",
+        "hm_max_abs_err": float((hm - hm_ref).abs().max()),
+        "score_max_abs_err": float((sc - rs).abs().max()),
+        "topk_index_agreement": float(same.float().mean()),            # same (class, position) at the same rank
+        "topk_class_agreement": float((cl == rc).float().mean()),
+        "topk_set_agreement": sum(len(g & r) for g, r in zip(got, ref)) / float(B * K),   # as unordered sets
+    }
 
 
 def roofline_pass(model, images, passes=2):
@@ -135,16 +262,124 @@ def roofline_pass(model, images, passes=2):
             eng()
         ops.PROFILE_ON = False
         torch.cuda.synchronize()
-        for name, flops, e0, e1, _bytes, _info in ops.PROFILE:
-            a = agg.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0})
-            a["ms"] += e0.elapsed_time(e1) / ops.PROFILE_REP
-            a["flops"] += flops
-            a["launches"] += 1
+        _aggregate(ops.PROFILE, agg)
     for a in agg.values():
-        a["ms"] /= passes
-        a["flops"] /= passes
+        for k in ("ms", "flops", "bytes"):
+            a[k] /= passes
         a["launches"] //= passes
     return agg
+
+
+def _aggregate(profile, agg):
+    for name, flops, e0, e1, nbytes, _info, reps in profile:
+        a = agg.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+        a["ms"] += e0.elapsed_time(e1) / reps
+        a["flops"] += flops
+        a["bytes"] += nbytes or 0.0
+        a["launches"] += 1
+    return agg
+
+
+def _traffic_for(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
+    this same command, corrected as MI355X_MICROARCH.md prescribes).  The summary records the sha256 of the kernel sources
+    it was measured on; a summary of other sources is stale and yields null."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "detectron2-centernet_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".h")):
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    cur = h.hexdigest()[:16]
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("csrc_sha16") == cur:
+            return t["bytes_per_launch"].get(kernel), os.path.basename(path)
+    return None, None
+
+
+def roofline_record(agg, peak_tflops, with_traffic):
+    conv = {k: v for k, v in agg.items() if v["flops"] > 0}
+    name, a = max(conv.items(), key=lambda kv: kv[1]["ms"])
+    ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+    total_ms = sum(v["ms"] for v in conv.values())
+    total_fl = sum(v["flops"] for v in conv.values())
+    traffic, src = _traffic_for(name) if with_traffic else (None, None)
+    rec = {
+        "bound": "mfma", "kernel": name, "achieved": ach, "peak": peak_tflops, "unit": "TFLOP/s", "frac": ach / peak_tflops,
+        "traffic": traffic, "traffic_source": src, "launches_per_step": a["launches"], "kernel_ms_per_step": a["ms"],
+        "all_conv_kernels": {"ms_per_step": total_ms, "achieved": total_fl / (total_ms * 1e-3) / 1e12,
+                             "frac": total_fl / (total_ms * 1e-3) / 1e12 / peak_tflops},
+        "per_kernel": {k: {"ms": round(v["ms"], 4), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                           "launches": v["launches"]} for k, v in sorted(conv.items(), key=lambda kv: -kv[1]["ms"])},
+    }
+    d = agg.get("decode")
+    if d is not None:   # peak-NMS + top-K decode: HBM-bound, algorithmic bytes = one read of the heat map
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        rec["decode"] = {"bound": "hbm", "ms_per_step": d["ms"], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": d["bytes"]}
+    return rec
+
+
+def timed_infer(model, images, steps, warmup, dist, backend, device):
+    """serving loop with one step in flight: the next batch is enqueued before the host reads back the previous batch's
+    detection counts and builds its Instances; every step's full result is materialised inside the timed region"""
+    with torch.no_grad():
+        for _ in range(warmup):
+            model.infer_batch_tensor(images)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pending = None
+        for _ in range(steps):
+            h = model.infer_batch_tensor_async(images)
+            if pending is not None:
+                out = pending.result()
+            pending = h
+        out = pending.result()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, out
+
+
+def train_roofline(model, cfg, B, size, rank, device):
+    """one instrumented eager training step (no graph): HIP events around the backward-side launches and every conv"""
+    from detectron2_centernet_amd import ops
+    from detectron2_centernet_amd.engine.bench_train import synthetic_batch
+
+    images, boxes, classes, counts = synthetic_batch(B, size, rank, device)
+    ops.PROFILE.clear()
+    ops.PROFILE_ON = True
+    try:
+        losses = model.train_batch_tensor(images, boxes, classes, counts)
+        sum(losses.values()).backward()
+    finally:
+        ops.PROFILE_ON = False
+    torch.cuda.synchronize()
+    agg = _aggregate(ops.PROFILE, {})
+    ops.PROFILE.clear()
+    model.zero_grad(set_to_none=True)
+    name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    if a["flops"] > 0:
+        ach, peak, unit, bound = a["flops"] / (a["ms"] * 1e-3) / 1e12, MFMA_F16_PEAK_TFLOPS, "TFLOP/s", "mfma"
+    else:
+        ach, peak, unit, bound = a["bytes"] / (a["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+    return {"bound": bound, "kernel": name, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+            "launches_per_step": a["launches"], "kernel_ms_per_step": a["ms"],
+            "per_kernel": {k: {"ms": round(v["ms"], 4), "launches": v["launches"],
+                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                               "GBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}}
 
 
 def main():
@@ -158,6 +393,9 @@ def main():
     ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-f32", action="store_true", help="skip the reference-precision (f32) sub-record")
+    ap.add_argument("--no-train", action="store_true", help="skip the training sub-record")
+    ap.add_argument("--require-graph", action="store_true", help="fail if the training step did not replay as a HIP graph")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -183,44 +421,22 @@ def main():
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
-    B = args.batch or (64 if args.task == "infer" else 16)
     model, cfg = build_model(args.precision, device)
 
     if args.task == "train":
         from detectron2_centernet_amd.engine.bench_train import run_train_bench
-        result = run_train_bench(model, cfg, args, B, rank, world, device, dist)
+        result = run_train_bench(model, cfg, args, args.batch or 16, rank, world, device, dist)
+        if args.require_graph and world == 1 and result["config"]["graph_state"] != "captured":
+            raise SystemExit(f"training step did not replay as a HIP graph: {result['config']['graph_state']}")
     else:
+        B = args.batch or 64
+        headline = B == 64 and args.size == 512
         model.eval()
         images = synthetic_images(B, args.size, rank, device)
-
-        # serving loop with one step in flight: the next batch is enqueued before the host reads back the previous
-        # batch's detection counts and builds its Instances; every step's full result is materialised inside the
-        # timed region (the last one after the loop)
-        with torch.no_grad():
-            for _ in range(args.warmup):
-                model.infer_batch_tensor(images)
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            pending = None
-            for _ in range(args.steps):
-                h = model.infer_batch_tensor_async(images)
-                if pending is not None:
-                    out = pending.result()
-                pending = h
-            out = pending.result()
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            elapsed = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        elapsed, out = timed_infer(model, images, args.steps, args.warmup, dist, backend, device)
         assert len(out) == B
         result = {
-            "metric": "images/sec at 512x512 (infer bs=64)" if (B == 64 and args.size == 512) else
+            "metric": "images/sec at 512x512 (infer bs=64)" if headline else
                       f"images/sec at {args.size}x{args.size} (infer bs={B})",
             "value": world * B * args.steps / elapsed,
             "unit": "images/s",
@@ -238,31 +454,55 @@ def main():
                                    f"{sum(len(o['instances']) for o in out) / max(1, len(out)):.0f} detections per image post-processed",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"replicas x{world}"},
         }
+        peak = MFMA_F16_PEAK_TFLOPS if args.precision == "f16" else FP32_PEAK_TFLOPS
         if rank == 0 and not args.no_roofline:
-            agg = roofline_pass(model, images)
-            name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
-            peak = MFMA_F16_PEAK_TFLOPS if args.precision == "f16" else FP32_PEAK_TFLOPS
-            ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
-            total_ms = sum(v["ms"] for v in agg.values())
-            total_fl = sum(v["flops"] for v in agg.values())
-            # HBM bytes per launch of that kernel: not measurable from inside this process; taken from the committed
-            # PMC summary (profiles/r01_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the same
-            # forward, corrected as MI355X_MICROARCH.md prescribes) when it covers the kernel, else null
-            traffic = None
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
-            if B == 64 and args.size == 512 and os.path.exists(tpath):
-                with open(tpath) as f:
-                    traffic = json.load(f)["bytes_per_launch"].get(name)
-            result["roofline"] = {
-                "bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": traffic, "launches_per_step": a["launches"], "kernel_ms_per_step": a["ms"],
-                "all_conv_kernels": {"ms_per_step": total_ms, "achieved": total_fl / (total_ms * 1e-3) / 1e12,
-                                     "frac": total_fl / (total_ms * 1e-3) / 1e12 / peak},
-                "per_kernel": {k: {"ms": round(v["ms"], 4), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                   "launches": v["launches"]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
-            }
+            result["roofline"] = roofline_record(roofline_pass(model, images), peak, with_traffic=headline)
+        oracle_out = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(model, cfg, args.size)
+            result["cpu_baseline"], oracle_out = cpu_baseline(model, cfg, args.size)
+            # the same two images through the HIP engine: error of this dtype against the reference's fp32 arithmetic
+            result["accuracy"] = accuracy_vs_oracle(model, cpu_sample_images(args.size), oracle_out)
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        model._engines = {}
+        del model
+        torch.cuda.empty_cache()
+
+        # ---- reference precision: the same workload with f32 activations / weights on the f32 matrix pipe
+        if rank == 0 and world == 1 and args.precision == "f16" and not args.no_f32:
+            m32, _ = build_model("f32", device, calibrate=False)   # same seed: the same weights ...
+            m32.load_state_dict(state)                                # ... and the same calibrated BatchNorm statistics
+            m32.eval()
+            st32, wu32 = max(3, args.steps // 5), 2
+            el32, _ = timed_infer(m32, images, st32, wu32, None, backend, device)
+            rec = {"value": B * st32 / el32, "unit": "images/s", "ms_per_step": 1000.0 * el32 / st32, "steps": st32,
+                   "warmup": wu32, "dtype": "f32", "note": "the reference's own arithmetic (fp32 in, fp32 accumulate); peak = "
+                   "157.3 TFLOP/s f32 MFMA: 64x3x512x512 needs >= 26.9 ms per step"}
+            if not args.no_roofline:
+                rec["roofline"] = roofline_record(roofline_pass(m32, images, passes=1), FP32_PEAK_TFLOPS, with_traffic=False)
+            if oracle_out is not None:
+                rec["accuracy"] = accuracy_vs_oracle(m32, cpu_sample_images(args.size), oracle_out)
+            result["f32"] = rec
+            m32._engines = {}
+            del m32
+            torch.cuda.empty_cache()
+
+        # ---- the training half of BASELINE.json's metric (train bs=16/GPU): every rank, data parallel when world > 1
+        if headline and not args.no_train:
+            from detectron2_centernet_amd.engine.bench_train import run_train_bench
+
+            tm, tcfg = build_model("f16", device)
+            targs = argparse.Namespace(steps=max(5, args.steps // 2), warmup=max(4, args.warmup // 2), size=args.size)
+            tr = run_train_bench(tm, tcfg, targs, 16, rank, world, device, dist)
+            rec = {k: tr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "scaling")}
+            rec["graph_state"] = tr["config"]["graph_state"]
+            rec["config"] = tr["config"]
+            if args.require_graph and world == 1 and rec["graph_state"] != "captured":
+                raise SystemExit(f"training step did not replay as a HIP graph: {rec['graph_state']}")
+            if rank == 0 and not args.no_roofline:
+                rec["roofline"] = train_roofline(tm, tcfg, 16, args.size, rank, device)
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                rec["cpu_baseline"] = cpu_train_baseline(tm, tcfg, args.size)
+            result["train"] = rec
 
     if rank == 0:
         print(json.dumps(result))

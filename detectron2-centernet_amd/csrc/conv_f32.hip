@@ -170,13 +170,177 @@ __global__ void __launch_bounds__(256) conv_f32_mfma_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Uniform-K form (Cin and every concat source a multiple of 16): the tap / channel position of a K step is the same
+// for every lane and lives in SGPRs; per lane only a row pointer and a 32-bit tap-validity mask remain, which fits
+// the 128 accumulators of the 256x128 tile into 256 registers -> two workgroups per CU, so one workgroup's LDS-DMA
+// issue, barrier and fragment reads overlap the other's MFMAs.  k stays tap-major (the order of the packed weights).
+// ------------------------------------------------------------------------------------------
+template <int BP, int BC, int WP, int WC_, bool CAT>
+__global__ void __launch_bounds__(256, 2) conv_f32_uk_kernel(const ConvArgs a) {
+  constexpr int KS = 16, EPV = 4;
+  constexpr int TP = BP / WP / 16;
+  constexpr int TC = BC / WC_ / 16;
+  constexpr int A_LD = BP / 64;
+  constexpr int BCL = BC < 64 ? 64 : BC;
+  constexpr int B_LD = BCL / 64;
+  constexpr int NLOAD = A_LD + B_LD;
+  constexpr int STAGE = (BP + BCL) * 64;
+  constexpr int NST = 3;
+  static_assert(WP * WC_ == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave / WC_, wc = wave % WC_;
+  int m_tile, n_tile;
+  if (!tile_of_block((a.M + BP - 1) / BP, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int m0 = m_tile * BP, n0 = n_tile * BC;
+  const float* zero = (const float*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+
+  const int lrow = tid >> 2, slot = tid & 3;
+  const int g = slot ^ swz(lrow);
+
+  const float* rowp[A_LD];  // conv: pixel of tap (0,0) + g*4 channels; cat: row of the current source + g*4
+  unsigned tapmask[A_LD];   // conv: bit t = tap t inside the image; cat: bit 0 = row < M
+  int rowm[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = m0 + lrow + 64 * i;
+    const bool ok = m < a.M;
+    const int mm = ok ? m : 0;
+    rowm[i] = mm;
+    unsigned mk = 0;
+    if constexpr (CAT) {
+      mk = ok ? 1u : 0u;
+      rowp[i] = (const float*)a.xs[0] + (long)mm * a.xs_stride[0] + g * EPV;
+    } else {
+      const int wo = mm % a.Wo, t = mm / a.Wo;
+      const int ho = t % a.Ho, b = t / a.Ho;
+      const int hb = ho * a.stride - a.pad, wb = wo * a.stride - a.pad;
+      if (ok)
+        for (int r = 0; r < a.R; ++r)
+          for (int s2 = 0; s2 < a.S; ++s2) {
+            const int hi = hb + r * a.dil, wi = wb + s2 * a.dil;
+            if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) mk |= 1u << (r * a.S + s2);
+          }
+      rowp[i] = (const float*)a.x + ((long)b * a.H * a.W + (long)hb * a.W + wb) * a.in_stride + g * EPV;
+    }
+    tapmask[i] = mk;
+  }
+  const float* wptr[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int L = lrow + 64 * j;
+    const int Lw = L % (16 * TC), wv = L / (16 * TC);
+    const int tt = Lw >> 4, r = Lw & 15;
+    const int cl = wv * 16 * TC + cout_of<TC>(tt, r >> 2, r & 3);
+    wptr[j] = (const float*)a.w + (long)(n0 + (L < BC ? cl : 0)) * a.Kpad + g * EPV;
+  }
+
+  // uniform K-step state (tap-major): 16 channels further inside the tap, then the next tap of the row, then the next row
+  const long step_s = (long)a.dil * a.in_stride - a.Cin;
+  const long step_r = ((long)a.dil * a.W - (long)(a.S - 1) * a.dil) * a.in_stride - a.Cin;
+  long dlt = 0;
+  unsigned tbit = 1u;
+  int ts = 0, cc = 0;
+  int sj = 0, sleft = CAT ? a.xs_cend[0] : 0;
+  long woff = 0;
+  auto advance_k = [&]() {
+    woff += KS;
+    dlt += KS;
+    if constexpr (CAT) {
+      sleft -= KS;
+      if (sleft == 0 && sj + 1 < a.nsrc) {
+        ++sj;
+        sleft = a.xs_cend[sj] - a.xs_cend[sj - 1];
+        dlt = 0;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) rowp[i] = (const float*)a.xs[sj] + (long)rowm[i] * a.xs_stride[sj] + g * EPV;
+      }
+    } else {
+      cc += KS;
+      if (cc == a.Cin) {
+        cc = 0;
+        tbit <<= 1;
+        if (++ts < a.S) dlt += step_s; else { ts = 0; dlt += step_r; }
+      }
+    }
+  };
+  auto issue = [&](char* sb) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) dma16((tapmask[i] & tbit) ? rowp[i] + dlt : zero, sb + i * 4096);
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) dma16(wptr[j] + woff, sb + BP * 64 + j * 4096);
+  };
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15;
+  const int frag_off = fr * 64 + (((lane >> 4) ^ swz(fr)) << 4);
+  const char* fragA = smem + (wp * 16 * TP) * 64 + frag_off;
+  const char* fragB = smem + BP * 64 + (wc * 16 * TC) * 64 + frag_off;
+  char* dmab = smem + wave * 1024;
+  const int nk = a.K / KS;   // K = R*S*Cin, Cin % 16 == 0
+
+  issue(dmab);
+  advance_k();
+  if (nk > 1) { issue(dmab + STAGE); advance_k(); }
+
+  auto kstep = [&](int kt, auto st_c, auto st_l) {
+    constexpr int ST = decltype(st_c)::value, SL = decltype(st_l)::value;
+    if (kt + 1 < nk) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) { issue(dmab + SL * STAGE); advance_k(); }
+    f32x4 wf[TC];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f32x4*)(fragB + ST * STAGE + c * 1024);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const f32x4 pf = *(const f32x4*)(fragA + ST * STAGE + p * 1024);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], pf[e], acc[p][c], 0, 0, 0);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  int kt = 0;
+  for (; kt + 2 < nk; kt += 3) {
+    kstep(kt, I0{}, I2{});
+    kstep(kt + 1, I1{}, I0{});
+    kstep(kt + 2, I2{}, I1{});
+  }
+  if (kt < nk) { kstep(kt, I0{}, I2{}); ++kt; }
+  if (kt < nk) { kstep(kt, I1{}, I0{}); ++kt; }
+
+  const int q = lane >> 4;
+  const int cb = n0 + wc * 16 * TC;
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int m = m0 + wp * 16 * TP + 16 * p + fr;
+    if (m >= a.M) continue;
+    epilogue_tiles<float, TC>(a, m, cb, q, acc[p]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // DCNv2, f32: Cin % 16 == 0, so the 16 k of a K step belong to one tap; the sampling geometry of a (pixel, tap) is
 // recomputed when the tap changes (every Cin/16 steps) and kept in registers.  Per K step a thread gathers the four
 // corners of its (row, 4 channels) for the NEXT step before the MFMAs of the current one, blends after them and
 // writes the blended float4 where the LDS-DMA of the plain kernel would have put it; weights stream by LDS-DMA.
 // ------------------------------------------------------------------------------------------
 template <int BP, int BC, int WP, int WC_>
-__global__ void __launch_bounds__(256) dcn_f32_mfma_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(256, 2) dcn_f32_mfma_kernel(const ConvArgs a) {
   constexpr int KS = 16, EPV = 4;
   constexpr int TP = BP / WP / 16;
   constexpr int TC = BC / WC_ / 16;
@@ -397,15 +561,39 @@ static bool f32_vector_ok(const ConvArgs& a, int bc) {
 }
 
 template <int BP, int BC, int WP, int WC_>
-static int launch_f32_mfma(const ConvArgs& a, bool deform, hipStream_t s) {
+static int launch_f32_mfma(const ConvArgs& a, int kind, hipStream_t s) {   // kind: 0 generic, 1 uniform-K
   const int nbx = (a.M + BP - 1) / BP, nby = a.Cout_pad / BC;
   dim3 grid(8 * ((nbx + 7) / 8) * nby);
-  if (deform)
-    hipLaunchKernelGGL((dcn_f32_mfma_kernel<BP, BC, WP, WC_>), grid, dim3(256), 0, s, a);
+  if (kind == 1 && a.nsrc > 1)
+    hipLaunchKernelGGL((conv_f32_uk_kernel<BP, BC, WP, WC_, true>), grid, dim3(256), 0, s, a);
+  else if (kind == 1)
+    hipLaunchKernelGGL((conv_f32_uk_kernel<BP, BC, WP, WC_, false>), grid, dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((conv_f32_mfma_kernel<BP, BC, WP, WC_>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
+}
+
+template <int BP, int BC, int WP, int WC_>
+static int launch_f32_dcn(const ConvArgs& a, hipStream_t s) {
+  const int nbx = (a.M + BP - 1) / BP, nby = a.Cout_pad / BC;
+  dim3 grid(8 * ((nbx + 7) / 8) * nby);
+  hipLaunchKernelGGL((dcn_f32_mfma_kernel<BP, BC, WP, WC_>), grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+static bool f32_uniform_k_ok(const ConvArgs& a) {
+  if (a.R * a.S > 32 || a.in_dil != 1 || a.Kpad != a.K) return false;
+  if (a.nsrc > 1) {
+    int prev = 0;
+    for (int j = 0; j < a.nsrc; ++j) {
+      if ((a.xs_cend[j] - prev) % 16) return false;
+      prev = a.xs_cend[j];
+    }
+    return true;
+  }
+  return a.Cin % 16 == 0;
 }
 
 int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s) {
@@ -417,11 +605,20 @@ int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s) {
   const bool vec = f32_vector_ok(a, bc) && (!deform || (a.Cin % 16 == 0 && a.nsrc <= 1));
   if (vec) {
     const bool big = ((long)a.M + 255) / 256 * (a.Cout_pad / bc) >= 512;
+    if (deform) {   // 128-pixel tiles: two or more workgroups per CU cover each other's gather latency
+      switch (bc) {
+        case 16: return launch_f32_dcn<128, 16, 4, 1>(a, s);
+        case 32: return launch_f32_dcn<128, 32, 4, 1>(a, s);
+        case 64: return launch_f32_dcn<128, 64, 2, 2>(a, s);
+        case 128: return launch_f32_dcn<128, 128, 2, 2>(a, s);
+      }
+    }
+    const int kind = f32_uniform_k_ok(a) ? 1 : 0;
     switch (bc) {
-      case 16: return launch_f32_mfma<256, 16, 4, 1>(a, deform, s);
-      case 32: return big ? launch_f32_mfma<256, 32, 4, 1>(a, deform, s) : launch_f32_mfma<128, 32, 4, 1>(a, deform, s);
-      case 64: return big ? launch_f32_mfma<256, 64, 4, 1>(a, deform, s) : launch_f32_mfma<128, 64, 2, 2>(a, deform, s);
-      case 128: return big ? launch_f32_mfma<256, 128, 2, 2>(a, deform, s) : launch_f32_mfma<128, 128, 2, 2>(a, deform, s);
+      case 16: return launch_f32_mfma<256, 16, 4, 1>(a, kind, s);
+      case 32: return big ? launch_f32_mfma<256, 32, 4, 1>(a, kind, s) : launch_f32_mfma<128, 32, 4, 1>(a, kind, s);
+      case 64: return big ? launch_f32_mfma<256, 64, 4, 1>(a, kind, s) : launch_f32_mfma<128, 64, 2, 2>(a, kind, s);
+      case 128: return big ? launch_f32_mfma<256, 128, 2, 2>(a, kind, s) : launch_f32_mfma<128, 128, 2, 2>(a, kind, s);
     }
   }
   const int CP = (a.Cout + 3) & ~3;

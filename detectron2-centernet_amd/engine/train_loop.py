@@ -98,15 +98,30 @@ class SimpleTrainer:
             g["graph"], g["inputs"] = graph, inputs
             g["losses"] = {k: v.detach() for k, v in loss_dict.items()}
             # the capture itself executed nothing: this call's step is the first replay
-        except Exception as e:  # capture is an optimisation: any op that cannot be captured keeps the eager path
+        except RuntimeError as e:
+            # capture is an optimisation, but a failed one must be visible: the step falls back to eager launches, the state
+            # is reported by `graph_state` (bench.py prints it) and the traceback is logged once
+            import logging
             import traceback
             g["failed"] = repr(e)
             g["traceback"] = traceback.format_exc()
+            logging.getLogger(__name__).warning("HIP-graph capture of the training step failed; running eagerly.\n%s",
+                                                g["traceback"])
             torch.cuda.synchronize()
         finally:
             self.reducer.enabled = True
             if gc_on:
                 gc.enable()
+
+    @property
+    def graph_state(self):
+        """"captured": the last tensor step replayed a HIP graph; "failed": a capture raised (eager fallback, traceback
+        logged and kept in _graphs[key]["traceback"]); "eager": no capture attempted (yet)"""
+        states = [("failed" if g.get("failed") else "captured" if g["graph"] is not None else "eager")
+                  for g in self._graphs.values()]
+        if "failed" in states:
+            return "failed"
+        return "captured" if "captured" in states else "eager"
 
     def _finish_step(self, loss_dict):
         losses = sum(loss_dict.values())

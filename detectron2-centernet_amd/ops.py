@@ -17,7 +17,8 @@ from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, F16, F32, U8, ConvDesc,
 _TORCH_DT = {F16: torch.float16, F32: torch.float32}
 
 # bench.py's roofline leg: when PROFILE_ON, every conv-shaped launch is bracketed by HIP events on the
-# launch stream and (kernel instantiation, algorithmic FLOPs, start, end) is appended to PROFILE.
+# launch stream and (kernel instantiation, algorithmic FLOPs, start, end, algorithmic bytes, info, repetitions) is
+# appended to PROFILE.
 PROFILE_ON = False
 PROFILE = []
 PROFILE_REP = 5   # each profiled launch is issued this many times back to back between one event pair
@@ -27,10 +28,12 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
     """mirrors the kernel selection of launch_conv_f16_t() in csrc/conv_igemm.hip"""
     bc = _lib.lib().ctdet_conv_cout_tile(p.Cout_eff)
     if p.compute != F16:
-        bp = 256 if ((M + 255) // 256) * (p.Cout_pad // bc) >= 512 else 128
-        if bc == 16:
-            bp = 256
-        return f"{'dcn' if deform else 'conv'}_f32_mfma_kernel<{bp}x{bc}>"
+        big = ((M + 255) // 256) * (p.Cout_pad // bc) >= 512
+        if deform:
+            return f"dcn_f32_mfma_kernel<128x{bc}>"
+        bp = 256 if (big or bc == 16) else 128
+        uk = p.R * p.S <= 32 and p.in_dil == 1 and p.Kpad == p.K and p.Cin % 16 == 0
+        return f"conv_f32_{'uk' if uk else 'mfma'}_kernel<{bp}x{bc}>"
     o = "f16" if out_dt == F16 else "f32"
     if deform:
         return f"dcn_window_kernel<128x{bc},{o}>"
@@ -77,7 +80,29 @@ class _Prof:
         if self.on:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            PROFILE.append((self.name, self.flops, self.e0, e1, self.bytes, self.info))
+            PROFILE.append((self.name, self.flops, self.e0, e1, self.bytes, self.info, PROFILE_REP))
+
+
+class prof_region:
+    """`with prof_region(name, flops=, nbytes=):` brackets the launches inside with HIP events on the launch stream when
+    PROFILE_ON (bench.py's live per-kernel timing of the decode and of the training step); free otherwise."""
+
+    def __init__(self, name, flops=0.0, nbytes=0.0, info=""):
+        self.rec = (name, flops, nbytes, info) if PROFILE_ON else None
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            name, flops, nbytes, info = self.rec
+            PROFILE.append((name, flops, self.e0, e1, nbytes, info, 1))
+        return False
 
 
 def _stream():
@@ -554,9 +579,10 @@ def decode(heat, wh, reg, K, down_ratio, workspace=None, check_status=False):
     scores = torch.empty(B, K, dtype=torch.float32, device=dev)
     classes = torch.empty(B, K, dtype=torch.int32, device=dev)
     inds = torch.empty(B, K, dtype=torch.int32, device=dev)
-    rc = _lib.lib().ctdet_decode(_ptr(heat), _ptr(wh), _nhwc_stride(wh), _ptr(reg),
-                                 _nhwc_stride(reg) if reg is not None else 0, B, H, W, Cc, K, float(down_ratio),
-                                 _ptr(workspace.buf), _ptr(boxes), _ptr(scores), _ptr(classes), _ptr(inds), _stream())
+    with prof_region("decode", nbytes=float(heat.numel() * 4), info=f"{B}x{H}x{W}x{Cc} K={K}"):
+        rc = _lib.lib().ctdet_decode(_ptr(heat), _ptr(wh), _nhwc_stride(wh), _ptr(reg),
+                                     _nhwc_stride(reg) if reg is not None else 0, B, H, W, Cc, K, float(down_ratio),
+                                     _ptr(workspace.buf), _ptr(boxes), _ptr(scores), _ptr(classes), _ptr(inds), _stream())
     _lib.check(rc, "ctdet_decode")
     if check_status:
         _lib.check(_lib.lib().ctdet_decode_status(_ptr(workspace.buf), B, _stream()), "ctdet_decode_status")

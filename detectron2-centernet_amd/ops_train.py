@@ -73,10 +73,11 @@ def bn_train_fwd(y, gamma, beta, running_mean, running_var, eps, momentum, res=N
     dev = y.device
     z = torch.empty(B, H, W, Cc, dtype=torch.float16, device=dev)
     mean, invstd, scale, shift = (torch.empty(Cc, dtype=torch.float32, device=dev) for _ in range(4))
-    rc = _lib.lib().ctdet_bn_train_fwd(_ptr(y), _nhwc_stride(y), _ptr(res), _nhwc_stride(res) if res is not None else 0,
-                                       _ptr(z), _nhwc_stride(z), B * H * W, Cc, _ptr(gamma), _ptr(beta), float(eps),
-                                       float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd),
-                                       _ptr(scale), _ptr(shift), _ptr(_ws(Cc, dev)), int(relu), _stream())
+    with ops.prof_region("bn_train_fwd", flops=0.0, nbytes=float(B * H * W * Cc * (6 if res is None else 8))):
+        rc = _lib.lib().ctdet_bn_train_fwd(_ptr(y), _nhwc_stride(y), _ptr(res), _nhwc_stride(res) if res is not None else 0,
+                                           _ptr(z), _nhwc_stride(z), B * H * W, Cc, _ptr(gamma), _ptr(beta), float(eps),
+                                           float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd),
+                                           _ptr(scale), _ptr(shift), _ptr(_ws(Cc, dev)), int(relu), _stream())
     _lib.check(rc, "ctdet_bn_train_fwd")
     return z, mean, invstd, scale
 
@@ -90,11 +91,12 @@ def bn_train_bwd(dz, z, y, mean, invstd, scale, relu=True, want_dres=False, grad
     dgb = torch.empty(2, Cc, dtype=torch.float32, device=dev)   # written, not accumulated
     dgamma, dbeta = dgb[0], dgb[1]
     gm = PARAM_GRAD_MULT if grad_mult is None else grad_mult
-    rc = _lib.lib().ctdet_bn_train_bwd(_ptr(dz), _nhwc_stride(dz), _ptr(z), _nhwc_stride(z) if z is not None else 0,
-                                       _ptr(y), _nhwc_stride(y) if y is not None else 0, _ptr(mean), _ptr(invstd),
-                                       _ptr(scale), B * H * W, Cc, int(relu), _ptr(dy), _nhwc_stride(dy), _ptr(dres),
-                                       _nhwc_stride(dres) if dres is not None else 0, _ptr(dgamma), _ptr(dbeta),
-                                       float(gm), _ptr(_ws(Cc, dev)), _stream())
+    with ops.prof_region("bn_train_bwd", flops=0.0, nbytes=float(B * H * W * Cc * 10)):
+        rc = _lib.lib().ctdet_bn_train_bwd(_ptr(dz), _nhwc_stride(dz), _ptr(z), _nhwc_stride(z) if z is not None else 0,
+                                           _ptr(y), _nhwc_stride(y) if y is not None else 0, _ptr(mean), _ptr(invstd),
+                                           _ptr(scale), B * H * W, Cc, int(relu), _ptr(dy), _nhwc_stride(dy), _ptr(dres),
+                                           _nhwc_stride(dres) if dres is not None else 0, _ptr(dgamma), _ptr(dbeta),
+                                           float(gm), _ptr(_ws(Cc, dev)), _stream())
     _lib.check(rc, "ctdet_bn_train_bwd")
     return dy, dres, dgamma, dbeta
 
@@ -109,8 +111,9 @@ def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1, scale=None):
     d.Cout, d.Ho, d.Wo, d.out_stride = Cout, Ho, Wo, _nhwc_stride(dy)
     d.R, d.S, d.stride, d.pad, d.dil = R, S, stride, pad, dil
     dw = _zeros_f32((Cout, R * S * Cin), x.device)
-    rc = _lib.lib().ctdet_conv_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
-                                     float(PARAM_GRAD_MULT if scale is None else scale), _stream())
+    with ops.prof_region(f"conv_wgrad<{R}x{S}>", flops=2.0 * B * Ho * Wo * Cout * R * S * Cin, nbytes=0.0):
+        rc = _lib.lib().ctdet_conv_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
+                                         float(PARAM_GRAD_MULT if scale is None else scale), _stream())
     _lib.check(rc, "ctdet_conv_wgrad")
     return dw
 
@@ -138,7 +141,8 @@ def dwconvT_bwd(x, dz, weight, f):
 def dcn_cols(x, om):
     B, H, W, Cin = x.shape
     col = torch.empty(B, H, W, 9 * Cin, dtype=torch.float16, device=x.device)
-    rc = _lib.lib().ctdet_dcn_cols(_ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(col), B, H, W, Cin, _stream())
+    with ops.prof_region("dcn_cols", flops=0.0, nbytes=float(B * H * W * Cin * (2 + 18) + B * H * W * 27 * 4)):
+        rc = _lib.lib().ctdet_dcn_cols(_ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(col), B, H, W, Cin, _stream())
     _lib.check(rc, "ctdet_dcn_cols")
     return col
 
@@ -147,8 +151,9 @@ def dcn_col2im_coord(dcol, x, om):
     B, H, W, Cin = x.shape
     dx = torch.zeros(B, H, W, Cin, dtype=torch.float32, device=x.device)
     dom = torch.zeros_like(om)
-    rc = _lib.lib().ctdet_dcn_col2im_coord(_ptr(dcol), _ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(dx),
-                                           _ptr(dom), B, H, W, Cin, _stream())
+    with ops.prof_region("dcn_col2im", flops=0.0, nbytes=float(B * H * W * Cin * (18 + 2 + 4) + B * H * W * 27 * 8)):
+        rc = _lib.lib().ctdet_dcn_col2im_coord(_ptr(dcol), _ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(dx),
+                                               _ptr(dom), B, H, W, Cin, _stream())
     _lib.check(rc, "ctdet_dcn_col2im_coord")
     return dx, dom
 

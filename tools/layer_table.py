@@ -28,8 +28,8 @@ torch.cuda.synchronize()
 tot = 0.0
 ideal = 0.0
 print(f"{'us':>8} {'TF/s':>7} {'GB/s':>7} {'frac':>5}  kernel / layer")
-for name, flops, e0, e1, nbytes, info in ops.PROFILE:
-    ms = e0.elapsed_time(e1) / ops.PROFILE_REP
+for name, flops, e0, e1, nbytes, info, reps in ops.PROFILE:
+    ms = e0.elapsed_time(e1) / reps
     t_roof = max(flops / 2.5e15, nbytes / 8e12) * 1e3
     tot += ms
     ideal += t_roof
