@@ -228,7 +228,7 @@ def accuracy_vs_oracle(model, imgs, oracle_out, K=100):
     finally:
         model.score_threshold = thr
     B, _, H, W = len(imgs), 3, imgs[0].shape[1], imgs[0].shape[2]
-    eng = model._engines[(B, H, W, H, W, torch.uint8)]
+    eng = list(model._engines.values())[-1]      # the engine of the call above (most recently used last)
     hm = eng.out[0].float().cpu().permute(0, 3, 1, 2)
     _b, sc, cl, ind = [t.cpu() for t in eng.dec]
     _rb, rs, rc, ri = O.ctdet_decode(hm_ref, z["wh"], z["reg"], down_ratio=4, K=K)

@@ -24,7 +24,8 @@ int launch_maxpool3x3s2(const void*, void*, int, int, int, int, int, int, int, h
 int launch_pack_weights(const float*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_dwconvT_add(const void*, const float*, const void*, void*, int, int, int, int, int, int, int, int, int,
                        hipStream_t);
-size_t decode_workspace_bytes(int B);
+size_t decode_workspace_bytes(int B, int H, int W, int C, int K);
+int decode_status_words(int H, int W, int C, int K, long* ws_words);
 int launch_decode(const DecArgs&, hipStream_t);
 int launch_postprocess(const float*, const float*, const int*, int, int, int, float, const float*, float*, float*, int*,
                        int*, hipStream_t);
@@ -87,7 +88,7 @@ static int fill_args(const ctdet_conv_desc* d, ConvArgs& a) {
 extern "C" {
 
 const char* ctdet_last_error(void) { return g_err; }
-int32_t ctdet_abi_version(void) { return 1; }
+int32_t ctdet_abi_version(void) { return 2; }
 int32_t ctdet_conv_cout_tile(int32_t cout) {
   if (cout <= 16) return 16;
   if (cout <= 32) return 32;
@@ -235,14 +236,17 @@ int32_t ctdet_dwconvT_add(const void* x, const float* w, const void* skip, void*
                             (hipStream_t)stream);
 }
 
-size_t ctdet_decode_workspace_bytes(int32_t B) { return decode_workspace_bytes(B); }
+size_t ctdet_decode_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C, int32_t K) {
+  return decode_workspace_bytes(B, H, W, C, K);
+}
 
-int32_t ctdet_decode(const float* heat, const float* wh, int32_t wh_stride, const float* reg, int32_t reg_stride,
-                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t K, float down_ratio, void* workspace,
-                     float* boxes, float* scores, int32_t* classes, int32_t* inds, void* stream) {
+int32_t ctdet_decode(const float* heat, int32_t heat_stride, const float* wh, int32_t wh_stride, const float* reg,
+                     int32_t reg_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t K, float down_ratio,
+                     void* workspace, float* boxes, float* scores, int32_t* classes, int32_t* inds, void* stream) {
   CTDET_CHECK(heat && wh && workspace && boxes && scores && classes, "decode: null pointer");
+  CTDET_CHECK(B >= 0 && H > 0 && W > 0, "decode: bad shape B=%d H=%d W=%d", B, H, W);
   DecArgs a;
-  a.heat = heat; a.wh = wh; a.reg = reg; a.wh_stride = wh_stride; a.reg_stride = reg_stride;
+  a.heat = heat; a.wh = wh; a.reg = reg; a.heat_stride = heat_stride; a.wh_stride = wh_stride; a.reg_stride = reg_stride;
   a.B = B; a.H = H; a.W = W; a.C = C; a.K = K; a.down_ratio = down_ratio;
   a.ws = (uint32_t*)workspace; a.boxes = boxes; a.scores = scores; a.classes = classes; a.inds = inds;
   return launch_decode(a, (hipStream_t)stream);
@@ -257,16 +261,17 @@ int32_t ctdet_postprocess(const float* boxes, const float* scores, const int32_t
                             out_classes, counts, (hipStream_t)stream);
 }
 
-int32_t ctdet_decode_status(const void* workspace, int32_t B, void* stream) {
-  const size_t per = decode_workspace_bytes(1);
+int32_t ctdet_decode_status(const void* workspace, int32_t B, int32_t H, int32_t W, int32_t C, int32_t K, void* stream) {
+  long words = 0;
+  const int flag = decode_status_words(H, W, C, K, &words);
   for (int b = 0; b < B; ++b) {
     uint32_t st[16];
-    hipError_t e = hipMemcpyAsync(st, (const char*)workspace + per * b, sizeof(st), hipMemcpyDeviceToHost,
+    hipError_t e = hipMemcpyAsync(st, (const char*)workspace + (size_t)words * 4 * b, sizeof(st), hipMemcpyDeviceToHost,
                                   (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     CTDET_CHECK(e == hipSuccess, "decode_status: copy failed: %s", hipGetErrorString(e));
-    if (st[7]) {
-      ctdet_set_error("decode: image %d overflowed the candidate buffer (degenerate heatmap)", b);
+    if (st[flag]) {
+      ctdet_set_error("decode: image %d overflowed the candidate buffer", b);
       return -75;
     }
   }

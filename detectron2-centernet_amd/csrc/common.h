@@ -98,7 +98,7 @@ int launch_dla_base(const BaseArgs& a, hipStream_t s);
 // argument block of the batched decode (decode.hip)
 struct DecArgs {
   const float* heat; const float* wh; const float* reg;
-  int wh_stride, reg_stride;
+  int heat_stride, wh_stride, reg_stride;   // pixel strides (elements)
   int B, H, W, C, K;
   float down_ratio;
   uint32_t* ws;

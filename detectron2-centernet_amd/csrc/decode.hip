@@ -2,252 +2,350 @@
 // Reference: detectron2/modeling/meta_arch/centernet.py:399-405 (_nms, `hmax == heat` exact equality,
 // plateaus all kept), :408-424 (_topk: per-class top-K then top-K of C*K == global top-K),
 // :426-458 (ctdet_decode).  The reference handles batch==1 only and loops over images in Python
-// (:224-233); here the whole batch is one set of launches with no host round trip.
+// (:224-233); here the whole batch is two launches with no host round trip.
 //
-// Layout: heat is f32 NHWC [B,H,W,C] (the layout the head conv writes).  Ordering contract
-// ("canonical order"): score descending, ties by the reference's flat NCHW index
+// Layout: heat is f32 NHWC [B,H,W,heat_stride] (the layout the head conv writes; the first C channels count).
+// Ordering contract ("canonical order"): score descending, ties by the reference's flat NCHW index
 // canon = c*H*W + y*W + x ascending.  torch.topk's own tie order is unspecified, so ties are
 // where a difference is permitted; fixtures are tie-free or assert the canonical rule.
 //
-// Selection = MSD radix select on the key (score bits, ~canon), 4096 bins per level: level 0 uses fine bins
-// over the sigmoid range [2^-15, 2); further levels run only while the bin holding the K-th key has more than
-// DEC_CAP entries (near-constant or tied maps) and early-exit otherwise.  They split what level 0 left: for an
-// interior level-0 bin the low 15 score bits + 24 index bits, for the two clamped end bins the full 32 + 24
-// bits, 12 bits per level.  Then the <= K-1 certain + <= CAP uncertain candidates are sorted by one workgroup
-// per image.
-// HBM traffic: heat is read twice (histogram pass, collect pass), each pass tile by tile so that the 3x3
-// neighbours come from L1.
+// One pass over the heat map (dec_tile_kernel): a workgroup brings an 8x16-pixel tile (+1 pixel halo, all channels) into
+// LDS once, zeroes everything that is not a positive 3x3 peak, and selects the tile's own K best peaks exactly -- MSD
+// radix select on the key (score bits, ~canon), 4096 bins per level, the further levels only while the bin that holds
+// the tile's K-th key is crowded (near-constant or tied maps: every level re-scans LDS, not memory).  A member of
+// the image's top K is a member of its tile's top K, so the <= K-1 + DEC_TILE_SLACK survivors per tile form a small
+// candidate list per image (tens of KB) in which dec_final_kernel (one workgroup per image) repeats the same select,
+// sorts the <= K-1 + DEC_CAP finalists and assembles the boxes.  HBM traffic: the heat map once (halo rows come from
+// L2) + ~1 % for the candidates; the first version read it two to three times in 15 launches.
 #include "common.h"
-#include <stdlib.h>
 
 #define DEC_CAP 2048            // max uncertain candidates carried to the final sort
 #define DEC_NCAND 4096          // sort width (>= K-1 + DEC_CAP)
 #define DEC_HIST 4096           // bins per level
 #define DEC_LEVELS 6            // 1 + ceil(56 / 12)
-// per-image workspace (uint32 words): [0..31] state, [32..32+DEC_HIST) histogram, then candidates (u64)
-#define DEC_ST_WORDS 32
-#define DEC_WS_WORDS (DEC_ST_WORDS + DEC_HIST + 2 * DEC_NCAND)
-enum { ST_RESOLVED = 0, ST_NABOVE = 1, ST_LEVEL = 2, ST_P0 = 3, ST_PR_LO = 4, ST_PR_HI = 5, ST_NCAND = 6,
-       ST_OVERFLOW = 7, ST_TAKEALL = 8 };
+#define DEC_TILE_SLACK 128      // a tile stops refining once its threshold bin holds at most this many keys
+#define DEC_TW 16
+#define DEC_LDS_TILE (60 * 1024)
+// per-image workspace (uint32 words): [0] candidate count, [1] overflow flag, [16..) candidates (u64)
+#define DEC_ST_WORDS 16
+enum { ST_NCAND = 0, ST_OVERFLOW = 1 };
 
 __device__ __forceinline__ int dec_d0(uint32_t bits) {
   const int d = ((int)bits - 0x38000000) >> 15;
   return d < 0 ? 0 : (d > 4095 ? 4095 : d);
 }
-// what is left to order after level 0, left-aligned in 60 bits (5 digits of 12)
-__device__ __forceinline__ uint64_t dec_rest(uint32_t bits, uint32_t canon, bool interior) {
-  const uint64_t inv = (uint64_t)(0xFFFFFFu - canon);
-  return interior ? ((((uint64_t)(bits & 0x7FFFu) << 24) | inv) << 21)   // 39 significant bits
-                  : ((((uint64_t)bits << 24) | inv) << 4);                // 56 significant bits
+__device__ __forceinline__ uint64_t dec_key(uint32_t bits, uint32_t canon) {
+  return ((uint64_t)bits << 24) | (uint64_t)(0xFFFFFFu - canon);     // 56 bits: larger key = better rank
 }
 
-// visits every positive peak of image b handled by this block: f(bits, canon).
-// A block owns a DEC_TH x DEC_TW pixel tile (all channels).  A thread walks a (pixel column, 4-channel vector) down
-// the tile rows with the separable form of the 3x3 max: per row it loads the three horizontal neighbours once
-// (consecutive threads -> consecutive 16-byte vectors), keeps the horizontal maxima of the last three rows in
-// registers, and tests the middle one.  3 (TH+2)/TH loads per element instead of 9, every heat element fetched from
-// L2/HBM about (TH+2)/TH times per pass.  (The first version strode the flat index space over the whole grid with 9
-// loads per element: rocprof showed 7x the heat map in FETCH_SIZE per pass.)
-#define DEC_TH 16
-#define DEC_TW 16
-template <typename F>
-__device__ __forceinline__ void for_each_peak(const DecArgs& a, int b, F f) {
-  const int CV = a.C >> 2;
-  const int strips = (a.W + DEC_TW - 1) / DEC_TW;
-  const int x0 = (blockIdx.x % strips) * DEC_TW, y0 = (blockIdx.x / strips) * DEC_TH;
-  const float* hb = a.heat + (long)b * a.H * a.W * a.C;
-  const int HW = a.H * a.W;
-  const int ncol = DEC_TW * CV;
-  const f32x4 neg = {-1.f, -1.f, -1.f, -1.f};   // below every candidate (only v > 0 can be a peak)
-  for (int i = threadIdx.x; i < ncol; i += blockDim.x) {
-    const int cv = i % CV;
-    const int x = x0 + i / CV;
-    if (x >= a.W) continue;
-    const bool hasl = x > 0, hasr = x + 1 < a.W;
-    const float* col = hb + (long)x * a.C + cv * 4;
-    // horizontal 3-max of a row (and its centre value); rows outside the image contribute nothing
-    auto hrow = [&](int y, f32x4& ctr) {
-      if (y < 0 || y >= a.H) { ctr = neg; return neg; }
-      const float* r = col + (long)y * a.W * a.C;
-      ctr = *(const f32x4*)r;
-      f32x4 m = ctr;
-      if (hasl) { const f32x4 n = *(const f32x4*)(r - a.C);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = n[e] > m[e] ? n[e] : m[e]; }
-      if (hasr) { const f32x4 n = *(const f32x4*)(r + a.C);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = n[e] > m[e] ? n[e] : m[e]; }
-      return m;
+// Exact "K-th largest key" search shared by both kernels: MSD radix select, 12-bit digits.
+// Level 0 bins the score bits finely over the sigmoid range [2^-15, 2) (dec_d0: no pre-pass needed, resolves every map
+// whose values are spread out).  While the bin that holds the K-th key has more than `slack` keys, further levels split
+// it -- on the 12 key bits from the most significant position in which its keys DIFFER downwards (AND / OR of the keys: the
+// common leading bits are skipped, so a plateau of equal scores -- the clamped background of a trained network -- is split
+// by its index bits at once instead of walking through 15 identical score bits first).  All keys of the group agree above
+// the window and the windows of successive levels descend, so "key restricted to the cared bits" orders the group like
+// its digits do.
+// The caller provides visit(f): calls f(bits, canon) for every key of its set (each thread its own share; the set must not
+// change between calls).  Result (uniform across the workgroup): a key is selected iff  d0 > p0  or  (d0 == p0 and
+// (key & care) >= want); the selected set holds `above` keys strictly above the threshold group plus the group's `inbin`
+// keys, above < need <= above + inbin, and inbin <= slack unless the keys cannot be split further (unique keys: never).
+struct DecSel { uint32_t p0; uint64_t care, want; uint32_t above, inbin; bool takeall; };
+
+template <int NT, typename V>
+__device__ __forceinline__ DecSel dec_select(V visit, uint32_t* lh, uint32_t need, uint32_t slack) {
+  constexpr int NW = NT / 64;
+  constexpr int per = DEC_HIST / NT;
+  __shared__ uint32_t wtot[NW];
+  __shared__ uint32_t sh_T, sh_above, sh_cnt;
+  __shared__ unsigned long long sh_and, sh_or;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  DecSel r;
+  r.p0 = 0; r.care = 0; r.want = 0; r.above = 0; r.inbin = 0; r.takeall = false;
+  int dshift = 0;         // the current level's digit is key bits [dshift, dshift + 12) (level >= 1)
+  for (int level = 0; level < 8; ++level) {
+    for (int i = t; i < DEC_HIST; i += NT) lh[i] = 0;
+    __syncthreads();
+    // run-length accumulation: consecutive keys of a thread usually share a bin (heat maps cluster around
+    // sigmoid(bias)); one LDS atomic per run removes most of the same-address serialisation
+    uint32_t run_bin = 0xFFFFFFFFu, run_cnt = 0;
+    auto count = [&](uint32_t bin) {
+      if (bin == run_bin) { ++run_cnt; return; }
+      if (run_cnt) atomicAdd(&lh[run_bin], run_cnt);
+      run_bin = bin; run_cnt = 1;
     };
-    f32x4 c_prev, c_cur, c_next;
-    f32x4 h_prev = hrow(y0 - 1, c_prev);
-    f32x4 h_cur = hrow(y0, c_cur);
-    for (int yl = 0; yl < DEC_TH; ++yl) {
-      const int y = y0 + yl;
-      if (y >= a.H) break;
-      const f32x4 h_next = hrow(y + 1, c_next);
-      const int p = y * a.W + x;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float mx = h_cur[e];
-        mx = h_prev[e] > mx ? h_prev[e] : mx;
-        mx = h_next[e] > mx ? h_next[e] : mx;
-        const float v = c_cur[e];
-        if (v == mx && v > 0.f) f(__float_as_uint(v), (uint32_t)((cv * 4 + e) * HW + p));
-      }
-      h_prev = h_cur; h_cur = h_next; c_cur = c_next;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256) dec_init_kernel(DecArgs a) {
-  uint32_t* ws = a.ws + (long)blockIdx.x * DEC_WS_WORDS;
-  for (int i = threadIdx.x; i < DEC_ST_WORDS + DEC_HIST; i += 256) ws[i] = 0;
-}
-
-__global__ void __launch_bounds__(256) dec_hist_kernel(DecArgs a, int level, int dbg) {
-  extern __shared__ uint32_t lh[];
-  const int b = blockIdx.y;
-  uint32_t* ws = a.ws + (long)b * DEC_WS_WORDS;
-  if (ws[ST_RESOLVED]) return;
-  const int nb = DEC_HIST;
-  for (int i = threadIdx.x; i < nb; i += 256) lh[i] = 0;
-  __syncthreads();
-  const uint32_t p0 = ws[ST_P0];
-  const bool interior = p0 > 0 && p0 < 4095;
-  const uint64_t pr = ((uint64_t)ws[ST_PR_HI] << 32) | ws[ST_PR_LO];
-  // run-length accumulation: a thread walks a pixel column, and real heat maps cluster (most values sit within a few
-  // fine bins around sigmoid(bias)), so consecutive peaks of a thread usually share a bin -- counting the run and issuing
-  // one LDS atomic per run removes most of the same-address serialisation
-  uint32_t run_bin = 0xFFFFFFFFu, run_cnt = 0;
-  auto count = [&](uint32_t bin) {
-    if (bin == run_bin) { ++run_cnt; return; }
+    visit([&](uint32_t bits, uint32_t canon) {
+      const uint32_t d0 = (uint32_t)dec_d0(bits);
+      if (level == 0) { count(d0); return; }
+      if (d0 != r.p0) return;
+      const uint64_t key = dec_key(bits, canon);
+      if ((key & r.care) != r.want) return;
+      const uint32_t dig = (uint32_t)(key >> dshift) & 0xFFFu;
+      count(dig);
+    });
     if (run_cnt) atomicAdd(&lh[run_bin], run_cnt);
-    run_bin = bin; run_cnt = 1;
-  };
-  for_each_peak(a, b, [&](uint32_t bits, uint32_t canon) {
-    if (level == 0) {
-      if (!(dbg & 1)) count((uint32_t)dec_d0(bits));
-    } else {
-      if ((uint32_t)dec_d0(bits) != p0) return;
-      const uint64_t r = dec_rest(bits, canon, interior);
-      if (level > 1 && (r >> (60 - 12 * (level - 1))) != pr) return;
-      count((uint32_t)(r >> (60 - 12 * level)) & 0xFFFu);
+    __syncthreads();
+    // suffix sums over the threads' bin ranges (wave shuffles + one LDS step), then the owner of the crossing bin
+    // publishes it
+    uint32_t loc[per], s = 0;
+#pragma unroll
+    for (int j = 0; j < per; ++j) { loc[j] = lh[t * per + j]; s += loc[j]; }
+    uint32_t suf = s;     // inclusive suffix sum within the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_down(suf, o, 64);
+      if (lane + o < 64) suf += v;
     }
-  });
-  if (run_cnt) atomicAdd(&lh[run_bin], run_cnt);
-  __syncthreads();
-  uint32_t* gh = ws + DEC_ST_WORDS;
-  if (dbg & 2) return;
-  for (int i = threadIdx.x; i < nb; i += 256)
-    if (lh[i]) atomicAdd(&gh[i], lh[i]);
-}
-
-// one workgroup per image: find the digit holding the K-th largest key at this level
-__global__ void __launch_bounds__(1024) dec_scan_kernel(DecArgs a, int level) {
-  __shared__ uint32_t part[1024];
-  __shared__ uint32_t sh_T, sh_above;
-  const int b = blockIdx.x;
-  uint32_t* ws = a.ws + (long)b * DEC_WS_WORDS;
-  if (ws[ST_RESOLVED]) return;
-  uint32_t* gh = ws + DEC_ST_WORDS;
-  const int nb = DEC_HIST;
-  const int per = nb / 1024;  // 4 bins per thread, thread t owns bins [t*per, (t+1)*per)
-  const int t = threadIdx.x;
-  uint32_t loc[4];
-  uint32_t s = 0;
-  for (int j = 0; j < per; ++j) { loc[j] = gh[t * per + j]; s += loc[j]; }
-  part[t] = s;
-  __syncthreads();
-  // inclusive suffix sum over threads (sum of bins owned by threads >= t)
-  for (int off = 1; off < 1024; off <<= 1) {
-    const uint32_t add = (t + off < 1024) ? part[t + off] : 0;
+    if (lane == 0) wtot[wv] = suf;
     __syncthreads();
-    part[t] += add;
-    __syncthreads();
-  }
-  const uint32_t need = (uint32_t)a.K - ws[ST_NABOVE];
-  const uint32_t total = part[0];
-  if (t == 0) { sh_T = 0xFFFFFFFFu; sh_above = 0; }
-  __syncthreads();
-  if (total >= need) {
-    const uint32_t above_me = (t + 1 < 1024) ? part[t + 1] : 0;  // keys in bins of higher threads
-    if (above_me < need && part[t] >= need) {
+    uint32_t higher = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const uint32_t v = wtot[w]; total += v; if (w > wv) higher += v; }
+    const uint32_t incl = suf + higher;          // keys in the bins of threads >= t
+    const uint32_t want_n = need - r.above;
+    if (total < want_n) {   // only possible at level 0: fewer keys than needed
+      r.takeall = true;
+      r.inbin = total;
+      __syncthreads();
+      return r;
+    }
+    const uint32_t above_me = incl - s;
+    if (above_me < want_n && incl >= want_n) {
       uint32_t cum = above_me;
+#pragma unroll
       for (int j = per - 1; j >= 0; --j) {
-        if (cum + loc[j] >= need) { sh_T = t * per + j; sh_above = cum; break; }
+        if (cum + loc[j] >= want_n) { sh_T = t * per + j; sh_above = cum; sh_cnt = loc[j]; break; }
         cum += loc[j];
       }
     }
-  }
-  __syncthreads();
-  for (int j = 0; j < per; ++j) gh[t * per + j] = 0;  // ready for the next level
-  if (t == 0) {
-    if (total < need) {
-      // fewer positive peaks than K (only possible at level 0): take them all
-      ws[ST_TAKEALL] = 1;
-      ws[ST_RESOLVED] = 1;
-      ws[ST_LEVEL] = 0;
-    } else {
-      const uint32_t T = sh_T;
-      ws[ST_NABOVE] += sh_above;
-      ws[ST_LEVEL] = level;
-      if (level == 0) ws[ST_P0] = T;
-      else {
-        const uint64_t pr = (((uint64_t)ws[ST_PR_HI] << 32) | ws[ST_PR_LO]);
-        const uint64_t npr = (level == 1 ? 0ull : (pr << 12)) | T;
-        ws[ST_PR_LO] = (uint32_t)npr;
-        ws[ST_PR_HI] = (uint32_t)(npr >> 32);
-      }
+    if (t == 0) { sh_and = ~0ull; sh_or = 0ull; }
+    __syncthreads();
+    const uint32_t T = sh_T, cnt = sh_cnt;
+    r.above += sh_above;
+    r.inbin = cnt;
+    if (level == 0) r.p0 = T;
+    else {
+      r.care |= 0xFFFull << dshift;
+      r.want |= (uint64_t)T << dshift;
     }
-  }
-  __syncthreads();
-  // the owner of bin T decides whether the uncertain bin fits the final sort
-  if (total >= need && sh_T != 0xFFFFFFFFu && (int)(sh_T / per) == t) {
-    const uint32_t cnt = loc[sh_T % per];
-    if (cnt <= DEC_CAP || level == DEC_LEVELS - 1) {
-      ws[ST_RESOLVED] = 1;
-      if (cnt > DEC_CAP) ws[ST_OVERFLOW] = 1;  // cannot happen: last level keys are unique
+    if (cnt <= slack) break;
+    // the positions in which the keys of the threshold group differ: its 12 highest ones are the next digit
+    uint64_t a_and = ~0ull, a_or = 0ull;
+    visit([&](uint32_t bits, uint32_t canon) {
+      if ((uint32_t)dec_d0(bits) != r.p0) return;
+      const uint64_t key = dec_key(bits, canon);
+      if ((key & r.care) != r.want) return;
+      a_and &= key; a_or |= key;
+    });
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a_and &= __shfl_down((unsigned long long)a_and, o, 64);
+      a_or |= __shfl_down((unsigned long long)a_or, o, 64);
     }
+    if (lane == 0) { atomicAnd(&sh_and, (unsigned long long)a_and); atomicOr(&sh_or, (unsigned long long)a_or); }
+    __syncthreads();
+    uint64_t diff = (sh_and ^ sh_or) & ~r.care & ((1ull << 56) - 1);
+    if (!diff) break;     // identical keys (impossible: canon is unique)
+    const int hi = 63 - __builtin_clzll(diff);
+    dshift = hi >= 11 ? hi - 11 : 0;
+    __syncthreads();
   }
+  return r;
 }
 
-__global__ void __launch_bounds__(256) dec_collect_kernel(DecArgs a) {
+__device__ __forceinline__ bool dec_selected(const DecSel& r, uint32_t bits, uint32_t canon) {
+  if (r.takeall) return true;
+  const uint32_t d0 = (uint32_t)dec_d0(bits);
+  if (d0 != r.p0) return d0 > r.p0;
+  return (dec_key(bits, canon) & r.care) >= r.want;
+}
+
+// geometry of the tile pass: TW = 16 columns, TH rows and CW channels per workgroup.  One thread owns one (tile column
+// incl. halo, 4-channel vector): 18 * CW/4 <= DEC_TNT, and both LDS images -- the (TH+2) x 18 x CW f32 tile and, after
+// the peak test, the compact peak list (u32 score bits + u16 position per possible peak) -- fit DEC_LDS_TILE
+// (C = 80: 8 rows x all channels = 60 KB + 16 KB histogram -> two workgroups per CU)
+#define DEC_TNT 512
+struct DecGeom { int TH, CW, tiles_x, tiles_y, cchunks; };
+static inline DecGeom dec_geom(int H, int W, int C) {
+  DecGeom g;
+  const int C4 = (C + 3) & ~3;
+  g.CW = C4 < 112 ? C4 : 112;
+  g.TH = 8;
+  while (g.TH > 1 && ((g.TH + 2) * (DEC_TW + 2) * g.CW * 4 > DEC_LDS_TILE || g.TH * DEC_TW * g.CW * 6 > DEC_LDS_TILE)) g.TH >>= 1;
+  g.tiles_x = (W + DEC_TW - 1) / DEC_TW;
+  g.tiles_y = (H + g.TH - 1) / g.TH;
+  g.cchunks = (C4 + g.CW - 1) / g.CW;
+  return g;
+}
+
+__global__ void __launch_bounds__(256) dec_init_kernel(DecArgs a, long ws_words) {
+  uint32_t* ws = a.ws + (long)blockIdx.x * ws_words;
+  if (threadIdx.x < DEC_ST_WORDS) ws[threadIdx.x] = 0;
+}
+
+template <int TH>
+__global__ void __launch_bounds__(DEC_TNT, 4) dec_tile_kernel(DecArgs a, int CW, int tiles_x, int tiles_y, long ws_words, int cap) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  uint32_t* lh = (uint32_t*)dsm;                    // DEC_HIST words
+  float* tile = (float*)(dsm + DEC_HIST * 4);       // [(TH+2)*(TW+2)][CW]
+  __shared__ uint32_t sh_base, sh_slot, sh_npk;
   const int b = blockIdx.y;
-  uint32_t* ws = a.ws + (long)b * DEC_WS_WORDS;
-  const int level = (int)ws[ST_LEVEL];
-  const uint32_t p0 = ws[ST_P0];
-  const uint64_t pr = ((uint64_t)ws[ST_PR_HI] << 32) | ws[ST_PR_LO];
-  const bool takeall = ws[ST_TAKEALL] != 0;
-  uint64_t* cand = (uint64_t*)(ws + DEC_ST_WORDS + DEC_HIST);
-  for_each_peak(a, b, [&](uint32_t bits, uint32_t canon) {
-    if (!takeall) {
-      const uint32_t d0 = (uint32_t)dec_d0(bits);
-      if (d0 < p0) return;
-      if (d0 == p0 && level > 0) {
-        const uint64_t r = dec_rest(bits, canon, p0 > 0 && p0 < 4095) >> (60 - 12 * level);
-        if (r < pr) return;
+  const int tx = blockIdx.x % tiles_x, t2 = blockIdx.x / tiles_x;
+  const int ty = t2 % tiles_y, cz = t2 / tiles_y;
+  const int x0 = tx * DEC_TW, y0 = ty * TH, c0 = cz * CW;
+  const int CV = CW >> 2;
+  constexpr int PW = DEC_TW + 2;
+  const int HW = a.H * a.W;
+  const float* hb = a.heat + (long)b * HW * a.heat_stride;
+  const bool vec = (a.heat_stride & 3) == 0;
+  const int t = threadIdx.x, lane = t & 63;
+  // this thread's column of the tile (px = 0 and 17 are the halo columns) and its 4 channels
+  const int px = t / CV, cv = t - px * CV;
+  const bool has_col = px < PW;
+  const int x = x0 + px - 1, c = c0 + cv * 4;
+  if (t == 0) sh_npk = 0;
+
+  // ---- the column, TH + 2 rows, -> LDS; all loads of a thread in flight before the first store (pixels outside the
+  // image and channels >= C read as -1: below every candidate)
+  if (has_col) {
+    f32x4 v[TH + 2];
+    const bool col_ok = x >= 0 && x < a.W && c < a.C;
+#pragma unroll
+    for (int r = 0; r < TH + 2; ++r) {
+      const int y = y0 + r - 1;
+      v[r] = (f32x4){-1.f, -1.f, -1.f, -1.f};
+      if (col_ok && y >= 0 && y < a.H) {
+        const float* src = hb + (long)(y * a.W + x) * a.heat_stride + c;
+        if (vec && c + 4 <= a.C) v[r] = *(const f32x4*)src;
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (c + e < a.C) v[r][e] = src[e];
+        }
       }
     }
-    const uint32_t slot = atomicAdd(&ws[ST_NCAND], 1u);
-    if (slot < DEC_NCAND) cand[slot] = ((uint64_t)bits << 32) | (uint64_t)(0xFFFFFFFFu - canon);
+#pragma unroll
+    for (int r = 0; r < TH + 2; ++r) *(f32x4*)(tile + (long)(r * PW + px) * CW + cv * 4) = v[r];
+  }
+  __syncthreads();
+  // ---- 3x3 peak test, separable: horizontal maxima of the TH + 2 rows, then the vertical maximum of three of them;
+  // exact equality with the window maximum, positive values only.  The centre values stay in registers.
+  f32x4 ctr[TH];
+  uint32_t pk = 0;
+  const bool interior = has_col && px >= 1 && px <= DEC_TW;
+  if (interior) {
+    f32x4 h[TH + 2];
+    const float* colp = tile + (long)px * CW + cv * 4;
+#pragma unroll
+    for (int r = 0; r < TH + 2; ++r) {
+      const float* p = colp + (long)r * PW * CW;
+      const f32x4 cc = *(const f32x4*)p, l = *(const f32x4*)(p - CW), rr = *(const f32x4*)(p + CW);
+      if (r >= 1 && r <= TH) ctr[r - 1] = cc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[r][e] = fmaxf(fmaxf(l[e], cc[e]), rr[e]);
+    }
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float m = fmaxf(fmaxf(h[r][e], h[r + 1][e]), h[r + 2][e]);
+        if (ctr[r][e] == m && ctr[r][e] > 0.f) pk |= 1u << (r * 4 + e);
+      }
+  }
+  __syncthreads();     // every thread has read its neighbours: the tile image may be overwritten
+  // ---- compact list of the tile's peaks in LDS (over the tile image): score bits + position (local channel << 7 | row
+  // << 4 | column).  Later passes cost per PEAK, not per element.
+  uint32_t* pbits = (uint32_t*)tile;
+  uint16_t* ppos = (uint16_t*)(pbits + TH * DEC_TW * CW);
+  {
+    // wave-level stream compaction, slot by slot: the lanes that hold a peak in register slot (r, e) write consecutive list
+    // entries (ballot + prefix count), so the LDS stores of a wave never collide (a per-lane running position strides by
+    // the lane's own peak count: 32-way bank conflicts on a plateau tile)
+    uint32_t total = 0;
+#pragma unroll
+    for (int sl = 0; sl < 4 * TH; ++sl) total += (uint32_t)__popcll(__ballot((pk >> sl) & 1u));
+    uint32_t run = 0;
+    if (lane == 0 && total) run = atomicAdd(&sh_npk, total);
+    run = __shfl(run, 0, 64);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (total) {
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool on = (pk >> (r * 4 + e)) & 1u;
+          const unsigned long long m = __ballot(on);
+          if (on) {
+            const uint32_t pos = run + (uint32_t)__popcll(m & lt);
+            pbits[pos] = __float_as_uint(ctr[r][e]);
+            ppos[pos] = (uint16_t)(((cv * 4 + e) << 7) | (r << 4) | (px - 1));
+          }
+          run += (uint32_t)__popcll(m);
+        }
+    }
+  }
+  __syncthreads();
+  const uint32_t npk = sh_npk;
+  // ---- the tile's own top K (exact superset), every level a scan of the compact list
+  auto visit = [&](auto f) {
+    for (uint32_t i = t; i < npk; i += DEC_TNT) {
+      const uint32_t lp = ppos[i];
+      const uint32_t pos = (uint32_t)((y0 + (int)((lp >> 4) & 7u)) * a.W + x0 + (int)(lp & 15u));
+      f(pbits[i], (uint32_t)(c0 + (int)(lp >> 7)) * (uint32_t)HW + pos);
+    }
+  };
+  const DecSel sel = dec_select<DEC_TNT>(visit, lh, (uint32_t)a.K, DEC_TILE_SLACK);
+  // ---- survivors -> the image's candidate list: one global atomic per tile reserves the range, an LDS counter hands out
+  // the slots
+  uint32_t* ws = a.ws + (long)b * ws_words;
+  if (t == 0) {
+    const uint32_t n = sel.above + sel.inbin;       // takeall: every key of the tile (above = 0, inbin = their number)
+    sh_slot = 0;
+    sh_base = n ? atomicAdd(&ws[ST_NCAND], n) : 0u;
+  }
+  __syncthreads();
+  uint64_t* cand = (uint64_t*)(ws + DEC_ST_WORDS);
+  const uint32_t base = sh_base;
+  visit([&](uint32_t bits, uint32_t canon) {
+    if (!dec_selected(sel, bits, canon)) return;
+    const uint32_t slot = base + atomicAdd(&sh_slot, 1u);
+    if (slot < (uint32_t)cap) cand[slot] = ((uint64_t)bits << 32) | (uint64_t)(0xFFFFFFFFu - canon);
     else ws[ST_OVERFLOW] = 1;
   });
 }
 
-// one workgroup per image: bitonic sort (descending) of the candidates, emit top K
-__global__ void __launch_bounds__(1024) dec_final_kernel(DecArgs a) {
+// one workgroup per image: exact top K of the candidate list, bitonic sort (descending) of the finalists, boxes
+__global__ void __launch_bounds__(1024) dec_final_kernel(DecArgs a, long ws_words, int cap) {
   __shared__ uint64_t keys[DEC_NCAND];
+  __shared__ uint32_t lh[DEC_HIST];
+  __shared__ uint32_t sh_n;
   const int b = blockIdx.x;
-  uint32_t* ws = a.ws + (long)b * DEC_WS_WORDS;
-  const uint64_t* cand = (const uint64_t*)(ws + DEC_ST_WORDS + DEC_HIST);
-  uint32_t n = ws[ST_NCAND];
-  if (n > DEC_NCAND) n = DEC_NCAND;
+  uint32_t* ws = a.ws + (long)b * ws_words;
+  const uint64_t* cand = (const uint64_t*)(ws + DEC_ST_WORDS);
+  uint32_t ncand = ws[ST_NCAND];
+  if (ncand > (uint32_t)cap) ncand = (uint32_t)cap;
   const int t = threadIdx.x;
-  // sort only as wide as needed: next power of two >= n (typically a few hundred candidates, not 4096)
+  auto visit = [&](auto f) {
+    for (uint32_t i = t; i < ncand; i += 1024) {
+      const uint64_t k = cand[i];
+      f((uint32_t)(k >> 32), 0xFFFFFFFFu - (uint32_t)k);
+    }
+  };
+  const DecSel sel = dec_select<1024>(visit, lh, (uint32_t)a.K, DEC_CAP);
+  if (t == 0) sh_n = 0;
+  __syncthreads();
+  visit([&](uint32_t bits, uint32_t canon) {
+    if (!dec_selected(sel, bits, canon)) return;
+    const uint32_t slot = atomicAdd(&sh_n, 1u);
+    if (slot < DEC_NCAND) keys[slot] = ((uint64_t)bits << 32) | (uint64_t)(0xFFFFFFFFu - canon);
+    else ws[ST_OVERFLOW] = 1;     // cannot happen: <= K-1 + DEC_CAP by construction
+  });
+  __syncthreads();
+  uint32_t n = sh_n;
+  if (n > DEC_NCAND) n = DEC_NCAND;
+  // sort only as wide as needed: next power of two >= n (typically a few hundred finalists, not 4096)
   int NS = 256;
   while ((uint32_t)NS < n) NS <<= 1;
-  for (int i = t; i < NS; i += 1024) keys[i] = (uint32_t)i < n ? cand[i] : 0ull;
+  for (int i = t; i < NS; i += 1024) if ((uint32_t)i >= n) keys[i] = 0ull;
   __syncthreads();
   for (int k = 2; k <= NS; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -340,24 +438,40 @@ int launch_postprocess(const float* boxes, const float* scores, const int* class
   return 0;
 }
 
-size_t decode_workspace_bytes(int B) { return (size_t)B * DEC_WS_WORDS * sizeof(uint32_t); }
+// candidates an image can produce: every tile keeps at most K-1 + DEC_TILE_SLACK
+static long dec_cap(int H, int W, int C, int K) {
+  const DecGeom g = dec_geom(H, W, C);
+  return (long)g.tiles_x * g.tiles_y * g.cchunks * (K - 1 + DEC_TILE_SLACK);
+}
+static long dec_ws_words(int H, int W, int C, int K) { return DEC_ST_WORDS + 2 * dec_cap(H, W, C, K); }
+
+size_t decode_workspace_bytes(int B, int H, int W, int C, int K) {
+  return (size_t)B * dec_ws_words(H, W, C, K) * sizeof(uint32_t);
+}
+int decode_status_words(int H, int W, int C, int K, long* ws_words) { *ws_words = dec_ws_words(H, W, C, K); return ST_OVERFLOW; }
 
 int launch_decode(const DecArgs& a, hipStream_t s) {
-  CTDET_CHECK(a.C % 4 == 0, "decode: C=%d must be a multiple of 4", a.C);
+  CTDET_CHECK(a.C >= 1 && a.heat_stride >= a.C, "decode: C=%d / heat_stride=%d invalid", a.C, a.heat_stride);
   CTDET_CHECK(a.K >= 1 && a.K <= 1024 && a.K - 1 + DEC_CAP <= DEC_NCAND, "decode: K=%d out of range", a.K);
   CTDET_CHECK((long)a.C * a.H * a.W < (1L << 24), "decode: C*H*W too large for the 24-bit index field");
   CTDET_CHECK(((uintptr_t)a.heat & 15) == 0, "decode: heat must be 16-byte aligned");
   if (a.B == 0) return 0;
-  const int chunks = ((a.H + DEC_TH - 1) / DEC_TH) * ((a.W + DEC_TW - 1) / DEC_TW);  // pixel tiles per image
-  hipLaunchKernelGGL(dec_init_kernel, dim3(a.B), dim3(256), 0, s, a);
-  for (int level = 0; level < DEC_LEVELS; ++level) {
-    const size_t lds = DEC_HIST * sizeof(uint32_t);
-    static const int dbg = getenv("CTDET_DEC_DEBUG") ? atoi(getenv("CTDET_DEC_DEBUG")) : 0;
-    hipLaunchKernelGGL(dec_hist_kernel, dim3(chunks, a.B), dim3(256), lds, s, a, level, dbg);
-    hipLaunchKernelGGL(dec_scan_kernel, dim3(a.B), dim3(1024), 0, s, a, level);
+  const DecGeom g = dec_geom(a.H, a.W, a.C);
+  const long words = dec_ws_words(a.H, a.W, a.C, a.K);
+  const long cap = dec_cap(a.H, a.W, a.C, a.K);
+  CTDET_CHECK(cap < (1L << 31), "decode: candidate list too large");
+  const size_t tile_b = (size_t)(g.TH + 2) * (DEC_TW + 2) * g.CW * 4, list_b = (size_t)g.TH * DEC_TW * g.CW * 6;
+  const size_t lds = DEC_HIST * 4 + (tile_b > list_b ? tile_b : list_b);
+  CTDET_CHECK((DEC_TW + 2) * (g.CW / 4) <= DEC_TNT && g.CW <= 112, "decode: tile geometry");
+  hipLaunchKernelGGL(dec_init_kernel, dim3(a.B), dim3(256), 0, s, a, words);
+  const dim3 grid(g.tiles_x * g.tiles_y * g.cchunks, a.B);
+  switch (g.TH) {
+    case 8: hipLaunchKernelGGL(dec_tile_kernel<8>, grid, dim3(DEC_TNT), lds, s, a, g.CW, g.tiles_x, g.tiles_y, words, (int)cap); break;
+    case 4: hipLaunchKernelGGL(dec_tile_kernel<4>, grid, dim3(DEC_TNT), lds, s, a, g.CW, g.tiles_x, g.tiles_y, words, (int)cap); break;
+    case 2: hipLaunchKernelGGL(dec_tile_kernel<2>, grid, dim3(DEC_TNT), lds, s, a, g.CW, g.tiles_x, g.tiles_y, words, (int)cap); break;
+    default: hipLaunchKernelGGL(dec_tile_kernel<1>, grid, dim3(DEC_TNT), lds, s, a, g.CW, g.tiles_x, g.tiles_y, words, (int)cap); break;
   }
-  hipLaunchKernelGGL(dec_collect_kernel, dim3(chunks, a.B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(dec_final_kernel, dim3(a.B), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(dec_final_kernel, dim3(a.B), dim3(1024), 0, s, a, words, (int)cap);
   CTDET_LAUNCH_CHECK();
   return 0;
 }

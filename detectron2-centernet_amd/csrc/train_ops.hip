@@ -74,6 +74,14 @@ __global__ void __launch_bounds__(256) gaussian_targets_kernel(const float* __re
   const int radius = radius_raw > 0 ? radius_raw : 0;
   const float ctx = (bx0 + bx1) / 2.f, cty = (by0 + by1) / 2.f;
   const int cx = (int)ctx, cy = (int)cty;  // astype(int32): truncation toward zero
+  if (cx < 0 || cx >= W || cy < 0 || cy >= H || ctx < 0.f || cty < 0.f) {
+    // a box whose centre lies outside the map (unclipped annotations): the reference's gather raises an index error for
+    // it (centernet.py:392-397); here the object is dropped instead of writing through an out-of-range index
+    if (threadIdx.x == 0) {
+      wh[o * 2] = 0.f; wh[o * 2 + 1] = 0.f; reg[o * 2] = 0.f; reg[o * 2 + 1] = 0.f; ind[o] = 0; reg_mask[o] = 0;
+    }
+    return;
+  }
   if (threadIdx.x == 0) {
     wh[o * 2] = w; wh[o * 2 + 1] = h;
     ind[o] = (int64_t)cy * W + cx;
@@ -146,12 +154,13 @@ __global__ void __launch_bounds__(256) focal_main_kernel(const float* __restrict
     f32x4 gr = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+      const int ce = c0 + e < C ? c0 + e : c0 + e - C;   // any class count: a vector may straddle two pixels
       const float s = ctdet_sigmoid_exact(x[e]);
       const float p = fminf(fmaxf(s, 1e-4f), 1.f - 1e-4f);
       const float dpdx = (s >= 1e-4f && s <= 1.f - 1e-4f) ? s * (1.f - s) : 0.f;
       float dLdp = 0.f;
       if (g[e] == 1.f) {
-        const float a = alpha[c0 + e], lp = logf(p), q = 1.f - p;
+        const float a = alpha[ce % C], lp = logf(p), q = 1.f - p;
         pos += a * (lp * (q * q));
         npos += 1.f;
         if (GRAD) dLdp = a * (q * q / p - 2.f * q * lp);
@@ -220,7 +229,7 @@ size_t focal_workspace_bytes(long numel) {
 int launch_focal_loss(const float* logits, const float* gt, const float* alpha, int B, int H, int W, int C,
                       float grad_scale, void* workspace, float* loss, float* stats, float* grad, hipStream_t s) {
   const long numel = (long)B * H * W * C;
-  CTDET_CHECK(C % 4 == 0, "focal_loss: C=%d must be a multiple of 4", C);
+  CTDET_CHECK(numel % 4 == 0, "focal_loss: B*H*W*C=%ld must be a multiple of 4 (any C; maps are multiples of 4 pixels)", numel);
   CTDET_CHECK(numel > 0, "focal_loss: empty input");
   const long nvec = numel / 4;
   const int nblocks = (int)((nvec + FL_VEC_PER_BLOCK - 1) / FL_VEC_PER_BLOCK);
@@ -254,8 +263,9 @@ __global__ void __launch_bounds__(256) reg_l1_kernel(const float* __restrict__ p
   const int total = B * N;
   for (int i = threadIdx.x; i < total; i += 256) {
     const int b = i / N;
-    const float m = (float)mask[i];
-    const float* p = pred + ((long)b * HW + ind[i]) * pred_stride;
+    const long id = ind[i];
+    const float m = (id >= 0 && id < HW) ? (float)mask[i] : 0.f;   // an index outside the map never reaches memory
+    const float* p = pred + ((long)b * HW + (m != 0.f ? id : 0)) * pred_stride;
     const float d0 = p[0] * m - target[i * 2] * m, d1 = p[1] * m - target[i * 2 + 1] * m;
     sum += (double)fabsf(d0) + (double)fabsf(d1);
     msum += 2.0 * m;
@@ -271,7 +281,7 @@ __global__ void __launch_bounds__(256) reg_l1_kernel(const float* __restrict__ p
   if (!grad) return;
   for (int i = threadIdx.x; i < total; i += 256) {
     const int b = i / N;
-    const float m = (float)mask[i];
+    const float m = (ind[i] >= 0 && ind[i] < HW) ? (float)mask[i] : 0.f;
     if (m == 0.f) continue;
     const float* p = pred + ((long)b * HW + ind[i]) * pred_stride;
     float* gp = grad + ((long)b * HW + ind[i]) * grad_stride;

@@ -43,7 +43,7 @@ def ctdet_decode(heat, wh, reg=None, down_ratio=1, cat_spec_wh=False, K=100):
         raise NotImplementedError("cat_spec_wh is not used by any CenterNet config of the reference")
     if not heat.is_cuda:
         raise NotImplementedError("ctdet_decode runs on the HIP device only")
-    h = heat.permute(0, 2, 3, 1).float().contiguous()
+    h = heat.permute(0, 2, 3, 1).float().contiguous()      # any class count (the kernel takes C and a pixel stride)
     w = wh.permute(0, 2, 3, 1).float().contiguous()
     r = reg.permute(0, 2, 3, 1).float().contiguous() if reg is not None else None
     boxes, scores, classes, _ = ops.decode(h, w, r, K, down_ratio)
@@ -52,21 +52,35 @@ def ctdet_decode(heat, wh, reg=None, down_ratio=1, cat_spec_wh=False, K=100):
     return boxes, scores, classes
 
 
+MAX_ENGINES = 16   # captured eval graphs kept per model (least recently used goes first)
+
+
+def _engine_key(fused_base, B, H, W, Hp, Wp, img_dtype):
+    return (B, Hp, Wp, img_dtype) if fused_base else (B, H, W, Hp, Wp, img_dtype)
+
+
 class _EvalEngine:
-    """Static-shape inference engine: buffers + a captured HIP graph of the whole eval forward."""
+    """Static-shape inference engine: buffers + a captured HIP graph of the whole eval forward.
+
+    The model is held through a weak reference (model -> _engines -> engine -> model would be a cycle that only the
+    cyclic collector frees -- possibly in the middle of a later stream capture, which aborts the process): an engine
+    dropped from the model's cache dies right there, by reference count, outside any capture."""
 
     def __init__(self, model, B, H, W, Hp, Wp, img_dtype, use_graph=True):
-        self.model, self.key = model, (B, H, W, Hp, Wp, img_dtype)
+        import weakref
+        self._model = weakref.ref(model)
         dev = model.device
-        self.images = torch.zeros(B, 3, H, W, dtype=img_dtype, device=dev)
+        self.B, self.img_dtype = B, img_dtype
         self.img_params = torch.zeros(B, 4, dtype=torch.float32, device=dev)
         # DLA-34: normalisation + base_layer + level0 + level1 run as one kernel straight from the image batch
         self.fused_base = model.backbone_type != "resnet" and model.backbone.images_fusable(model._ctx, Hp, Wp)
+        # the base kernel runs outside the captured graph and reads the caller's image batch in place, whatever its
+        # unpadded size: the graph only depends on the padded size
+        self.key = _engine_key(self.fused_base, B, H, W, Hp, Wp, img_dtype)
+        self.images = torch.zeros(B, 3, H, W, dtype=img_dtype, device=dev)
         # otherwise: normalised input with a 3-pixel zero frame (the 7x7 stem's padding), cleared once, interior rewritten
         # per call
         self.xpad = None if self.fused_base else torch.zeros(B, Hp + 6, Wp + 6, 8, dtype=model._ctx.dtype, device=dev)
-        # the base kernel runs outside the captured graph and reads the caller's image batch in place (no staging copy);
-        # the graph starts from its output
         self.l1 = torch.empty(B, Hp // 2, Wp // 2, 32, dtype=torch.float16, device=dev) if self.fused_base else None
         self.l1p = torch.empty(B, Hp // 4, Wp // 4, 32, dtype=torch.float16, device=dev) if self.fused_base else None
         self.graph = None
@@ -76,8 +90,9 @@ class _EvalEngine:
         self._run()                      # warm-up: packs weights, sizes the allocator
         torch.cuda.synchronize()
         if use_graph:
-            # no garbage collection while the stream is capturing: a collection that happens to free device objects of
-            # an earlier engine (graphs, events) inside the capture aborts the process
+            # nothing may be released while the stream is capturing: the warm-up above has filled every packed-weight
+            # cache (a capture replaces none), evicted engines were destroyed before this constructor ran, and the cyclic
+            # collector -- which could still free unrelated device objects (graphs, events) -- is off for the window
             import gc
             gc.collect()
             gc_was_on = gc.isenabled()
@@ -90,6 +105,20 @@ class _EvalEngine:
                 if gc_was_on:
                     gc.enable()
             self.graph = g
+
+    @property
+    def model(self):
+        m = self._model()
+        if m is None:
+            raise RuntimeError("the model of this eval engine no longer exists")
+        return m
+
+    def staging(self, H, W):
+        """[B,3,H,W] staging buffer for list inputs (fused base: any unpadded size, re-made when it changes)"""
+        if tuple(self.images.shape[2:]) != (H, W):
+            assert self.fused_base, "this engine's graph reads a fixed-size image buffer"
+            self.images = torch.zeros(self.B, 3, H, W, dtype=self.img_dtype, device=self.images.device)
+        return self.images
 
     def _base(self, images):
         m = self.model
@@ -244,6 +273,21 @@ class CenterNet(nn.Module):
             self._engines = {}
         return super().train(mode)
 
+    def _engine(self, B, H, W, Hp, Wp, img_dtype):
+        """the captured engine of this input geometry (least recently used ones beyond MAX_ENGINES are destroyed here, before
+        a new one is built, i.e. never inside a stream capture)"""
+        fused = self.backbone_type != "resnet" and self.backbone.images_fusable(self._ctx, Hp, Wp)
+        key = _engine_key(fused, B, H, W, Hp, Wp, img_dtype)
+        eng = self._engines.get(key)
+        if eng is not None:
+            self._engines[key] = self._engines.pop(key)      # most recently used last
+            return eng
+        while len(self._engines) >= MAX_ENGINES:
+            old = self._engines.pop(next(iter(self._engines)))
+            del old
+        eng = self._engines[key] = _EvalEngine(self, B, H, W, Hp, Wp, img_dtype, self.use_hip_graph)
+        return eng
+
     # ------------------------------------------------------------------ network (NHWC, HIP kernels)
     def _head_outputs(self, y, apply_sigmoid):
         """y NHWC [B,h,w,64] -> dict head -> f32 NHWC buffer (channels padded to a multiple of 4)."""
@@ -323,6 +367,8 @@ class CenterNet(nn.Module):
         z = self._head_outputs(y, apply_sigmoid)
         hm = z["hm"]
         assert hm.shape[3] == self.num_classes or hm.shape[3] == ops.round_up(self.num_classes, 4)
+        # class counts that are not multiples of 4: the padded buffer stays, consumers get the channel-slice view (the
+        # decode and the loss kernels take a pixel stride)
         return hm[..., :self.num_classes] if hm.shape[3] != self.num_classes else hm, z["wh"][..., :2], z["reg"][..., :2]
 
     # ------------------------------------------------------------------ reference API
@@ -344,12 +390,10 @@ class CenterNet(nn.Module):
             return self._forward_eval_ragged(batched_inputs, imgs, sizes, Hp, Wp)
         H, W = sizes[0]
         img_dtype = torch.uint8 if imgs[0].dtype == torch.uint8 else torch.float32
-        key = (B, H, W, Hp, Wp, img_dtype)
-        eng = self._engines.get(key)
-        if eng is None:
-            eng = self._engines[key] = _EvalEngine(self, B, H, W, Hp, Wp, img_dtype, self.use_hip_graph)
+        eng = self._engine(B, H, W, Hp, Wp, img_dtype)
+        stage = eng.staging(H, W)
         for b, im in enumerate(imgs):
-            eng.images[b].copy_(im if im.dtype == img_dtype else im.to(img_dtype), non_blocking=True)
+            stage[b].copy_(im if im.dtype == img_dtype else im.to(img_dtype), non_blocking=True)
         return self._finish_eval(eng, batched_inputs, sizes)
 
     def infer_batch_tensor(self, images, out_sizes=None):
@@ -365,10 +409,7 @@ class CenterNet(nn.Module):
         B, _, H, W = images.shape
         Hp, Wp = ImageList.padded_size([(H, W)], self.size_divisibility)
         img_dtype = torch.uint8 if images.dtype == torch.uint8 else torch.float32
-        key = (B, H, W, Hp, Wp, img_dtype)
-        eng = self._engines.get(key)
-        if eng is None:
-            eng = self._engines[key] = _EvalEngine(self, B, H, W, Hp, Wp, img_dtype, self.use_hip_graph)
+        eng = self._engine(B, H, W, Hp, Wp, img_dtype)
         if images.dtype != img_dtype or not images.is_contiguous():
             images = images.to(img_dtype).contiguous()
         inputs = [{} if out_sizes is None else {"height": out_sizes[b][0], "width": out_sizes[b][1]} for b in range(B)]

@@ -560,32 +560,35 @@ def dwconvT_add(x, weight, f, skip=None, out=None, fresh_weight=False):
 
 
 class DecodeWorkspace:
-    def __init__(self, B, device):
-        n = _lib.lib().ctdet_decode_workspace_bytes(B)
-        self.B = B
+    """candidate lists of ctdet_decode for a (B, H, W, C, K) problem"""
+
+    def __init__(self, B, H, W, Cc, K, device):
+        n = _lib.lib().ctdet_decode_workspace_bytes(B, H, W, Cc, K)
+        self.key = (B, H, W, Cc, K)
         self.buf = torch.empty(n // 4, dtype=torch.int32, device=device)
 
 
 def decode(heat, wh, reg, K, down_ratio, workspace=None, check_status=False):
-    """Batched ctdet_decode. heat f32 NHWC [B,H,W,C]; wh/reg f32 NHWC (2 channels, may be slices).
+    """Batched ctdet_decode. heat f32 NHWC [B,H,W,C] (may be the channel slice [..., :C] of a wider buffer: padded head
+    outputs are decoded in place); wh/reg f32 NHWC (2 channels, may be slices).
     Returns boxes [B,K,4], scores [B,K], classes [B,K] (int32), inds [B,K] (int32)."""
     _require_cuda(heat, wh, reg)
-    assert heat.dtype == torch.float32 and heat.is_contiguous()
+    assert heat.dtype == torch.float32
     B, H, W, Cc = heat.shape
-    if workspace is None or workspace.B < B:
-        workspace = DecodeWorkspace(B, heat.device)
+    if workspace is None or workspace.key != (B, H, W, Cc, K):
+        workspace = DecodeWorkspace(B, H, W, Cc, K, heat.device)
     dev = heat.device
     boxes = torch.empty(B, K, 4, dtype=torch.float32, device=dev)
     scores = torch.empty(B, K, dtype=torch.float32, device=dev)
     classes = torch.empty(B, K, dtype=torch.int32, device=dev)
     inds = torch.empty(B, K, dtype=torch.int32, device=dev)
-    with prof_region("decode", nbytes=float(heat.numel() * 4), info=f"{B}x{H}x{W}x{Cc} K={K}"):
-        rc = _lib.lib().ctdet_decode(_ptr(heat), _ptr(wh), _nhwc_stride(wh), _ptr(reg),
+    with prof_region("decode", nbytes=float(B * H * W * Cc * 4), info=f"{B}x{H}x{W}x{Cc} K={K}"):
+        rc = _lib.lib().ctdet_decode(_ptr(heat), _nhwc_stride(heat), _ptr(wh), _nhwc_stride(wh), _ptr(reg),
                                      _nhwc_stride(reg) if reg is not None else 0, B, H, W, Cc, K, float(down_ratio),
                                      _ptr(workspace.buf), _ptr(boxes), _ptr(scores), _ptr(classes), _ptr(inds), _stream())
     _lib.check(rc, "ctdet_decode")
     if check_status:
-        _lib.check(_lib.lib().ctdet_decode_status(_ptr(workspace.buf), B, _stream()), "ctdet_decode_status")
+        _lib.check(_lib.lib().ctdet_decode_status(_ptr(workspace.buf), B, H, W, Cc, K, _stream()), "ctdet_decode_status")
     return boxes, scores, classes, inds
 
 

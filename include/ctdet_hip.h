@@ -139,13 +139,14 @@ int32_t ctdet_dwconvT_add(const void* x, const float* w, const void* skip, void*
                           int32_t H, int32_t W, int32_t C, int32_t f, int32_t in_stride, int32_t skip_stride,
                           int32_t out_stride, void* stream);
 
-/* Batched ctdet_decode (centernet.py:399-458): heat f32 NHWC [B,H,W,C] (already sigmoid+clamp), wh/reg f32
- * with pixel strides; outputs boxes [B,K,4] f32, scores [B,K] f32, classes [B,K] i32, inds [B,K] i32
- * (spatial index y*W+x; may be NULL).  Order: score desc, ties by c*H*W+y*W+x asc.  reg may be NULL. */
-size_t ctdet_decode_workspace_bytes(int32_t B);
-int32_t ctdet_decode(const float* heat, const float* wh, int32_t wh_stride, const float* reg, int32_t reg_stride,
-                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t K, float down_ratio, void* workspace,
-                     float* boxes, float* scores, int32_t* classes, int32_t* inds, void* stream);
+/* Batched ctdet_decode (centernet.py:399-458): heat f32 NHWC [B,H,W,heat_stride] (already sigmoid+clamp; the first C
+ * channels are classes, any C >= 1), wh/reg f32 with pixel strides; outputs boxes [B,K,4] f32, scores [B,K] f32, classes
+ * [B,K] i32, inds [B,K] i32 (spatial index y*W+x; may be NULL).  Order: score desc, ties by c*H*W+y*W+x asc.  reg may
+ * be NULL.  The heat map is read once; workspace: ctdet_decode_workspace_bytes of the same B, H, W, C, K. */
+size_t ctdet_decode_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C, int32_t K);
+int32_t ctdet_decode(const float* heat, int32_t heat_stride, const float* wh, int32_t wh_stride, const float* reg,
+                     int32_t reg_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t K, float down_ratio,
+                     void* workspace, float* boxes, float* scores, int32_t* classes, int32_t* inds, void* stream);
 /* CenterNet.inference_single_image (centernet.py:251-261) + detector_postprocess
  * (detectron2/modeling/postprocessing.py:11-72, structures/boxes.py:184-213,271-278) for a whole batch:
  * keep k < max_det with score > score_thresh, scale boxes by (scale_x, scale_y), clip to (out_w, out_h), drop
@@ -154,9 +155,9 @@ int32_t ctdet_postprocess(const float* boxes, const float* scores, const int32_t
                           int32_t max_det, float score_thresh, const float* img_params, float* out_boxes,
                           float* out_scores, int32_t* out_classes, int32_t* counts, void* stream);
 /* reads back the per-image status words of the last decode on this workspace (device->host copy + sync):
- * returns 0 if every image decoded exactly, -75 (EOVERFLOW) if a degenerate input overflowed the
- * candidate buffer.  Test/diagnostic helper, not on the hot path. */
-int32_t ctdet_decode_status(const void* workspace, int32_t B, void* stream);
+ * returns 0 if every image decoded exactly, -75 (EOVERFLOW) if a candidate buffer overflowed (cannot happen for a
+ * workspace of the queried size).  Test/diagnostic helper, not on the hot path. */
+int32_t ctdet_decode_status(const void* workspace, int32_t B, int32_t H, int32_t W, int32_t C, int32_t K, void* stream);
 
 /* gen_heatmap + gaussian_radius + draw_umich_gaussian, batched on device
  * (detectron2/data/detection_utils.py:600-705).  boxes f32 [B,Nmax,4] XYXY input pixels, classes i64

@@ -24,7 +24,7 @@ def setup():
 
 
 def _engine(model, B):
-    return next(e for k, e in model._engines.items() if k[0] == B)
+    return next(e for e in model._engines.values() if e.B == B)
 
 
 def test_fullsize_decode_matches_oracle_and_invariants(setup):

@@ -157,7 +157,7 @@ def test_eval_odd_sizes_match_oracle(tmp_path, dev, case):
         img = img.float()
     out = model.infer_batch_tensor(img.to(dev))
     assert len(out) == B and out[0]["instances"].image_size == (H, W)
-    eng = [e for k, e in model._engines.items() if k[0] == B and k[1] == H and k[2] == W][0]
+    eng = list(model._engines.values())[-1]      # the engine of the call above (most recently used last)
     hm, wh, reg = [t.float().cpu().permute(0, 3, 1, 2) for t in eng.out]
     res, hm_ref, _ = MR.centernet_inference(cpu_state_dict(model), [i for i in img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD,
                                             thresh=0.0)
@@ -280,3 +280,183 @@ def test_export_split_matches_forward(dev):
     res2 = em.inference({"images": inputs["images"].clone(), "im_info": inputs["im_info"]})
     assert torch.allclose(res2["hm"].float(), res["hm"].float(), atol=1e-6)
 
+
+
+def _topk_vs_oracle(model, cfg, img, K=100):
+    """(HIP hm, scores, classes, inds) and the fp32 oracle's (hm, scores of the K+1 best, classes, inds) for a byte batch"""
+    model.score_threshold = 0.0
+    with torch.no_grad():
+        model.infer_batch_tensor(img.to(model.device))
+    eng = list(model._engines.values())[-1]
+    hm = eng.out[0].float().cpu().permute(0, 3, 1, 2)
+    _b, sc, cl, ind = [t.cpu() for t in eng.dec]
+    sd = cpu_state_dict(model)
+    with torch.no_grad():
+        _res, hm_ref, z = MR.centernet_inference(sd, [i for i in img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, thresh=0.0)
+    _rb, rs, rc, ri = O.ctdet_decode(hm_ref, z["wh"], z["reg"], down_ratio=4, K=K + 1)
+    return hm, sc, cl, ind.long(), hm_ref, rs, rc, ri
+
+
+def test_f32_topk_indices_equal_fp32_oracle(dev):
+    """north_star: bit-exact peak indices / top-K against the reference CPU path.  The f32 engine (f32 MFMA, exact f32
+    arithmetic) on a BatchNorm-calibrated network (O(1) activations, spread-out heat map) must return the SAME
+    (class, position) at every rank whose score is separated from its neighbours by more than the summation-order noise;
+    the heat map itself within 1e-5 (north_star allows 1e-3)."""
+    import bench
+
+    model, cfg = bench.build_model("f32", dev, seed=5)
+    model.eval()
+    K = 100
+    hm, sc, cl, ind, hm_ref, rs, rc, ri = _topk_vs_oracle(model, cfg, images(2, 256, 256, seed=21), K)
+    err = (hm - hm_ref).abs().max().item()
+    assert hm_ref.std().item() > 3e-3, "degenerate heat map: the comparison would be meaningless"
+    assert err <= 1e-5, err
+    margin = 10 * max(err, 1e-7)
+    gap_prev = torch.cat([torch.full((2, 1), 1.0), rs[:, :K - 1] - rs[:, 1:K]], dim=1)   # to the better neighbour
+    gap_next = rs[:, :K] - rs[:, 1:K + 1]                                                # to the worse neighbour
+    safe = (gap_prev > margin) & (gap_next > margin)
+    assert safe.float().mean().item() > 0.8, "too few tie-free ranks for the test to mean anything"
+    same = (cl == rc[:, :K]) & (ind == ri[:, :K])
+    assert bool(same[safe].all()), f"{int((~same[safe]).sum())} tie-free ranks differ from the fp32 oracle"
+    assert (sc - rs[:, :K]).abs().max().item() <= 1e-5
+    print("f32: hm err", err, "tie-free ranks", float(safe.float().mean()), "rank agreement", float(same.float().mean()))
+
+
+def test_f16_topk_agreement_reported(dev):
+    """the f16 throughput mode on the same calibrated network: its heat map deviates from the fp32 oracle by a few 1e-3
+    (storage rounding of ~40 layers of f16 activations), so the top-K is NOT bit-exact against the fp32 reference -- the
+    figure is measured and bounded here and reported by bench.py (`accuracy`), not hidden: detections whose score is
+    separated by more than the f16 error are still found"""
+    import bench
+
+    model, cfg = bench.build_model("f16", dev, seed=5)
+    model.eval()
+    K = 100
+    hm, sc, cl, ind, hm_ref, rs, rc, ri = _topk_vs_oracle(model, cfg, images(2, 256, 256, seed=21), K)
+    err = (hm - hm_ref).abs().max().item()
+    assert err <= 2e-2, err
+    got = [set(zip(cl[b].tolist(), ind[b].tolist())) for b in range(2)]
+    ref = [set(zip(rc[b, :K].tolist(), ri[b, :K].tolist())) for b in range(2)]
+    overlap = sum(len(g & r) for g, r in zip(got, ref)) / (2.0 * K)
+    # oracle detections that clear the K-th score by more than twice the measured error must be present (a peak whose
+    # 3x3 neighbourhood holds a value within the error can change its peak status, hence the small allowance)
+    clear = missed = 0
+    for b in range(2):
+        kth = rs[b, K - 1].item()
+        for r in range(K):
+            if rs[b, r].item() - kth > 2 * err + 1e-6:
+                clear += 1
+                missed += (int(rc[b, r]), int(ri[b, r])) not in got[b]
+    assert missed <= max(2, clear // 20), (missed, clear)
+    print("f16: hm err", err, "top-K set overlap", overlap)
+    assert overlap > 0.5
+
+
+def test_engine_cache_is_bounded_and_survives_gc(tmp_path, dev, monkeypatch):
+    """the eval-engine cache: (a) keyed on the PADDED size when the fused base kernel reads the images in place, so the
+    reference's test pipeline (a different size per image, ResizeShortestEdge) does not build an engine per image;
+    (b) capped, least recently used first; (c) engines die by reference count when dropped -- two engines built back to
+    back with the cyclic collector enabled, the first one dropped before the second captures (the abort of round 1 came
+    from a collection inside a capture); results stay equal to a fresh model's"""
+    import gc
+    from detectron2_centernet_amd.modeling.meta_arch import centernet as CN
+
+    model, cfg = make_model(tmp_path, "f16", seed=9)
+    model.score_threshold = 0.0
+    model.wh[2].bias.data.fill_(3.0)
+    a = images(1, 70, 100, seed=1)
+    b = images(1, 90, 120, seed=2)              # same padded size (96 x 128) as a: one engine serves both
+    ra = model([{"image": a[0]}])
+    rb = model([{"image": b[0]}])
+    assert len(model._engines) == 1
+    assert ra[0]["instances"].image_size == (70, 100) and rb[0]["instances"].image_size == (90, 120)
+    ra2 = model([{"image": a[0]}])
+    assert torch.equal(ra[0]["instances"].scores, ra2[0]["instances"].scores)
+    assert not torch.equal(ra[0]["instances"].scores[:5], rb[0]["instances"].scores[:5])
+    monkeypatch.setattr(CN, "MAX_ENGINES", 2)
+    assert gc.isenabled()
+    import weakref
+    first = weakref.ref(next(iter(model._engines.values())))
+    for k, (h, w) in enumerate(((64, 64), (64, 96), (96, 64), (128, 64))):
+        model.infer_batch_tensor(images(1, h, w, seed=k).to(dev))
+        assert len(model._engines) <= 2
+    assert first() is None, "an evicted engine must be released by reference count, not wait for the cyclic collector"
+    rc = model([{"image": a[0]}])               # rebuilt after eviction: same result
+    assert torch.equal(ra[0]["instances"].scores, rc[0]["instances"].scores)
+
+
+@pytest.mark.parametrize("num_classes", [1, 3, 6])
+def test_class_counts_not_multiple_of_4(tmp_path, dev, num_classes):
+    """the class count comes from the dataset metadata (centernet.py:59-63): counts that are not multiples of 4 run through
+    the padded head buffers -- eval (decode of the channel-slice view, bit-exact against the oracle's decode; padded
+    channels never produce detections) and one training step (focal loss / targets on C real classes)"""
+    from detectron2_centernet_amd.config import get_cfg
+    from detectron2_centernet_amd.data.catalog import register_synthetic, synthetic_sample
+    from detectron2_centernet_amd.modeling import build_model
+    from detectron2_centernet_amd.structures import Boxes, Instances
+
+    (tmp_path / "Base-CenterNet.yaml").write_text(BASE)
+    (tmp_path / "c.yaml").write_text(YAML)
+    cfg = get_cfg()
+    cfg.merge_from_file(str(tmp_path / "c.yaml"))
+    name = f"synthetic_{num_classes}_classes"
+    cfg.DATASETS.TRAIN = (name,)
+    register_synthetic(name, num_classes=num_classes)
+    torch.manual_seed(3)
+    model = build_model(cfg).eval()
+    randomize(model, 3)
+    model.score_threshold = 0.0
+    model.wh[2].bias.data.fill_(3.0)
+    assert model.num_classes == num_classes and model.hm[2].weight.shape[0] == num_classes
+    img = images(2, 64, 96, seed=num_classes)
+    out = model.infer_batch_tensor(img.to(dev))
+    eng = list(model._engines.values())[-1]
+    hm, wh, reg = [t.float().cpu().permute(0, 3, 1, 2) for t in eng.out]
+    assert hm.shape[1] == num_classes
+    _res, hm_ref, _ = MR.centernet_inference(cpu_state_dict(model), [i for i in img], cfg.MODEL.PIXEL_MEAN,
+                                             cfg.MODEL.PIXEL_STD, thresh=0.0)
+    assert (hm - hm_ref).abs().max().item() <= 1e-3
+    rb, rs, rc, ri = O.ctdet_decode(hm, wh, reg, down_ratio=4, K=100)
+    boxes, scores, classes, inds = [t.cpu() for t in eng.dec]
+    assert torch.equal(scores, rs) and torch.equal(classes, rc) and torch.equal(inds.long(), ri)
+    assert int(classes.max()) < num_classes and len(out[0]["instances"]) > 0
+    # one training step on the same model
+    model.train()
+    inputs = []
+    for i in range(2):
+        smp = synthetic_sample(i, size=128, num_classes=num_classes, max_boxes=5)
+        inst = Instances((128, 128))
+        inst.gt_boxes, inst.gt_classes = Boxes(smp["boxes"]), smp["classes"]
+        inputs.append({"image": smp["image"], "instances": inst})
+    losses = model(inputs)
+    sd = cpu_state_dict(model)
+    x_ref, _ = O.preprocess([d["image"] for d in inputs], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 32)
+    with torch.no_grad():
+        z = MR.centernet_forward(sd, x_ref, training=True, f16_activations=True)
+    targets = [O.gen_heatmap(d["instances"].gt_boxes.tensor, d["instances"].gt_classes, 32, 32, num_classes) for d in inputs]
+    ref = MR.centernet_losses(z, targets, [1.0])
+    assert abs(losses["hm_loss"].item() - ref["hm_loss"].item()) <= 2e-3 * max(1.0, abs(ref["hm_loss"].item()))
+    sum(losses.values()).backward()
+    g = model.hm[2].weight.grad
+    assert g is not None and g.shape[0] == num_classes and torch.isfinite(g).all() and g.abs().max() > 0
+
+
+def test_out_of_image_boxes_do_not_reach_memory(dev):
+    """a box whose centre lies outside the map (unclipped annotations): the reference's gather raises an index error
+    (centernet.py:392-397); the device path drops the object -- no out-of-range index is produced or followed"""
+    import detectron2_centernet_amd.ops as ops
+    boxes = torch.tensor([[[10., 10., 50., 60.], [600., 40., 700., 90.], [-300., 10., -200., 50.], [20., 500., 60., 560.]]])
+    classes = torch.tensor([[1, 2, 3, 4]])
+    t = ops.gaussian_targets(boxes.to(dev), classes.to(dev), torch.tensor([4], dtype=torch.int32, device=dev), 32, 32, 8)
+    assert t["reg_mask"][0, :4].tolist() == [1, 0, 0, 0]
+    assert int(t["ind"].max()) < 32 * 32 and int(t["ind"].min()) >= 0
+    assert t["hm"][0, :, :, 2:5].abs().max() == 0                  # nothing splatted for the dropped objects
+    # a hand-made out-of-range index is ignored by the L1 kernel (loss and gradient)
+    pred = torch.randn(1, 32, 32, 2, device=dev)
+    ind = torch.tensor([[5, 99999, -7]], device=dev)
+    mask = torch.ones(1, 3, dtype=torch.uint8, device=dev)
+    tgt = torch.zeros(1, 3, 2, device=dev)
+    loss, grad = ops.reg_l1_loss(pred, mask, ind, tgt)
+    want = pred.view(-1, 2)[5].abs().sum() / (2 + 1e-4)
+    assert torch.allclose(loss[0], want, rtol=1e-5)
+    assert int((grad != 0).sum()) == 2
