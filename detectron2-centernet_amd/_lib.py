@@ -48,15 +48,15 @@ SIGNATURES = {
     "ctdet_reg_l1_loss": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _vp]),
     "ctdet_chan_workspace_bytes": (_sz, [_i32]),
     "ctdet_bn_train_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
-                                   _vp, _vp, _vp, _i32, _vp]),
+                                   _vp, _vp, _vp, _i32, _i32, _vp]),
     "ctdet_bn_train_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32,
-                                   _vp, _vp, _f32, _vp, _vp]),
+                                   _vp, _vp, _f32, _vp, _i32, _vp]),
     "ctdet_conv_wgrad": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _f32, _vp]),
     "ctdet_depth_to_space2": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "ctdet_maxpool2x2_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "ctdet_dwconvT_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "ctdet_dcn_cols": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "ctdet_dcn_col2im_coord": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_maxpool2x2_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_dwconvT_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_dcn_cols": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_dcn_col2im_coord": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_sgd_momentum": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _i32, _vp]),
     "ctdet_sgd_momentum_runs": (_i32, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _i32, _f32, _i32, _vp]),
 }

@@ -53,12 +53,23 @@ int launch_bn_train_fwd(const f16*, int, const f16*, int, f16*, int, int, int, c
 int launch_bn_train_bwd(const f16*, int, const f16*, int, const f16*, int, const float*, const float*, const float*, int,
                         int, int, f16*, int, f16*, int, float*, float*, float, void*, hipStream_t);
 int launch_conv_wgrad(const WgradArgs&, hipStream_t);
+int launch_conv_wgrad_f32(const WgradArgs&, hipStream_t);
+int launch_bn_train_fwd_f32(const float*, int, const float*, int, float*, int, int, int, const float*, const float*, float,
+                            float, float*, float*, float*, float*, float*, float*, void*, int, hipStream_t);
+int launch_bn_train_bwd_f32(const float*, int, const float*, int, const float*, int, const float*, const float*, const float*,
+                            int, int, int, float*, int, float*, int, float*, float*, float, void*, hipStream_t);
+int launch_maxpool2x2_bwd_f32(const float*, int, const float*, int, float*, int, int, int, int, int, hipStream_t);
+int launch_dwconvT_bwd_f32(const float*, int, const float*, int, const float*, float*, int, float*, int, int, int, int, int,
+                           hipStream_t);
+int launch_dcn_cols_f32(const float*, int, const float*, int, float*, int, int, int, int, int, hipStream_t);
+int launch_dcn_col2im_coord_f32(const float*, const float*, int, const float*, int, float*, float*, int, int, int, int, int,
+                                hipStream_t);
 int launch_maxpool2x2_bwd(const f16*, int, const f16*, int, f16*, int, int, int, int, int, hipStream_t);
 int launch_depth_to_space2(const f16*, int, f16*, int, int, int, int, int, int, int, hipStream_t);
 int launch_dwconvT_bwd(const f16*, int, const f16*, int, const float*, f16*, int, float*, int, int, int, int, int,
                        hipStream_t);
-int launch_dcn_cols(const f16*, int, const float*, int, f16*, int, int, int, int, hipStream_t);
-int launch_dcn_col2im_coord(const f16*, const f16*, int, const float*, int, float*, float*, int, int, int, int,
+int launch_dcn_cols(const f16*, int, const float*, int, f16*, int, int, int, int, int, hipStream_t);
+int launch_dcn_col2im_coord(const f16*, const f16*, int, const float*, int, float*, float*, int, int, int, int, int,
                             hipStream_t);
 
 static int fill_args(const ctdet_conv_desc* d, ConvArgs& a) {
@@ -314,9 +325,14 @@ size_t ctdet_chan_workspace_bytes(int32_t C) { return chan_reduce_workspace_byte
 int32_t ctdet_bn_train_fwd(const void* y, int32_t y_stride, const void* res, int32_t res_stride, void* z,
                            int32_t z_stride, int32_t M, int32_t C, const float* gamma, const float* beta, float eps,
                            float momentum, float* running_mean, float* running_var, float* save_mean,
-                           float* save_invstd, float* scale, float* shift, void* workspace, int32_t relu, void* stream) {
+                           float* save_invstd, float* scale, float* shift, void* workspace, int32_t relu, int32_t dtype,
+                           void* stream) {
   CTDET_CHECK(y && z && gamma && beta && save_mean && save_invstd && scale && shift && workspace, "bn_train_fwd: null pointer");
   CTDET_CHECK(M > 0, "bn_train_fwd: empty batch");
+  if (dtype == CTDET_DT_F32)
+    return launch_bn_train_fwd_f32((const float*)y, y_stride, (const float*)res, res_stride, (float*)z, z_stride, M, C, gamma,
+                                   beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift,
+                                   workspace, relu, (hipStream_t)stream);
   return launch_bn_train_fwd((const f16*)y, y_stride, (const f16*)res, res_stride, (f16*)z, z_stride, M, C, gamma, beta,
                              eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift, workspace,
                              relu, (hipStream_t)stream);
@@ -325,10 +341,14 @@ int32_t ctdet_bn_train_fwd(const void* y, int32_t y_stride, const void* res, int
 int32_t ctdet_bn_train_bwd(const void* dz, int32_t dz_stride, const void* z, int32_t z_stride, const void* y,
                            int32_t y_stride, const float* mean, const float* invstd, const float* scale, int32_t M,
                            int32_t C, int32_t relu, void* dy, int32_t dy_stride, void* dres, int32_t dres_stride,
-                           float* dgamma, float* dbeta, float grad_mult, void* workspace, void* stream) {
+                           float* dgamma, float* dbeta, float grad_mult, void* workspace, int32_t dtype, void* stream) {
   CTDET_CHECK(dz && dy && dgamma && dbeta && workspace, "bn_train_bwd: null pointer");
   CTDET_CHECK(!relu || z, "bn_train_bwd: relu backward needs z");
   CTDET_CHECK(!y || (mean && invstd && scale), "bn_train_bwd: statistics missing");
+  if (dtype == CTDET_DT_F32)
+    return launch_bn_train_bwd_f32((const float*)dz, dz_stride, (const float*)z, z_stride, (const float*)y, y_stride, mean,
+                                   invstd, scale, M, C, relu, (float*)dy, dy_stride, (float*)dres, dres_stride, dgamma,
+                                   dbeta, grad_mult, workspace, (hipStream_t)stream);
   return launch_bn_train_bwd((const f16*)dz, dz_stride, (const f16*)z, z_stride, (const f16*)y, y_stride, mean, invstd,
                              scale, M, C, relu, (f16*)dy, dy_stride, (f16*)dres, dres_stride, dgamma, dbeta, grad_mult,
                              workspace, (hipStream_t)stream);
@@ -342,6 +362,7 @@ int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy
   a.Wo = d->Wo; a.dy_stride = d->out_stride; a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
   a.K = d->R * d->S * d->Cin; a.M = d->B * d->Ho * d->Wo; a.msplit = 1; a.scale = scale;
   if (a.M == 0) return 0;
+  if (d->compute_dtype == CTDET_DT_F32) return launch_conv_wgrad_f32(a, (hipStream_t)stream);
   return launch_conv_wgrad(a, (hipStream_t)stream);
 }
 
@@ -352,31 +373,44 @@ int32_t ctdet_depth_to_space2(const void* src, int32_t src_stride, void* dst, in
 }
 
 int32_t ctdet_maxpool2x2_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, void* dx,
-                             int32_t dx_stride, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+                             int32_t dx_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
   CTDET_CHECK(x && dz && dx, "maxpool2x2_bwd: null pointer");
+  if (dtype == CTDET_DT_F32)
+    return launch_maxpool2x2_bwd_f32((const float*)x, x_stride, (const float*)dz, dz_stride, (float*)dx, dx_stride, B, H, W, C,
+                                     (hipStream_t)stream);
   return launch_maxpool2x2_bwd((const f16*)x, x_stride, (const f16*)dz, dz_stride, (f16*)dx, dx_stride, B, H, W, C,
                                (hipStream_t)stream);
 }
 
 int32_t ctdet_dwconvT_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, const float* w, void* dx,
                           int32_t dx_stride, float* dw, int32_t B, int32_t H, int32_t W, int32_t C, int32_t f,
-                          void* stream) {
+                          int32_t dtype, void* stream) {
   CTDET_CHECK(x && dz && w && dx && dw, "dwconvT_bwd: null pointer");
+  if (dtype == CTDET_DT_F32)
+    return launch_dwconvT_bwd_f32((const float*)x, x_stride, (const float*)dz, dz_stride, w, (float*)dx, dx_stride, dw, B, H,
+                                  W, C, f, (hipStream_t)stream);
   return launch_dwconvT_bwd((const f16*)x, x_stride, (const f16*)dz, dz_stride, w, (f16*)dx, dx_stride, dw, B, H, W, C, f,
                             (hipStream_t)stream);
 }
 
 int32_t ctdet_dcn_cols(const void* x, int32_t x_stride, const float* om, int32_t om_stride, void* col, int32_t B,
-                       int32_t H, int32_t W, int32_t Cin, void* stream) {
+                       int32_t H, int32_t W, int32_t Cin, int32_t mask_is_prob, int32_t dtype, void* stream) {
   CTDET_CHECK(x && om && col, "dcn_cols: null pointer");
-  return launch_dcn_cols((const f16*)x, x_stride, om, om_stride, (f16*)col, B, H, W, Cin, (hipStream_t)stream);
+  if (dtype == CTDET_DT_F32)
+    return launch_dcn_cols_f32((const float*)x, x_stride, om, om_stride, (float*)col, B, H, W, Cin, mask_is_prob,
+                               (hipStream_t)stream);
+  return launch_dcn_cols((const f16*)x, x_stride, om, om_stride, (f16*)col, B, H, W, Cin, mask_is_prob, (hipStream_t)stream);
 }
 
 int32_t ctdet_dcn_col2im_coord(const void* dcol, const void* x, int32_t x_stride, const float* om, int32_t om_stride,
-                               float* dx, float* dom, int32_t B, int32_t H, int32_t W, int32_t Cin, void* stream) {
+                               float* dx, float* dom, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t mask_is_prob,
+                               int32_t dtype, void* stream) {
   CTDET_CHECK(dcol && x && om && dx && dom, "dcn_col2im_coord: null pointer");
+  if (dtype == CTDET_DT_F32)
+    return launch_dcn_col2im_coord_f32((const float*)dcol, (const float*)x, x_stride, om, om_stride, dx, dom, B, H, W, Cin,
+                                       mask_is_prob, (hipStream_t)stream);
   return launch_dcn_col2im_coord((const f16*)dcol, (const f16*)x, x_stride, om, om_stride, dx, dom, B, H, W, Cin,
-                                 (hipStream_t)stream);
+                                 mask_is_prob, (hipStream_t)stream);
 }
 
 int32_t ctdet_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, const float* lr_dev,

@@ -361,12 +361,35 @@ __global__ void __launch_bounds__(1024) dec_final_kernel(DecArgs a, long ws_word
     }
   }
   const int HW = a.H * a.W;
+  // fewer positive peaks than K: the reference's topk (centernet.py:408-424) then returns entries of the NMS-ed map that
+  // are exactly 0 -- in canonical order the non-peak positions of lowest flat index.  Rare (tiny maps): a serial fill.
+  uint32_t* fill = lh;                      // the histogram is free now: [0, 2K) flags, [2048, 2048 + K) the fill list
+  if (n < (uint32_t)a.K) {
+    const uint32_t span = 2u * (uint32_t)a.K < (uint32_t)a.C * HW ? 2u * (uint32_t)a.K : (uint32_t)a.C * HW;
+    for (uint32_t c = t; c < span; c += 1024) {
+      uint32_t is_peak = 0;
+      for (uint32_t i = 0; i < n; ++i) is_peak |= (0xFFFFFFFFu - (uint32_t)keys[i]) == c ? 1u : 0u;
+      fill[c] = is_peak;
+    }
+    __syncthreads();
+    if (t == 0) {
+      uint32_t got = 0;
+      for (uint32_t c = 0; c < span && n + got < (uint32_t)a.K; ++c)
+        if (!fill[c]) fill[2048 + got++] = c;
+      for (; n + got < (uint32_t)a.K; ++got) fill[2048 + got] = 0;      // map smaller than K positions
+    }
+    __syncthreads();
+  }
   for (int k = t; k < a.K; k += 1024) {
     const uint64_t key = k < NS ? keys[k] : 0ull;
     float score = 0.f; int cls = 0, ind = 0;
     if ((uint32_t)k < n) {
       score = __uint_as_float((uint32_t)(key >> 32));
       const uint32_t canon = 0xFFFFFFFFu - (uint32_t)key;
+      cls = (int)(canon / HW);
+      ind = (int)(canon % HW);
+    } else {
+      const uint32_t canon = fill[2048 + k - n];
       cls = (int)(canon / HW);
       ind = (int)(canon % HW);
     }

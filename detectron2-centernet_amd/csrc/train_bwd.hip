@@ -576,11 +576,12 @@ struct DcnGeom {
   float hh, hw, lh, lw, mask;
   bool inside;
 };
-__device__ __forceinline__ DcnGeom dcn_geom(const float* om, int tap, int b, int ho, int wo, int H, int W, int stride_elems) {
+__device__ __forceinline__ DcnGeom dcn_geom(const float* om, int tap, int b, int ho, int wo, int H, int W, int stride_elems,
+                                            int mask_is_prob) {
   DcnGeom g;
   const int tr = tap / 3, ts = tap - tr * 3;
   const float h_im = (float)(ho - 1 + tr) + om[2 * tap], w_im = (float)(wo - 1 + ts) + om[2 * tap + 1];
-  g.mask = ctdet_sigmoid_exact(om[18 + tap]);
+  g.mask = mask_is_prob ? om[18 + tap] : ctdet_sigmoid_exact(om[18 + tap]);   // prob: the reference's functional form
   g.inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
 #pragma unroll
   for (int q = 0; q < 4; ++q) { g.off[q] = -1; g.w[q] = 0.f; }
@@ -600,7 +601,7 @@ __device__ __forceinline__ DcnGeom dcn_geom(const float* om, int tap, int b, int
 
 // col[m][tap*Cin + c] = mask * bilinear(x)   (the `columns` of the reference, f16, tap-major)
 __global__ void __launch_bounds__(256) dcn_cols_kernel(const f16* __restrict__ x, int x_stride, const float* __restrict__ om,
-                                                       int om_stride, f16* __restrict__ col, int B, int H, int W, int Cin) {
+                                                       int om_stride, f16* __restrict__ col, int B, int H, int W, int Cin, int mask_is_prob) {
   const int CV = Cin >> 3;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const long total = (long)B * H * W * 9 * CV;
@@ -612,7 +613,7 @@ __global__ void __launch_bounds__(256) dcn_cols_kernel(const f16* __restrict__ x
   const int wo = (int)(m % W);
   const long t2 = m / W;
   const int ho = (int)(t2 % H), b = (int)(t2 / H);
-  const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride);
+  const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride, mask_is_prob);
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -636,7 +637,7 @@ __global__ void __launch_bounds__(256) dcn_cols_kernel(const f16* __restrict__ x
 __global__ void __launch_bounds__(256) dcn_col2im_coord_kernel(const f16* __restrict__ dcol, const f16* __restrict__ x,
                                                                int x_stride, const float* __restrict__ om, int om_stride,
                                                                float* __restrict__ dx, float* __restrict__ dom, int B, int H,
-                                                               int W, int Cin) {
+                                                               int W, int Cin, int mask_is_prob) {
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long nwork = (long)B * H * W * 9;
@@ -646,7 +647,7 @@ __global__ void __launch_bounds__(256) dcn_col2im_coord_kernel(const f16* __rest
     const int wo = (int)(m % W);
     const long t2 = m / W;
     const int ho = (int)(t2 % H), b = (int)(t2 / H);
-    const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride);  // wave-uniform
+    const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride, mask_is_prob);  // wave-uniform
     float val_dot = 0.f, dh = 0.f, dwv = 0.f;
     if (g.inside) {
       const f16* dcp = dcol + m * (9L * Cin) + (long)tap * Cin;
@@ -674,7 +675,7 @@ __global__ void __launch_bounds__(256) dcn_col2im_coord_kernel(const f16* __rest
       float* d = dom + m * om_stride;
       d[2 * tap] = dh * g.mask;
       d[2 * tap + 1] = dwv * g.mask;
-      d[18 + tap] = val_dot * g.mask * (1.f - g.mask);  // through the sigmoid of the mask logit
+      d[18 + tap] = mask_is_prob ? val_dot : val_dot * g.mask * (1.f - g.mask);  // through the sigmoid of the mask logit
     }
   }
 }
@@ -703,7 +704,7 @@ struct ColGeo {        // staged per (pixel, tap): 32 bytes
 __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __restrict__ dcol, const f16* __restrict__ x,
                                                                 int x_stride, const float* __restrict__ om, int om_stride,
                                                                 float* __restrict__ dx, float* __restrict__ dom, int B, int H,
-                                                                int W, int Cin) {
+                                                                int W, int Cin, int mask_is_prob) {
   constexpr int TH = 8, TW = 16, MG = 4, WR = TH + 2 + 2 * MG, WC = TW + 2 + 2 * MG, NPX = WR * WC;  // 18 x 26 = 468
   // d(input) window, int32 fixed point, laid out [e = channel % 8][window pixel][q = channel / 8]: the 64 lanes (16
   // pixels x 4 groups) of one ds_add then touch 64 consecutive words
@@ -727,7 +728,7 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
     const int tr = tap / 3, ts = tap - tr * 3;
     const float h_im = (float)(py - 1 + tr) + omr[2 * tap], w_im = (float)(pxx - 1 + ts) + omr[2 * tap + 1];
     ColGeo g;
-    g.mask = ctdet_sigmoid_exact(omr[18 + tap]);
+    g.mask = mask_is_prob ? omr[18 + tap] : ctdet_sigmoid_exact(omr[18 + tap]);
     g.off = 0; g.valid = 0; g.hh = g.hw = g.lh = g.lw = 0.f; g.pad = 0.f;
     if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
       const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
@@ -864,7 +865,7 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
       float* o = dom + m * om_stride;
       o[2 * t] = bh * mk;
       o[2 * t + 1] = bw * mk;
-      o[18 + t] = a * mk * (1.f - mk);   // through the sigmoid of the mask logit
+      o[18 + t] = mask_is_prob ? a : a * mk * (1.f - mk);   // through the sigmoid of the mask logit
     }
   }
 }
@@ -1352,30 +1353,407 @@ int launch_dwconvT_bwd(const f16* x, int x_stride, const f16* dz, int dz_stride,
 }
 
 int launch_dcn_cols(const f16* x, int x_stride, const float* om, int om_stride, f16* col, int B, int H, int W, int Cin,
-                    hipStream_t s) {
+                    int mask_is_prob, hipStream_t s) {
   CTDET_CHECK(Cin % 8 == 0 && om_stride >= 27, "dcn_cols: bad shape");
   const long total = (long)B * H * W * 9 * (Cin / 8);
   if (total == 0) return 0;
-  hipLaunchKernelGGL(dcn_cols_kernel, dim3(nblk256(total)), dim3(256), 0, s, x, x_stride, om, om_stride, col, B, H, W, Cin);
+  hipLaunchKernelGGL(dcn_cols_kernel, dim3(nblk256(total)), dim3(256), 0, s, x, x_stride, om, om_stride, col, B, H, W, Cin,
+                     mask_is_prob);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_dcn_col2im_coord(const f16* dcol, const f16* x, int x_stride, const float* om, int om_stride, float* dx,
-                            float* dom, int B, int H, int W, int Cin, hipStream_t s) {
+                            float* dom, int B, int H, int W, int Cin, int mask_is_prob, hipStream_t s) {
   CTDET_CHECK(Cin % 8 == 0, "dcn_col2im: Cin=%d must be a multiple of 8", Cin);
   const long nwork = (long)B * H * W * 9;
   if (nwork == 0) return 0;
   if (H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && x_stride % 8 == 0 && !getenv("CTDET_NO_COL2IM_WINDOW")) {
     hipLaunchKernelGGL(dcn_col2im_window_kernel, dim3((unsigned)(B * (H / 8) * (W / 16))), dim3(512), 0, s, dcol, x, x_stride,
-                       om, om_stride, dx, dom, B, H, W, Cin);
+                       om, om_stride, dx, dom, B, H, W, Cin, mask_is_prob);
     CTDET_LAUNCH_CHECK();
     return 0;
   }
   long nb = (nwork + 3) / 4;
   if (nb > 256 * 32) nb = 256 * 32;
   hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3((unsigned)nb), dim3(256), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
-                     B, H, W, Cin);
+                     B, H, W, Cin, mask_is_prob);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ================================================================================================================
+// f32 training kernels: the reference's own precision end to end (f32 activations, gradients and statistics), used to
+// show that the ALGORITHM of the training step is exact (tests compare against the fp32 oracle at 1e-3 on the losses and
+// 0.999 cosine on every gradient group).  Plain, unvectorised kernels: one thread per element or per (row lane,
+// channel); the throughput path is the f16 one above.
+// ================================================================================================================
+struct ChanRedArgsF {
+  const float* y; int y_stride;
+  const float* dz; int dz_stride;
+  const float* z; int z_stride;
+  const float* mean; const float* invstd;
+  int M, C, mode, relu;
+  float* partial;
+};
+
+// same contract as chan_reduce_kernel (partial[blk][2][C]); thread = (row lane, channel)
+__global__ void __launch_bounds__(256) chan_reduce_f32_kernel(ChanRedArgsF a) {
+  __shared__ float red[2][256];
+  const int CT = a.C < 256 ? a.C : 256;
+  const int rpp = 256 / CT;
+  const int ct = threadIdx.x % CT, rl = threadIdx.x / CT;
+  for (int c0 = 0; c0 < a.C; c0 += CT) {
+    const int c = c0 + ct;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < a.C && rl < rpp) {
+      const float mu = (a.mode == 1 && a.y) ? a.mean[c] : 0.f, is = (a.mode == 1 && a.y) ? a.invstd[c] : 0.f;
+      for (long m = (long)blockIdx.x * rpp + rl; m < a.M; m += (long)gridDim.x * rpp) {
+        if (a.mode == 0) {
+          const float f = a.y[m * a.y_stride + c];
+          s0 += f; s1 += f * f;
+        } else {
+          float g = a.dz[m * a.dz_stride + c];
+          if (a.relu && !(a.z[m * a.z_stride + c] > 0.f)) g = 0.f;
+          s0 += g;
+          if (a.y) s1 += g * ((a.y[m * a.y_stride + c] - mu) * is);
+        }
+      }
+    }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (c < a.C && rl == 0) {
+      for (int r = 1; r < rpp; ++r) { s0 += red[0][threadIdx.x + r * CT]; s1 += red[1][threadIdx.x + r * CT]; }
+      a.partial[((long)blockIdx.x * 2 + 0) * a.C + c] = s0;
+      a.partial[((long)blockIdx.x * 2 + 1) * a.C + c] = s1;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) affine_act_f32_kernel(const float* __restrict__ y, int y_stride,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ res, int res_stride,
+                                                             float* __restrict__ z, int z_stride, long M, int C, int relu) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * C) return;
+  const int c = (int)(idx % C);
+  const long m = idx / C;
+  float f = y[m * y_stride + c] * scale[c] + shift[c];
+  if (res) f += res[m * res_stride + c];
+  if (relu) f = fmaxf(f, 0.f);
+  z[m * z_stride + c] = f;
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_f32_kernel(const float* __restrict__ dz, int dz_stride,
+                                                               const float* __restrict__ z, int z_stride,
+                                                               const float* __restrict__ y, int y_stride,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ scale, const float* __restrict__ s0,
+                                                               const float* __restrict__ s1, float* __restrict__ dy,
+                                                               int dy_stride, float* __restrict__ dres, int dres_stride, long M,
+                                                               int C, int relu) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * C) return;
+  const int c = (int)(idx % C);
+  const long m = idx / C;
+  float g = dz[m * dz_stride + c];
+  if (relu && !(z[m * z_stride + c] > 0.f)) g = 0.f;
+  const float invM = 1.f / (float)M;
+  float o = g;
+  if (y) {
+    const float xh = (y[m * y_stride + c] - mean[c]) * invstd[c];
+    o = scale[c] * (g - s0[c] * invM - xh * s1[c] * invM);
+  }
+  dy[m * dy_stride + c] = o;
+  if (dres) dres[m * dres_stride + c] = g;
+}
+
+// dW[n][k] += scale * sum_m dY[m][n] * im2col(x)[m][k], k = tap*Cin + c.  Block = 16 couts x 16 k, 16 pixels per step
+// staged in LDS, pixel range split over blockIdx.z, f32 atomics at the end.
+struct WgradArgsF {
+  const float* x; const float* dy; float* dw;
+  int B, H, W, Cin, in_stride, Cout, Ho, Wo, dy_stride, R, S, stride, pad, dil, K, M, msplit;
+  float scale;
+};
+__global__ void __launch_bounds__(256) conv_wgrad_f32_kernel(const WgradArgsF a) {
+  __shared__ float sdy[16][17], sa[16][17];
+  const int tk = threadIdx.x & 15, tn = threadIdx.x >> 4;
+  const int k0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+  const long per = ((long)a.M + a.msplit - 1) / a.msplit;
+  const long mb = (long)blockIdx.z * per;
+  const long me = mb + per < a.M ? mb + per : a.M;
+  // the k this thread LOADS (column tk of the staged A tile): tap and channel
+  const int kl = k0 + tk;
+  const bool k_ok = kl < a.K;
+  const int tap = k_ok ? kl / a.Cin : 0, ch = k_ok ? kl - tap * a.Cin : 0;
+  const int tr = tap / a.S, ts = tap - tr * a.S;
+  float acc = 0.f;
+  for (long m0 = mb; m0 < me; m0 += 16) {
+    const long m = m0 + tn;                 // pixel this thread loads (row tn of both staged tiles)
+    float dyv = 0.f, av = 0.f;
+    if (m < me) {
+      if (n0 + tk < a.Cout) dyv = a.dy[m * a.dy_stride + n0 + tk];
+      if (k_ok) {
+        const int wo = (int)(m % a.Wo);
+        const long t = m / a.Wo;
+        const int ho = (int)(t % a.Ho), b = (int)(t / a.Ho);
+        const int hi = ho * a.stride - a.pad + tr * a.dil, wi = wo * a.stride - a.pad + ts * a.dil;
+        if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) av = a.x[((long)(b * a.H + hi) * a.W + wi) * a.in_stride + ch];
+      }
+    }
+    sdy[tn][tk] = dyv; sa[tn][tk] = av;
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc = fmaf(sdy[p][tn], sa[p][tk], acc);   // output element (n0 + tn, k0 + tk)
+    __syncthreads();
+  }
+  if (n0 + tn < a.Cout && k_ok && acc != 0.f) atomicAdd(a.dw + (long)(n0 + tn) * a.K + kl, acc * a.scale);
+}
+
+__global__ void __launch_bounds__(256) maxpool2x2_bwd_f32_kernel(const float* __restrict__ x, int x_stride,
+                                                                 const float* __restrict__ dz, int dz_stride,
+                                                                 float* __restrict__ dx, int dx_stride, int B, int H, int W,
+                                                                 int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * Ho * Wo * C) return;
+  const int c = (int)(idx % C);
+  long t = idx / C;
+  const int wo = (int)(t % Wo); t /= Wo;
+  const int ho = (int)(t % Ho);
+  const int b = (int)(t / Ho);
+  const long p00 = (long)(b * H + 2 * ho) * W + 2 * wo;
+  const long offs[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+  int best = 0;
+  float bv = x[offs[0] * x_stride + c];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) { const float v = x[offs[i] * x_stride + c]; if (v > bv) { bv = v; best = i; } }
+  const float g = dz[((long)(b * Ho + ho) * Wo + wo) * dz_stride + c];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dx[offs[i] * dx_stride + c] = i == best ? g : 0.f;
+}
+
+__global__ void __launch_bounds__(256) dwconvT_dx_f32_kernel(const float* __restrict__ dz, int dz_stride,
+                                                             const float* __restrict__ w, float* __restrict__ dx, int dx_stride,
+                                                             int B, int H, int W, int C, int f) {
+  const int k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * H * W * C) return;
+  const int c = (int)(idx % C);
+  const long pix = idx / C;
+  const int ix = (int)(pix % W);
+  const long t = pix / W;
+  const int iy = (int)(t % H), b = (int)(t / H);
+  float acc = 0.f;
+  for (int ky = 0; ky < k; ++ky) {
+    const int oy = iy * f - p + ky;
+    if (oy < 0 || oy >= Ho) continue;
+    for (int kx = 0; kx < k; ++kx) {
+      const int ox = ix * f - p + kx;
+      if (ox < 0 || ox >= Wo) continue;
+      acc += dz[((long)(b * Ho + oy) * Wo + ox) * dz_stride + c] * w[(long)(ky * k + kx) * C + c];
+    }
+  }
+  dx[pix * dx_stride + c] = acc;
+}
+
+// dw[ky][kx][c] = sum over (b, iy, ix) of x * dz[b, iy*f - p + ky, ix*f - p + kx]: block = (tap, 64-channel chunk), the
+// 4 pixel lanes of a channel reduced through LDS; every dw element written once (no atomics)
+__global__ void __launch_bounds__(256) dwconvT_dw_f32_kernel(const float* __restrict__ x, int x_stride,
+                                                             const float* __restrict__ dz, int dz_stride, float* __restrict__ dw,
+                                                             int B, int H, int W, int C, int f) {
+  __shared__ float red[256];
+  const int k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f;
+  const int tap = blockIdx.x, ky = tap / k, kx = tap - ky * k;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < C)
+    for (long pos = pl; pos < (long)B * H * W; pos += 4) {
+      const int ix = (int)(pos % W);
+      const long t = pos / W;
+      const int iy = (int)(t % H), b = (int)(t / H);
+      const int oy = iy * f - p + ky, ox = ix * f - p + kx;
+      if (oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
+      acc += x[pos * x_stride + c] * dz[((long)(b * Ho + oy) * Wo + ox) * dz_stride + c];
+    }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (pl == 0 && c < C) dw[(long)tap * C + c] += (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+
+__global__ void __launch_bounds__(256) dcn_cols_f32_kernel(const float* __restrict__ x, int x_stride,
+                                                           const float* __restrict__ om, int om_stride, float* __restrict__ col,
+                                                           int B, int H, int W, int Cin, int mask_is_prob) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * H * W * 9 * Cin) return;
+  const int c = (int)(idx % Cin);
+  long t = idx / Cin;
+  const int tap = (int)(t % 9);
+  const long m = t / 9;
+  const int wo = (int)(m % W);
+  const long t2 = m / W;
+  const int ho = (int)(t2 % H), b = (int)(t2 / H);
+  const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride, mask_is_prob);
+  float v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = g.off[q] >= 0 ? x[g.off[q] + c] : 0.f;
+  const float val = g.w[0] * v[0] + g.w[1] * v[1] + g.w[2] * v[2] + g.w[3] * v[3];
+  col[m * (9L * Cin) + (long)tap * Cin + c] = val * g.mask;
+}
+
+// the generic coordinate / col2im kernel above for f32 columns and inputs (same wave-per-(pixel, tap) structure)
+__global__ void __launch_bounds__(256) dcn_col2im_coord_f32_kernel(const float* __restrict__ dcol, const float* __restrict__ x,
+                                                                   int x_stride, const float* __restrict__ om, int om_stride,
+                                                                   float* __restrict__ dx, float* __restrict__ dom, int B,
+                                                                   int H, int W, int Cin, int mask_is_prob) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwork = (long)B * H * W * 9;
+  for (long wk = wave_id; wk < nwork; wk += (long)gridDim.x * 4) {
+    const int tap = (int)(wk % 9);
+    const long m = wk / 9;
+    const int wo = (int)(m % W);
+    const long t2 = m / W;
+    const int ho = (int)(t2 % H), b = (int)(t2 / H);
+    const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride, mask_is_prob);
+    float val_dot = 0.f, dh = 0.f, dwv = 0.f;
+    if (g.inside) {
+      const float* dcp = dcol + m * (9L * Cin) + (long)tap * Cin;
+      for (int c = lane; c < Cin; c += 64) {
+        const float d = dcp[c];
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = g.off[q] >= 0 ? x[g.off[q] + c] : 0.f;
+        val_dot += d * (g.w[0] * v[0] + g.w[1] * v[1] + g.w[2] * v[2] + g.w[3] * v[3]);
+        dh += d * (-g.hw * v[0] - g.lw * v[1] + g.hw * v[2] + g.lw * v[3]);
+        dwv += d * (-g.hh * v[0] + g.hh * v[1] - g.lh * v[2] + g.lh * v[3]);
+        const float dm = d * g.mask;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (g.off[q] >= 0) atomicAdd(dx + g.off[q] / x_stride * (long)Cin + c, g.w[q] * dm);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      val_dot += __shfl_down(val_dot, o, 64);
+      dh += __shfl_down(dh, o, 64);
+      dwv += __shfl_down(dwv, o, 64);
+    }
+    if (lane == 0) {
+      float* d = dom + m * om_stride;
+      d[2 * tap] = dh * g.mask;
+      d[2 * tap + 1] = dwv * g.mask;
+      d[18 + tap] = mask_is_prob ? val_dot : val_dot * g.mask * (1.f - g.mask);
+    }
+  }
+}
+
+static int chan_blocks_f32(int M, int C) {
+  const int rpp = C < 256 ? 256 / C : 1;
+  long nb = ((long)M + rpp * 16 - 1) / (rpp * 16);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+int launch_bn_train_fwd_f32(const float* y, int y_stride, const float* res, int res_stride, float* z, int z_stride, int M, int C,
+                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, float* mean, float* invstd, float* scale, float* shift, void* workspace,
+                            int relu, hipStream_t s) {
+  ChanRedArgsF a = {};
+  a.y = y; a.y_stride = y_stride; a.M = M; a.C = C; a.mode = 0; a.partial = (float*)workspace;
+  const int nb = chan_blocks_f32(M, C);
+  hipLaunchKernelGGL(chan_reduce_f32_kernel, dim3(nb), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(chan_finalize_kernel, dim3(C), dim3(256), 0, s, (const float*)workspace, nb, C, M, 0, eps,
+                     momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
+  hipLaunchKernelGGL(affine_act_f32_kernel, dim3(nblk256((long)M * C)), dim3(256), 0, s, y, y_stride, scale, shift, res,
+                     res_stride, z, z_stride, (long)M, C, relu);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bn_train_bwd_f32(const float* dz, int dz_stride, const float* z, int z_stride, const float* y, int y_stride,
+                            const float* mean, const float* invstd, const float* scale, int M, int C, int relu, float* dy,
+                            int dy_stride, float* dres, int dres_stride, float* dgamma, float* dbeta, float grad_mult,
+                            void* workspace, hipStream_t s) {
+  ChanRedArgsF a = {};
+  a.y = y; a.y_stride = y_stride; a.dz = dz; a.dz_stride = dz_stride; a.z = z; a.z_stride = z_stride;
+  a.mean = mean; a.invstd = invstd; a.M = M; a.C = C; a.mode = 1; a.relu = relu; a.partial = (float*)workspace;
+  const int nb = chan_blocks_f32(M, C);
+  hipLaunchKernelGGL(chan_reduce_f32_kernel, dim3(nb), dim3(256), 0, s, a);
+  float* sums = (float*)workspace + (size_t)1024 * 2 * C;
+  hipLaunchKernelGGL(chan_finalize_kernel, dim3(C), dim3(256), 0, s, (const float*)workspace, nb, C, M, 1,
+                     grad_mult, 0.f, (const float*)nullptr, (const float*)nullptr, dbeta, dgamma, sums, sums + C,
+                     (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_apply_f32_kernel, dim3(nblk256((long)M * C)), dim3(256), 0, s, dz, dz_stride, z, z_stride, y,
+                     y_stride, mean, invstd, scale, (const float*)sums, (const float*)(sums + C), dy, dy_stride, dres,
+                     dres_stride, (long)M, C, relu);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_conv_wgrad_f32(const WgradArgs& h, hipStream_t s) {
+  WgradArgsF a;
+  a.x = (const float*)h.x; a.dy = (const float*)h.dy; a.dw = h.dw;
+  a.B = h.B; a.H = h.H; a.W = h.W; a.Cin = h.Cin; a.in_stride = h.in_stride; a.Cout = h.Cout; a.Ho = h.Ho; a.Wo = h.Wo;
+  a.dy_stride = h.dy_stride; a.R = h.R; a.S = h.S; a.stride = h.stride; a.pad = h.pad; a.dil = h.dil; a.K = h.K; a.M = h.M;
+  a.scale = h.scale;
+  const int nkb = (a.K + 15) / 16, nnb = (a.Cout + 15) / 16;
+  long ms = 4096 / ((long)nkb * nnb);
+  if (ms < 1) ms = 1;
+  const long maxs = ((long)a.M + 63) / 64;
+  if (ms > maxs) ms = maxs;
+  if (ms > 65535) ms = 65535;
+  a.msplit = (int)ms;
+  if (a.M == 0) return 0;
+  hipLaunchKernelGGL(conv_wgrad_f32_kernel, dim3(nkb, nnb, (unsigned)ms), dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_maxpool2x2_bwd_f32(const float* x, int x_stride, const float* dz, int dz_stride, float* dx, int dx_stride, int B,
+                              int H, int W, int C, hipStream_t s) {
+  CTDET_CHECK(H % 2 == 0 && W % 2 == 0, "maxpool_bwd: bad shape");
+  const long total = (long)B * (H / 2) * (W / 2) * C;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(maxpool2x2_bwd_f32_kernel, dim3(nblk256(total)), dim3(256), 0, s, x, x_stride, dz, dz_stride, dx,
+                     dx_stride, B, H, W, C);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_dwconvT_bwd_f32(const float* x, int x_stride, const float* dz, int dz_stride, const float* w, float* dx,
+                           int dx_stride, float* dw, int B, int H, int W, int C, int f, hipStream_t s) {
+  CTDET_CHECK(f % 2 == 0, "dwconvT_bwd: bad factor %d", f);
+  if ((long)B * H * W * C == 0) return 0;
+  hipLaunchKernelGGL(dwconvT_dw_f32_kernel, dim3(4 * f * f, (C + 63) / 64), dim3(256), 0, s, x, x_stride, dz, dz_stride, dw, B,
+                     H, W, C, f);
+  hipLaunchKernelGGL(dwconvT_dx_f32_kernel, dim3(nblk256((long)B * H * W * C)), dim3(256), 0, s, dz, dz_stride, w, dx,
+                     dx_stride, B, H, W, C, f);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_dcn_cols_f32(const float* x, int x_stride, const float* om, int om_stride, float* col, int B, int H, int W, int Cin,
+                        int mask_is_prob, hipStream_t s) {
+  CTDET_CHECK(om_stride >= 27, "dcn_cols: bad shape");
+  const long total = (long)B * H * W * 9 * Cin;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(dcn_cols_f32_kernel, dim3(nblk256(total)), dim3(256), 0, s, x, x_stride, om, om_stride, col, B, H, W, Cin,
+                     mask_is_prob);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_dcn_col2im_coord_f32(const float* dcol, const float* x, int x_stride, const float* om, int om_stride, float* dx,
+                                float* dom, int B, int H, int W, int Cin, int mask_is_prob, hipStream_t s) {
+  const long nwork = (long)B * H * W * 9;
+  if (nwork == 0) return 0;
+  long nb = (nwork + 3) / 4;
+  if (nb > 256 * 32) nb = 256 * 32;
+  hipLaunchKernelGGL(dcn_col2im_coord_f32_kernel, dim3((unsigned)nb), dim3(256), 0, s, dcol, x, x_stride, om, om_stride, dx,
+                     dom, B, H, W, Cin, mask_is_prob);
   CTDET_LAUNCH_CHECK();
   return 0;
 }

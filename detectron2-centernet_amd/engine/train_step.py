@@ -3,7 +3,8 @@ graph of dla.py and DeformConvV2 of deform_conv.py:498-519, all modules in train
 
 The module tree is walked functionally; every node is an autograd Function from ops_train (HIP kernels forward and
 backward).  Root's torch.cat is materialised here (a device copy) -- the concat-free multi-source kernel is
-inference-only for now.
+inference-only for now.  The mode follows MODEL.CENTERNET.HIP_PRECISION: f16 (throughput) or f32 (the reference's
+precision: every activation, gradient and statistic in f32).
 """
 import torch
 
@@ -112,8 +113,6 @@ def centernet_train_forward(model, batched_inputs):
     """list[dict] with "image" and "instances" -> {"hm_loss","wh_loss","off_loss"} (0-d tensors with autograd)."""
     if model.device.type != "cuda":
         raise NotImplementedError("the CenterNet HIP path has no CPU implementation (MODEL.DEVICE must be cuda)")
-    if model._ctx.compute != ops.F16:
-        raise NotImplementedError("training runs in the f16-MFMA / f32-accumulate mode (HIP_PRECISION: f16)")
     assert "instances" in batched_inputs[0], "Instance annotations are missing in training!"
     images, targets = model.preprocess_image(batched_inputs)
     return train_forward_tensors(model, images.nhwc, targets)

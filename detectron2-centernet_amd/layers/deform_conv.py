@@ -24,23 +24,38 @@ def _check_supported(groups, deformable_groups, stride, dilation):
 
 def modulated_deform_conv(input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
                           deformable_groups=1):
-    """Functional DCNv2 with the reference's signature (deform_conv.py:182-194): NCHW `input`,
-    `offset` [B,2*kh*kw,Ho,Wo], `mask` [B,kh*kw,Ho,Wo] (already sigmoid-ed), `weight` [Co,Ci,kh,kw].
-    Forward only here; the differentiable form lives in the training path."""
+    """Functional DCNv2 with the reference's signature and contract (`_ModulatedDeformConv.apply`, deform_conv.py:180-306):
+    NCHW `input`, `offset` [B,2*kh*kw,Ho,Wo] (ch 2k = dh, 2k+1 = dw of tap k), `mask` [B,kh*kw,Ho,Wo] (already
+    sigmoid-ed), `weight` [Co,Ci,kh,kw], optional `bias`; returns NCHW.  Differentiable in input, offset, mask, weight and
+    bias (backward = deform_conv_cuda.cu:929-1129 on the HIP kernels) for the 3x3 / stride 1 / pad 1 / dilation 1
+    geometry every DCN of the CenterNet path has; other geometries run forward only.  float16 input -> f16 MFMA mode,
+    float32 input -> the reference's own arithmetic on the f32 matrix pipe."""
     if not input.is_cuda:
         raise NotImplementedError("Deformable Conv is not supported on CPUs!")  # deform_conv.py:203-204
     _check_supported(groups, deformable_groups, stride, dilation)
+    from ..ops_train import DCNFn
+
     compute = F16 if input.dtype == torch.float16 else F32
     ctx = hipnn.Ctx(compute)
-    kh, kw = weight.shape[2:]
-    x = hipnn.to_nhwc(input, ctx)
+    Co, _, kh, kw = weight.shape
+    x = input.permute(0, 2, 3, 1).to(ctx.dtype).contiguous()
     B, Ho, Wo = offset.shape[0], offset.shape[2], offset.shape[3]
-    om = torch.zeros(B, Ho, Wo, ops.round_up(3 * kh * kw, 4), dtype=torch.float32, device=input.device)
-    om[..., : 2 * kh * kw] = offset.permute(0, 2, 3, 1)
-    om[..., 2 * kh * kw: 3 * kh * kw] = mask.permute(0, 2, 3, 1)
-    p = ops.PackedConv(weight, None, bias, stride=stride, pad=padding, dil=dilation, compute=compute)
-    y = ops.dcnv2(x, om, p, mask_is_prob=True)
-    return hipnn.to_nchw_view(y, weight.shape[0])
+    npad = ops.round_up(3 * kh * kw, 4) - 3 * kh * kw
+    parts = [offset.float(), mask.float()]
+    if npad:
+        parts.append(torch.zeros(B, npad, Ho, Wo, dtype=torch.float32, device=input.device))
+    om = torch.cat(parts, dim=1).permute(0, 2, 3, 1).contiguous()
+    needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (input, offset, mask, weight, bias))
+    if (kh, kw) == (3, 3) and _pair(stride) == (1, 1) and _pair(padding) == (1, 1) and _pair(dilation) == (1, 1):
+        y = DCNFn.apply(x, om, weight, bias, True, 1.0)       # unscaled parameter gradients (no loss-scale protocol here)
+    else:
+        if needs_grad:
+            raise NotImplementedError("modulated_deform_conv backward: only 3x3 / stride 1 / padding 1 / dilation 1")
+        p = ops.PackedConv(weight, None, bias, stride=stride, pad=padding, dil=dilation, compute=compute,
+                           cout_align=64 if compute == F16 else None)
+        y = ops.dcnv2(x, om, p, mask_is_prob=True)
+    y = y[..., :Co].permute(0, 3, 1, 2)
+    return y if y.dtype == input.dtype else y.to(input.dtype)
 
 
 class ModulatedDeformConv(nn.Module):
@@ -102,9 +117,18 @@ class DCN(nn.Module):
         return ops.dcnv2(x, om, p, act=act)
 
     def forward(self, x):
-        """logical NCHW in / out, like the reference module."""
+        """logical NCHW in / out, like the reference module; differentiable (offset/mask conv and the deformable conv go
+        through the training autograd nodes) whenever a gradient is asked for."""
         ctx = hipnn.Ctx(F16 if x.dtype == torch.float16 else F32)
-        return hipnn.to_nchw_view(self.hip_forward(hipnn.to_nhwc(x, ctx), ctx), self.out_channels)
+        xh = x.permute(0, 2, 3, 1).contiguous()
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            from ..ops_train import ConvFn, DCNFn
+            om = ConvFn.apply(xh, self.conv_offset_mask.weight, self.conv_offset_mask.bias, self.stride, self.padding,
+                              False, True, 1.0)
+            y = DCNFn.apply(xh, om, self.weight, self.bias, False, 1.0)
+        else:
+            y = self.hip_forward(xh, ctx)
+        return hipnn.to_nchw_view(y, self.out_channels)
 
 
 class DeformConvV2(nn.Module):

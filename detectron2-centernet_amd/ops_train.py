@@ -1,8 +1,9 @@
 """Training-side op wrappers (C ABI) and the torch.autograd.Function glue of the CenterNet training path.
 
 Autograd is used as the tape only: every forward and backward body below is one or a few HIP kernel launches.
-Activations and activation-gradients are f16 NHWC, parameters and parameter-gradients f32 (the reference trains in
-f32; mixed precision with f32 accumulation everywhere is this build's throughput mode).  A static loss scale keeps
+Two modes, chosen by the dtype of the activations that enter: f16 NHWC activations / activation gradients with f32
+parameters and parameter gradients (the throughput mode: mixed precision with f32 accumulation everywhere), or f32
+throughout (the reference's own precision: the mode in which the whole step is compared with the fp32 oracle).  A static loss scale keeps
 small heatmap gradients inside the f16 range: it is applied in the loss backward and removed again on every
 parameter gradient, so `param.grad` and the returned loss values are unscaled.
 """
@@ -12,7 +13,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import ConvDesc
-from .ops import ACT_NONE, ACT_RELU, F16, _nhwc_stride, _ptr, _require_cuda, _stream
+from .ops import ACT_NONE, ACT_RELU, F16, F32, _nhwc_stride, _ptr, _require_cuda, _stream, dt_of
 
 GRAD_SCALE = 1024.0
 # parameter gradients are multiplied by PARAM_GRAD_MULT = 1 / (GRAD_SCALE * world_size): removes the loss scale and
@@ -71,13 +72,13 @@ def _ws(Cc, device):
 def bn_train_fwd(y, gamma, beta, running_mean, running_var, eps, momentum, res=None, relu=True):
     B, H, W, Cc = y.shape
     dev = y.device
-    z = torch.empty(B, H, W, Cc, dtype=torch.float16, device=dev)
+    z = torch.empty(B, H, W, Cc, dtype=y.dtype, device=dev)
     mean, invstd, scale, shift = (torch.empty(Cc, dtype=torch.float32, device=dev) for _ in range(4))
     with ops.prof_region("bn_train_fwd", flops=0.0, nbytes=float(B * H * W * Cc * (6 if res is None else 8))):
         rc = _lib.lib().ctdet_bn_train_fwd(_ptr(y), _nhwc_stride(y), _ptr(res), _nhwc_stride(res) if res is not None else 0,
                                            _ptr(z), _nhwc_stride(z), B * H * W, Cc, _ptr(gamma), _ptr(beta), float(eps),
                                            float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd),
-                                           _ptr(scale), _ptr(shift), _ptr(_ws(Cc, dev)), int(relu), _stream())
+                                           _ptr(scale), _ptr(shift), _ptr(_ws(Cc, dev)), int(relu), dt_of(y), _stream())
     _lib.check(rc, "ctdet_bn_train_fwd")
     return z, mean, invstd, scale
 
@@ -86,8 +87,8 @@ def bn_train_bwd(dz, z, y, mean, invstd, scale, relu=True, want_dres=False, grad
     """dgamma / dbeta come back multiplied by grad_mult (default: PARAM_GRAD_MULT, what every parameter gradient carries)"""
     B, H, W, Cc = dz.shape
     dev = dz.device
-    dy = torch.empty(B, H, W, Cc, dtype=torch.float16, device=dev)
-    dres = torch.empty(B, H, W, Cc, dtype=torch.float16, device=dev) if want_dres else None
+    dy = torch.empty(B, H, W, Cc, dtype=dz.dtype, device=dev)
+    dres = torch.empty(B, H, W, Cc, dtype=dz.dtype, device=dev) if want_dres else None
     dgb = torch.empty(2, Cc, dtype=torch.float32, device=dev)   # written, not accumulated
     dgamma, dbeta = dgb[0], dgb[1]
     gm = PARAM_GRAD_MULT if grad_mult is None else grad_mult
@@ -96,7 +97,7 @@ def bn_train_bwd(dz, z, y, mean, invstd, scale, relu=True, want_dres=False, grad
                                            _ptr(y), _nhwc_stride(y) if y is not None else 0, _ptr(mean), _ptr(invstd),
                                            _ptr(scale), B * H * W, Cc, int(relu), _ptr(dy), _nhwc_stride(dy), _ptr(dres),
                                            _nhwc_stride(dres) if dres is not None else 0, _ptr(dgamma), _ptr(dbeta),
-                                           float(gm), _ptr(_ws(Cc, dev)), _stream())
+                                           float(gm), _ptr(_ws(Cc, dev)), dt_of(dz), _stream())
     _lib.check(rc, "ctdet_bn_train_bwd")
     return dy, dres, dgamma, dbeta
 
@@ -110,6 +111,8 @@ def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1, scale=None):
     d.B, d.H, d.W, d.Cin, d.in_stride = B, H, W, Cin, _nhwc_stride(x)
     d.Cout, d.Ho, d.Wo, d.out_stride = Cout, Ho, Wo, _nhwc_stride(dy)
     d.R, d.S, d.stride, d.pad, d.dil = R, S, stride, pad, dil
+    d.compute_dtype = dt_of(x)
+    assert dy.dtype == x.dtype
     dw = _zeros_f32((Cout, R * S * Cin), x.device)
     with ops.prof_region(f"conv_wgrad<{R}x{S}>", flops=2.0 * B * Ho * Wo * Cout * R * S * Cin, nbytes=0.0):
         rc = _lib.lib().ctdet_conv_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
@@ -120,9 +123,9 @@ def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1, scale=None):
 
 def maxpool2x2_bwd(x, dz):
     B, H, W, Cc = x.shape
-    dx = torch.empty(B, H, W, Cc, dtype=torch.float16, device=x.device)
+    dx = torch.empty(B, H, W, Cc, dtype=x.dtype, device=x.device)
     rc = _lib.lib().ctdet_maxpool2x2_bwd(_ptr(x), _nhwc_stride(x), _ptr(dz), _nhwc_stride(dz), _ptr(dx), _nhwc_stride(dx),
-                                         B, H, W, Cc, _stream())
+                                         B, H, W, Cc, dt_of(x), _stream())
     _lib.check(rc, "ctdet_maxpool2x2_bwd")
     return dx
 
@@ -130,37 +133,37 @@ def maxpool2x2_bwd(x, dz):
 def dwconvT_bwd(x, dz, weight, f):
     B, H, W, Cc = x.shape
     w = weight.detach().reshape(Cc, 2 * f, 2 * f).to(torch.float32).permute(1, 2, 0).contiguous()
-    dx = torch.empty(B, H, W, Cc, dtype=torch.float16, device=x.device)
+    dx = torch.empty(B, H, W, Cc, dtype=x.dtype, device=x.device)
     dw = torch.zeros(2 * f, 2 * f, Cc, dtype=torch.float32, device=x.device)
     rc = _lib.lib().ctdet_dwconvT_bwd(_ptr(x), _nhwc_stride(x), _ptr(dz), _nhwc_stride(dz), _ptr(w), _ptr(dx),
-                                      _nhwc_stride(dx), _ptr(dw), B, H, W, Cc, f, _stream())
+                                      _nhwc_stride(dx), _ptr(dw), B, H, W, Cc, f, dt_of(x), _stream())
     _lib.check(rc, "ctdet_dwconvT_bwd")
     return dx, dw.permute(2, 0, 1).reshape(Cc, 1, 2 * f, 2 * f)
 
 
-def dcn_cols(x, om):
+def dcn_cols(x, om, mask_is_prob=False):
     B, H, W, Cin = x.shape
-    col = torch.empty(B, H, W, 9 * Cin, dtype=torch.float16, device=x.device)
+    col = torch.empty(B, H, W, 9 * Cin, dtype=x.dtype, device=x.device)
     with ops.prof_region("dcn_cols", flops=0.0, nbytes=float(B * H * W * Cin * (2 + 18) + B * H * W * 27 * 4)):
-        rc = _lib.lib().ctdet_dcn_cols(_ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(col), B, H, W, Cin, _stream())
+        rc = _lib.lib().ctdet_dcn_cols(_ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(col), B, H, W, Cin, int(mask_is_prob), dt_of(x), _stream())
     _lib.check(rc, "ctdet_dcn_cols")
     return col
 
 
-def dcn_col2im_coord(dcol, x, om):
+def dcn_col2im_coord(dcol, x, om, mask_is_prob=False):
     B, H, W, Cin = x.shape
     dx = torch.zeros(B, H, W, Cin, dtype=torch.float32, device=x.device)
     dom = torch.zeros_like(om)
     with ops.prof_region("dcn_col2im", flops=0.0, nbytes=float(B * H * W * Cin * (18 + 2 + 4) + B * H * W * 27 * 8)):
         rc = _lib.lib().ctdet_dcn_col2im_coord(_ptr(dcol), _ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(dx),
-                                               _ptr(dom), B, H, W, Cin, _stream())
+                                               _ptr(dom), B, H, W, Cin, int(mask_is_prob), dt_of(x), _stream())
     _lib.check(rc, "ctdet_dcn_col2im_coord")
     return dx, dom
 
 
 # ------------------------------------------------------------------------------------------ helpers
-def _fwd_pack(weight, stride, pad, cin_pad=None, bias=None):
-    return ops.PackedConv(weight, None, bias, stride=stride, pad=pad, compute=F16, cin_pad=cin_pad)
+def _fwd_pack(weight, stride, pad, cin_pad=None, bias=None, compute=F16):
+    return ops.PackedConv(weight, None, bias, stride=stride, pad=pad, compute=compute, cin_pad=cin_pad)
 
 
 _PHASE_TAPS = {}
@@ -208,8 +211,16 @@ def _conv_dgrad_s2_phases(dy, weight, in_hw):
 
 def conv_dgrad(dy, weight, stride, pad, in_hw):
     """dx of y = conv(x, weight): a conv over dy with the taps flipped and in/out channels swapped;
-    3x3 / stride 2 / pad 1 goes through the four-phase form, other strides read dy as zero-stuffed (in_dil)."""
+    f16: 3x3 / stride 2 / pad 1 goes through the four-phase form, other strides read dy as zero-stuffed (in_dil);
+    f32: always the zero-stuffed form on the f32 MFMA kernel."""
     Cout, Cin, R, S = weight.shape
+    if dy.dtype == torch.float32:
+        wt = weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()      # [Cin, Cout, R, S]: dX = conv(dY, wt)
+        p = ops.PackedConv(wt, None, None, stride=1, pad=R - 1 - pad, compute=F32)
+        p.in_dil = stride
+        dx = torch.empty(dy.shape[0], in_hw[0], in_hw[1], p.Cout_eff, dtype=torch.float32, device=dy.device)
+        ops.conv2d(dy, p, out=dx)
+        return dx if p.Cout_eff == Cin else dx[..., :Cin]
     if stride == 2 and R == 3 and S == 3 and pad == 1 and dy.shape[3] % 8 == 0:
         return _conv_dgrad_s2_phases(dy, weight, in_hw)
     p = ops.PackedConv(weight.detach(), None, None, stride=1, pad=R - 1 - pad, compute=F16, tap_major=stride > 1,
@@ -227,12 +238,18 @@ def _wgrad_to_oihw(dw, Cout, Cin_real, Cin_used, R, S):
 
 # ------------------------------------------------------------------------------------------ autograd Functions
 class ConvFn(torch.autograd.Function):
-    """y = conv(x, weight) (+bias)(+relu) without BatchNorm; x f16 NHWC."""
+    """y = conv(x, weight) (+bias)(+relu) without BatchNorm; x NHWC, f16 or f32 (the mode)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu, out_f32):
-        p = _fwd_pack(weight, stride, pad, cin_pad=x.shape[3] if x.shape[3] != weight.shape[1] else None, bias=bias)
-        y = ops.conv2d(x, p, act=ACT_RELU if relu else ACT_NONE, out_dtype=torch.float32 if out_f32 else torch.float16)
+    def forward(ctx, x, weight, bias, stride, pad, relu, out_f32, param_grad_mult=None):
+        """param_grad_mult: multiplier on the parameter gradients; None = PARAM_GRAD_MULT (the training step's loss-scale /
+        world-size protocol), 1.0 for stand-alone use behind the reference's module interface"""
+        ctx.pgm = param_grad_mult
+        f32 = x.dtype == torch.float32
+        p = _fwd_pack(weight, stride, pad, cin_pad=x.shape[3] if x.shape[3] != weight.shape[1] else None, bias=bias,
+                      compute=F32 if f32 else F16)
+        y = ops.conv2d(x, p, act=ACT_RELU if relu else ACT_NONE,
+                       out_dtype=torch.float32 if (out_f32 or f32) else torch.float16)
         ctx.cfg = (stride, pad, relu, weight.shape[0], bias is not None)
         ctx.save_for_backward(x, weight, y if relu else None)
         return y
@@ -242,28 +259,31 @@ class ConvFn(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         stride, pad, relu, Cout, has_bias = ctx.cfg
         Cout, Cin, R, S = weight.shape
-        if dy.dtype != torch.float16:
-            dy = dy.half()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
         dy = _pad_c(dy.contiguous())          # channel count -> multiple of 8 (padded channels carry zeros)
         Cw = dy.shape[3]
         dbias = None
         if relu or has_bias:
-            dy, _, _, db = bn_train_bwd(dy, _pad_c(y) if relu else None, None, None, None, None, relu=relu)
+            dy, _, _, db = bn_train_bwd(dy, _pad_c(y) if relu else None, None, None, None, None, relu=relu, grad_mult=ctx.pgm)
             dbias = db[:Cout] if has_bias else None
-        dw = conv_wgrad(x, dy, Cw, R, S, stride, pad)[:Cout]
+        dw = conv_wgrad(x, dy, Cw, R, S, stride, pad, scale=ctx.pgm)[:Cout]
         dwt = _wgrad_to_oihw(dw, Cout, Cin, x.shape[3], R, S)
         dx = None
         if ctx.needs_input_grad[0]:
             wpad = weight if Cw == Cout else torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
+            if x.shape[3] != Cin:             # input channels were padded (the 3 -> 8 channel image): so is dX
+                wpad = torch.nn.functional.pad(wpad.detach(), (0, 0, 0, 0, 0, x.shape[3] - Cin))
             dx = conv_dgrad(dy, wpad, stride, pad, x.shape[1:3])
-        return dx, dwt, dbias, None, None, None, None
+        return dx, dwt, dbias, None, None, None, None, None
 
 
 def _pad_c(t):
-    """channel count up to a multiple of 8 (kernels vectorise 8 f16 channels)"""
-    if t is None or t.shape[3] % 8 == 0:
+    """channel count up to a multiple of 8 (the f16 kernels vectorise 8 channels) / 4 (f32)"""
+    q = 8 if t is not None and t.dtype == torch.float16 else 4
+    if t is None or t.shape[3] % q == 0:
         return t
-    return torch.nn.functional.pad(t, (0, 8 - t.shape[3] % 8))
+    return torch.nn.functional.pad(t, (0, q - t.shape[3] % q))
 
 
 class BNActFn(torch.autograd.Function):
@@ -316,12 +336,18 @@ class DCNFn(torch.autograd.Function):
     """modulated deformable conv (3x3/s1/p1) for training.  Forward: the fused sampling + MFMA kernel of the inference path
     (no column tensor).  Backward: the columns are materialised once there (as the reference does for both directions,
     deform_conv_cuda.cu:874-917) so dW and d(columns) are plain 1x1 contractions on the MFMA kernels; nothing of size
-    9*Cin per pixel lives between forward and backward."""
+    9*Cin per pixel lives between forward and backward.  om: raw f32 [.., >=27] output of conv_offset_mask (mask logits);
+    mask_is_prob: the reference's functional form passes sigmoid-ed masks instead (deform_conv.py:182-194)."""
 
     @staticmethod
-    def forward(ctx, x, om, weight, bias):
-        p = ops.PackedConv(weight.detach(), None, bias, stride=1, pad=1, compute=F16, cout_align=64)
-        y = ops.dcnv2(x, om, p)
+    def forward(ctx, x, om, weight, bias, mask_is_prob=False, param_grad_mult=None):
+        ctx.pgm = param_grad_mult
+        f32 = x.dtype == torch.float32
+        p = ops.PackedConv(weight.detach(), None, bias, stride=1, pad=1, compute=F32 if f32 else F16,
+                           cout_align=None if f32 else 64)
+        y = ops.dcnv2(x, om, p, mask_is_prob=mask_is_prob)
+        ctx.mask_is_prob = mask_is_prob
+        ctx.has_bias = bias is not None
         ctx.save_for_backward(x, om, weight)
         return y
 
@@ -330,14 +356,21 @@ class DCNFn(torch.autograd.Function):
         x, om, weight = ctx.saved_tensors
         Cout, Cin = weight.shape[:2]
         dy = dy.contiguous()
-        col = dcn_cols(x, om)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        if dy.shape[3] != Cout:
+            dy = dy[..., :Cout].contiguous()
+        dyp = _pad_c(dy)
+        col = dcn_cols(x, om, ctx.mask_is_prob)
         wmat = weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
-        _, _, _, dbias = bn_train_bwd(dy, None, None, None, None, None, relu=False)
-        dw = conv_wgrad(col, dy, Cout, 1, 1, 1, 0)                       # [Cout, 9*Cin]
+        if dyp.shape[3] != Cout:
+            wmat = torch.nn.functional.pad(wmat, (0, 0, 0, 0, 0, 0, 0, dyp.shape[3] - Cout))
+        _, _, _, dbias = bn_train_bwd(dyp, None, None, None, None, None, relu=False, grad_mult=ctx.pgm)
+        dw = conv_wgrad(col, dyp, dyp.shape[3], 1, 1, 1, 0, scale=ctx.pgm)[:Cout]         # [Cout, 9*Cin]
         dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
-        dcol = conv_dgrad(dy, wmat, 1, 0, x.shape[1:3])                  # [M, 9*Cin]
-        dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om)
-        return dx32.half(), dom, dwt, dbias
+        dcol = conv_dgrad(dyp, wmat, 1, 0, x.shape[1:3])                   # [M, 9*Cin]
+        dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om, ctx.mask_is_prob)
+        return dx32.to(x.dtype), dom, dwt, dbias[:Cout] if ctx.has_bias else None, None, None
 
 
 class FocalLossFn(torch.autograd.Function):

@@ -199,8 +199,10 @@ int32_t ctdet_sgd_momentum_runs(float* param, const float* grad, float* momentum
                                 const int32_t* run_lr_index, const float* run_weight_decay, const float* lr_table,
                                 int32_t nruns, float momentum, int32_t first_step, void* stream);
 
-/* ---- training-side entry points (f16 activations, f32 statistics and weight gradients) ------------------------
- * Input gradients of plain convs are ctdet_conv2d_fwd calls with transposed/flipped weights (in_dil for stride 2). */
+/* ---- training-side entry points (f32 statistics and weight gradients; activations and activation gradients f16 --
+ * the throughput mode -- or f32 -- the reference's precision -- selected by `dtype` (ctdet_dtype) / the descriptor's
+ * compute_dtype).  Input gradients of plain convs are ctdet_conv2d_fwd calls with transposed/flipped weights (in_dil
+ * for strided layers). */
 
 /* nn.BatchNorm2d in training mode + optional residual add + ReLU (dla.py:59-73,86-94; deform_conv.py:501-519):
  * z = act(gamma*(y-mean)*invstd + beta + res); batch statistics over the M rows; running stats updated with
@@ -209,7 +211,8 @@ size_t ctdet_chan_workspace_bytes(int32_t C);
 int32_t ctdet_bn_train_fwd(const void* y, int32_t y_stride, const void* res, int32_t res_stride, void* z,
                            int32_t z_stride, int32_t M, int32_t C, const float* gamma, const float* beta, float eps,
                            float momentum, float* running_mean, float* running_var, float* save_mean,
-                           float* save_invstd, float* scale, float* shift, void* workspace, int32_t relu, void* stream);
+                           float* save_invstd, float* scale, float* shift, void* workspace, int32_t relu, int32_t dtype,
+                           void* stream);
 /* backward of the above: g = dz*(z>0) if relu; dgamma = sum g*xhat, dbeta = sum g,
  * dy = scale*(g - dbeta/M - xhat*dgamma/M); dres (optional) = g.  With y == NULL it is the backward of
  * "bias + activation" (dy = g, dbeta = bias gradient, dgamma untouched semantics: 0).  dgamma / dbeta are written (not
@@ -218,9 +221,9 @@ int32_t ctdet_bn_train_fwd(const void* y, int32_t y_stride, const void* res, int
 int32_t ctdet_bn_train_bwd(const void* dz, int32_t dz_stride, const void* z, int32_t z_stride, const void* y,
                            int32_t y_stride, const float* mean, const float* invstd, const float* scale, int32_t M,
                            int32_t C, int32_t relu, void* dy, int32_t dy_stride, void* dres, int32_t dres_stride,
-                           float* dgamma, float* dbeta, float grad_mult, void* workspace, void* stream);
+                           float* dgamma, float* dbeta, float grad_mult, void* workspace, int32_t dtype, void* stream);
 /* weight gradient of a conv: dw f32 [Cout][R*S*Cin] (tap-major k) += scale * sum over pixels; dw must be zeroed by
- * the caller.  Geometry from the descriptor (out_stride = pixel stride of dy). */
+ * the caller.  Geometry from the descriptor (out_stride = pixel stride of dy; compute_dtype = dtype of x and dy). */
 int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy, float* dw, float scale, void* stream);
 /* Interleave of the four output phases of a stride-2 3x3 conv's input gradient (f16 NHWC):
  * dst[b,y,x,c] = src[b,(y+1)/2,(x+1)/2,((y&1)*2+(x&1))*C + c]; src is the [B,Hs,Ws,>=4C] result of the 2x2 "phase" conv
@@ -228,18 +231,20 @@ int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy
 int32_t ctdet_depth_to_space2(const void* src, int32_t src_stride, void* dst, int32_t dst_stride, int32_t B, int32_t H,
                               int32_t W, int32_t C, int32_t Hs, int32_t Ws, void* stream);
 int32_t ctdet_maxpool2x2_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, void* dx,
-                             int32_t dx_stride, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+                             int32_t dx_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 /* depthwise ConvTranspose2d backward: dx f16, dw f32 [2f][2f][C] (+=, zeroed by the caller); w as in the forward */
 int32_t ctdet_dwconvT_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, const float* w, void* dx,
                           int32_t dx_stride, float* dw, int32_t B, int32_t H, int32_t W, int32_t C, int32_t f,
-                          void* stream);
+                          int32_t dtype, void* stream);
 /* DCNv2 3x3/s1/p1 training pieces: columns [M][9*Cin] f16 (= modulated_deformable_im2col, kernel.cu:786-868) and the
  * backward through the sampler (col2im :871-949 + coordinate/mask gradients :952-1066): dcol [M][9*Cin] f16 ->
- * dx f32 dense [B*H*W][Cin] (+= atomics, zeroed by the caller), dom f32 [M][om_stride] (offset and mask-logit grads) */
+ * dx f32 dense [B*H*W][Cin] (+= atomics, zeroed by the caller), dom f32 [M][om_stride] (offset and mask-logit grads).
+ * mask_is_prob: channels 18..26 of om are sigmoid-ed masks (the reference's functional API) and dom carries d/d(mask). */
 int32_t ctdet_dcn_cols(const void* x, int32_t x_stride, const float* om, int32_t om_stride, void* col, int32_t B,
-                       int32_t H, int32_t W, int32_t Cin, void* stream);
+                       int32_t H, int32_t W, int32_t Cin, int32_t mask_is_prob, int32_t dtype, void* stream);
 int32_t ctdet_dcn_col2im_coord(const void* dcol, const void* x, int32_t x_stride, const float* om, int32_t om_stride,
-                               float* dx, float* dom, int32_t B, int32_t H, int32_t W, int32_t Cin, void* stream);
+                               float* dx, float* dom, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t mask_is_prob,
+                               int32_t dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -284,6 +284,103 @@ def dcnv2_forward(x, offset, mask, weight, bias=None, stride=1, pad=1, dil=1):
     return out
 
 
+def dcnv2_backward(x, offset, mask, weight, grad_out, stride=1, pad=1, dil=1, with_bias=True):
+    """modulated_deform_conv_cuda_backward (deform_conv_cuda.cu:929-1129) restated kernel by kernel, NOT derived by
+    autograd: per image  columns = W^T @ grad_out (:1003-1009);  the coordinate kernel (kernel.cu:952-1066) -> grad_offset,
+    grad_mask;  col2im (kernel.cu:871-949) -> grad_input;  im2col (:786-868) -> grad_weight += grad_out @ columns^T
+    (:1098-1103), grad_bias += grad_out @ ones (:1104-1110).  Kept faithfully: the `(int)` truncation toward zero and the +-2
+    window with the |d| < 1 test of col2im (:928-934) whose weight comes from dmcn_get_gradient_weight (:702-731, floor-based
+    corners, `<= -1 / >= size` emptiness test); in the coordinate kernel the `inv_h = inv_w = -2` sentinel (:1028-1029), the
+    corner guards of dmcn_get_coordinate_weight (:733-783) and of dmcn_im2col_bilinear (:666-699).
+    x [B,C,H,W], offset [B,2RS,Ho,Wo], mask [B,RS,Ho,Wo] (already sigmoid-ed), weight [Co,C,R,S], grad_out [B,Co,Ho,Wo].
+    Returns (grad_input, grad_offset, grad_mask, grad_weight, grad_bias or None).  groups = deformable_groups = 1."""
+    B, C, H, W = x.shape
+    Co, _, R, S = weight.shape
+    Ho = (H + 2 * pad - (dil * (R - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (S - 1) + 1)) // stride + 1
+    P = Ho * Wo
+    dt = x.dtype
+    gx = torch.zeros_like(x)
+    goff = torch.zeros(B, 2 * R * S, Ho, Wo, dtype=dt)
+    gmask = torch.zeros(B, R * S, Ho, Wo, dtype=dt)
+    gw = torch.zeros(Co, C * R * S, dtype=dt)
+    gb = torch.zeros(Co, dtype=dt) if with_bias else None
+    wmat = weight.reshape(Co, C * R * S)
+    h_in = (torch.arange(Ho) * stride - pad).view(Ho, 1).expand(Ho, Wo).reshape(P)
+    w_in = (torch.arange(Wo) * stride - pad).view(1, Wo).expand(Ho, Wo).reshape(P)
+    cols_fwd, _, _ = dcnv2_columns(x, offset, mask, R, S, stride, pad, dil)           # [B, C, RS, P]
+    for b in range(B):
+        go = grad_out[b].reshape(Co, P)
+        col = (wmat.t() @ go).reshape(C, R * S, P)        # columns[c*RS + tap][p], :1003-1009
+        xb = x[b].reshape(C, H * W)
+        off = offset[b].reshape(2 * R * S, P)
+        msk = mask[b].reshape(R * S, P)
+        gxb = torch.zeros(C, H * W, dtype=dt)
+        for i in range(R):
+            for j in range(S):
+                k = i * S + j
+                inv_h = (h_in + i * dil).to(dt) + off[2 * k]
+                inv_w = (w_in + j * dil).to(dt) + off[2 * k + 1]
+                colk = col[:, k]                          # [C, P]
+                # ---------------- coordinate kernel (kernel.cu:1010-1051)
+                outside = (inv_h <= -1) | (inv_w <= -1) | (inv_h >= H) | (inv_w >= W)       # :1027
+                ih = torch.where(outside, torch.full_like(inv_h, -2.0), inv_h)             # :1028-1029
+                iw = torch.where(outside, torch.full_like(inv_w, -2.0), inv_w)
+                hl, wl = torch.floor(ih).long(), torch.floor(iw).long()
+                hh_, wh_ = hl + 1, wl + 1
+
+                def corner(hq, wq, ok):
+                    idx = (hq.clamp(0, H - 1) * W + wq.clamp(0, W - 1)).unsqueeze(0).expand(C, -1)
+                    return xb.gather(1, idx) * ok.unsqueeze(0).to(dt)
+                ok1 = (hl >= 0) & (wl >= 0)
+                ok2 = (hl >= 0) & (wh_ <= W - 1)
+                ok3 = (hh_ <= H - 1) & (wl >= 0)
+                ok4 = (hh_ <= H - 1) & (wh_ <= W - 1)
+                v1, v2, v3, v4 = corner(hl, wl, ok1), corner(hl, wh_, ok2), corner(hh_, wl, ok3), corner(hh_, wh_, ok4)
+                # mval (:1030-1039): bilinear sample only when inside
+                lh, lw = ih - hl.to(dt), iw - wl.to(dt)
+                hh, hw = 1 - lh, 1 - lw
+                bil = (hh * hw) * v1 + (hh * lw) * v2 + (lh * hw) * v3 + (lh * lw) * v4
+                gmask[b, k] = ((colk * bil).sum(0) * (~outside).to(dt)).reshape(Ho, Wo)
+                # dmcn_get_coordinate_weight (:733-783); its emptiness test is true for the -2 sentinel
+                empty = ((ih <= -1) | (ih >= H) | (iw <= -1) | (iw >= W)).to(dt)
+                wl1, wh1 = (wl + 1).to(dt) - iw, iw - wl.to(dt)
+                hl1, hh1 = (hl + 1).to(dt) - ih, ih - hl.to(dt)
+                w_dir0 = -wl1 * v1 - wh1 * v2 + wl1 * v3 + wh1 * v4          # bp_dir 0: d/dh
+                w_dir1 = -hl1 * v1 + hl1 * v2 - hh1 * v3 + hh1 * v4          # bp_dir 1: d/dw
+                goff[b, 2 * k] = ((w_dir0 * colk).sum(0) * msk[k] * (1 - empty)).reshape(Ho, Wo)       # :1049
+                goff[b, 2 * k + 1] = ((w_dir1 * colk).sum(0) * msk[k] * (1 - empty)).reshape(Ho, Wo)
+                # ---------------- col2im (kernel.cu:917-947): truncation, +-2 window, |d| < 1
+                top = colk * msk[k]                        # cur_top_grad [C, P]
+                cur_h = inv_h.to(torch.int64)              # (int): toward zero, like the C cast (:927-928)
+                cur_w = inv_w.to(torch.int64)
+                for dy in range(-2, 3):
+                    for dx in range(-2, 3):
+                        yy, xx = cur_h + dy, cur_w + dx
+                        cond = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W) & \
+                            ((inv_h - yy.to(dt)).abs() < 1) & ((inv_w - xx.to(dt)).abs() < 1)
+                        if not bool(cond.any()):
+                            continue
+                        # dmcn_get_gradient_weight(inv_h, inv_w, yy, xx) (:702-731)
+                        emp = (inv_h <= -1) | (inv_h >= H) | (inv_w <= -1) | (inv_w >= W)
+                        al, aw = torch.floor(inv_h).long(), torch.floor(inv_w).long()
+                        ah, awh = al + 1, aw + 1
+                        yf, xf = yy.to(dt), xx.to(dt)
+                        wgt = torch.zeros_like(inv_h)
+                        wgt = torch.where((yy == al) & (xx == aw), (yf + 1 - inv_h) * (xf + 1 - inv_w), wgt)
+                        wgt = torch.where((yy == al) & (xx == awh), (yf + 1 - inv_h) * (inv_w + 1 - xf), wgt)
+                        wgt = torch.where((yy == ah) & (xx == aw), (inv_h + 1 - yf) * (xf + 1 - inv_w), wgt)
+                        wgt = torch.where((yy == ah) & (xx == awh), (inv_h + 1 - yf) * (inv_w + 1 - xf), wgt)
+                        wgt = wgt * (~emp).to(dt) * cond.to(dt)
+                        idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1))
+                        gxb.index_add_(1, idx, top * wgt.unsqueeze(0))
+        gx[b] = gxb.reshape(C, H, W)
+        gw += go @ cols_fwd[b].reshape(C * R * S, P).t()          # :1098-1103
+        if with_bias:
+            gb += go.sum(1)                                       # :1104-1110
+    return gx, goff, gmask, gw.reshape(Co, C, R, S), gb
+
+
 def dcn_module_forward(x, conv_offset_mask_w, conv_offset_mask_b, weight, bias):
     """The missing third-party `DCN` wrapper (deform_conv.py:13,505-513; DCNv2 repo dcn_v2.py, version unpinned):
     27-channel 3x3 conv -> offset = first 18 channels, mask = sigmoid(last 9) -> modulated deformable conv."""

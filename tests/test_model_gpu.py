@@ -311,11 +311,11 @@ def test_f32_topk_indices_equal_fp32_oracle(dev):
     err = (hm - hm_ref).abs().max().item()
     assert hm_ref.std().item() > 3e-3, "degenerate heat map: the comparison would be meaningless"
     assert err <= 1e-5, err
-    margin = 10 * max(err, 1e-7)
+    margin = 2 * max(err, 1e-7)        # two scores further apart than twice the largest error cannot swap
     gap_prev = torch.cat([torch.full((2, 1), 1.0), rs[:, :K - 1] - rs[:, 1:K]], dim=1)   # to the better neighbour
     gap_next = rs[:, :K] - rs[:, 1:K + 1]                                                # to the worse neighbour
     safe = (gap_prev > margin) & (gap_next > margin)
-    assert safe.float().mean().item() > 0.8, "too few tie-free ranks for the test to mean anything"
+    assert safe.float().mean().item() > 0.5, "too few tie-free ranks for the test to mean anything"
     same = (cl == rc[:, :K]) & (ind == ri[:, :K])
     assert bool(same[safe].all()), f"{int((~same[safe]).sum())} tie-free ranks differ from the fp32 oracle"
     assert (sc - rs[:, :K]).abs().max().item() <= 1e-5
@@ -401,6 +401,7 @@ def test_class_counts_not_multiple_of_4(tmp_path, dev, num_classes):
     cfg.merge_from_file(str(tmp_path / "c.yaml"))
     name = f"synthetic_{num_classes}_classes"
     cfg.DATASETS.TRAIN = (name,)
+    cfg.MODEL.CENTERNET.HIP_PRECISION = "f32"     # the reference's arithmetic: kernel errors are not masked by f16 rounding
     register_synthetic(name, num_classes=num_classes)
     torch.manual_seed(3)
     model = build_model(cfg).eval()
@@ -432,10 +433,11 @@ def test_class_counts_not_multiple_of_4(tmp_path, dev, num_classes):
     sd = cpu_state_dict(model)
     x_ref, _ = O.preprocess([d["image"] for d in inputs], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 32)
     with torch.no_grad():
-        z = MR.centernet_forward(sd, x_ref, training=True, f16_activations=True)
+        z = MR.centernet_forward(sd, x_ref, training=True)
     targets = [O.gen_heatmap(d["instances"].gt_boxes.tensor, d["instances"].gt_classes, 32, 32, num_classes) for d in inputs]
     ref = MR.centernet_losses(z, targets, [1.0])
-    assert abs(losses["hm_loss"].item() - ref["hm_loss"].item()) <= 2e-3 * max(1.0, abs(ref["hm_loss"].item()))
+    for k in ("hm_loss", "wh_loss", "off_loss"):
+        assert abs(losses[k].item() - ref[k].item()) <= 1e-3 * max(1.0, abs(ref[k].item())), (k, losses[k].item(), ref[k].item())
     sum(losses.values()).backward()
     g = model.hm[2].weight.grad
     assert g is not None and g.shape[0] == num_classes and torch.isfinite(g).all() and g.abs().max() > 0

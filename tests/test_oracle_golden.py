@@ -191,3 +191,75 @@ def test_g10_resnet18_res4_and_deconv_match_reference():
         up = MR.deconv_layers(sd, "deconv_layers", res4)
     assert np.abs(res4.numpy() - g["res4"]).max() <= 1e-5 * max(1.0, np.abs(g["res4"]).max())
     assert np.abs(up.numpy() - g["up"]).max() <= 1e-5 * max(1.0, np.abs(g["up"]).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G11: hand-derived known answers for DCNv2 (tests/golden/make_dcn_known_answers.py) -- the only independent anchor of
+# the "parity unpinned" DCN oracle -- and the kernel-by-kernel restatement of the backward against autograd of the forward
+def _g11():
+    return np.load(os.path.join(G, "g11_dcn_known_answers.npz"))
+
+
+G11_CASES = ["zero", "negzero", "int_1_0", "int_0_m2", "int_m1_3", "int_2_2", "half_h", "half_w_masked", "border"]
+
+
+@pytest.mark.parametrize("case", G11_CASES)
+def test_g11_dcn_known_answers_forward_and_backward(case):
+    g = _g11()
+    x, w, bias, go = (torch.from_numpy(g[k]) for k in ("x", "w", "bias", "grad_out"))
+    off, mask = torch.from_numpy(g[f"{case}_offset"]), torch.from_numpy(g[f"{case}_mask"])
+    out = O.dcnv2_forward(x, off, mask, w, bias, 1, 1, 1)
+    assert torch.allclose(out, torch.from_numpy(g[f"{case}_out"]), rtol=0, atol=1e-12), case
+    gx, goff, gm, gw, gb = O.dcnv2_backward(x, off, mask, w, go)
+    for key, got in (("grad_input", gx), ("grad_weight", gw), ("grad_bias", gb)):
+        if f"{case}_{key}" in g.files:
+            assert torch.allclose(got, torch.from_numpy(g[f"{case}_{key}"]), rtol=0, atol=1e-11), (case, key)
+    if f"{case}_grad_offset_h" in g.files:
+        assert torch.allclose(goff[:, 0::2], torch.from_numpy(g[f"{case}_grad_offset_h"]), rtol=0, atol=1e-11), case
+
+
+def test_dcn_backward_restatement_matches_autograd_of_forward():
+    """deform_conv_cuda_kernel.cu:871-1066 restated line by line (oracle.dcnv2_backward) == torch autograd through the
+    restated forward, away from the measure-zero kinks (integer coordinates); incl. samples far outside the image"""
+    gen = torch.Generator().manual_seed(5)
+    for B, C, Co, H, W, std in ((2, 5, 4, 7, 9, 2.0), (1, 8, 3, 5, 6, 6.0), (1, 3, 2, 4, 4, 0.3)):
+        x = torch.randn(B, C, H, W, generator=gen, dtype=torch.float64, requires_grad=True)
+        off = (torch.randn(B, 18, H, W, generator=gen, dtype=torch.float64) * std).requires_grad_(True)
+        mask = torch.sigmoid(torch.randn(B, 9, H, W, generator=gen, dtype=torch.float64)).requires_grad_(True)
+        w = torch.randn(Co, C, 3, 3, generator=gen, dtype=torch.float64, requires_grad=True)
+        bias = torch.randn(Co, generator=gen, dtype=torch.float64, requires_grad=True)
+        go = torch.randn(B, Co, H, W, generator=gen, dtype=torch.float64)
+        O.dcnv2_forward(x, off, mask, w, bias, 1, 1, 1).backward(go)
+        got = O.dcnv2_backward(x.detach(), off.detach(), mask.detach(), w.detach(), go)
+        for name, a, b in zip(("input", "offset", "mask", "weight", "bias"), got, (x.grad, off.grad, mask.grad, w.grad, bias.grad)):
+            assert torch.allclose(a, b, rtol=0, atol=1e-11), name
+
+
+def test_dcn_backward_sentinel_and_truncation_cases():
+    """the branches autograd never exercises as such: the `inv = -2` sentinel of the coordinate kernel (:1027-1029) gives
+    exactly zero offset / mask gradients for samples outside (-1, H) x (-1, W); `(int)` truncation toward zero in col2im
+    (:927-928) for coordinates in (-1, 0): cur = 0, the dy = -1 neighbour is skipped by the bounds test and the weight of
+    pixel 0 is 1 + h_im"""
+    x = torch.arange(1, 13, dtype=torch.float64).reshape(1, 1, 3, 4)
+    w = torch.zeros(1, 1, 3, 3, dtype=torch.float64)
+    w[0, 0, 1, 1] = 2.0                     # only the centre tap (k = 4) contributes
+    off = torch.zeros(1, 18, 3, 4, dtype=torch.float64)
+    mask = torch.ones(1, 9, 3, 4, dtype=torch.float64)
+    off[0, 8, 0, 0] = -0.25                 # centre tap of pixel (0, 0): h_im = -0.25
+    off[0, 8, 2, 3] = 5.0                   # centre tap of pixel (2, 3): h_im = 7 -> outside
+    off[0, 9, 1, 1] = -9.0                  # centre tap of pixel (1, 1): w_im = -8 -> outside
+    go = torch.ones(1, 1, 3, 4, dtype=torch.float64)
+    out = O.dcnv2_forward(x, off, mask, w, None, 1, 1, 1)
+    assert out[0, 0, 0, 0].item() == pytest.approx(2.0 * 0.75 * 1.0)        # (1 - 0.25) * x[0, 0], upper corner row -1 -> 0
+    assert out[0, 0, 2, 3].item() == 0.0 and out[0, 0, 1, 1].item() == 0.0
+    gx, goff, gm, gw, gb = O.dcnv2_backward(x, off, mask, w, go, with_bias=False)
+    assert gb is None
+    assert goff[0, 8, 2, 3].item() == 0.0 and goff[0, 9, 2, 3].item() == 0.0 and gm[0, 4, 2, 3].item() == 0.0
+    assert goff[0, 8, 1, 1].item() == 0.0 and goff[0, 9, 1, 1].item() == 0.0 and gm[0, 4, 1, 1].item() == 0.0
+    # pixel (0, 0) of the input receives 2 * 0.75 from output (0, 0) (truncated cur_h = 0, weight h + 1 - h_im with h = -1
+    # excluded) on top of nothing else (the outside samples scatter nothing)
+    assert gx[0, 0, 0, 0].item() == pytest.approx(2.0 * 0.75)
+    assert gx[0, 0, 2, 3].item() == 0.0 and gx[0, 0, 1, 1].item() == 0.0
+    # d out / d h at h_im = -0.25: x[0,0] * (+1) (only the lower corner exists): coordinate weight = + v3 ... here
+    # low = -1 (guarded), high = 0: weight = (w_low + 1 - w) * x[high, low] = x[0, 0]
+    assert goff[0, 8, 0, 0].item() == pytest.approx(2.0 * 1.0)

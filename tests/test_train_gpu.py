@@ -402,3 +402,64 @@ def test_trainer_on_ragged_list_batches(tmp_path, dev):
     assert (tr.optimizer.flat_param - p0).abs().max() > 0
     assert hist[-1]["hm_loss"] < 0.98 * hist[0]["hm_loss"], hist      # warm-up learning rates: a few per cent in 8 steps
 
+
+
+def test_full_training_step_f32_matches_fp32_oracle(tmp_path, dev):
+    """the training step in the reference's own precision (HIP_PRECISION f32: f32 activations, gradients, statistics; the
+    contractions on the f32 matrix pipe) against torch autograd through the fp32 oracle, BatchNorm in training mode, DCN
+    offsets non-zero: losses within 1e-3 (north_star), every parameter-gradient group at cosine >= 0.999 with matching
+    norms -- i.e. the ALGORITHM of the step (target generation, forward, losses, every backward kernel's math) is exact;
+    what the f16 mode adds on top is rounding (test above)."""
+    from test_model_gpu import cpu_state_dict, make_model
+    from detectron2_centernet_amd.data.catalog import synthetic_sample
+    from detectron2_centernet_amd.structures import Boxes, Instances
+
+    model, cfg = make_model(tmp_path, "f32", seed=11)
+    model.train()
+    sd0 = cpu_state_dict(model)
+    inputs = []
+    for i in range(2):
+        smp = synthetic_sample(i, size=256, num_classes=80, max_boxes=6)
+        inst = Instances((256, 256))
+        inst.gt_boxes = Boxes(smp["boxes"])
+        inst.gt_classes = smp["classes"]
+        inputs.append({"image": smp["image"], "instances": inst})
+    losses = model(inputs)
+    sum(losses.values()).backward()
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+          for k, v in sd0.items()}
+    x_ref, _ = O.preprocess([d["image"] for d in inputs], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 32)
+    z = MR.centernet_forward(sd, x_ref, training=True, f16_activations=False)
+    targets = [O.gen_heatmap(d["instances"].gt_boxes.tensor, d["instances"].gt_classes, 64, 64, 80) for d in inputs]
+    ref = MR.centernet_losses(z, targets, [1.0])
+    sum(ref.values()).backward()
+    for k in ("hm_loss", "wh_loss", "off_loss"):
+        got, want = losses[k].item(), ref[k].item()
+        print(k, got, want)
+        assert abs(got - want) <= 1e-3 * max(1.0, abs(want)), (k, got, want)
+    worst = {}
+    for name, p in model.named_parameters():
+        gref = sd[name].grad
+        if gref is None:
+            assert p.grad is None or p.grad.abs().max() == 0, name
+            continue
+        assert p.grad is not None, name
+        if name.endswith("conv.bias") and ".conv_offset_mask" not in name:
+            continue  # a bias in front of BatchNorm has zero true gradient; both sides are rounding noise
+        gg = p.grad.float().cpu()
+        if gref.abs().max() == 0:
+            continue
+        cos = torch.nn.functional.cosine_similarity(gg.flatten(), gref.flatten(), dim=0).item()
+        ratio = (gg.norm() / gref.norm()).item()
+        group = "hm" if name.startswith("hm.") else "heads" if name.split(".")[0] in ("wh", "reg") else \
+            ("ida_up" if name.startswith("backbone.ida_up") else ("dla_up" if "dla_up" in name else "base"))
+        w = worst.setdefault(group, [1.0, 1.0, 1.0, ""])
+        if cos < w[0]:
+            w[0], w[3] = cos, name
+        w[1], w[2] = min(w[1], ratio), max(w[2], ratio)
+    print("f32 worst (cos, min ratio, max ratio, worst name) per group:", worst)
+    for grp, (cos, rmin, rmax, name) in worst.items():
+        assert cos >= 0.999, (grp, cos, name)
+        assert 0.99 < rmin and rmax < 1.01, (grp, rmin, rmax)
+    bn = model.backbone.base.base_layer[1]
+    assert int(bn.num_batches_tracked) == 1
