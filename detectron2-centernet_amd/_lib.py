@@ -59,6 +59,11 @@ SIGNATURES = {
     "ctdet_dcn_col2im_coord": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_sgd_momentum": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _i32, _vp]),
     "ctdet_sgd_momentum_runs": (_i32, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _i32, _f32, _i32, _vp]),
+    "ctdet_comm_unique_id": (_i32, [_vp]),
+    "ctdet_comm_init": (_i32, [_vp, _i32, _i32, C.POINTER(C.c_void_p)]),
+    "ctdet_allreduce_bucket": (_i32, [_vp, _vp, _i64, _vp]),
+    "ctdet_bcast": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "ctdet_comm_destroy": (_i32, [_vp]),
 }
 
 _lib = None

@@ -1,3 +1,4 @@
+from .launch import launch
 from .train_loop import SimpleTrainer
 
-__all__ = ["SimpleTrainer"]
+__all__ = ["SimpleTrainer", "launch"]

@@ -14,8 +14,11 @@ import torch.distributed as dist
 
 
 class BucketedReducer:
-    def __init__(self, optimizer, bucket_bytes=32 << 20, process_group=None):
-        self.opt, self.group = optimizer, process_group
+    def __init__(self, optimizer, bucket_bytes=32 << 20, process_group=None, comm=None):
+        """comm: an engine.rccl.RcclComm -- the buckets then go through the C ABI (`ctdet_allreduce_bucket`) on a side
+        stream instead of torch.distributed's collectives (the process group, if any, only bootstrapped the communicator)"""
+        self.opt, self.group, self.comm = optimizer, process_group, comm
+        self._side = None
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets = []  # [start, end, n_params]
         self.bucket_of = []
@@ -49,6 +52,14 @@ class BucketedReducer:
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
+        if self.comm is not None:
+            # RCCL through the C ABI: ordered after the gradients produced so far, on a side stream so that the rest of
+            # backward keeps running; finish() joins the streams
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(torch.cuda.current_stream())
+            self.comm.all_reduce_(self.opt.flat_grad[s:e], stream=self._side)
+            return
         self._handles.append(dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                              async_op=True))
 
@@ -68,12 +79,18 @@ class BucketedReducer:
         for h in self._handles:
             h.wait()
         self._handles = []
+        if self.comm is not None and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def reduce_all(self):
         """all buckets, back to back, after a backward pass that ran without the hooks (the captured-graph step: forward +
         backward replay as one HIP graph, the exchange and the SGD launch follow it; the hooks only exist while autograd
         runs eagerly)"""
         if self.world == 1:
+            return
+        if self.comm is not None:
+            for s, e, _ in self.buckets:
+                self.comm.all_reduce_(self.opt.flat_grad[s:e])
             return
         handles = [dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                    for s, e, _ in self.buckets]
@@ -83,6 +100,14 @@ class BucketedReducer:
     def broadcast_parameters(self, buffers=()):
         """DDP's initial synchronisation: rank 0's parameters (and BN buffers) to everyone."""
         if self.world == 1:
+            return
+        if self.comm is not None:
+            self.comm.broadcast_(self.opt.flat_param, 0)
+            for b in buffers:
+                if b.dtype == torch.float32 and b.is_contiguous():
+                    self.comm.broadcast_(b.view(-1), 0)
+                else:
+                    dist.broadcast(b, src=0, group=self.group)
             return
         dist.broadcast(self.opt.flat_param, src=0, group=self.group)
         for b in buffers:

@@ -9,7 +9,8 @@ precision: every activation, gradient and statistic in f32).
 import torch
 
 from .. import ops
-from ..ops_train import BNActFn, ConvFn, DCNFn, DwConvTAddFn, FocalLossFn, MaxPoolFn, RegL1Fn
+from ..layers import hipnn
+from ..ops_train import BNActFn, ConvFn, ConvTransposeFn, DCNFn, DwConvTAddFn, FocalLossFn, FrozenConvFn, MaxPoolFn, RegL1Fn
 
 
 def conv_bn(x, conv, bn, relu=True, res=None):
@@ -97,6 +98,55 @@ def dla34(m, x):
     return y
 
 
+# ---------------------------------------------------------------------------------------------- ResNet configs
+def _frozen_conv(x, conv, relu, res=None):
+    """Conv2d + FrozenBatchNorm2d (+ residual)(+ ReLU) as an autograd node (resnet.py:100-112, 196-214)"""
+    scale, bias = hipnn.fold_bn(conv.norm)
+    return FrozenConvFn.apply(x, conv.weight, scale, bias, res, conv.stride[0], conv.padding[0], relu)
+
+
+def resnet_block(m, x):
+    sc = x if m.shortcut is None else _frozen_conv(x, m.shortcut, False)
+    out = _frozen_conv(x, m.conv1, True)
+    if hasattr(m, "conv3"):              # BottleneckBlock
+        out = _frozen_conv(out, m.conv2, True)
+        return _frozen_conv(out, m.conv3, True, res=sc)
+    return _frozen_conv(out, m.conv2, True, res=sc)
+
+
+def resnet_features(backbone, x, ctx, want="res4"):
+    """stem + stages up to `want`.  Frozen blocks (MODEL.BACKBONE.FREEZE_AT, resnet.py:478-492) run on the inference kernels
+    without a tape -- nothing upstream of them needs a gradient -- the others as autograd nodes."""
+    frozen = lambda mod: not any(p.requires_grad for p in mod.parameters())
+    if frozen(backbone.stem):
+        with torch.no_grad():
+            x = backbone.stem.hip_forward(x, ctx)
+    else:
+        raise NotImplementedError("training an unfrozen stem (FREEZE_AT < 1) is not part of the CenterNet ResNet configs")
+    for stage, name in backbone.stages_and_names:
+        for block in stage:
+            if frozen(block) and not x.requires_grad:
+                with torch.no_grad():
+                    x = block.hip_forward(x, ctx)
+            else:
+                x = resnet_block(block, x)
+        if name == want:
+            return x
+    raise KeyError(want)
+
+
+def deconv_layers(model, y):
+    """(ConvTranspose2d 4x4 s2 p1, BatchNorm2d, ReLU) x 2 in training mode (centernet.py:268-293)"""
+    mods = list(model.deconv_layers)
+    for i in range(0, len(mods), 3):
+        up, bn = mods[i], mods[i + 1]
+        y = ConvTransposeFn.apply(y, up.weight, up.stride[0], up.padding[0])
+        if bn.training and bn.track_running_stats:
+            bn.num_batches_tracked += 1
+        y = BNActFn.apply(y.contiguous(), bn.weight, bn.bias, None, bn.running_mean, bn.running_var, bn.eps, bn.momentum, True)
+    return y
+
+
 def heads(model, y):
     out = {}
     for name in (h.lower() for h in model.heads):
@@ -119,7 +169,10 @@ def centernet_train_forward(model, batched_inputs):
 
 
 def train_forward_tensors(model, x_nhwc, targets):
-    y = dla34(model.backbone, x_nhwc)[-1]
+    if model.backbone_type == "resnet":
+        y = deconv_layers(model, resnet_features(model.backbone, x_nhwc, model._ctx))
+    else:
+        y = dla34(model.backbone, x_nhwc)[-1]
     z = heads(model, y)
     C = model.num_classes
     hm = z["hm"] if z["hm"].shape[3] == C else z["hm"][..., :C].contiguous()

@@ -522,8 +522,6 @@ class CenterNet(nn.Module):
         """training forward on a device-resident batch: images uint8/float [B,3,H,W] (0..255), boxes f32 [B,N,4] XYXY
         in input pixels, classes i64 [B,N], counts i32 [B].  Returns the loss dict (0-d tensors with autograd)."""
         from ...engine.train_step import train_forward_tensors
-        if self.backbone_type != "dla34":
-            raise NotImplementedError("training is built for the DLA-34 path; the ResNet config runs inference only")
         B, _, H, W = images.shape
         Hp, Wp = ImageList.padded_size([(H, W)], self.size_divisibility)
         x = ops.preprocess(images, self._mean_host, self._std_host, Hp, Wp, out_dtype=self._ctx.dtype)

@@ -278,6 +278,78 @@ class ConvFn(torch.autograd.Function):
         return dx, dwt, dbias, None, None, None, None, None
 
 
+class FrozenConvFn(torch.autograd.Function):
+    """z = act(conv(x, w) * scale + bias + res): a conv followed by FrozenBatchNorm2d -- an affine whose scale / bias are
+    buffers (detectron2/layers/batch_norm.py:13-99) -- with the optional residual add and ReLU of the ResNet blocks
+    (modeling/backbone/resnet.py:100-112, 196-214), one kernel launch forward.  Backward: g = dz * (z > 0); d res = g;
+    d conv = g * scale; the weight gradient only if the conv is not frozen (FREEZE_AT)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, bias, res, stride, pad, relu):
+        f32 = x.dtype == torch.float32
+        p = ops.PackedConv(weight.detach(), scale, bias, stride=stride, pad=pad, compute=F32 if f32 else F16,
+                           cin_pad=x.shape[3] if x.shape[3] != weight.shape[1] else None)
+        z = ops.conv2d(x, p, act=ACT_RELU if relu else ACT_NONE, residual=res)
+        ctx.cfg = (stride, pad, relu, res is not None)
+        ctx.save_for_backward(x, weight, scale, z if relu else None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, weight, scale, z = ctx.saved_tensors
+        stride, pad, relu, has_res = ctx.cfg
+        Cout, Cin, R, S = weight.shape
+        dz = _pad_c(dz.contiguous().to(x.dtype))
+        g = dz
+        if relu:
+            g, _, _, _ = bn_train_bwd(dz, _pad_c(z), None, None, None, None, relu=True)
+        dres = (g if g.shape[3] == Cout else g[..., :Cout]) if has_res else None
+        sc = scale if g.shape[3] == Cout else torch.nn.functional.pad(scale, (0, g.shape[3] - Cout))
+        dconv = g * sc.to(g.dtype)
+        Cw = dconv.shape[3]
+        dwt = None
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(x, dconv, Cw, R, S, stride, pad)[:Cout]
+            dwt = _wgrad_to_oihw(dw, Cout, Cin, x.shape[3], R, S)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wpad = weight if Cw == Cout else torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
+            dx = conv_dgrad(dconv, wpad, stride, pad, x.shape[1:3])
+        return dx, dwt, None, None, dres, None, None, None
+
+
+class ConvTransposeFn(torch.autograd.Function):
+    """dense nn.ConvTranspose2d (weight [Cin, Cout, k, k], no bias, output_padding 0) of CenterNet._make_deconv_layer
+    (centernet.py:268-293).  Forward: a conv over the input read as zero-stuffed in place.  Backward: dX = conv2d(dY, W,
+    stride, padding) -- the transposed conv's adjoint is the plain strided conv with the same weight read as
+    [out = Cin][in = Cout] -- and dW[ci][co] = the weight gradient of that conv with the roles of input (dY) and output
+    gradient (X) as they stand."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        f32 = x.dtype == torch.float32
+        y = ops.conv_transpose2d(x, weight.detach(), None, None, stride, pad, F32 if f32 else F16)
+        ctx.cfg = (stride, pad)
+        ctx.save_for_backward(x, weight)
+        return y if y.shape[3] == weight.shape[1] else y[..., :weight.shape[1]]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        Cin, Cout, k, _ = weight.shape
+        dy = _pad_c(dy.contiguous().to(x.dtype))
+        Cw = dy.shape[3]
+        wpad = weight.detach() if Cw == Cout else torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, Cw - Cout))
+        f32 = x.dtype == torch.float32
+        p = ops.PackedConv(wpad, None, None, stride=stride, pad=pad, compute=F32 if f32 else F16)   # rows = Cin, channels = Cw
+        dx = ops.conv2d(dy, p)
+        dx = dx if dx.shape[3] == Cin else dx[..., :Cin]
+        dw = conv_wgrad(dy, _pad_c(x), _pad_c(x).shape[3], k, k, stride, pad)[:Cin]         # [Cin, k*k*Cw]
+        dwt = dw.view(Cin, k, k, Cw)[..., :Cout].permute(0, 3, 1, 2)
+        return dx, dwt, None, None
+
+
 def _pad_c(t):
     """channel count up to a multiple of 8 (the f16 kernels vectorise 8 channels) / 4 (f32)"""
     q = 8 if t is not None and t.dtype == torch.float16 else 4

@@ -246,6 +246,20 @@ int32_t ctdet_dcn_col2im_coord(const void* dcol, const void* x, int32_t x_stride
                                float* dx, float* dom, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t mask_is_prob,
                                int32_t dtype, void* stream);
 
+/* ---- data-parallel exchange over RCCL / xGMI (one process per GPU) ---------------------------------------------
+ * What DistributedDataParallel's reducer does over NCCL in the reference (detectron2/engine/defaults.py:279-285,
+ * launched per process by engine/launch.py:24-94).  Rank 0 makes a unique id and hands its CTDET_COMM_ID_BYTES to the
+ * other ranks by any out-of-band channel; every rank then calls ctdet_comm_init with the GPU it owns current.
+ * ctdet_allreduce_bucket: in-place SUM all-reduce of `count` f32 of the flat gradient buffer on `stream` (gradients are
+ * pre-divided by the world size on the producer side, so SUM is DDP's mean); ctdet_bcast: the initial parameter
+ * broadcast.  librccl.so is opened on first use. */
+#define CTDET_COMM_ID_BYTES 128
+int32_t ctdet_comm_unique_id(void* id_out);
+int32_t ctdet_comm_init(const void* id, int32_t rank, int32_t world, void** comm_out);
+int32_t ctdet_allreduce_bucket(void* comm, float* buf, int64_t count, void* stream);
+int32_t ctdet_bcast(void* comm, float* buf, int64_t count, int32_t root, void* stream);
+int32_t ctdet_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

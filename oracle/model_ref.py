@@ -192,21 +192,25 @@ def resnet_features(sd, p, x, blocks=(3, 4, 6), bottleneck=True, stride_in_1x1=T
     return x
 
 
-def deconv_layers(sd, p, x):
-    """centernet.py:268-293: (ConvTranspose2d 4x4 s2 p1 no bias, BatchNorm2d, ReLU) x 2, eval mode."""
+def deconv_layers(sd, p, x, training=False):
+    """centernet.py:268-293: (ConvTranspose2d 4x4 s2 p1 no bias, BatchNorm2d, ReLU) x 2; `training`: batch statistics."""
     i = 0
     while f"{p}.{i}.weight" in sd:
         x = F.conv_transpose2d(x, sd[f"{p}.{i}.weight"], None, stride=2, padding=1)
         q = f"{p}.{i + 1}"
-        x = F.relu(F.batch_norm(x, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"],
-                                False, 0.1, 1e-5))
+        if training:
+            x = F.relu(F.batch_norm(x, None, None, sd[q + ".weight"], sd[q + ".bias"], True, 0.1, 1e-5))
+        else:
+            x = F.relu(F.batch_norm(x, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"],
+                                    False, 0.1, 1e-5))
         i += 3
     return x
 
 
-def centernet_resnet_forward(sd, images_nchw, blocks=(3, 4, 6)):
-    """centernet.py:140-154 for backbone_type == 'resnet': res4 -> deconv_layers -> heads (1x1 final convs)."""
-    y = deconv_layers(sd, "deconv_layers", resnet_features(sd, "backbone", images_nchw, blocks))
+def centernet_resnet_forward(sd, images_nchw, blocks=(3, 4, 6), training=False):
+    """centernet.py:140-154 for backbone_type == 'resnet': res4 -> deconv_layers -> heads (1x1 final convs).  The ResNet's
+    FrozenBatchNorm2d layers are affine in both modes; `training` switches the deconv BatchNorms to batch statistics."""
+    y = deconv_layers(sd, "deconv_layers", resnet_features(sd, "backbone", images_nchw, blocks), training)
     return centernet_heads(Net(sd), y)
 
 

@@ -207,3 +207,57 @@ def test_resnet50_larger_batch_is_deterministic_and_matches_oracle(tmp_path, dev
         ref = torch.clamp(torch.sigmoid(z["hm"]), 1e-4, 1 - 1e-4)
         err = (hm[b:b + 1] - ref).abs().max().item()
         assert err <= 1e-3, (b, err)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_resnet50_training_step_matches_oracle(tmp_path, dev, precision):
+    """config 5's training path (ctdet_res_50_1x.yaml): frozen stem + res2 (FREEZE_AT 2), res3 / res4 with FrozenBatchNorm
+    as autograd nodes, dense ConvTranspose2d 4x4 s2 + BatchNorm (batch statistics) + ReLU, 256-channel heads, the three
+    losses -- against torch autograd through the oracle (pinned to the reference's own ResNet / deconv modules by G9).
+    f32: losses 1e-3, gradients cos >= 0.999; f16: rounding-level agreement."""
+    from detectron2_centernet_amd.data.catalog import synthetic_sample
+    from detectron2_centernet_amd.structures import Boxes, Instances
+
+    model, cfg, sd0 = _make(tmp_path, precision)
+    model.train()
+    frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
+    assert any(n.startswith("backbone.stem") for n in frozen) and any(n.startswith("backbone.res2") for n in frozen)
+    assert not any(n.startswith(("backbone.res3", "backbone.res4", "deconv_layers", "hm", "wh", "reg")) for n in frozen)
+    inputs = []
+    for i in range(2):
+        smp = synthetic_sample(i, size=128, num_classes=80, max_boxes=6)
+        inst = Instances((128, 128))
+        inst.gt_boxes, inst.gt_classes = Boxes(smp["boxes"]), smp["classes"]
+        inputs.append({"image": smp["image"], "instances": inst})
+    losses = model(inputs)
+    sum(losses.values()).backward()
+    sd = {k: (v.float().clone().requires_grad_(True) if v.dtype.is_floating_point and not k.startswith(("backbone.stem", "backbone.res2"))
+              and "running" not in k and ".norm." not in k else v.float().clone()) for k, v in sd0.items()}
+    x_ref, _ = O.preprocess([d["image"] for d in inputs], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 16)
+    z = MR.centernet_resnet_forward(sd, x_ref, training=True)
+    targets = [O.gen_heatmap(d["instances"].gt_boxes.tensor, d["instances"].gt_classes, 32, 32, 80) for d in inputs]
+    ref = MR.centernet_losses(z, targets, [1.0])
+    sum(ref.values()).backward()
+    ltol = 1e-3 if precision == "f32" else 1e-2
+    for k in ("hm_loss", "wh_loss", "off_loss"):
+        got, want = losses[k].item(), ref[k].item()
+        print(precision, k, got, want)
+        assert abs(got - want) <= ltol * max(1.0, abs(want)), (k, got, want)
+    worst, name_of = 1.0, ""
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        gref = sd[name].grad
+        assert p.grad is not None and gref is not None, name
+        if gref.abs().max() == 0:
+            continue
+        cos = torch.nn.functional.cosine_similarity(p.grad.float().cpu().flatten(), gref.flatten(), dim=0).item()
+        ratio = (p.grad.float().cpu().norm() / gref.norm()).item()
+        if cos < worst:
+            worst, name_of = cos, name
+        assert (0.99 if precision == "f32" else 0.9) < ratio < (1.01 if precision == "f32" else 1.1), (name, ratio)
+    print(precision, "worst gradient cosine", worst, name_of)
+    assert worst >= (0.999 if precision == "f32" else 0.98), (worst, name_of)
+    bn = model.deconv_layers[1]
+    assert int(bn.num_batches_tracked) == 1

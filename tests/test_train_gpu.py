@@ -463,3 +463,48 @@ def test_full_training_step_f32_matches_fp32_oracle(tmp_path, dev):
         assert 0.99 < rmin and rmax < 1.01, (grp, rmin, rmax)
     bn = model.backbone.base.base_layer[1]
     assert int(bn.num_batches_tracked) == 1
+
+
+def test_rccl_c_abi_single_rank(dev):
+    """ctdet_comm_unique_id / ctdet_comm_init / ctdet_allreduce_bucket / ctdet_bcast / ctdet_comm_destroy on a
+    world of one: the communicator binds to this GPU, SUM all-reduce and broadcast leave the buffer as it is, the calls
+    are stream-ordered (a side stream here) -- the multi-GPU run is the driver's"""
+    from detectron2_centernet_amd.engine.rccl import RcclComm
+
+    comm = RcclComm(0, 1)
+    x = torch.randn(1 << 20, device=dev)
+    ref = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    comm.all_reduce_(x, stream=side)
+    comm.broadcast_(x, 0, stream=side)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    comm.close()
+
+
+def test_inference_on_dataset_loop(tmp_path, dev):
+    """evaluation/evaluator.py:101-180: batches from a fixed-length loader through the model in eval mode, per-image COCO
+    records collected and written, timing recorded, the model's mode restored"""
+    import json
+    from test_model_gpu import make_model
+    from detectron2_centernet_amd.evaluation import COCOResultsWriter, inference_on_dataset
+
+    model, cfg = make_model(tmp_path, "f16", seed=8)
+    model.score_threshold = 0.0
+    model.wh[2].bias.data.fill_(3.0)
+    model.train()
+    g = torch.Generator().manual_seed(0)
+    loader = [[{"image": torch.randint(0, 256, (3, 64, 96), generator=g, dtype=torch.uint8), "image_id": 10 * i + j,
+                "height": 128, "width": 192} for j in range(2)] for i in range(7)]
+    ev = COCOResultsWriter(str(tmp_path / "out"), {1000 + c: c for c in range(80)})
+    res = inference_on_dataset(model, loader, ev)
+    assert model.training                                   # mode restored (inference_context)
+    assert res["bbox"]["num_detections"] > 0
+    recs = json.load(open(tmp_path / "out" / "coco_instances_results.json"))
+    assert len(recs) == res["bbox"]["num_detections"]
+    assert {r["image_id"] for r in recs} == {10 * i + j for i in range(7) for j in range(2)}
+    assert all(1000 <= r["category_id"] < 1080 and len(r["bbox"]) == 4 and r["bbox"][2] > 0 for r in recs)
+    t = inference_on_dataset.last_timing
+    assert t["iters"] == 2 and t["compute_s_per_iter"] > 0
