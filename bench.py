@@ -64,7 +64,33 @@ VERSION: 2
 """
 
 
-def build_model(precision, device, seed=0, calibrate=True):
+RES50_YAML = """
+_BASE_: "./Base-CenterNet.yaml"
+MODEL:
+  BACKBONE:
+    NAME: "build_resnet_backbone"
+  CENTERNET:
+    FOCAL_LOSS_ALPHA: [1]
+DATASETS:
+  TRAIN: ("bulb_train",)
+  TEST: ("bulb_val",)
+INPUT:
+  FORMAT: "RGB"
+  MIN_SIZE_TRAIN: (640, 672, 704, 736, 768, 800)
+SOLVER:
+  IMS_PER_BATCH: 2
+  BASE_LR: 2.5e-4
+  STEPS: (225100, 337650)
+  MAX_ITER: 450200
+  CHECKPOINT_PERIOD: 9004
+TEST:
+  EVAL_PERIOD: 18008
+OUTPUT_DIR: "./output"
+VERSION: 2
+"""
+
+
+def build_model(precision, device, seed=0, calibrate=True, config="dla34"):
     import tempfile
 
     from detectron2_centernet_amd.config import get_cfg
@@ -74,10 +100,11 @@ def build_model(precision, device, seed=0, calibrate=True):
     d = tempfile.mkdtemp(prefix="ctdet_cfg_")
     with open(os.path.join(d, "Base-CenterNet.yaml"), "w") as f:
         f.write(BASE_YAML)
-    with open(os.path.join(d, "ctdet_dla_34_1x.yaml"), "w") as f:
-        f.write(DLA_YAML)
+    name = "ctdet_dla_34_1x.yaml" if config == "dla34" else "ctdet_res_50_1x.yaml"
+    with open(os.path.join(d, name), "w") as f:
+        f.write(DLA_YAML if config == "dla34" else RES50_YAML)
     cfg = get_cfg()
-    cfg.merge_from_file(os.path.join(d, "ctdet_dla_34_1x.yaml"))
+    cfg.merge_from_file(os.path.join(d, name))
     cfg.MODEL.CENTERNET.HIP_PRECISION = precision
     cfg.MODEL.DEVICE = str(device)
     register_synthetic("bulb_train", num_classes=80)   # COCO-shaped: 80 classes
@@ -94,6 +121,13 @@ def build_model(precision, device, seed=0, calibrate=True):
     # dropped as empty, and the step would end with no detections to post-process.  A constant wh bias gives 12-pixel boxes, so
     # each image yields its full 100 detections (threshold 0.05 < the ~0.1 scores of the -2.19 hm bias).
     model.wh[-1].bias.data.fill_(3.0)
+    if config != "dla34":
+        # the reference initialises the deconv / final head weights with std 0.001 (centernet.py:295-320) and fetches ImageNet
+        # weights for the ResNet; offline: sane random scales so that activations neither vanish nor overflow
+        for m in model.deconv_layers.modules():
+            if isinstance(m, torch.nn.ConvTranspose2d):
+                m.weight.data.normal_(0, (2.0 / (m.weight.shape[0] * 4)) ** 0.5, generator=None)
+        return model, cfg
     if calibrate and torch.device(device).type == "cuda":
         if precision == "f16":
             calibrate_batchnorm(model, seed)
@@ -391,6 +425,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64 infer / 16 train)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--config", default="dla34", choices=["dla34", "r50"],
+                    help="dla34: BASELINE.json configs[1] (+[2]); r50: configs[4], ResNet-50 CenterNet 800x800 bs 8 per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the reference-precision (f32) sub-record")
@@ -421,7 +457,11 @@ def main():
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
-    model, cfg = build_model(args.precision, device)
+    if args.config == "r50":
+        args.size = 800 if args.size == 512 else args.size
+        args.batch = args.batch or 8
+        args.no_f32, args.no_cpu_baseline = True, True
+    model, cfg = build_model(args.precision, device, config=args.config)
 
     if args.task == "train":
         from detectron2_centernet_amd.engine.bench_train import run_train_bench
@@ -430,7 +470,7 @@ def main():
             raise SystemExit(f"training step did not replay as a HIP graph: {result['config']['graph_state']}")
     else:
         B = args.batch or 64
-        headline = B == 64 and args.size == 512
+        headline = B == 64 and args.size == 512 and args.config == "dla34"
         model.eval()
         images = synthetic_images(B, args.size, rank, device)
         elapsed, out = timed_infer(model, images, args.steps, args.warmup, dist, backend, device)
@@ -449,7 +489,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
-            "config": {"workload": f"DLA-34 CenterNet eval forward+decode, {B}x3x{args.size}x{args.size} uint8 per GPU, "
+            "config": {"workload": f"{'DLA-34' if args.config == 'dla34' else 'ResNet-50'} CenterNet eval forward+decode, {B}x3x{args.size}x{args.size} uint8 per GPU, "
                                    "80 classes, K=100, random-init weights, DCN offsets ~N(0,1px), "
                                    f"{sum(len(o['instances']) for o in out) / max(1, len(out)):.0f} detections per image post-processed",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"replicas x{world}"},
@@ -487,19 +527,20 @@ def main():
             torch.cuda.empty_cache()
 
         # ---- the training half of BASELINE.json's metric (train bs=16/GPU): every rank, data parallel when world > 1
-        if headline and not args.no_train:
+        if (headline or args.config == "r50") and not args.no_train:
             from detectron2_centernet_amd.engine.bench_train import run_train_bench
 
-            tm, tcfg = build_model("f16", device)
+            tm, tcfg = build_model("f16", device, config=args.config)
+            tB = 16 if args.config == "dla34" else B
             targs = argparse.Namespace(steps=max(5, args.steps // 2), warmup=max(4, args.warmup // 2), size=args.size)
-            tr = run_train_bench(tm, tcfg, targs, 16, rank, world, device, dist)
+            tr = run_train_bench(tm, tcfg, targs, tB, rank, world, device, dist)
             rec = {k: tr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "scaling")}
             rec["graph_state"] = tr["config"]["graph_state"]
             rec["config"] = tr["config"]
             if args.require_graph and world == 1 and rec["graph_state"] != "captured":
                 raise SystemExit(f"training step did not replay as a HIP graph: {rec['graph_state']}")
             if rank == 0 and not args.no_roofline:
-                rec["roofline"] = train_roofline(tm, tcfg, 16, args.size, rank, device)
+                rec["roofline"] = train_roofline(tm, tcfg, tB, args.size, rank, device)
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 rec["cpu_baseline"] = cpu_train_baseline(tm, tcfg, args.size)
             result["train"] = rec

@@ -56,7 +56,7 @@ def run_train_bench(model, cfg, args, B, rank, world, device, dist):
         "vs_baseline": None,
         "dtype": "f16",
         "data": "synthetic",
-        "config": {"workload": f"DLA-34 CenterNet train step (targets+fwd+loss+bwd+allreduce+SGD), {B}x3x{args.size}x"
+        "config": {"workload": f"{'DLA-34' if model.backbone_type == 'dla34' else 'ResNet'} CenterNet train step (targets+fwd+loss+bwd+allreduce+SGD), {B}x3x{args.size}x"
                                f"{args.size} per GPU, 80 classes, f16 activations / f32 master weights",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "final_losses": losses, "graph_state": trainer.graph_state},

@@ -189,3 +189,44 @@ def test_fullsize_dcn_backward_scatter_window_vs_atomics():
         del os.environ["CTDET_NO_COL2IM_WINDOW"]
     assert (dx_w - dx_a).abs().max().item() <= dx_a.abs().max().item() * 2.0 ** -14
     assert (dom_w - dom_a).abs().max().item() <= dom_a.abs().max().item() * 2e-4
+
+
+def test_resnet50_800x800_bs8_properties(dev):
+    """BASELINE.json configs[4] at full size: ResNet-50 CenterNet, 8 x 3 x 800 x 800 per GPU.  Eval: finite outputs, a
+    bit-exact graph replay, the decode of the HIP heat map equal to the oracle's decode, batch-composition independence
+    (image 0 alone == image 0 in the batch of 8).  Train: one whole step at this size is finite, moves the trainable
+    parameters and leaves the frozen stem / res2 untouched."""
+    import bench
+    from detectron2_centernet_amd.engine.bench_train import synthetic_batch
+    from detectron2_centernet_amd.engine.train_loop import SimpleTrainer
+
+    model, cfg = bench.build_model("f16", dev, seed=2, config="r50")
+    model.eval()
+    model.score_threshold = 0.0
+    images = bench.synthetic_images(8, 800, 0, dev)
+    out = model.infer_batch_tensor(images)
+    eng = _engine(model, 8)
+    hm, wh, reg = [t.float().cpu().permute(0, 3, 1, 2) for t in eng.out]
+    assert hm.shape == (8, 80, 200, 200) and torch.isfinite(hm).all() and torch.isfinite(wh).all()
+    first = [t.clone() for t in eng.out]
+    model.infer_batch_tensor(images)
+    for a, b in zip(first, eng.out):
+        assert torch.equal(a, b)
+    boxes, scores, classes, inds = [t.cpu() for t in eng.dec]
+    rb, rs, rc, ri = O.ctdet_decode(hm[:2], wh[:2], reg[:2], down_ratio=4, K=100)
+    assert torch.equal(scores[:2], rs) and torch.equal(classes[:2], rc) and torch.equal(inds[:2].long(), ri)
+    assert (scores[:, :-1] >= scores[:, 1:]).all() and len(out) == 8
+    model.infer_batch_tensor(images[:1].contiguous())
+    solo = _engine(model, 1)
+    assert torch.equal(solo.out[0][0], first[0][0])
+    # one full training step
+    model._engines = {}
+    cfg.SOLVER.IMS_PER_BATCH = 8
+    tr = SimpleTrainer(model, None, cfg)
+    p0 = tr.optimizer.flat_param.clone()
+    stem0 = model.backbone.stem.conv1.weight.detach().clone()
+    losses = tr.run_step_tensors(*synthetic_batch(8, 800, 0, dev))
+    vals = {k: float(v) for k, v in losses.items()}
+    assert all(v == v and abs(v) < 1e9 for v in vals.values()), vals
+    assert torch.isfinite(tr.optimizer.flat_param).all() and (tr.optimizer.flat_param - p0).abs().max() > 0
+    assert torch.equal(model.backbone.stem.conv1.weight.detach(), stem0)
