@@ -484,6 +484,114 @@ __global__ void __launch_bounds__(256, 2) dcn_f32_mfma_kernel(const ConvArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------
+// LDS-window form for the narrow layers of the DLA base in f32 (7x7 stem on the 8-channel padded image, level0 3x3
+// 16->16, level1 3x3 16->32 stride 2): with 8 or 16 input channels the im2col-on-the-fly kernels above fetch every
+// input pixel R*S times through L2 (26 GB for the stem at batch 64: 8.2 ms for 79 GFLOP).  Here a workgroup owns a
+// TH x TW output tile, brings the input window into LDS once, keeps ALL weights in registers and reads every MFMA
+// B fragment (4 channels of 16 consecutive pixels) with one ds_read_b128 at a compile-time offset.
+// Pixels must be contiguous in memory (in_stride == CIN); maps divisible by the tile.
+// ------------------------------------------------------------------------------------------
+template <int R, int CIN, int TC, int STRIDE, int TH, bool NOCHECK>
+__global__ void __launch_bounds__(256) conv_f32_win_kernel(const ConvArgs a) {
+  constexpr int TW = STRIDE == 1 ? 64 : 32;
+  constexpr int WH = (TH - 1) * STRIDE + R, WW = (TW - 1) * STRIDE + R;
+  constexpr int PB = CIN * 4;                       // bytes per pixel
+  constexpr int PPR = WW * PB / 16;                 // 16-byte pieces per window row
+  constexpr int NP = WH * PPR, ROUNDS = (NP + 255) / 256;
+  constexpr int K = R * R * CIN, NK = (K + 15) / 16;
+  constexpr int GPT = CIN / 4;                      // 4-channel k-groups per tap
+  constexpr int NT = TW / 16, RW = TH / 4;          // pixel tiles per tile row; tile rows per wave
+  static_assert(TH % 4 == 0 && ROUNDS * 4096 <= 65536, "tile");
+  __shared__ __attribute__((aligned(16))) char win[ROUNDS * 4096];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, q = lane >> 4;
+  const int tiles_x = a.Wo / TW, tiles_y = a.Ho / TH;
+  const int tx0 = (blockIdx.x % tiles_x) * TW;
+  const int ty0 = ((blockIdx.x / tiles_x) % tiles_y) * TH;
+  const int b = blockIdx.x / (tiles_x * tiles_y);
+  const float* zero = (const float*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+  const float* ximg = (const float*)a.x + (long)b * a.H * a.W * CIN;
+  const int iy0 = ty0 * STRIDE - a.pad, ix0 = tx0 * STRIDE - a.pad;   // image coordinates of window pixel (0,0)
+
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    const int pid = tid + 256 * i;
+    const int wr = pid / PPR, cp = pid - wr * PPR;
+    const int y = iy0 + wr, x = ix0 + cp / (PB / 16);
+    bool ok = pid < NP;
+    if constexpr (!NOCHECK) ok = ok && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    dma16(ok ? ximg + ((long)y * a.W + ix0) * CIN + cp * 4 : zero, win + (wave * 64 + 256 * i) * 16);
+  }
+  // weights: fragment (kt, c) of this lane = 4 k of cout row cout_of(c, fr/4, fr%4), straight into registers
+  f32x4 wf[NK][TC];
+#pragma unroll
+  for (int c = 0; c < TC; ++c) {
+    const float* wr = (const float*)a.w + (long)cout_of<TC>(c, fr >> 2, fr & 3) * a.Kpad + q * 4;
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) wf[kt][c] = *(const f32x4*)(wr + kt * 16);
+  }
+  // per K step: LDS byte address of this lane's k-group for tile pixel (row 0 of the wave, column fr)
+  int kaddr[NK];
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt) {
+    const int G = kt * 4 + q;
+    const int tap = G / GPT;
+    const bool tail = tap >= R * R;                  // K tail: zero weights; read tap (0,0)
+    const int tr = tail ? 0 : tap / R, ts = tail ? 0 : tap - (tap / R) * R;
+    kaddr[kt] = ((wave * RW * STRIDE + tr) * WW + fr * STRIDE + ts) * PB + (tail ? 0 : (G - tap * GPT) * 16);
+  }
+  wait_vmcnt<0>();
+  __syncthreads();
+
+  // two pixel tiles at a time: two independent accumulator chains per cout tile (a 16x16x4 f32 MFMA has 40 cycles of
+  // dependent latency against 32 of issue)
+  static_assert(NT % 2 == 0, "pixel tiles come in pairs");
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) {
+#pragma unroll
+    for (int tc = 0; tc < NT; tc += 2) {
+      const int toff = (rr * STRIDE * WW + tc * 16 * STRIDE) * PB;   // compile time after unrolling
+      f32x4 acc[2][TC];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int c = 0; c < TC; ++c) acc[u][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < NK; ++kt) {
+        const f32x4 pf0 = *(const f32x4*)(win + kaddr[kt] + toff);
+        const f32x4 pf1 = *(const f32x4*)(win + kaddr[kt] + toff + 16 * STRIDE * PB);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < TC; ++c) {
+            acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kt][c][e], pf0[e], acc[0][c], 0, 0, 0);
+            acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kt][c][e], pf1[e], acc[1][c], 0, 0, 0);
+          }
+      }
+      const int m = (b * a.Ho + ty0 + wave * RW + rr) * a.Wo + tx0 + tc * 16 + fr;
+      epilogue_tiles<float, TC>(a, m, 0, q, acc[0]);
+      epilogue_tiles<float, TC>(a, m + 16, 0, q, acc[1]);
+    }
+  }
+}
+
+template <int R, int CIN, int TC, int STRIDE, int TH>
+static int launch_f32_win(const ConvArgs& a, hipStream_t s) {
+  constexpr int TW = STRIDE == 1 ? 64 : 32;
+  const int tiles = a.B * (a.Ho / TH) * (a.Wo / TW);
+  // pad 0 (a pre-padded image: ops.preprocess border): the window never leaves the tensor -> no bounds checks
+  if (a.pad == 0)
+    hipLaunchKernelGGL((conv_f32_win_kernel<R, CIN, TC, STRIDE, TH, true>), dim3(tiles), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_f32_win_kernel<R, CIN, TC, STRIDE, TH, false>), dim3(tiles), dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // Direct form: one thread per (pixel, cout), f32 FMA chain in k order (any Cin / stride).
 // ------------------------------------------------------------------------------------------
 template <bool DEFORM>
@@ -603,6 +711,16 @@ int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s) {
               a.Cout_pad, a.Kpad, a.Cout, a.K);
   const int bc = pick_bc(a.Cout);
   const bool vec = f32_vector_ok(a, bc) && (!deform || (a.Cin % 16 == 0 && a.nsrc <= 1));
+  if (vec && !deform && (a.Cin == 8 || a.Cin == 16) && a.in_dil == 1 && a.nsrc <= 1 && a.R == a.S && a.dil == 1 &&
+      a.in_stride == a.Cin && a.Cout_pad == bc && !a.res && a.Kpad == ((a.K + 15) & ~15)) {
+    // the three narrow DLA base layers on tile-divisible maps
+    if (a.R == 7 && a.Cin == 8 && bc == 16 && a.stride == 1 && a.Ho % 8 == 0 && a.Wo % 64 == 0 && (a.pad == 0 || a.pad == 3))
+      return launch_f32_win<7, 8, 1, 1, 8>(a, s);
+    if (a.R == 3 && a.Cin == 16 && bc == 16 && a.stride == 1 && a.Ho % 8 == 0 && a.Wo % 64 == 0 && a.pad == 1)
+      return launch_f32_win<3, 16, 1, 1, 8>(a, s);
+    if (a.R == 3 && a.Cin == 16 && bc == 32 && a.stride == 2 && a.Ho % 4 == 0 && a.Wo % 32 == 0 && a.pad == 1)
+      return launch_f32_win<3, 16, 2, 2, 4>(a, s);
+  }
   if (vec) {
     const bool big = ((long)a.M + 255) / 256 * (a.Cout_pad / bc) >= 512;
     if (deform) {   // 128-pixel tiles: two or more workgroups per CU cover each other's gather latency

@@ -32,6 +32,12 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
         if deform:
             return f"dcn_f32_mfma_kernel<128x{bc}>"
         bp = 256 if (big or bc == 16) else 128
+        H, W = (x_shape[1], x_shape[2]) if x_shape is not None else (0, 0)
+        if p.Cin in (8, 16) and p.R == p.S and p.dil == 1 and nsrc <= 1 and H:
+            Ho, Wo = p.out_hw(H, W)
+            if ((p.R, p.Cin, bc, p.stride) in ((7, 8, 16, 1), (3, 16, 16, 1)) and Ho % 8 == 0 and Wo % 64 == 0) or \
+                    ((p.R, p.Cin, bc, p.stride) == (3, 16, 32, 2) and Ho % 4 == 0 and Wo % 32 == 0):
+                return f"conv_f32_win_kernel<{p.R}x{p.R},Cin{p.Cin},Cout{bc},s{p.stride}>"
         uk = p.R * p.S <= 32 and p.in_dil == 1 and p.Kpad == p.K and p.Cin % 16 == 0
         return f"conv_f32_{'uk' if uk else 'mfma'}_kernel<{bp}x{bc}>"
     o = "f16" if out_dt == F16 else "f32"

@@ -133,3 +133,26 @@ def test_dcnv2_f32_random_shapes(ops, dev):
         y = ops.dcnv2(nhwc(x).to(dev), om_d.to(dev), pc, act=ops.ACT_RELU)
         err = (nchw(y[..., :Cout].cpu()) - ref).abs().max().item()
         assert err <= 2e-5 * max(1.0, ref.abs().max().item()), f"case {it}: B{B} {H}x{W} {Cin}->{Cout} std {off_std}: {err}"
+
+
+@pytest.mark.parametrize("case", [(7, 8, 16, 1, 3, 2, 32, 128), (7, 8, 16, 1, 0, 1, 16, 64), (3, 16, 16, 1, 1, 3, 24, 64),
+                                  (3, 16, 32, 2, 1, 2, 32, 128)])
+def test_conv_f32_window_kernel(ops, dev, case):
+    """conv_f32_win_kernel (the narrow DLA base layers in f32): stem 7x7 on the 8-channel image with its padding in the
+    kernel (pad 3) or as a zero frame in memory (pad 0), level0 3x3 16->16, level1 3x3 16->32 stride 2 -- vs torch"""
+    k, Cin, Cout, stride, pad, B, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    if Cin == 8:
+        x[:, 3:] = 0
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale, bias = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref = (F.conv2d(x, w, None, stride, k // 2) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)).relu()
+    pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=stride, pad=pad, compute=ops.F32)
+    xin = nhwc(x)
+    if pad == 0 and k > 1:      # zero frame in memory
+        xin = F.pad(xin, (0, 0, k // 2, k // 2, k // 2, k // 2))
+    y = ops.conv2d(xin.to(dev), pc, act=ops.ACT_RELU)
+    got = nchw(y[..., :Cout].cpu())
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item())
