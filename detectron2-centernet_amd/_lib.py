@@ -35,6 +35,9 @@ SIGNATURES = {
     "ctdet_dla_base_fwd": (_i32, [_vp] * 14),
     "ctdet_maxpool2x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_maxpool3x3s2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_maxpool3x3s2_ceil": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_global_avgpool": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ctdet_ese_scale": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_pack_weights": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_dwconvT_add": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_decode_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
@@ -59,6 +62,8 @@ SIGNATURES = {
     "ctdet_dcn_col2im_coord": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_sgd_momentum": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _i32, _vp]),
     "ctdet_sgd_momentum_runs": (_i32, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _i32, _f32, _i32, _vp]),
+    "ctdet_set_tuning_flags": (_i32, [C.c_uint32]),
+    "ctdet_get_tuning_flags": (C.c_uint32, []),
     "ctdet_comm_unique_id": (_i32, [_vp]),
     "ctdet_comm_init": (_i32, [_vp, _i32, _i32, C.POINTER(C.c_void_p)]),
     "ctdet_allreduce_bucket": (_i32, [_vp, _vp, _i64, _vp]),
@@ -105,3 +110,22 @@ class HeadDesc(C.Structure):
                 ("in_stride", C.c_int32), ("w2", C.c_void_p * 4), ("b2", C.c_void_p * 4), ("y", C.c_void_p * 4),
                 ("y_stride", C.c_int32 * 4), ("cout", C.c_int32 * 4), ("act", C.c_int32 * 4),
                 ("clamp_lo", C.c_float), ("clamp_hi", C.c_float)]
+
+
+TUNE_NO_HALO, TUNE_NO_WIN, TUNE_DCN_MIXED, TUNE_NO_WGRAD_WINDOW, TUNE_NO_COL2IM_WINDOW = 1, 2, 4, 8, 16
+
+
+class tuning:
+    """`with _lib.tuning(_lib.TUNE_DCN_MIXED): ...` -- kernel-selection switches of the library for the block (tests, tools)"""
+
+    def __init__(self, flags):
+        self.flags = flags
+
+    def __enter__(self):
+        self.prev = lib().ctdet_get_tuning_flags()
+        lib().ctdet_set_tuning_flags(self.prev | self.flags)
+        return self
+
+    def __exit__(self, *exc):
+        lib().ctdet_set_tuning_flags(self.prev)
+        return False

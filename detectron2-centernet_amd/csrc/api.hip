@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 void ctdet_set_error(const char* fmt, ...) {
@@ -20,7 +21,9 @@ void ctdet_set_error(const char* fmt, ...) {
 int launch_preprocess(const void*, int, void*, int, int, int, int, int, int, long, const float*, const float*, int, int,
                       hipStream_t);
 int launch_maxpool2x2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
-int launch_maxpool3x3s2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
+int launch_maxpool3x3s2(const void*, void*, int, int, int, int, int, int, int, int, hipStream_t);
+int launch_global_avgpool(const void*, int, int, int, int, int, float*, hipStream_t);
+int launch_ese_scale(const void*, int, const float*, const void*, int, void*, int, int, int, int, int, hipStream_t);
 int launch_pack_weights(const float*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_dwconvT_add(const void*, const float*, const void*, void*, int, int, int, int, int, int, int, int, int,
                        hipStream_t);
@@ -96,9 +99,27 @@ static int fill_args(const ctdet_conv_desc* d, ConvArgs& a) {
   return 0;
 }
 
+static std::atomic<unsigned> g_tuning{0};
+unsigned ctdet_tuning_flags() { return g_tuning.load(std::memory_order_relaxed); }
+
+int ctdet_device_cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 extern "C" {
 
 const char* ctdet_last_error(void) { return g_err; }
+int32_t ctdet_set_tuning_flags(uint32_t flags) { g_tuning.store(flags, std::memory_order_relaxed); return 0; }
+uint32_t ctdet_get_tuning_flags(void) { return g_tuning.load(std::memory_order_relaxed); }
 int32_t ctdet_abi_version(void) { return 2; }
 int32_t ctdet_conv_cout_tile(int32_t cout) {
   if (cout <= 16) return 16;
@@ -230,7 +251,25 @@ int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32
 int32_t ctdet_maxpool3x3s2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
                            int32_t in_stride, int32_t out_stride, void* stream) {
   CTDET_CHECK(x && y, "maxpool3x3s2: null pointer");
-  return launch_maxpool3x3s2(x, y, dtype, B, H, W, C, in_stride, out_stride, (hipStream_t)stream);
+  return launch_maxpool3x3s2(x, y, dtype, B, H, W, C, in_stride, out_stride, 0, (hipStream_t)stream);
+}
+
+int32_t ctdet_maxpool3x3s2_ceil(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
+                                int32_t in_stride, int32_t out_stride, void* stream) {
+  CTDET_CHECK(x && y, "maxpool3x3s2_ceil: null pointer");
+  return launch_maxpool3x3s2(x, y, dtype, B, H, W, C, in_stride, out_stride, 1, (hipStream_t)stream);
+}
+
+int32_t ctdet_global_avgpool(const void* x, int32_t dtype, int32_t B, int32_t HW, int32_t C, int32_t stride, float* out,
+                             void* stream) {
+  CTDET_CHECK(x && out, "global_avgpool: null pointer");
+  return launch_global_avgpool(x, dtype, B, HW, C, stride, out, (hipStream_t)stream);
+}
+
+int32_t ctdet_ese_scale(const void* x, int32_t x_stride, const float* s, const void* identity, int32_t identity_stride,
+                        void* y, int32_t y_stride, int32_t dtype, int32_t B, int32_t HW, int32_t C, void* stream) {
+  CTDET_CHECK(x && s && y, "ese_scale: null pointer");
+  return launch_ese_scale(x, x_stride, s, identity, identity_stride, y, y_stride, dtype, B, HW, C, (hipStream_t)stream);
 }
 
 int32_t ctdet_pack_weights(const float* w, void* packed, int32_t O, int32_t I, int32_t R, int32_t S, int32_t chans_pad,

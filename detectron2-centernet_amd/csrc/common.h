@@ -108,6 +108,19 @@ struct DecArgs {
 __device__ __forceinline__ float ctdet_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
 __device__ __forceinline__ float ctdet_sigmoid_exact(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+// Kernel-selection switches (ctdet_set_tuning_flags in the C ABI; a process-wide word read with one relaxed load per launch
+// -- no getenv on the launch path).  0 = every specialised kernel enabled.
+enum {
+  CTDET_TUNE_NO_HALO = 1,            // 3x3 halo-resident conv -> uniform-K kernel
+  CTDET_TUNE_NO_WIN = 2,             // LDS-window kernels of the narrow DLA base layers -> small-channel kernel
+  CTDET_TUNE_DCN_MIXED = 4,          // DCNv2 window kernel: per-lane instead of per-wave out-of-window gathers
+  CTDET_TUNE_NO_WGRAD_WINDOW = 8,    // weight-gradient window kernel -> generic kernel
+  CTDET_TUNE_NO_COL2IM_WINDOW = 16,  // DCNv2 backward LDS-window scatter -> global-atomic kernel
+};
+unsigned ctdet_tuning_flags();
+// number of CUs of the CURRENT device (cached per device ordinal, not per process)
+int ctdet_device_cu_count();
+
 // launchers implemented in the .hip files (return 0 or negative errno)
 int launch_conv_f16(const ConvArgs& a, int out_dtype, bool deform, hipStream_t s);
 int launch_head_fused(const HeadArgs& a, hipStream_t s);

@@ -739,7 +739,7 @@ int launch_head_fused(const HeadArgs& a, hipStream_t s) {
 static bool halo_ok(const ConvArgs& a) {
   return a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.in_dil == 1 && a.nsrc <= 1 &&
          a.korder == 1 && a.Cin % 32 == 0 && a.Kpad == a.K && a.H % 8 == 0 && a.W % 32 == 0 && a.Ho == a.H &&
-         a.Wo == a.W && !getenv("CTDET_NO_HALO");
+         a.Wo == a.W && !(ctdet_tuning_flags() & CTDET_TUNE_NO_HALO);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1160,8 +1160,7 @@ template <int BC, int WP, int WC_, typename TOut>
 static int launch_dcn_window(const ConvArgs& a, hipStream_t s) {
   const int nbx = a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16), nby = a.Cout_pad / BC;
   dim3 grid(8 * ((nbx + 7) / 8) * nby);
-  const char* mx = getenv("CTDET_DCN_MIXED");     // read per launch: tests flip it
-  const bool mixed = mx && atoi(mx) != 0;
+  const bool mixed = (ctdet_tuning_flags() & CTDET_TUNE_DCN_MIXED) != 0;
   if (mixed && a.H % 8 == 0 && a.W % 16 == 0 && a.H <= 4094 && a.W <= 4094)
     hipLaunchKernelGGL((dcn_window_kernel<BC, (BC > 64 ? 4 : 8), false, TOut, true>), grid, dim3(256), 0, s, a);
   else if (a.H % 8 == 0 && a.W % 16 == 0)
@@ -1452,7 +1451,7 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   if ((a.Cin == 8 || a.Cin == 16) && a.in_dil == 1 && a.korder == 0 && a.nsrc <= 1 && a.Wo % 64 == 0 && a.Cout_pad <= 32 && a.Cout_pad == bc) {
     const int nk = a.Kpad / 32;
     // LDS-window form for the three DLA base layers (tile-divisible maps, contiguous pixels)
-    if (!getenv("CTDET_NO_WIN") && a.R == a.S && a.dil == 1 && a.in_stride == a.Cin && a.Kpad == nk * 32) {
+    if (!(ctdet_tuning_flags() & CTDET_TUNE_NO_WIN) && a.R == a.S && a.dil == 1 && a.in_stride == a.Cin && a.Kpad == nk * 32) {
       if (a.R == 7 && a.Cin == 8 && bc == 16 && a.stride == 1 && a.Ho % 16 == 0 && a.Wo % 64 == 0 && (a.pad == 0 || a.pad == 3))
         return launch_win<7, 8, 1, 1, TOut>(a, s);
       if (a.R == 3 && a.Cin == 16 && bc == 16 && a.stride == 1 && a.Ho % 16 == 0 && a.Wo % 64 == 0 && a.pad == 1)

@@ -359,13 +359,7 @@ int launch_dla_base(const BaseArgs& a, hipStream_t s) {
   CTDET_CHECK(tiles < (1L << 31), "dla_base: too many tiles");
   // persistent workgroups: 2 per CU, each walks tiles blockIdx.x, + gridDim.x, ... with its weights in
   // registers and the next tile's image window in flight
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
-    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int ncu = ctdet_device_cu_count();
   const long want = 2L * ncu;
   const unsigned blocks = (unsigned)(tiles < want ? tiles : want);
   if (a.img_dtype == CTDET_U8)

@@ -74,10 +74,10 @@ __global__ void __launch_bounds__(256) maxpool2x2_kernel(const T* __restrict__ x
 // (detectron2/modeling/backbone/resnet.py:341-345); padded taps are skipped (= -inf padding).
 template <typename T>
 __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W,
-                                                           int C, int in_stride, int out_stride) {
+                                                           int C, int in_stride, int out_stride, int pad, int Ho, int Wo) {
   using V = typename Vec<T>::type;
   constexpr int N = Vec<T>::N;
-  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, CV = C / N;
+  const int CV = C / N;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)B * Ho * Wo * CV) return;
   const int cv = (int)(idx % CV);
@@ -90,11 +90,11 @@ __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const T* __restrict__
   for (int e = 0; e < N; ++e) m[e] = -INFINITY;
 #pragma unroll
   for (int dy = -1; dy <= 1; ++dy) {
-    const int yy = 2 * ho + dy;
+    const int yy = 2 * ho + dy + 1 - pad;
     if (yy < 0 || yy >= H) continue;
 #pragma unroll
     for (int dx = -1; dx <= 1; ++dx) {
-      const int xx = 2 * wo + dx;
+      const int xx = 2 * wo + dx + 1 - pad;
       if (xx < 0 || xx >= W) continue;
       const V v = *(const V*)(x + ((long)(b * H + yy) * W + xx) * in_stride + cv * N);
 #pragma unroll
@@ -302,19 +302,102 @@ int launch_maxpool2x2(const void* x, void* y, int dtype, int B, int H, int W, in
   return 0;
 }
 
+// pad 1: F.max_pool2d(x, 3, 2, 1) (BasicStem); pad 0 + ceil: nn.MaxPool2d(3, 2, ceil_mode=True) (VoVNet stages): the last
+// window may hang over the bottom / right edge, positions outside the map do not take part
 int launch_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, int in_stride, int out_stride,
-                        hipStream_t s) {
+                        int ceil_nopad, hipStream_t s) {
   const int N = dtype == CTDET_F16 ? 8 : 4;
   CTDET_CHECK(C % N == 0 && in_stride % N == 0 && out_stride % N == 0, "maxpool3x3s2: channels must be multiples of %d", N);
-  const long total = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / N);
+  int Ho, Wo, pad;
+  if (ceil_nopad) {
+    pad = 0;
+    Ho = (H - 3 + 1) / 2 + 1; Wo = (W - 3 + 1) / 2 + 1;             // ceil((H - 3) / 2) + 1
+    if ((Ho - 1) * 2 >= H) --Ho;                                    // the last window must start inside the map
+    if ((Wo - 1) * 2 >= W) --Wo;
+    CTDET_CHECK(H >= 3 && W >= 3, "maxpool3x3s2(ceil): map %dx%d smaller than the window", H, W);
+  } else {
+    pad = 1;
+    Ho = (H - 1) / 2 + 1; Wo = (W - 1) / 2 + 1;
+  }
+  const long total = (long)B * Ho * Wo * (C / N);
   if (total == 0) return 0;
   if (dtype == CTDET_F16)
     hipLaunchKernelGGL((maxpool3x3s2_kernel<f16>), dim3(nblk(total)), dim3(256), 0, s, (const f16*)x, (f16*)y, B, H, W, C,
-                       in_stride, out_stride);
+                       in_stride, out_stride, pad, Ho, Wo);
   else if (dtype == CTDET_F32)
     hipLaunchKernelGGL((maxpool3x3s2_kernel<float>), dim3(nblk(total)), dim3(256), 0, s, (const float*)x, (float*)y, B,
-                       H, W, C, in_stride, out_stride);
+                       H, W, C, in_stride, out_stride, pad, Ho, Wo);
   else CTDET_CHECK(false, "maxpool3x3s2: bad dtype %d", dtype);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- eSE attention of VoVNet (vovnet.py:200-213): out[b][c] = mean over the pixels of x[b, :, :, c] (f32), and
+// y = x * hsigmoid(s[b][c]) (+ identity), hsigmoid(v) = relu6(v + 3) / 6
+template <typename T>
+__global__ void __launch_bounds__(256) global_avgpool_kernel(const T* __restrict__ x, int stride, int HW, int C,
+                                                             float* __restrict__ out) {
+  __shared__ float red[256];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < C)
+    for (int p = pl; p < HW; p += 4) acc += (float)x[((long)b * HW + p) * stride + c];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (pl == 0 && c < C)
+    out[(long)b * C + c] = ((red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192])) / (float)HW;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) ese_scale_kernel(const T* __restrict__ x, int x_stride, const float* __restrict__ s,
+                                                        const T* __restrict__ idn, int idn_stride, T* __restrict__ y,
+                                                        int y_stride, int B, int HW, int C) {
+  using V = typename Vec<T>::type;
+  constexpr int N = Vec<T>::N;
+  const int CV = C / N;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * HW * CV) return;
+  const int cv = (int)(idx % CV);
+  const long m = idx / CV;
+  const int b = (int)(m / HW);
+  const V v = *(const V*)(x + m * x_stride + cv * N);
+  V r;
+  V id = v;
+  if (idn) id = *(const V*)(idn + m * idn_stride + cv * N);
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    const float g = fminf(fmaxf(s[(long)b * C + cv * N + e] + 3.f, 0.f), 6.f) / 6.f;
+    float f = (float)v[e] * g;
+    if (idn) f += (float)id[e];
+    r[e] = (T)f;
+  }
+  *(V*)(y + m * y_stride + cv * N) = r;
+}
+
+int launch_global_avgpool(const void* x, int dtype, int B, int HW, int C, int stride, float* out, hipStream_t s) {
+  if ((long)B * HW * C == 0) return 0;
+  const dim3 grid((C + 63) / 64, B);
+  if (dtype == CTDET_F16) hipLaunchKernelGGL((global_avgpool_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x, stride, HW, C, out);
+  else if (dtype == CTDET_F32) hipLaunchKernelGGL((global_avgpool_kernel<float>), grid, dim3(256), 0, s, (const float*)x, stride, HW, C, out);
+  else CTDET_CHECK(false, "global_avgpool: bad dtype %d", dtype);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ese_scale(const void* x, int x_stride, const float* sc, const void* idn, int idn_stride, void* y, int y_stride,
+                     int dtype, int B, int HW, int C, hipStream_t s) {
+  const int N = dtype == CTDET_F16 ? 8 : 4;
+  CTDET_CHECK(C % N == 0 && x_stride % N == 0 && y_stride % N == 0 && (!idn || idn_stride % N == 0),
+              "ese_scale: channels / strides must be multiples of %d", N);
+  const long total = (long)B * HW * (C / N);
+  if (total == 0) return 0;
+  if (dtype == CTDET_F16)
+    hipLaunchKernelGGL((ese_scale_kernel<f16>), dim3(nblk(total)), dim3(256), 0, s, (const f16*)x, x_stride, sc, (const f16*)idn,
+                       idn_stride, (f16*)y, y_stride, B, HW, C);
+  else if (dtype == CTDET_F32)
+    hipLaunchKernelGGL((ese_scale_kernel<float>), dim3(nblk(total)), dim3(256), 0, s, (const float*)x, x_stride, sc,
+                       (const float*)idn, idn_stride, (float*)y, y_stride, B, HW, C);
+  else CTDET_CHECK(false, "ese_scale: bad dtype %d", dtype);
   CTDET_LAUNCH_CHECK();
   return 0;
 }

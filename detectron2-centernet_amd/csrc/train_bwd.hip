@@ -1230,23 +1230,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_narrow_kernel(const WgradAr
   }
 }
 
-static int device_cu_count() {
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
-    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  return ncu;
-}
+static int device_cu_count() { return ctdet_device_cu_count(); }
 
 int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
   WgradArgs a = a0;
   const bool window_ok = a.stride == 1 && a.dil == 1 && a.R == a.S && a.pad == a.R / 2 && a.H % 8 == 0 && a.W % 32 == 0 &&
                          a.Ho == a.H && a.Wo == a.W && a.in_stride % 8 == 0 && a.dy_stride % 8 == 0 &&
                          (long)a.B * a.H * a.W * (a.in_stride > a.dy_stride ? a.in_stride : a.dy_stride) * 2 < (1L << 31) &&
-                         !getenv("CTDET_NO_WGRAD_WINDOW");
+                         !(ctdet_tuning_flags() & CTDET_TUNE_NO_WGRAD_WINDOW);
   if (window_ok && a.Cout <= 16 && ((a.R == 7 && a.Cin == 8) || (a.R == 3 && a.Cin == 16))) {
     const int ntiles = a.B * (a.H / 8) * (a.W / 32);
     int blocks = device_cu_count();   // 1x / 2x / 4x CUs measured the same within noise; fewest atomics wins
@@ -1368,7 +1359,7 @@ int launch_dcn_col2im_coord(const f16* dcol, const f16* x, int x_stride, const f
   CTDET_CHECK(Cin % 8 == 0, "dcn_col2im: Cin=%d must be a multiple of 8", Cin);
   const long nwork = (long)B * H * W * 9;
   if (nwork == 0) return 0;
-  if (H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && x_stride % 8 == 0 && !getenv("CTDET_NO_COL2IM_WINDOW")) {
+  if (H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && x_stride % 8 == 0 && !(ctdet_tuning_flags() & CTDET_TUNE_NO_COL2IM_WINDOW)) {
     hipLaunchKernelGGL(dcn_col2im_window_kernel, dim3((unsigned)(B * (H / 8) * (W / 16))), dim3(512), 0, s, dcol, x, x_stride,
                        om, om_stride, dx, dom, B, H, W, Cin, mask_is_prob);
     CTDET_LAUNCH_CHECK();

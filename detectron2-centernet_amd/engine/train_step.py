@@ -10,13 +10,29 @@ import torch
 
 from .. import ops
 from ..layers import hipnn
-from ..ops_train import BNActFn, ConvFn, ConvTransposeFn, DCNFn, DwConvTAddFn, FocalLossFn, FrozenConvFn, MaxPoolFn, RegL1Fn
+from ..ops_train import (BNActFn, ConvFn, ConvTransposeFn, DeformConvFn, DwConvTAddFn, FocalLossFn, FrozenConvFn, MaxPoolFn,
+                         RegL1Fn)
+
+
+_COUNTERS = []
+
+
+def _count(bn):
+    """nn.BatchNorm2d increments num_batches_tracked per forward (torch/nn/modules/batchnorm.py); 59 one-element launches per
+    step here -- the counters are collected and advanced by ONE foreach launch at the end of the forward"""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        _COUNTERS.append(bn.num_batches_tracked)
+
+
+def _flush_counters():
+    if _COUNTERS:
+        torch._foreach_add_(_COUNTERS, 1)
+        _COUNTERS.clear()
 
 
 def conv_bn(x, conv, bn, relu=True, res=None):
     y = ConvFn.apply(x, conv.weight, None, conv.stride[0], conv.padding[0], False, False)
-    if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked += 1
+    _count(bn)
     return BNActFn.apply(y, bn.weight, bn.bias, res, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
 
 
@@ -65,10 +81,8 @@ def dla_base(m, x):
 
 def deform_conv_v2(m, x):
     dcn, bn = m.conv, m.actf[0]
-    om = ConvFn.apply(x, dcn.conv_offset_mask.weight, dcn.conv_offset_mask.bias, 1, 1, False, True)  # f32 [.,28]
-    y = DCNFn.apply(x, om, dcn.weight, dcn.bias)
-    if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked += 1
+    y = DeformConvFn.apply(x, dcn.conv_offset_mask.weight, dcn.conv_offset_mask.bias, dcn.weight, dcn.bias)
+    _count(bn)
     return BNActFn.apply(y, bn.weight, bn.bias, None, bn.running_mean, bn.running_var, bn.eps, bn.momentum, True)
 
 
@@ -141,8 +155,7 @@ def deconv_layers(model, y):
     for i in range(0, len(mods), 3):
         up, bn = mods[i], mods[i + 1]
         y = ConvTransposeFn.apply(y, up.weight, up.stride[0], up.padding[0])
-        if bn.training and bn.track_running_stats:
-            bn.num_batches_tracked += 1
+        _count(bn)
         y = BNActFn.apply(y.contiguous(), bn.weight, bn.bias, None, bn.running_mean, bn.running_var, bn.eps, bn.momentum, True)
     return y
 
@@ -171,9 +184,12 @@ def centernet_train_forward(model, batched_inputs):
 def train_forward_tensors(model, x_nhwc, targets):
     if model.backbone_type == "resnet":
         y = deconv_layers(model, resnet_features(model.backbone, x_nhwc, model._ctx))
+    elif model.backbone_type != "dla34":
+        raise NotImplementedError(f"training of the '{model.backbone_type}' backbone is not built (inference only)")
     else:
         y = dla34(model.backbone, x_nhwc)[-1]
     z = heads(model, y)
+    _flush_counters()
     C = model.num_classes
     hm = z["hm"] if z["hm"].shape[3] == C else z["hm"][..., :C].contiguous()
     hm_loss = FocalLossFn.apply(hm, targets["hm"], model._alpha_tensor())

@@ -73,14 +73,16 @@ class _EvalEngine:
         self.B, self.img_dtype = B, img_dtype
         self.img_params = torch.zeros(B, 4, dtype=torch.float32, device=dev)
         # DLA-34: normalisation + base_layer + level0 + level1 run as one kernel straight from the image batch
-        self.fused_base = model.backbone_type != "resnet" and model.backbone.images_fusable(model._ctx, Hp, Wp)
+        self.fused_base = model.backbone_type == "dla34" and model.backbone.images_fusable(model._ctx, Hp, Wp)
         # the base kernel runs outside the captured graph and reads the caller's image batch in place, whatever its
         # unpadded size: the graph only depends on the padded size
         self.key = _engine_key(self.fused_base, B, H, W, Hp, Wp, img_dtype)
         self.images = torch.zeros(B, 3, H, W, dtype=img_dtype, device=dev)
         # otherwise: normalised input with a 3-pixel zero frame (the 7x7 stem's padding), cleared once, interior rewritten
         # per call
-        self.xpad = None if self.fused_base else torch.zeros(B, Hp + 6, Wp + 6, 8, dtype=model._ctx.dtype, device=dev)
+        self.border = int(getattr(model.backbone, "stem_border", 3))      # VoVNet's 3x3 stem pads in the kernel: 0
+        self.xpad = None if self.fused_base else torch.zeros(B, Hp + 2 * self.border, Wp + 2 * self.border, 8,
+                                                             dtype=model._ctx.dtype, device=dev)
         self.l1 = torch.empty(B, Hp // 2, Wp // 2, 32, dtype=torch.float16, device=dev) if self.fused_base else None
         self.l1p = torch.empty(B, Hp // 4, Wp // 4, 32, dtype=torch.float16, device=dev) if self.fused_base else None
         self.graph = None
@@ -129,8 +131,8 @@ class _EvalEngine:
         if self.fused_base:
             self.out = m._network_outputs(None, apply_sigmoid=True, level1=(self.l1, self.l1p))
         else:
-            x = ops.preprocess(self.images, m._mean_host, m._std_host, self.Hp, self.Wp, out=self.xpad, border=3)
-            self.out = m._network_outputs(x, apply_sigmoid=True, prepadded=True)
+            x = ops.preprocess(self.images, m._mean_host, m._std_host, self.Hp, self.Wp, out=self.xpad, border=self.border)
+            self.out = m._network_outputs(x, apply_sigmoid=True, prepadded=self.border > 0)
         hm, wh, reg = self.out
         self.dec = ops.decode(hm, wh, reg, m.topk_candidates, m.backbone.down_ratio)
 
@@ -189,18 +191,19 @@ class CenterNet(nn.Module):
 
         self.backbone_type = backbone_type.split("_")[1]
         self.backbone = build_backbone(cfg)
-        if self.backbone_type == "resnet":
-            # centernet.py:71-108: res4 -> two (ConvTranspose2d 4x4 s2 p1, BN, ReLU) stages -> heads on 256 channels
+        if self.backbone_type in ("resnet", "vovnet"):
+            # centernet.py:70-108: res4 / stage4 -> two (ConvTranspose2d 4x4 s2 p1, BN, ReLU) stages -> heads on 256 channels
             self.backbone.down_ratio = 4
             self.size_divisibility = 16
-            self.deconv_layers = self._make_deconv_layer(self.backbone._out_feature_channels["res4"], 2, [256, 256],
-                                                         [4, 4])
+            self.deconv_feature = "res4" if self.backbone_type == "resnet" else "stage4"
+            self.deconv_layers = self._make_deconv_layer(self.backbone._out_feature_channels[self.deconv_feature], 2,
+                                                         [256, 256], [4, 4])
             cin, final_kernel = 256, 1
         elif self.backbone_type == "dla34":
             self.size_divisibility = self.backbone.size_divisibility
             cin = self.backbone.channels[self.backbone.first_level]
         else:
-            raise NotImplementedError(f"backbone '{backbone_type}': DLA-34 and ResNet are built (SURVEY.md 8(a))")
+            raise NotImplementedError(f"backbone '{backbone_type}': DLA-34, ResNet and VoVNet are built (SURVEY.md 8(a), 8(f))")
         self.head_conv = head_conv
         for head in self.heads:
             classes = self.heads[head]
@@ -221,7 +224,7 @@ class CenterNet(nn.Module):
                 else:
                     fill_fc_weights(fc)
             self.__setattr__(head.lower(), fc)
-        if self.backbone_type == "resnet":
+        if self.backbone_type == "resnet":      # centernet.py:108: only the ResNet branch re-initialises deconv / heads
             self.init_weights()
         self._engines = {}
         self.use_hip_graph = True
@@ -276,7 +279,7 @@ class CenterNet(nn.Module):
     def _engine(self, B, H, W, Hp, Wp, img_dtype):
         """the captured engine of this input geometry (least recently used ones beyond MAX_ENGINES are destroyed here, before
         a new one is built, i.e. never inside a stream capture)"""
-        fused = self.backbone_type != "resnet" and self.backbone.images_fusable(self._ctx, Hp, Wp)
+        fused = self.backbone_type == "dla34" and self.backbone.images_fusable(self._ctx, Hp, Wp)
         key = _engine_key(fused, B, H, W, Hp, Wp, img_dtype)
         eng = self._engines.get(key)
         if eng is not None:
@@ -360,8 +363,8 @@ class CenterNet(nn.Module):
         return y
 
     def _network_outputs(self, x_nhwc, apply_sigmoid, prepadded=False, level1=None):
-        if self.backbone_type == "resnet":
-            y = self._deconv_forward(self.backbone.hip_forward(x_nhwc, self._ctx, prepadded)["res4"])
+        if self.backbone_type in ("resnet", "vovnet"):
+            y = self._deconv_forward(self.backbone.hip_forward(x_nhwc, self._ctx, prepadded)[self.deconv_feature])
         else:
             y = self.backbone.hip_forward(x_nhwc, self._ctx, prepadded, level1=level1)[-1]
         z = self._head_outputs(y, apply_sigmoid)

@@ -54,7 +54,7 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
         Ho = (H + 2 * p.pad - p.dil * (p.R - 1) - 1) // p.stride + 1
         win = ((p.R, p.Cin, bc, p.stride) in ((7, 8, 16, 1), (3, 16, 16, 1)) and Ho % 16 == 0) or \
               ((p.R, p.Cin, bc, p.stride) == (3, 16, 32, 2) and Ho % 8 == 0 and Wo % 32 == 0)
-        if win and p.R == p.S and p.dil == 1 and os.environ.get("CTDET_NO_WIN") is None:
+        if win and p.R == p.S and p.dil == 1 and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_WIN):
             return f"conv_win_kernel<{p.R}x{p.R},Cin{p.Cin},Cout{bc},s{p.stride},{o}>"
         return f"conv_smallc_kernel<Cout{bc},K{p.Kpad},{o}>"
     if p.Kpad == p.K and p.R * p.S <= 32 and p.in_dil == 1 and (p.korder == 1 or p.R * p.S == 1) and p.Cin % 32 == 0:
@@ -499,6 +499,51 @@ def maxpool3x3s2(x, out=None):
     rc = _lib.lib().ctdet_maxpool3x3s2(_ptr(x), _ptr(out), dt_of(x), B, H, W, Cc, _nhwc_stride(x), _nhwc_stride(out),
                                        _stream())
     _lib.check(rc, "ctdet_maxpool3x3s2")
+    return out
+
+
+def maxpool3x3s2_ceil(x, out=None):
+    """nn.MaxPool2d(3, stride=2, ceil_mode=True) on NHWC (VoVNet stages, vovnet.py:291-292)."""
+    _require_cuda(x, out)
+    B, H, W, Cc = x.shape
+    Ho, Wo = -(-(H - 3) // 2) + 1, -(-(W - 3) // 2) + 1
+    if (Ho - 1) * 2 >= H:
+        Ho -= 1
+    if (Wo - 1) * 2 >= W:
+        Wo -= 1
+    if out is None:
+        out = torch.empty(B, Ho, Wo, Cc, dtype=x.dtype, device=x.device)
+    assert tuple(out.shape[:3]) == (B, Ho, Wo)
+    rc = _lib.lib().ctdet_maxpool3x3s2_ceil(_ptr(x), _ptr(out), dt_of(x), B, H, W, Cc, _nhwc_stride(x), _nhwc_stride(out),
+                                            _stream())
+    _lib.check(rc, "ctdet_maxpool3x3s2_ceil")
+    return out
+
+
+def global_avgpool(x):
+    """NHWC x -> f32 [B, C]: the mean over the pixels (nn.AdaptiveAvgPool2d(1) of the eSE module, vovnet.py:203)."""
+    _require_cuda(x)
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().ctdet_global_avgpool(_ptr(x), dt_of(x), B, H * W, Cc, _nhwc_stride(x), _ptr(out), _stream())
+    _lib.check(rc, "ctdet_global_avgpool")
+    return out
+
+
+def ese_scale(x, s, identity=None, out=None):
+    """y = x * hsigmoid(s[b, c]) (+ identity); s f32 [B, C] (vovnet.py:186-213, 268-271)."""
+    _require_cuda(x, s, identity, out)
+    B, H, W, Cc = x.shape
+    s = s.contiguous()
+    assert s.dtype == torch.float32 and tuple(s.shape) == (B, Cc)
+    if out is None:
+        out = torch.empty(B, H, W, Cc, dtype=x.dtype, device=x.device)
+    if identity is not None:
+        assert identity.dtype == x.dtype and tuple(identity.shape) == tuple(x.shape)
+    rc = _lib.lib().ctdet_ese_scale(_ptr(x), _nhwc_stride(x), _ptr(s), _ptr(identity),
+                                    _nhwc_stride(identity) if identity is not None else 0, _ptr(out), _nhwc_stride(out),
+                                    dt_of(x), B, H * W, Cc, _stream())
+    _lib.check(rc, "ctdet_ese_scale")
     return out
 
 

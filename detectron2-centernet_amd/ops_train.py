@@ -445,6 +445,61 @@ class DCNFn(torch.autograd.Function):
         return dx32.to(x.dtype), dom, dwt, dbias[:Cout] if ctx.has_bias else None, None, None
 
 
+class DeformConvFn(torch.autograd.Function):
+    """The DCN wrapper as ONE autograd node: om = conv_offset_mask(x) (3x3, 27 channels, f32 out), y = dcn(x, om).  x feeds both
+    convs; as two nodes autograd adds their two input gradients with a generic elementwise kernel after a separate
+    f32 -> f16 cast of the scatter result -- here the offset conv's input gradient is produced in f32 ON TOP of the scatter
+    buffer (the conv kernel's residual input) and cast once."""
+
+    @staticmethod
+    def forward(ctx, x, w_off, b_off, weight, bias):
+        f32 = x.dtype == torch.float32
+        comp = F32 if f32 else F16
+        p_off = _fwd_pack(w_off, 1, 1, bias=b_off, compute=comp)
+        om = ops.conv2d(x, p_off, out_dtype=torch.float32)
+        p = ops.PackedConv(weight.detach(), None, bias, stride=1, pad=1, compute=comp, cout_align=None if f32 else 64)
+        y = ops.dcnv2(x, om, p)
+        ctx.save_for_backward(x, om, w_off, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, om, w_off, weight = ctx.saved_tensors
+        Cout, Cin = weight.shape[:2]
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dyp = _pad_c(dy if dy.shape[3] == Cout else dy[..., :Cout].contiguous())
+        # ---- main conv: dW, d(columns) -> scatter (d input, f32) + d(offset / mask logits)
+        col = dcn_cols(x, om)
+        wmat = weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
+        if dyp.shape[3] != Cout:
+            wmat = torch.nn.functional.pad(wmat, (0, 0, 0, 0, 0, 0, 0, dyp.shape[3] - Cout))
+        _, _, _, dbias = bn_train_bwd(dyp, None, None, None, None, None, relu=False)
+        dw = conv_wgrad(col, dyp, dyp.shape[3], 1, 1, 1, 0)[:Cout]
+        dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        dcol = conv_dgrad(dyp, wmat, 1, 0, x.shape[1:3])
+        dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om)
+        # ---- offset / mask conv: bias and weight gradients from dom; its input gradient lands on top of dx32
+        dom_t = dom if x.dtype == torch.float32 else dom.to(x.dtype)      # [M, 28] (27 used + a zero pad channel)
+        n_om = w_off.shape[0]
+        _, _, _, db_off = bn_train_bwd(_pad_c(dom_t), None, None, None, None, None, relu=False)
+        dw_off = conv_wgrad(x, _pad_c(dom_t), _pad_c(dom_t).shape[3], 3, 3, 1, 1)[:n_om]
+        dw_off_t = _wgrad_to_oihw(dw_off, n_om, Cin, x.shape[3], 3, 3)
+        Cw = _pad_c(dom_t).shape[3]
+        wpad = torch.nn.functional.pad(w_off.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - n_om)) if Cw != n_om else w_off.detach()
+        if x.dtype == torch.float32:
+            wt = wpad.flip(2, 3).permute(1, 0, 2, 3).contiguous()
+            pt = ops.PackedConv(wt, None, None, stride=1, pad=1, compute=F32)
+        else:
+            pt = ops.PackedConv(wpad, None, None, stride=1, pad=1, compute=F16, transposed=True)
+        dx = ops.conv2d(_pad_c(dom_t), pt, out=dx32 if pt.Cout_eff == Cin else None, residual=dx32 if pt.Cout_eff == Cin else None,
+                        out_dtype=torch.float32)
+        if pt.Cout_eff != Cin:
+            dx = dx[..., :Cin] + dx32
+        return dx.to(x.dtype), dw_off_t, db_off[:n_om], dwt, dbias[:Cout]
+
+
 class FocalLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, gt, alpha):

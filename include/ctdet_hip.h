@@ -47,6 +47,14 @@ typedef struct ctdet_conv_desc {
 
 const char* ctdet_last_error(void);
 int32_t ctdet_abi_version(void);
+/* Kernel-selection switches for tests and tuning (bit set = that specialised kernel is NOT used / the alternative form IS
+ * used); process-wide, default 0.  The launch path reads this word, never the environment. */
+enum ctdet_tuning {
+  CTDET_TUNING_NO_HALO = 1, CTDET_TUNING_NO_WIN = 2, CTDET_TUNING_DCN_MIXED = 4, CTDET_TUNING_NO_WGRAD_WINDOW = 8,
+  CTDET_TUNING_NO_COL2IM_WINDOW = 16
+};
+int32_t ctdet_set_tuning_flags(uint32_t flags);
+uint32_t ctdet_get_tuning_flags(void);
 int32_t ctdet_conv_cout_tile(int32_t cout);
 
 /* y = act(conv(x, w) * scale + bias + residual).  Replaces torch.nn.Conv2d (+BatchNorm2d eval +ReLU
@@ -125,6 +133,18 @@ int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32
  * output [B, (H-1)/2+1, (W-1)/2+1, C]; padded taps do not take part. */
 int32_t ctdet_maxpool3x3s2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
                            int32_t in_stride, int32_t out_stride, void* stream);
+/* nn.MaxPool2d(kernel_size=3, stride=2, ceil_mode=True) of the VoVNet stages (detectron2/modeling/backbone/vovnet.py:291-292),
+ * NHWC; output [B, ceil((H-3)/2)+1, ceil((W-3)/2)+1, C] (a last window that would start outside the map is dropped). */
+int32_t ctdet_maxpool3x3s2_ceil(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
+                                int32_t in_stride, int32_t out_stride, void* stream);
+/* eSE attention of VoVNet (vovnet.py:200-213): ctdet_global_avgpool: out f32 [B][C] = mean over the HW pixels of NHWC x;
+ * ctdet_ese_scale: y = x * hsigmoid(s[b][c]) (+ identity), hsigmoid(v) = relu6(v + 3) / 6 (vovnet.py:186-197); s is the
+ * raw output of the module's 1x1 `fc` conv on the pooled vector; identity (may be NULL) is the block input of the later
+ * OSA blocks of a stage (vovnet.py:268-271). */
+int32_t ctdet_global_avgpool(const void* x, int32_t dtype, int32_t B, int32_t HW, int32_t C, int32_t stride, float* out,
+                             void* stream);
+int32_t ctdet_ese_scale(const void* x, int32_t x_stride, const float* s, const void* identity, int32_t identity_stride,
+                        void* y, int32_t y_stride, int32_t dtype, int32_t B, int32_t HW, int32_t C, void* stream);
 
 /* Packs an f32 OIHW conv weight [O,I,R,S] (nn.Conv2d.weight as the reference stores it) into the f16 [rows_pad][Kpad]
  * operand of ctdet_conv2d_fwd / ctdet_dcnv2_fwd, zero padding included.  korder as in ctdet_conv_desc.  transposed = 0:

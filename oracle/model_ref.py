@@ -214,6 +214,57 @@ def centernet_resnet_forward(sd, images_nchw, blocks=(3, 4, 6), training=False):
     return centernet_heads(Net(sd), y)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# VoVNet-v2 (eSE) path.  Pinned by tests/golden/g12_vovnet19slim.npz, generated from the reference's own
+# `VoVNet` (detectron2/modeling/backbone/vovnet.py).
+VOVNET_SPECS = {
+    "V-19-slim-eSE": dict(layer_per_block=3, block_per_stage=[1, 1, 1, 1]),
+    "V-19-eSE": dict(layer_per_block=3, block_per_stage=[1, 1, 1, 1]),
+    "V-39-eSE": dict(layer_per_block=5, block_per_stage=[1, 1, 2, 2]),
+}
+
+
+def _vov_cnr(sd, name, x, stride=1, pad=1):
+    """conv3x3 / conv1x1 triple of vovnet.py:120-163: conv (no bias) -> FrozenBatchNorm2d -> ReLU"""
+    return F.relu(frozen_bn(sd, name + "/norm", F.conv2d(x, sd[name + "/conv.weight"], None, stride, pad)))
+
+
+def vovnet_osa(sd, p, name, x, layers, identity):
+    """_OSA_module.forward (vovnet.py:250-273) + eSEModule (:200-213) with Hsigmoid (:186-197)"""
+    outs, ident = [x], x
+    for i in range(layers):
+        x = _vov_cnr(sd, f"{p}.layers.{i}.{name}_{i}", x)
+        outs.append(x)
+    xt = _vov_cnr(sd, f"{p}.concat.{name}_concat", torch.cat(outs, 1), 1, 0)
+    s = F.conv2d(xt.mean((2, 3), keepdim=True), sd[p + ".ese.fc.weight"], sd[p + ".ese.fc.bias"])
+    xt = xt * (F.relu6(s + 3.0) / 6.0)
+    return xt + ident if identity else xt
+
+
+def vovnet_features(sd, p, x, body="V-19-slim-eSE"):
+    """VoVNet.forward (vovnet.py:397-407): stem (3x3 s2, 3x3, 3x3 s2) + stage2..5 -> dict of stage outputs"""
+    spec = VOVNET_SPECS[body]
+    x = _vov_cnr(sd, p + ".stem.stem_1", x, 2)
+    x = _vov_cnr(sd, p + ".stem.stem_2", x, 1)
+    x = _vov_cnr(sd, p + ".stem.stem_3", x, 2)
+    outs = {}
+    for si in range(4):
+        stage = si + 2
+        if stage != 2:
+            x = F.max_pool2d(x, kernel_size=3, stride=2, ceil_mode=True)        # vovnet.py:291-292
+        for bi in range(spec["block_per_stage"][si]):
+            name = f"OSA{stage}_{bi + 1}"
+            x = vovnet_osa(sd, f"{p}.stage{stage}.{name}", name, x, spec["layer_per_block"], identity=bi > 0)
+        outs[f"stage{stage}"] = x
+    return outs
+
+
+def centernet_vovnet_forward(sd, images_nchw, body="V-19-slim-eSE"):
+    """centernet.py:140-154 for backbone_type == 'vovnet': stage4 -> deconv_layers -> heads"""
+    y = deconv_layers(sd, "deconv_layers", vovnet_features(sd, "backbone", images_nchw, body)["stage4"])
+    return centernet_heads(Net(sd), y)
+
+
 def centernet_losses(z, targets, alpha, hm_w=1.0, wh_w=0.1, off_w=1.0):
     """centernet.py:191-212: targets = list of gen_heatmap dicts (numpy)."""
     gt_hm = torch.stack([torch.from_numpy(t["hm"]) for t in targets])

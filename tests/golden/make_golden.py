@@ -380,6 +380,22 @@ def main():
             f.write(f"backbone.{k} {tuple(r18.state_dict()[k].shape)}\n")
         for k in sorted(deconv18.state_dict().keys()):
             f.write(f"deconv_layers.{k} {tuple(deconv18.state_dict()[k].shape)}\n")
+    # ---------------- G12: VoVNet-19-slim-eSE (the ctdet_vovnet2_19_slim config's backbone), FrozenBN, stages 2..5 --------
+    sys.modules["detectron2.modeling.backbone"].Backbone = load("detectron2.modeling.backbone.backbone").Backbone
+    vov = load("detectron2.modeling.backbone.vovnet")
+    from types import SimpleNamespace as NS
+    vcfg = NS(MODEL=NS(VOVNET=NS(NORM="FrozenBN", CONV_BODY="V-19-slim-eSE"), BACKBONE=NS(FREEZE_AT=0)))
+    torch.manual_seed(12)
+    v19 = vov.VoVNet(vcfg, 3, out_features=["stage2", "stage3", "stage4", "stage5"]).eval()
+    v19.load_state_dict(fill_state_dict(v19.state_dict(), seed=13))
+    gg = torch.Generator().manual_seed(1200)
+    x = torch.randn(1, 3, 70, 100, generator=gg)       # odd sizes: the ceil-mode pooling matters
+    with torch.no_grad():
+        outs = v19(x)
+    np.savez_compressed(os.path.join(HERE, "g12_vovnet19slim.npz"), x=x.numpy(), **{k: v.numpy() for k, v in outs.items()})
+    with open(os.path.join(HERE, "g12_vovnet19slim_state_dict_keys.txt"), "w") as f:
+        for k in sorted(v19.state_dict().keys()):
+            f.write(f"backbone.{k} {tuple(v19.state_dict()[k].shape)}\n")
     print("golden vectors written to", HERE)
 
 

@@ -17,6 +17,8 @@ def fill_state_dict(sd, seed):
             out[k] = torch.rand(v.shape, generator=g) * 0.5 + 0.75
         elif k.endswith("running_mean"):
             out[k] = torch.randn(v.shape, generator=g) * 0.1
+        elif "/norm.weight" in k:
+            out[k] = torch.rand(v.shape, generator=g) * 0.5 + 0.75      # VoVNet's FrozenBN scales (keys carry a '/')
         elif "actf.0.weight" in k or ".bn" in k and k.endswith("weight") or k.endswith(".1.weight") and v.dim() == 1:
             out[k] = torch.rand(v.shape, generator=g) * 0.5 + 0.75
         elif v.dim() == 1:

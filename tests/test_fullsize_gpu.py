@@ -182,11 +182,9 @@ def test_fullsize_dcn_backward_scatter_window_vs_atomics():
     om[..., :18] *= 2.0
     om = om.to(dev)
     dx_w, dom_w = ot.dcn_col2im_coord(dcol, x, om)
-    os.environ["CTDET_NO_COL2IM_WINDOW"] = "1"
-    try:
+    from detectron2_centernet_amd import _lib
+    with _lib.tuning(_lib.TUNE_NO_COL2IM_WINDOW):
         dx_a, dom_a = ot.dcn_col2im_coord(dcol, x, om)
-    finally:
-        del os.environ["CTDET_NO_COL2IM_WINDOW"]
     assert (dx_w - dx_a).abs().max().item() <= dx_a.abs().max().item() * 2.0 ** -14
     assert (dom_w - dom_a).abs().max().item() <= dom_a.abs().max().item() * 2e-4
 

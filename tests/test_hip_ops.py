@@ -379,11 +379,8 @@ DCN_WINDOW_CASES = [(2, 16, 32, 64, 64, 1.0), (1, 8, 16, 128, 64, 0.0), (2, 16, 
 @pytest.mark.parametrize("mixed", [False, True])
 @pytest.mark.parametrize("case", DCN_WINDOW_CASES)
 def test_dcnv2_window(ops, dev, case, mixed, monkeypatch):
-    """mixed: the CTDET_DCN_MIXED=1 instantiation (only the lanes that left the window gather from global memory)"""
-    if mixed:
-        monkeypatch.setenv("CTDET_DCN_MIXED", "1")
-    else:
-        monkeypatch.delenv("CTDET_DCN_MIXED", raising=False)
+    """mixed: the CTDET_TUNING_DCN_MIXED instantiation (only the lanes that left the window gather from global memory)"""
+    from detectron2_centernet_amd import _lib
     B, H, W, Cin, Cout, off_std = case
     g = torch.Generator().manual_seed(Cin + Cout + H + 1)
     x = h16(torch.randn(B, Cin, H, W, generator=g))
@@ -404,7 +401,8 @@ def test_dcnv2_window(ops, dev, case, mixed, monkeypatch):
     om_d = torch.zeros(B, H, W, 28)
     om_d[..., :27] = nhwc(om)
     xd = nhwc(x).half().to(dev)
-    y = ops.dcnv2(xd, om_d.to(dev), pc, act=ops.ACT_RELU)
+    with _lib.tuning(_lib.TUNE_DCN_MIXED if mixed else 0):
+        y = ops.dcnv2(xd, om_d.to(dev), pc, act=ops.ACT_RELU)
     got = nchw(y[..., :Cout].float().cpu())
     err = (got - ref).abs().max().item()
     assert err <= 6e-3 * max(1.0, ref.abs().max().item()), f"max err {err}"

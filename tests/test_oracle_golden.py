@@ -263,3 +263,25 @@ def test_dcn_backward_sentinel_and_truncation_cases():
     # d out / d h at h_im = -0.25: x[0,0] * (+1) (only the lower corner exists): coordinate weight = + v3 ... here
     # low = -1 (guarded), high = 0: weight = (w_low + 1 - w) * x[high, low] = x[0, 0]
     assert goff[0, 8, 0, 0].item() == pytest.approx(2.0 * 1.0)
+
+
+def test_g12_vovnet_oracle_matches_reference_module():
+    """oracle.model_ref.vovnet_features == the reference's own VoVNet (V-19-slim-eSE, FrozenBN) on a 70x100 input
+    (ceil-mode pooling, eSE attention, OSA concat), and the local module's state-dict keys == the reference's"""
+    g = np.load(os.path.join(G, "g12_vovnet19slim.npz"))
+    keys = [l.split(" ")[0] for l in open(os.path.join(G, "g12_vovnet19slim_state_dict_keys.txt"))]
+    shapes = {l.split(" ")[0]: eval(l.split(" ", 1)[1]) for l in open(os.path.join(G, "g12_vovnet19slim_state_dict_keys.txt"))}
+    sd = fill_state_dict({k[len("backbone."):]: torch.zeros(shapes[k]) for k in keys}, seed=13)
+    sd = {"backbone." + k: v for k, v in sd.items()}
+    outs = MR.vovnet_features(sd, "backbone", torch.from_numpy(g["x"]))
+    for name in ("stage2", "stage3", "stage4", "stage5"):
+        ref = torch.from_numpy(g[name])
+        assert outs[name].shape == ref.shape, name
+        assert (outs[name] - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()), name
+    # the local VoVNet has the same parameters / buffers under the same names
+    from types import SimpleNamespace as NS
+    from detectron2_centernet_amd.modeling.backbone.vovnet import VoVNet
+    cfg = NS(MODEL=NS(VOVNET=NS(NORM="FrozenBN", CONV_BODY="V-19-slim-eSE"), BACKBONE=NS(FREEZE_AT=0)))
+    m = VoVNet(cfg, 3, out_features=["stage2", "stage3", "stage4", "stage5"])
+    mine = {"backbone." + k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert mine == shapes

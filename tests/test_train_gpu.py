@@ -227,11 +227,9 @@ def test_dcn_col2im_window_fixed_point_vs_atomics(T, dev, scale):
     om[..., :18] *= 2.5
     om = om.to(dev)
     dx_w, dom_w = ot.dcn_col2im_coord(dcol, x, om)
-    os.environ["CTDET_NO_COL2IM_WINDOW"] = "1"
-    try:
+    from detectron2_centernet_amd import _lib
+    with _lib.tuning(_lib.TUNE_NO_COL2IM_WINDOW):
         dx_a, dom_a = ot.dcn_col2im_coord(dcol, x, om)
-    finally:
-        del os.environ["CTDET_NO_COL2IM_WINDOW"]
     mx = dx_a.abs().max().item()
     assert mx > 0
     assert (dx_w - dx_a).abs().max().item() <= mx * 2.0 ** -15

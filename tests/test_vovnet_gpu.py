@@ -1,0 +1,122 @@
+"""VoVNet-v2 (eSE) CenterNet configs: `ctdet_vovnet2_19_slim_1x.yaml` ingested unchanged, eval forward on
+the HIP kernels against the CPU oracle (pinned to the reference's own VoVNet module by G12), and the new pieces (ceil-mode
+3x3/2 max pool, eSE attention) against torch."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ctdet_oracle as O
+from oracle import model_ref as MR
+
+pytestmark = pytest.mark.gpu
+
+VOV_YAML = """
+_BASE_: "./Base-CenterNet.yaml"
+MODEL:
+  BACKBONE:
+    NAME: "build_vovnet_backbone"
+  WEIGHTS: "/autox-sz/users/chenxiaoniu/models/vovnet19_ese_slim_detectron2.pth"
+  VOVNET:
+    OUT_FEATURES: ["stage2", "stage3", "stage4", "stage5"]
+    CONV_BODY: "V-19-slim-eSE"
+  CENTERNET:
+    HEAD_CONV: 64
+    FOCAL_LOSS_ALPHA: [1]
+DATASETS:
+  TRAIN: ("bulb_train",)
+  TEST: ("bulb_val",)
+INPUT:
+  FORMAT: "RGB"
+  MIN_SIZE_TRAIN: (640, 672, 704, 736, 768, 800)
+SOLVER:
+  IMS_PER_BATCH: 24
+  BASE_LR: 2.5e-4
+VERSION: 2
+"""
+BASE = """
+MODEL:
+  META_ARCHITECTURE: "CenterNet"
+  PIXEL_MEAN: [0.408, 0.447, 0.470]
+  PIXEL_STD: [0.289, 0.274, 0.278]
+VERSION: 2
+"""
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.float32])
+def test_vovnet_pool_and_ese_kernels(dev, tdt):
+    import detectron2_centernet_amd.ops as ops
+    g = torch.Generator().manual_seed(3)
+    for H, W in ((17, 25), (16, 24), (35, 50), (3, 3), (4, 7)):
+        x = torch.randn(2, 16, H, W, generator=g).half().float()
+        y = ops.maxpool3x3s2_ceil(nhwc(x).to(tdt).to(dev))
+        ref = F.max_pool2d(x, kernel_size=3, stride=2, ceil_mode=True)
+        assert tuple(y.shape) == (2, ref.shape[2], ref.shape[3], 16), (H, W, y.shape, ref.shape)
+        assert torch.equal(nchw(y.float().cpu()), ref), (H, W)
+    x = torch.randn(3, 80, 9, 13, generator=g).half().float()
+    idn = torch.randn(3, 80, 9, 13, generator=g).half().float()
+    s = torch.randn(3, 80, generator=g) * 3
+    pooled = ops.global_avgpool(nhwc(x).to(tdt).to(dev))
+    assert torch.allclose(pooled.cpu(), x.mean((2, 3)), atol=1e-5)
+    ref = x * (F.relu6(s + 3) / 6).view(3, 80, 1, 1)
+    tol = 2e-3 if tdt == torch.float16 else 1e-6
+    out = ops.ese_scale(nhwc(x).to(tdt).to(dev), s.to(dev))
+    assert (nchw(out.float().cpu()) - ref).abs().max() <= tol * ref.abs().max()
+    out = ops.ese_scale(nhwc(x).to(tdt).to(dev), s.to(dev), identity=nhwc(idn).to(tdt).to(dev))
+    assert (nchw(out.float().cpu()) - (ref + idn)).abs().max() <= tol * (ref + idn).abs().max()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_vovnet19_slim_centernet_eval_matches_oracle(tmp_path, dev, precision):
+    import sys
+    from detectron2_centernet_amd.config import get_cfg
+    from detectron2_centernet_amd.data.catalog import register_synthetic
+    from detectron2_centernet_amd.modeling import build_model
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from weights import fill_state_dict
+
+    (tmp_path / "Base-CenterNet.yaml").write_text(BASE)
+    (tmp_path / "ctdet_vovnet2_19_slim_1x.yaml").write_text(VOV_YAML)
+    cfg = get_cfg()
+    cfg.merge_from_file(str(tmp_path / "ctdet_vovnet2_19_slim_1x.yaml"))
+    cfg.MODEL.CENTERNET.HIP_PRECISION = precision
+    register_synthetic("bulb_train", num_classes=80)
+    model = build_model(cfg).eval()
+    assert model.backbone_type == "vovnet" and model.size_divisibility == 16 and model.head_conv == 64
+    keys = sorted(k for k in model.state_dict() if k.startswith("backbone."))
+    ref_keys = [l.split(" ")[0] for l in open(os.path.join(os.path.dirname(__file__), "golden",
+                                                           "g12_vovnet19slim_state_dict_keys.txt"))]
+    assert keys == sorted(ref_keys)
+    sd = fill_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, seed=31)
+    model.load_state_dict({k: v.to(model.device) for k, v in sd.items()})
+    g = torch.Generator().manual_seed(6)
+    img = torch.randint(0, 256, (2, 3, 90, 120), generator=g, dtype=torch.uint8)      # padded to 96 x 128
+    model.score_threshold = 0.0
+    out = model([{"image": img[b]} for b in range(2)])
+    eng = next(iter(model._engines.values()))
+    hm, wh, reg = [t.float().cpu().permute(0, 3, 1, 2) for t in eng.out]
+    assert hm.shape == (2, 80, 24, 32)
+    x, _ = O.preprocess([i for i in img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 16)
+    sdf = {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        z = MR.centernet_vovnet_forward(sdf, x)
+    hm_ref = torch.clamp(torch.sigmoid(z["hm"]), 1e-4, 1 - 1e-4)
+    err = (hm - hm_ref).abs().max().item()
+    print(precision, "vovnet19-slim heatmap err", err)
+    assert err <= (1e-5 if precision == "f32" else 1e-3)
+    assert (wh - z["wh"]).abs().max().item() <= (2e-4 if precision == "f32" else 2e-2) * max(1.0, z["wh"].abs().max().item())
+    rb, rs, rc, _ = O.ctdet_decode(hm, wh, reg, down_ratio=4, K=100)
+    for b in range(2):
+        inst = out[b]["instances"]
+        bb, ss, cc = O.inference_single_image(rb[b], rs[b], rc[b], 100, 0.0)
+        bb, keep = O.detector_postprocess(bb, (90, 120), 90, 120)
+        assert torch.equal(inst.scores.cpu(), ss[keep]) and torch.equal(inst.pred_classes.cpu(), cc[keep])
