@@ -17,9 +17,14 @@ class _Incompatible:
 
 
 class DetectionCheckpointer:
-    def __init__(self, model, save_dir="", *, save_to_disk=True, **checkpointables):
+    def __init__(self, model, save_dir="", *, save_to_disk=None, **checkpointables):
+        """save_to_disk: None = only the main process writes (detection_checkpoint.py:18-25: `comm.is_main_process()`),
+        so data-parallel ranks do not race on the same `.pth` / `last_checkpoint`"""
+        from ..utils.comm import is_main_process
+
         self.model = model.module if hasattr(model, "module") and isinstance(model.module, torch.nn.Module) else model
-        self.save_dir, self.save_to_disk = save_dir, save_to_disk
+        self.save_dir = save_dir
+        self.save_to_disk = is_main_process() if save_to_disk is None else save_to_disk
         self.checkpointables = dict(checkpointables)
         self.logger = logging.getLogger(__name__)
 

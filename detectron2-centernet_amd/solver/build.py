@@ -104,9 +104,41 @@ class FlatSGD:
         return {"momentum": self.flat_mom.clone(), "first": self._first}
 
     def load_state_dict(self, sd):
-        self.flat_mom.copy_(sd["momentum"])
-        self._first = sd["first"]
+        """this optimizer's own state, or the `torch.optim.SGD` state dict a reference checkpoint carries under "optimizer"
+        ({"state": {index: {"momentum_buffer": t}}, "param_groups": [{"params": [indices], ...}]}): the reference builds one
+        group per parameter in module order (solver/build.py:100-137), the order of `param_groups` here, so buffer i
+        belongs to parameter i of that order"""
+        if "momentum" in sd:
+            self.flat_mom.copy_(sd["momentum"])
+            self._first = sd["first"]
+            return
+        if "state" not in sd or "param_groups" not in sd:
+            raise KeyError("optimizer state: neither FlatSGD's {'momentum', 'first'} nor a torch.optim.SGD state dict")
+        order = [i for g in sd["param_groups"] for i in g["params"]]
+        if len(order) != len(self.params):
+            raise ValueError(f"optimizer state holds {len(order)} parameters, the model has {len(self.params)} trainable ones")
+        # self.params is the reversed module order
+        loaded = 0
+        for k, idx in enumerate(order):
+            st = sd["state"].get(idx, {})
+            buf = st.get("momentum_buffer")
+            off, n = self.offsets[len(order) - 1 - k]
+            if buf is None:
+                self.flat_mom[off:off + n].zero_()
+                continue
+            if buf.numel() != n:
+                raise ValueError(f"momentum buffer {idx}: {buf.numel()} elements, parameter has {n}")
+            self.flat_mom[off:off + n].copy_(buf.reshape(-1).to(self.flat_mom.device, torch.float32))
+            loaded += 1
+        self._first = loaded == 0
 
 
 def build_optimizer(cfg, model):
+    """solver/build.py:93-137.  Options of the reference's builder that this optimizer does not implement are refused
+    instead of being silently dropped."""
+    if cfg.SOLVER.get("NESTEROV", False):
+        raise NotImplementedError("SOLVER.NESTEROV: the fused SGD kernel implements plain momentum")
+    clip = cfg.SOLVER.get("CLIP_GRADIENTS", None)
+    if clip is not None and clip.get("ENABLED", False):
+        raise NotImplementedError("SOLVER.CLIP_GRADIENTS: gradient clipping is not implemented")
     return FlatSGD(param_groups(cfg, model), cfg.SOLVER.BASE_LR, cfg.SOLVER.MOMENTUM)

@@ -243,3 +243,41 @@ def test_coco_json_handoff():
     empty.pred_boxes, empty.scores, empty.pred_classes = Boxes(torch.zeros(0, 4)), torch.zeros(0), torch.zeros(0, dtype=torch.long)
     flat = results_to_coco_json([{"instances": inst}, {"instances": empty}], [42, 43], {1: 0, 7: 1, 9: 2, 17: 3})
     assert [r["category_id"] for r in flat] == [17, 1] and all(r["image_id"] == 42 for r in flat)
+
+
+def test_flat_sgd_accepts_torch_sgd_state_and_refuses_unimplemented_options():
+    """a reference checkpoint's "optimizer" entry is a torch.optim.SGD state dict with one group per parameter in module
+    order (solver/build.py:100-137): its momentum buffers land in the flat momentum buffer; NESTEROV / CLIP_GRADIENTS
+    are refused instead of silently ignored"""
+    import torch
+    from detectron2_centernet_amd.config import get_cfg
+    from detectron2_centernet_amd.solver.build import FlatSGD, build_optimizer, param_groups
+
+    cfg = get_cfg()
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 2, 1))
+    groups = param_groups(cfg, net)
+    ref = torch.optim.SGD([{"params": [p], "lr": 0.1 * lf, "weight_decay": wd} for p, lf, wd in groups], lr=0.1, momentum=0.9)
+    for p, _, _ in groups:
+        p.grad = torch.randn_like(p)
+    ref.step()
+    want = [ref.state[p]["momentum_buffer"].clone() for p, _, _ in groups]
+    opt = FlatSGD(groups, 0.1, 0.9)
+    opt.load_state_dict(ref.state_dict())
+    assert opt._first is False
+    for p, buf in zip([g[0] for g in groups], want):
+        i = [id(q) for q in opt.params].index(id(p))
+        off, n = opt.offsets[i]
+        assert torch.equal(opt.flat_mom[off:off + n], buf.reshape(-1))
+    own = opt.state_dict()
+    opt2 = FlatSGD(param_groups(cfg, net), 0.1, 0.9)
+    opt2.load_state_dict(own)
+    assert torch.equal(opt2.flat_mom, opt.flat_mom)
+    with pytest.raises(KeyError):
+        opt.load_state_dict({"foo": 1})
+    cfg.SOLVER.NESTEROV = True
+    with pytest.raises(NotImplementedError):
+        build_optimizer(cfg, net)
+    cfg.SOLVER.NESTEROV = False
+    cfg.SOLVER.CLIP_GRADIENTS.ENABLED = True
+    with pytest.raises(NotImplementedError):
+        build_optimizer(cfg, net)
