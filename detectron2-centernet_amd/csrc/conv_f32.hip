@@ -727,7 +727,7 @@ int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s) {
       switch (bc) {
         case 16: return launch_f32_dcn<128, 16, 4, 1>(a, s);
         case 32: return launch_f32_dcn<128, 32, 4, 1>(a, s);
-        case 64: return launch_f32_dcn<128, 64, 2, 2>(a, s);
+        case 64: return launch_f32_dcn<64, 64, 2, 2>(a, s);
         case 128: return launch_f32_dcn<128, 128, 2, 2>(a, s);
       }
     }

@@ -24,13 +24,17 @@ ap.add_argument("--off-std", type=float, default=1.0)
 ap.add_argument("--f32out", action="store_true")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--tap-major", action="store_true")
+ap.add_argument("--f32", action="store_true", help="the f32 (reference precision) kernels")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 x = torch.randn(a.B, a.H, a.W, a.cin, generator=g).half().to(dev)
+if a.f32:
+    x = x.float()
 w = (torch.randn(a.cout, a.cin, a.k, a.k, generator=g) / (a.cin * a.k * a.k) ** 0.5).to(dev)
-p = ops.PackedConv(w, None, None, stride=a.stride, pad=a.k // 2, compute=ops.F16, tap_major=a.tap_major and not a.dcn)
-od = torch.float32 if a.f32out else torch.float16
+p = ops.PackedConv(w, None, None, stride=a.stride, pad=a.k // 2, compute=ops.F32 if a.f32 else ops.F16,
+                   tap_major=a.tap_major and not a.dcn)
+od = torch.float32 if (a.f32out or a.f32) else torch.float16
 if a.dcn:
     om = torch.randn(a.B, a.H, a.W, 28, generator=g)
     om[..., :18] *= a.off_std
