@@ -116,6 +116,7 @@ enum {
   CTDET_TUNE_DCN_MIXED = 4,          // DCNv2 window kernel: per-lane instead of per-wave out-of-window gathers
   CTDET_TUNE_NO_WGRAD_WINDOW = 8,    // weight-gradient window kernel -> generic kernel
   CTDET_TUNE_NO_COL2IM_WINDOW = 16,  // DCNv2 backward LDS-window scatter -> global-atomic kernel
+  CTDET_TUNE_NO_F32_DCN_WINDOW = 32, // f32 DCNv2 LDS-window kernel -> global-gather kernel
 };
 unsigned ctdet_tuning_flags();
 // number of CUs of the CURRENT device (cached per device ordinal, not per process)

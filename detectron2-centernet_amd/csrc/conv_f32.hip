@@ -484,6 +484,244 @@ __global__ void __launch_bounds__(256, 2) dcn_f32_mfma_kernel(const ConvArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------
+// DCNv2 3x3 / stride 1 / pad 1 in f32 from an LDS window (maps divisible by 8x16, Cin % 16 == 0): the gather form above
+// pulls four 64-byte corner pieces per (pixel, tap, 16 channels) through L2 -- 9.7 GB for one 64->64 @128^2 layer at batch
+// 64, 9 TB/s, twice the time of its MFMAs.  Here (the f16 dcn_window_kernel's structure in f32) a workgroup owns an 8x16
+// tile; per 16-channel chunk the 18x26 window (+-4 px margin for the learned offsets; 64 bytes per pixel, the same image as
+// the f16 kernel's 32-channel chunk) is brought into LDS ONCE and all nine taps sample it: lane (pixel, 4-channel group)
+// reads its 4 corners with ds_read_b128, blends in f32 in the reference's operation order
+// (val = w1 v1 + w2 v2 + w3 v3 + w4 v4; val * mask, kernel.cu:697, :862) and the four results ARE its B operands of the next
+// four 16x16x4 MFMAs -- the sampled tile never goes through LDS.  Geometry ({lh, lw, mask, window offset}) once per
+// (pixel, tap), staged in LDS.  Samples outside the window are gathered from global memory by the lanes concerned.
+// Weights stay tap-major in memory (k = tap*Cin + c): the K loop runs chunk-major and fetches the 64-byte piece it needs.
+// ------------------------------------------------------------------------------------------
+template <int BC>
+__global__ void __launch_bounds__(256, 2) dcn_f32_window_kernel(const ConvArgs a) {
+  constexpr int TH = 8, TW = 16, BP = 128, MG = 4;
+  constexpr int WR = TH + 2 + 2 * MG, WCOLS = TW + 2 + 2 * MG;  // 18 x 26 window pixels
+  constexpr int NPIECE = WR * WCOLS * 4;                        // 1872 16-byte pieces
+  constexpr int W_LD = (NPIECE + 255) / 256;                    // 8 DMA rounds; the last one only on waves 0-1
+  constexpr int WINB = ((NPIECE + 63) / 64) * 1024;             // 30720
+  constexpr int GEOB = 9 * BP * 16, GEOC = 9 * BP * 4;          // {lh, lw, mask, code} and the image coordinates of far samples
+  constexpr int TP = 2, TC = BC / 16;                           // wave = 32 pixels (2 tile rows) x all BC couts
+  constexpr int B_LD = BC / 64, WST = BC * 64, NST = 2, STG = 3 * WST;   // a stage = the three taps of a kernel row
+  static_assert(BC % 64 == 0 && WINB + GEOB + GEOC + NST * STG <= 81920, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) char smem[WINB + GEOB + GEOC + NST * STG];
+  char* const win = smem;
+  char* const geo = smem + WINB;
+  char* const geoc = smem + WINB + GEOB;
+  char* const ring = smem + WINB + GEOB + GEOC;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  int m_tile, n_tile;
+  if (!tile_of_block(a.B * tiles_y * tiles_x, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int tx0 = (m_tile % tiles_x) * TW;
+  const int ty0 = ((m_tile / tiles_x) % tiles_y) * TH;
+  const int b = m_tile / (tiles_x * tiles_y);
+  const int n0 = n_tile * BC;
+  const float* zero = (const float*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+  const float* ximg = (const float*)a.x + (long)b * a.H * a.W * a.in_stride;
+  const int wy0 = ty0 - 1 - MG, wx0 = tx0 - 1 - MG;  // image coordinates of window pixel (0,0)
+  const int nch = a.Cin / 16, nk = nch * 9;
+
+  // ---- loaders
+  const int lrow = tid >> 2, slotw = tid & 3;
+  const int gwk = slotw ^ swz(lrow);
+  const float* wptr[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int L = lrow + 64 * j;
+    const int tt = L >> 4, r = L & 15;
+    wptr[j] = (const float*)a.w + (long)(n0 + cout_of<TC>(tt, r >> 2, r & 3)) * a.Kpad + gwk * 4;
+  }
+  auto issue_w = [&](int chunk, int tr, int st) {      // step (chunk, kernel row tr): 3 taps x 16 channels of every cout
+#pragma unroll
+    for (int ts = 0; ts < 3; ++ts)
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j)
+        dma16(wptr[j] + (tr * 3 + ts) * a.Cin + chunk * 16, ring + st * STG + ts * WST + wave * 1024 + j * 4096);
+  };
+  int wofs[W_LD];
+#pragma unroll
+  for (int i = 0; i < W_LD; ++i) {
+    const int pid = tid + 256 * i;
+    const int pw = pid >> 2, sl = pid & 3;
+    const int wr = pw / WCOLS, wcn = pw - wr * WCOLS;
+    const int y = wy0 + wr, x = wx0 + wcn;
+    const bool ok = pid < NPIECE && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    // slot sl of a pixel in an odd window row holds channel group sl^2 (conflict-free corner reads over two rows)
+    wofs[i] = ok ? (y * a.W + x) * a.in_stride + (sl ^ (2 * (wr & 1))) * 4 : -1;
+  }
+  auto issue_window = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < W_LD; ++i) {
+      if (i < W_LD - 1 || (wave * 64 + 256 * i) * 16 < WINB)  // wave-uniform: the last round ends with the window
+        dma16(wofs[i] >= 0 ? ximg + wofs[i] + chunk * 16 : zero, win + (wave * 64 + 256 * i) * 16);
+    }
+  };
+  issue_window(0);
+  issue_w(0, 0, 0);
+
+  // ---- sampling geometry, once per (pixel, tap): thread = pixel gp, taps gh, gh+2, ...
+  {
+    const int gp = tid & 127, gh = tid >> 7;
+    const int py = ty0 + (gp >> 4), pxx = tx0 + (gp & 15);
+    const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int t = 2 * i + gh;
+      if (t < 9) {
+        const int tr = t / 3, ts = t - 3 * tr;
+        const float h_im = (float)(py - 1 + tr) + omrow[2 * t], w_im = (float)(pxx - 1 + ts) + omrow[2 * t + 1];
+        const float mraw = omrow[18 + t];
+        const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W;     // kernel.cu:852
+        const float mk = valid ? (a.mask_is_prob ? mraw : ctdet_sigmoid_exact(mraw)) : 0.f;           // invalid: contributes 0
+        const float fh = floorf(h_im), fw = floorf(w_im);
+        const int h_low = (int)fh, w_low = (int)fw;
+        const int wr = h_low - wy0, wcn = w_low - wx0;  // window coordinates of corner (h_low, w_low)
+        // every in-image corner of a valid sample inside the window => the out-of-image ones are too (1 px outside the
+        // image, where the window is zero-filled): the window read then IS the guarded read of kernel.cu:683-693
+        const bool inside = wr >= 0 && wr + 1 < WR && wcn >= 0 && wcn + 1 < WCOLS;
+        const bool oow = valid && !inside;
+        const unsigned code = (valid && inside) ? ((unsigned)((wr * WCOLS + wcn) * 64) | ((unsigned)(wr & 1) << 16)) : (oow ? 0x80000000u : 0u);
+        f32x4 gv;
+        gv[0] = valid ? h_im - fh : 0.f; gv[1] = valid ? w_im - fw : 0.f; gv[2] = mk; gv[3] = __uint_as_float(code);
+        *(f32x4*)(geo + (t * BP + gp) * 16) = gv;
+        *(unsigned*)(geoc + (t * BP + gp) * 4) = oow ? (((unsigned)(h_low + 1) << 12) | (unsigned)(w_low + 1)) : 0u;
+      }
+    }
+  }
+  wait_vmcnt<0>();
+  __syncthreads();
+  // ---- consumer mapping: lane (fr, q) samples tile pixel (row 2*wave + fr/8, col 8p + fr%8), channels 4q..4q+3 of the chunk
+  const int fr = lane & 15, q = lane >> 4;
+  const int prow = 2 * wave + (fr >> 3), pcol = fr & 7;
+
+  // sampled * mask for tap t of the current chunk, both pixel tiles of this lane
+  auto sample = [&](int t, int chunk, f32x4 (&pf)[TP]) {
+    f32x4 g[TP];
+    unsigned far = 0;
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      g[p] = *(const f32x4*)(geo + (t * BP + prow * 16 + 8 * p + pcol) * 16);
+      far |= __float_as_uint(g[p][3]) >> 31;
+    }
+    const bool any_far = __builtin_amdgcn_ballot_w64(far != 0) != 0;      // wave-uniform
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const unsigned code = __float_as_uint(g[p][3]);
+      const unsigned ofs = (code & 0xFFFFu) + ((q ^ (2 * ((code >> 16) & 1u))) << 4);
+      const char* c0p = win + ofs;
+      const char* c2p = win + (ofs ^ 32u) + WCOLS * 64;       // next window row: the other slot swizzle
+      f32x4 v1 = *(const f32x4*)(c0p), v2 = *(const f32x4*)(c0p + 64);
+      f32x4 v3 = *(const f32x4*)(c2p), v4 = *(const f32x4*)(c2p + 64);
+      if (any_far) {
+        const bool out = code >> 31;
+        const unsigned cc = *(const unsigned*)(geoc + (t * BP + prow * 16 + 8 * p + pcol) * 4);
+        const int h_low = (int)((cc >> 12) & 0xFFFFFu) - 1, w_low = (int)(cc & 0xFFFu) - 1;
+        const bool r0 = out && h_low >= 0, r1 = out && h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
+        const long o0 = ((long)h_low * a.W + w_low) * a.in_stride, o2 = o0 + (long)a.W * a.in_stride;
+        const float* base = ximg + chunk * 16 + q * 4;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 g1 = (r0 && c0) ? *(const f32x4*)(base + o0) : z;
+        const f32x4 g2 = (r0 && c1) ? *(const f32x4*)(base + o0 + a.in_stride) : z;
+        const f32x4 g3 = (r1 && c0) ? *(const f32x4*)(base + o2) : z;
+        const f32x4 g4 = (r1 && c1) ? *(const f32x4*)(base + o2 + a.in_stride) : z;
+        if (out) { v1 = g1; v2 = g2; v3 = g3; v4 = g4; }
+      }
+      const float lh = g[p][0], lw = g[p][1], mk = g[p][2];
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float val = w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+        pf[p][e] = val * mk;
+      }
+    }
+  };
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const char* fragB = ring + fr * 64 + ((q ^ swz(fr)) << 4);
+
+  // One barrier per kernel row (96 MFMAs per wave): its three weight taps are one ring stage, fetched a row ahead.  Inside
+  // the row the operands of tap t+1 (weight fragments, sampled pixels) are read into registers during the MFMAs of tap t.
+  auto frags = [&](int st, int ts, f32x4 (&wf)[TC]) {
+#pragma unroll
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f32x4*)(fragB + st * STG + ts * WST + c * 1024);
+  };
+  f32x4 pf[TP], wf[TC];
+  sample(0, 0, pf);
+  const int ns = nch * 3;
+
+  auto tap = [&](int s, int chunk, auto tc) {
+    constexpr int T = decltype(tc)::value, TS = T % 3;
+    const int st = s & 1;
+    if (TS == 0) {
+      wait_vmcnt<0>();                                             // this row's weights (issued a row ago)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + 1 < ns) issue_w(T == 6 ? chunk + 1 : chunk, T == 6 ? 0 : T / 3 + 1, st ^ 1);
+      frags(st, 0, wf);
+    }
+    f32x4 wfn[TC], pfn[TP];
+    if (TS < 2) frags(st, TS + 1, wfn);
+    if (T < 8) {
+      sample(T + 1, chunk, pfn);
+    } else if (chunk + 1 < nch) {                                  // tap 8 was sampled during tap 7: the window is free
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_window(chunk + 1);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int p = 0; p < TP; ++p)
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], pf[p][e], acc[p][c], 0, 0, 0);
+    if (T == 8 && chunk + 1 < nch) {
+      wait_vmcnt<0>();                                             // next chunk's window, behind this tap's MFMAs
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      sample(0, chunk + 1, pfn);
+    }
+#pragma unroll
+    for (int p = 0; p < TP; ++p) pf[p] = pfn[p];
+    if (TS < 2) {
+#pragma unroll
+      for (int c = 0; c < TC; ++c) wf[c] = wfn[c];
+    }
+  };
+  for (int chunk = 0; chunk < nch; ++chunk) {
+    const int s = chunk * 3;
+    tap(s, chunk, std::integral_constant<int, 0>{});
+    tap(s, chunk, std::integral_constant<int, 1>{});
+    tap(s, chunk, std::integral_constant<int, 2>{});
+    tap(s + 1, chunk, std::integral_constant<int, 3>{});
+    tap(s + 1, chunk, std::integral_constant<int, 4>{});
+    tap(s + 1, chunk, std::integral_constant<int, 5>{});
+    tap(s + 2, chunk, std::integral_constant<int, 6>{});
+    tap(s + 2, chunk, std::integral_constant<int, 7>{});
+    tap(s + 2, chunk, std::integral_constant<int, 8>{});
+  }
+
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int m = (b * a.H + ty0 + prow) * a.W + tx0 + 8 * p + pcol;
+    epilogue_tiles<float, TC>(a, m, n0, q, acc[p]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // LDS-window form for the narrow layers of the DLA base in f32 (7x7 stem on the 8-channel padded image, level0 3x3
 // 16->16, level1 3x3 16->32 stride 2): with 8 or 16 input channels the im2col-on-the-fly kernels above fetch every
 // input pixel R*S times through L2 (26 GB for the stem at batch 64: 8.2 ms for 79 GFLOP).  Here a workgroup owns a
@@ -723,6 +961,15 @@ int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s) {
   }
   if (vec) {
     const bool big = ((long)a.M + 255) / 256 * (a.Cout_pad / bc) >= 512;
+    if (deform && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.H % 8 == 0 && a.W % 16 == 0 &&
+        a.H <= 4094 && a.W <= 4094 && a.Kpad == a.K && a.Cout_pad % 64 == 0 && !(ctdet_tuning_flags() & CTDET_TUNE_NO_F32_DCN_WINDOW)) {
+      // 64 couts per workgroup (128 would spill under two workgroups per CU); wider layers sample the window once per cout tile
+      const int nbx = a.B * (a.H / 8) * (a.W / 16);
+      dim3 grid(8 * ((nbx + 7) / 8) * (a.Cout_pad / 64));
+      hipLaunchKernelGGL((dcn_f32_window_kernel<64>), grid, dim3(256), 0, s, a);
+      CTDET_LAUNCH_CHECK();
+      return 0;
+    }
     if (deform) {   // 128-pixel tiles: two or more workgroups per CU cover each other's gather latency
       switch (bc) {
         case 16: return launch_f32_dcn<128, 16, 4, 1>(a, s);

@@ -30,7 +30,11 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
     if p.compute != F16:
         big = ((M + 255) // 256) * (p.Cout_pad // bc) >= 512
         if deform:
-            return f"dcn_f32_mfma_kernel<128x{bc}>"
+            H, W = (x_shape[1], x_shape[2]) if x_shape is not None else (0, 0)
+            win = (p.R == 3 and p.stride == 1 and p.pad == 1 and p.dil == 1 and H and H % 8 == 0 and W % 16 == 0 and
+                   p.Kpad == p.K and p.Cout_pad % 64 == 0 and p.Cin % 16 == 0 and
+                   not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_F32_DCN_WINDOW))
+            return f"dcn_f32_window_kernel<8x16,{p.Cout_pad}>" if win else f"dcn_f32_mfma_kernel<128x{bc}>"
         bp = 256 if (big or bc == 16) else 128
         H, W = (x_shape[1], x_shape[2]) if x_shape is not None else (0, 0)
         if p.Cin in (8, 16) and p.R == p.S and p.dil == 1 and nsrc <= 1 and H:

@@ -156,3 +156,36 @@ def test_conv_f32_window_kernel(ops, dev, case):
     got = nchw(y[..., :Cout].cpu())
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(1, 8, 16, 16, 64, 0.0), (2, 16, 32, 32, 64, 0.7), (1, 24, 48, 64, 128, 2.0), (2, 8, 32, 16, 40, 5.0),
+                                  (1, 16, 16, 128, 132, 30.0), (3, 40, 48, 64, 64, 3.0)])
+def test_dcnv2_f32_window_kernel(ops, dev, case):
+    """dcn_f32_window_kernel (8x16 tiles sampling an 18x26 LDS window; far samples from global memory) vs the oracle, and
+    bit-for-bit against nothing less: the gather kernel (TUNE_NO_F32_DCN_WINDOW) must agree with it to f32 rounding"""
+    from detectron2_centernet_amd import _lib
+
+    B, H, W, Cin, Cout, off_std = case
+    g = torch.Generator().manual_seed(int(sum(case[:5])))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    om = torch.randn(B, 27, H, W, generator=g)
+    om[:, :18] *= off_std
+    om[:, 0, 0, 0], om[:, 1, 0, 0], om[:, 2, -1, -1], om[:, 3, 1, 1] = -0.0, -1.0, 1.0, 0.5
+    om[:, 4, 2, 2], om[:, 5, 2, 2] = -4.0, 4.0        # exactly the window margin
+    om[:, 6, 3, 3], om[:, 7, 3, 3] = -5.25, 5.5       # just beyond it
+    om[:, 8, 0, 5], om[:, 9, 0, 5] = -float(H), float(W) + 3   # outside the image: contributes 0
+    bias = torch.randn(Cout, generator=g)
+    ref = O.dcnv2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, bias, 1, 1, 1).relu()
+    pc = ops.PackedConv(w.to(dev), None, bias.to(dev), stride=1, pad=1, compute=ops.F32)
+    om_d = torch.zeros(B, H, W, 28)
+    om_d[..., :27] = nhwc(om)
+    xd, omd = nhwc(x).to(dev), om_d.to(dev)
+    y = ops.dcnv2(xd, omd, pc, act=ops.ACT_RELU)
+    with _lib.tuning(_lib.TUNE_NO_F32_DCN_WINDOW):
+        y_gather = ops.dcnv2(xd, omd, pc, act=ops.ACT_RELU)
+    scale = max(1.0, ref.abs().max().item())
+    err = (nchw(y[..., :Cout].cpu()) - ref).abs().max().item()
+    assert err <= 2e-5 * scale, f"{case}: window kernel vs oracle {err}"
+    assert (y - y_gather).abs().max().item() <= 2e-5 * scale
+    assert y[..., Cout:].abs().max().item() == 0 if y.shape[-1] > Cout else True

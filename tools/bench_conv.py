@@ -25,8 +25,12 @@ ap.add_argument("--f32out", action="store_true")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--tap-major", action="store_true")
 ap.add_argument("--f32", action="store_true", help="the f32 (reference precision) kernels")
+ap.add_argument("--tune", type=int, default=0, help="ctdet_set_tuning_flags bits (see _lib.TUNE_*)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
+if a.tune:
+    from detectron2_centernet_amd import _lib
+    _lib.lib().ctdet_set_tuning_flags(a.tune)
 g = torch.Generator().manual_seed(0)
 x = torch.randn(a.B, a.H, a.W, a.cin, generator=g).half().to(dev)
 if a.f32:
