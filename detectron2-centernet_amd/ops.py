@@ -354,7 +354,7 @@ def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_pro
     out = _alloc_out(x, p, out, out_dtype)
     assert tuple(offset_mask.shape[:3]) == tuple(out.shape[:3])
     d = p.desc(x, out, act, None)
-    prof = _Prof(p, d.B * d.Ho * d.Wo, True, d.out_dtype)
+    prof = _Prof(p, d.B * d.Ho * d.Wo, True, d.out_dtype, x.shape)
     for _ in range(prof.reps()):
         rc = _lib.lib().ctdet_dcnv2_fwd(C.byref(d), _ptr(x), _ptr(offset_mask), _nhwc_stride(offset_mask),
                                         int(mask_is_prob), _ptr(p.w), _ptr(p.scale), _ptr(p.bias), _ptr(out), _stream())
