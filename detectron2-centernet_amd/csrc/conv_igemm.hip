@@ -1156,11 +1156,306 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same tile / window / operand mapping with the per-tile instruction count cut (the kernel above is issue-bound:
+// ~3.6 k instructions per wave for the 64->64 layers, of which 576 blend + 144 MFMA + 216 LDS reads are the work).
+// For 64-cout layers on tile-divisible maps:
+//   * window rows padded to 32 pixels: a DMA round is two window rows (thread = row parity, column, slot), so the piece
+//     offsets and the sample -> window address are shifts instead of divisions by 26;
+//   * geometry as ONE 16-byte LDS record per (tap, pixel) {f16 w0|w1, w2|w3 (already * mask), window byte offset with the
+//     row-parity swizzle folded in, image coordinates for far samples}, read when the tap is sampled (one ds_read_b128
+//     broadcast to the pixel's four lanes) instead of being unpacked into 54 VGPRs up front;
+//   * out-of-image corners are not tested: a valid in-window sample reads them from the zero-filled window border;
+//   * the "some lane samples outside the window" flags come from the staging pass (one ballot per tap);
+//   * one barrier per kernel ROW: its three weight taps are one ring stage (two stages, fetched a row ahead), operands of
+//     tap t+1 are read during the MFMAs of tap t.
+// ------------------------------------------------------------------------------------------
+template <typename TOut>
+__global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs a) {
+  constexpr int BC = 64, TH = 8, TW = 16, BP = 128, MG = 4, TP = 2, TC = 4;
+  constexpr int WR = TH + 2 + 2 * MG, WCU = TW + 2 + 2 * MG, WCP = 32;   // 18 rows x 26 used of 32 columns
+  constexpr int WINB = WR * WCP * 64;                                    // 36864
+  constexpr int ROWB = WCP * 64;                                         // 2048 bytes per window row
+  constexpr int W_LD = WR / 2;                                           // 9 DMA rounds of two rows
+  constexpr int GEOB = 9 * BP * 16;                                      // 18432
+  constexpr int WST = BC * 64, STG = 3 * WST, NST = 2;                   // a stage = the three taps of a kernel row
+  constexpr int SBB = 2 * BC * 4, FLG = 4 * 2 * 4;
+  static_assert(WINB + GEOB + NST * STG + SBB + FLG <= 81920, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) char smem[WINB + GEOB + NST * STG + SBB + FLG];
+  char* const win = smem;
+  char* const geo = smem + WINB;
+  char* const ring = smem + WINB + GEOB;
+  float* const sbuf = (float*)(smem + WINB + GEOB + NST * STG);
+  unsigned* const slowf = (unsigned*)(smem + WINB + GEOB + NST * STG + SBB);   // [consumer wave][tap parity]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  int m_tile, n_tile;
+  if (!tile_of_block(a.B * tiles_y * tiles_x, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int tx0 = (m_tile % tiles_x) * TW;
+  const int ty0 = ((m_tile / tiles_x) % tiles_y) * TH;
+  const int b = m_tile / (tiles_x * tiles_y);
+  const int n0 = n_tile * BC;
+  const f16* zero = (const f16*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+  const f16* ximg = (const f16*)a.x + (long)b * a.H * a.W * a.in_stride;
+  const int wy0 = ty0 - 1 - MG, wx0 = tx0 - 1 - MG;  // image coordinates of window pixel (0,0)
+  const int nch = a.Cin / 32, ns = nch * 3;
+
+  // ---- loaders ----
+  const int lrow = tid >> 2, slotw = tid & 3;
+  const int tt = lrow >> 4, r16 = lrow & 15;
+  const f16* wptr = (const f16*)a.w + (long)(n0 + cout_of<TC>(tt, r16 >> 2, r16 & 3)) * a.Kpad + (slotw ^ swz(lrow)) * 8;
+  auto issue_w = [&](int s, int st) {            // row-step s = chunk*3 + kernel row: taps 3s..3s+2 of the chunk-major K order
+#pragma unroll
+    for (int ts = 0; ts < 3; ++ts) dma16(wptr + (s * 3 + ts) * 32, ring + st * STG + ts * WST + wave * 1024);
+  };
+  // DMA round i fetches window rows 2i and 2i+1: thread = (row parity, column, 16-byte slot).  Slot sl of an odd row holds
+  // channel group sl^2 (the 16 lanes of a ds_read_b128 phase then touch 16 different bank groups).
+  const int wrs = tid >> 7, wcol = (tid >> 2) & 31, wsl = tid & 3;
+  const int wx = wx0 + wcol;
+  const bool wxok = wcol < WCU && wx >= 0 && wx < a.W;
+  const int wrow_stride = 2 * a.W * a.in_stride;
+  const int wbase = ((wy0 + wrs) * a.W + wx) * a.in_stride + (wsl ^ (2 * wrs)) * 8;
+  auto issue_window = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < W_LD; ++i) {
+      const bool ok = wxok && (unsigned)(wy0 + wrs + 2 * i) < (unsigned)a.H;
+      dma16(ok ? ximg + wbase + i * wrow_stride + chunk * 32 : zero, win + (2 * i) * ROWB + wave * 1024);
+    }
+  };
+  issue_window(0);
+  issue_w(0, 0);
+
+  if (tid < BC) {
+    const int c = n0 + tid;
+    sbuf[tid] = (a.scale && c < a.Cout) ? a.scale[c] : 1.f;
+    sbuf[BC + tid] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
+  }
+  // ---- sampling geometry, once per (pixel, tap): thread = pixel gp, taps gh, gh+2, ... ----
+  {
+    const int gp = tid & 127, gh = tid >> 7;
+    const int py = ty0 + (gp >> 4), pxx = tx0 + (gp & 15);
+    const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
+    float oh[5], ow[5], om_[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int t = 2 * i + gh;
+      const bool on = t < 9;
+      oh[i] = on ? omrow[2 * t] : 0.f; ow[i] = on ? omrow[2 * t + 1] : 0.f; om_[i] = on ? omrow[18 + t] : 0.f;
+    }
+    unsigned far_lo = 0, far_hi = 0;     // taps with a far sample among lanes 0-31 / 32-63 (= consumer waves 2*(w&1), +1)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int t = 2 * i + gh;
+      if (t < 9) {
+        const int tr = t / 3, ts = t - 3 * tr;
+        const float h_im = (float)(py - 1 + tr) + oh[i], w_im = (float)(pxx - 1 + ts) + ow[i];
+        const float mk = a.mask_is_prob ? om_[i] : __builtin_amdgcn_rcpf(1.f + __expf(-om_[i]));
+        const float fh = floorf(h_im), fw = floorf(w_im);
+        const int h_low = (int)fh, w_low = (int)fw;
+        const float lh = h_im - fh, lw = w_im - fw, hh = 1.f - lh, hw = 1.f - lw;
+        const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W;
+        const float mv = valid ? mk : 0.f;
+        const float w0 = hh * hw * mv, w1 = hh * lw * mv, w2 = lh * hw * mv, w3 = lh * lw * mv;
+        const int wr = h_low - wy0, wcn = w_low - wx0;  // window coordinates of corner 0
+        // every in-image corner inside the window => the out-of-image ones are too (1 px outside the image, where the
+        // window is zero-filled): the window read is the guarded read of deform_conv_cuda_kernel.cu:683-693
+        const bool inside = (unsigned)wr < (unsigned)(WR - 1) && (unsigned)wcn < (unsigned)(WCU - 1);
+        const bool oow = valid && !inside;
+        const unsigned off = (valid && inside) ? (unsigned)(wr * ROWB + wcn * 64) | ((unsigned)(wr & 1) << 5) : 0u;
+        const f16 h0 = (f16)w0, h1 = (f16)w1, h2 = (f16)w2, h3 = (f16)w3;
+        u32x4 rec;
+        rec.x = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+        rec.y = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
+        rec.z = off | (oow ? 0x80000000u : 0u);
+        rec.w = ((unsigned)(h_low + 1) << 16) | (unsigned)((w_low + 1) & 0xFFFF);   // far samples: h_low, w_low >= -1
+        *(u32x4*)(geo + (t * BP + gp) * 16) = rec;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(oow);
+        far_lo |= ((unsigned)bal != 0u ? 1u : 0u) << t;
+        far_hi |= ((unsigned)(bal >> 32) != 0u ? 1u : 0u) << t;
+      }
+    }
+    if (lane == 0) {
+      const int cw = 2 * (wave & 1);
+      slowf[cw * 2 + gh] = far_lo;
+      slowf[(cw + 1) * 2 + gh] = far_hi;
+    }
+  }
+  wait_vmcnt<0>();
+  __syncthreads();
+  // ---- consumer mapping: lane (fr, q) blends tile pixel (row 2*wave + fr/8, col 8p + fr%8), channels 8q..8q+7 of the chunk
+  const int fr = lane & 15, q = lane >> 4;
+  const int prow = 2 * wave + (fr >> 3), pcol = fr & 7;
+  const unsigned slow_taps = __builtin_amdgcn_readfirstlane(slowf[wave * 2] | slowf[wave * 2 + 1]);
+  const unsigned q4 = (unsigned)q << 4;
+  const char* georow = geo + (prow * 16 + pcol) * 16;
+  typedef const u32x4 __attribute__((address_space(1)))* gp16;
+
+  // corner fragments of tap t for both pixel tiles (+ the weights): raw[p][0..3], wts[p] = {w01, w23}
+  auto gather = [&](int t, int chunk, u32x4 (&raw)[TP][4], unsigned (&wts)[TP][2]) {
+    u32x4 g[TP];
+#pragma unroll
+    for (int p = 0; p < TP; ++p) g[p] = *(const u32x4*)(georow + (t * BP + 8 * p) * 16);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const unsigned A = (g[p].z & 0xFFFFu) ^ q4;
+      const char* c0p = win + A;
+      const char* c2p = win + (A ^ 32u);                  // next window row: the other slot swizzle
+      raw[p][0] = *(const u32x4*)(c0p);
+      raw[p][1] = *(const u32x4*)(c0p + 64);
+      raw[p][2] = *(const u32x4*)(c2p + ROWB);
+      raw[p][3] = *(const u32x4*)(c2p + ROWB + 64);
+      wts[p][0] = g[p].x; wts[p][1] = g[p].y;
+    }
+    if ((slow_taps >> t) & 1u) {                          // wave-uniform: the lanes concerned read global memory instead
+#pragma unroll
+      for (int p = 0; p < TP; ++p) {
+        const bool out = g[p].z >> 31;
+        const int h_low = (int)(g[p].w >> 16) - 1, w_low = (int)(g[p].w & 0xFFFFu) - 1;
+        const bool r0 = out && h_low >= 0, r1 = out && h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
+        const int o0 = (h_low * a.W + w_low) * a.in_stride, o2 = o0 + a.W * a.in_stride;
+        const f16* base = ximg + chunk * 32 + q * 8;
+        const u32x4 g0 = *(gp16)((r0 && c0) ? base + o0 : zero);
+        const u32x4 g1 = *(gp16)((r0 && c1) ? base + o0 + a.in_stride : zero);
+        const u32x4 g2 = *(gp16)((r1 && c0) ? base + o2 : zero);
+        const u32x4 g3 = *(gp16)((r1 && c1) ? base + o2 + a.in_stride : zero);
+        if (out) { raw[p][0] = g0; raw[p][1] = g1; raw[p][2] = g2; raw[p][3] = g3; }
+      }
+    }
+  };
+  auto blend = [&](const u32x4 (&raw)[TP][4], const unsigned (&wts)[TP][2], f16x8 (&pf)[TP]) {
+#pragma unroll
+    for (int p = 0; p < TP; ++p)
+      pf[p] = __builtin_bit_cast(f16x8, dcn_blend(raw[p][0], raw[p][1], raw[p][2], raw[p][3], wts[p][0], wts[p][1]));
+  };
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const char* fragB = ring + fr * 64 + ((q ^ swz(fr)) << 4);
+  auto frags = [&](int st, int ts, f16x8 (&wf)[TC]) {
+#pragma unroll
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(fragB + st * STG + ts * WST + c * 1024);
+  };
+
+  f16x8 pf[TP], wf[TC];
+  {
+    u32x4 raw[TP][4];
+    unsigned wts[TP][2];
+    gather(0, 0, raw, wts);
+    blend(raw, wts, pf);
+  }
+  auto tap = [&](int s, int chunk, auto tc) {
+    constexpr int T = decltype(tc)::value, TS = T % 3;
+    const int st = s & 1;
+    if (TS == 0) {
+      wait_vmcnt<0>();                                   // this row's weights (issued a row ago)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + 1 < ns) issue_w(s + 1, st ^ 1);
+      frags(st, 0, wf);
+    }
+    f16x8 wfn[TC], pfn[TP];
+    u32x4 raw[TP][4];
+    unsigned wts[TP][2];
+    if (TS < 2) frags(st, TS + 1, wfn);
+    if (T < 8) {
+      gather(T + 1, chunk, raw, wts);
+    } else if (chunk + 1 < nch) {                        // tap 8 was sampled during tap 7: the window is free
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_window(chunk + 1);
+    }
+#pragma unroll
+    for (int p = 0; p < TP; ++p)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf[p], acc[p][c], 0, 0, 0);
+    if (T < 8) {
+      blend(raw, wts, pfn);
+    } else if (chunk + 1 < nch) {
+      wait_vmcnt<0>();                                   // next chunk's window, behind this tap's MFMAs
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      gather(0, chunk + 1, raw, wts);
+      blend(raw, wts, pfn);
+    }
+#pragma unroll
+    for (int p = 0; p < TP; ++p) pf[p] = pfn[p];
+    if (TS < 2) {
+#pragma unroll
+      for (int c = 0; c < TC; ++c) wf[c] = wfn[c];
+    }
+  };
+  for (int chunk = 0; chunk < nch; ++chunk) {
+    const int s = chunk * 3;
+    tap(s, chunk, std::integral_constant<int, 0>{});
+    tap(s, chunk, std::integral_constant<int, 1>{});
+    tap(s, chunk, std::integral_constant<int, 2>{});
+    tap(s + 1, chunk, std::integral_constant<int, 3>{});
+    tap(s + 1, chunk, std::integral_constant<int, 4>{});
+    tap(s + 1, chunk, std::integral_constant<int, 5>{});
+    tap(s + 2, chunk, std::integral_constant<int, 6>{});
+    tap(s + 2, chunk, std::integral_constant<int, 7>{});
+    tap(s + 2, chunk, std::integral_constant<int, 8>{});
+  }
+
+  // epilogue: per cout-tile pair h a lane holds 8 consecutive couts (cout_of) of 2 pixels; scale/bias from LDS, 16-byte stores
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const long m = (long)(b * a.H + ty0 + prow) * a.W + tx0 + 8 * p + pcol;
+#pragma unroll
+    for (int h = 0; h < TC / 2; ++h) {
+      const int cl = h * 32 + q * 8;
+      TOut* yp = (TOut*)a.y + m * a.out_stride + n0 + cl;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = acc[p][2 * h + (j >> 2)][j & 3] * sbuf[cl + j] + sbuf[BC + cl + j];
+        if (a.act == CTDET_ACT_RELU) t = fmaxf(t, 0.f);
+        else if (a.act == CTDET_ACT_SIGMOID_CLAMP) t = fminf(fmaxf(ctdet_sigmoid_exact(t), a.clamp_lo), a.clamp_hi);
+        v[j] = t;
+      }
+      if (n0 + cl + 8 <= a.Cout) {
+        if constexpr (sizeof(TOut) == 2) {
+          f16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
+          *(f16x8*)yp = o;
+        } else {
+          *(f32x4*)yp = (f32x4){v[0], v[1], v[2], v[3]};
+          *(f32x4*)(yp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        }
+      } else if (n0 + cl + 4 <= a.Cout) {
+        if constexpr (sizeof(TOut) == 2) {
+          f16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (f16)v[j];
+          *(f16x4*)yp = o;
+        } else {
+          *(f32x4*)yp = (f32x4){v[0], v[1], v[2], v[3]};
+        }
+      }
+    }
+  }
+}
+
 template <int BC, int WP, int WC_, typename TOut>
 static int launch_dcn_window(const ConvArgs& a, hipStream_t s) {
   const int nbx = a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16), nby = a.Cout_pad / BC;
   dim3 grid(8 * ((nbx + 7) / 8) * nby);
   const bool mixed = (ctdet_tuning_flags() & CTDET_TUNE_DCN_MIXED) != 0;
+  if (BC == 64 && !mixed && a.H % 8 == 0 && a.W % 16 == 0 && a.H <= 65534 && a.W <= 65534 &&
+      !(ctdet_tuning_flags() & CTDET_TUNE_DCN_WINDOW_V1)) {
+    hipLaunchKernelGGL((dcn_window_rows_kernel<TOut>), grid, dim3(256), 0, s, a);
+    CTDET_LAUNCH_CHECK();
+    return 0;
+  }
   if (mixed && a.H % 8 == 0 && a.W % 16 == 0 && a.H <= 4094 && a.W <= 4094)
     hipLaunchKernelGGL((dcn_window_kernel<BC, (BC > 64 ? 4 : 8), false, TOut, true>), grid, dim3(256), 0, s, a);
   else if (a.H % 8 == 0 && a.W % 16 == 0)

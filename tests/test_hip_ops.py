@@ -376,10 +376,12 @@ DCN_WINDOW_CASES = [(2, 16, 32, 64, 64, 1.0), (1, 8, 16, 128, 64, 0.0), (2, 16, 
                     (1, 16, 48, 64, 40, 2.5)]
 
 
-@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("variant", ["default", "v1", "mixed"])
 @pytest.mark.parametrize("case", DCN_WINDOW_CASES)
-def test_dcnv2_window(ops, dev, case, mixed, monkeypatch):
-    """mixed: the CTDET_TUNING_DCN_MIXED instantiation (only the lanes that left the window gather from global memory)"""
+def test_dcnv2_window(ops, dev, case, variant):
+    """default: dcn_window_rows_kernel for the 64-cout layers, dcn_window_kernel for wider ones; v1: dcn_window_kernel for all
+    (CTDET_TUNING_DCN_WINDOW_V1); mixed: its CTDET_TUNING_DCN_MIXED instantiation (only the lanes that left the window
+    gather from global memory)"""
     from detectron2_centernet_amd import _lib
     B, H, W, Cin, Cout, off_std = case
     g = torch.Generator().manual_seed(Cin + Cout + H + 1)
@@ -401,7 +403,7 @@ def test_dcnv2_window(ops, dev, case, mixed, monkeypatch):
     om_d = torch.zeros(B, H, W, 28)
     om_d[..., :27] = nhwc(om)
     xd = nhwc(x).half().to(dev)
-    with _lib.tuning(_lib.TUNE_DCN_MIXED if mixed else 0):
+    with _lib.tuning({"default": 0, "v1": _lib.TUNE_DCN_WINDOW_V1, "mixed": _lib.TUNE_DCN_MIXED}[variant]):
         y = ops.dcnv2(xd, om_d.to(dev), pc, act=ops.ACT_RELU)
     got = nchw(y[..., :Cout].float().cpu())
     err = (got - ref).abs().max().item()

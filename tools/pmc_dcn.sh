@@ -1,5 +1,7 @@
 #!/bin/bash
-# usage: tools/pmc_dcn.sh  (run on the GPU box): PMC passes over the DCN window microbench
+# usage: tools/pmc_dcn.sh <tag> [bench_conv args]  (run on the GPU box): SQ counter passes over the DCN microbench,
+# summarised per kernel into gpurun_out/pmc_dcn_<tag>.txt
+TAG=${1:-dcn}; shift
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
@@ -9,5 +11,16 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL" \
            "SQ_IFETCH SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM"; do
   n=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --pmc $grp --kernel-trace -d $R/gpurun_out/pmc_$n -o p --output-format csv -- python3 $R/tools/bench_conv.py --dcn --window --B 64 --H 128 --W 128 --cin 64 --cout 64 --off-std 0 --reps 3 > $R/gpurun_out/pmc_$n.log 2>&1 || exit 1
+  rocprofv3 --pmc $grp --kernel-trace -d $R/gpurun_out/pmc_${TAG}_$n -o p --output-format csv -- python3 $R/tools/bench_conv.py --dcn --B 64 --H 128 --W 128 --cin 64 --cout 64 --off-std 0.5 --reps 3 "$@" > $R/gpurun_out/pmc_${TAG}_$n.log 2>&1 || exit 1
 done
+python3 - "$R/gpurun_out" "$TAG" <<'PY' > $R/gpurun_out/pmc_dcn_${TAG}.txt
+import csv, glob, sys, collections
+root, tag = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(list)
+for f in glob.glob(f"{root}/pmc_{tag}_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "dcn" in r["Kernel_Name"]:
+            acc[(r["Kernel_Name"].split("(")[0][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (k, c), v in sorted(acc.items()):
+    print(f"{k:60s} {c:32s} mean_per_dispatch={sum(v)/len(v):.4g}  n={len(v)}")
+PY
