@@ -55,11 +55,13 @@ SIGNATURES = {
     "ctdet_bn_train_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32,
                                    _vp, _vp, _f32, _vp, _i32, _vp]),
     "ctdet_conv_wgrad": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _f32, _vp]),
+    "ctdet_conv_wgrad_oihw": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_grad_scatter_oihw": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ctdet_depth_to_space2": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_maxpool2x2_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_dwconvT_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_dcn_cols": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "ctdet_dcn_col2im_coord": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_dcn_col2im_coord": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_sgd_momentum": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _i32, _vp]),
     "ctdet_sgd_momentum_runs": (_i32, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _i32, _f32, _i32, _vp]),
     "ctdet_set_tuning_flags": (_i32, [C.c_uint32]),

@@ -49,7 +49,9 @@ struct WgradArgs {
   int B, H, W, Cin, in_stride, Cout, Ho, Wo, dy_stride, R, S, stride, pad, dil, K, M, msplit;
   float scale;
   int lw, lh;
+  int perm_rs, perm_cin, cin_real, cout_real;
 };
+int launch_grad_scatter_oihw(const void* const*, void* const*, const int*, const int*, const int*, const int*, int, hipStream_t);
 size_t chan_reduce_workspace_bytes(int C);
 int launch_bn_train_fwd(const f16*, int, const f16*, int, f16*, int, int, int, const float*, const float*, float, float,
                         float*, float*, float*, float*, float*, float*, void*, int, hipStream_t);
@@ -65,14 +67,14 @@ int launch_maxpool2x2_bwd_f32(const float*, int, const float*, int, float*, int,
 int launch_dwconvT_bwd_f32(const float*, int, const float*, int, const float*, float*, int, float*, int, int, int, int, int,
                            hipStream_t);
 int launch_dcn_cols_f32(const float*, int, const float*, int, float*, int, int, int, int, int, hipStream_t);
-int launch_dcn_col2im_coord_f32(const float*, const float*, int, const float*, int, float*, float*, int, int, int, int, int,
+int launch_dcn_col2im_coord_f32(const float*, const float*, int, const float*, int, float*, float*, int, int, int, int, int, int,
                                 hipStream_t);
 int launch_maxpool2x2_bwd(const f16*, int, const f16*, int, f16*, int, int, int, int, int, hipStream_t);
 int launch_depth_to_space2(const f16*, int, f16*, int, int, int, int, int, int, int, hipStream_t);
 int launch_dwconvT_bwd(const f16*, int, const f16*, int, const float*, f16*, int, float*, int, int, int, int, int,
                        hipStream_t);
 int launch_dcn_cols(const f16*, int, const float*, int, f16*, int, int, int, int, int, hipStream_t);
-int launch_dcn_col2im_coord(const f16*, const f16*, int, const float*, int, float*, float*, int, int, int, int, int,
+int launch_dcn_col2im_coord(const f16*, const f16*, int, const float*, int, float*, void*, int, int, int, int, int, int, int,
                             hipStream_t);
 
 static int fill_args(const ctdet_conv_desc* d, ConvArgs& a) {
@@ -394,8 +396,17 @@ int32_t ctdet_bn_train_bwd(const void* dz, int32_t dz_stride, const void* z, int
 }
 
 int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy, float* dw, float scale, void* stream) {
+  return ctdet_conv_wgrad_oihw(d, x, dy, dw, scale, 0, 0, 0, 0, stream);
+}
+
+int32_t ctdet_conv_wgrad_oihw(const ctdet_conv_desc* d, const void* x, const void* dy, float* dw, float scale, int32_t taps,
+                              int32_t cin_k, int32_t cin_real, int32_t cout_real, void* stream) {
   CTDET_CHECK(d && x && dy && dw, "conv_wgrad: null pointer");
+  CTDET_CHECK(taps == 0 || (cin_k > 0 && cin_real > 0 && cin_real <= cin_k && taps * cin_k == d->R * d->S * d->Cin &&
+                            cout_real > 0 && cout_real <= d->Cout),
+              "conv_wgrad_oihw: taps=%d cin_k=%d cin_real=%d do not factor K=%d", taps, cin_k, cin_real, d->R * d->S * d->Cin);
   WgradArgs a;
+  a.perm_rs = taps; a.perm_cin = cin_k; a.cin_real = cin_real; a.cout_real = cout_real;
   a.x = (const f16*)x; a.dy = (const f16*)dy; a.dw = dw;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_stride = d->in_stride; a.Cout = d->Cout; a.Ho = d->Ho;
   a.Wo = d->Wo; a.dy_stride = d->out_stride; a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
@@ -403,6 +414,12 @@ int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy
   if (a.M == 0) return 0;
   if (d->compute_dtype == CTDET_DT_F32) return launch_conv_wgrad_f32(a, (hipStream_t)stream);
   return launch_conv_wgrad(a, (hipStream_t)stream);
+}
+
+int32_t ctdet_grad_scatter_oihw(const void* const* src, void* const* dst, const int32_t* cout, const int32_t* cin_real,
+                                const int32_t* cin_k, const int32_t* taps, int32_t n, void* stream) {
+  CTDET_CHECK(n >= 0 && (n == 0 || (src && dst && cout && cin_real && cin_k && taps)), "grad_scatter_oihw: null pointer");
+  return launch_grad_scatter_oihw(src, dst, cout, cin_real, cin_k, taps, n, (hipStream_t)stream);
 }
 
 int32_t ctdet_depth_to_space2(const void* src, int32_t src_stride, void* dst, int32_t dst_stride, int32_t B, int32_t H,
@@ -442,14 +459,16 @@ int32_t ctdet_dcn_cols(const void* x, int32_t x_stride, const float* om, int32_t
 }
 
 int32_t ctdet_dcn_col2im_coord(const void* dcol, const void* x, int32_t x_stride, const float* om, int32_t om_stride,
-                               float* dx, float* dom, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t mask_is_prob,
-                               int32_t dtype, void* stream) {
+                               float* dx, void* dom, int32_t dom_stride, int32_t dom_dtype, int32_t B, int32_t H, int32_t W,
+                               int32_t Cin, int32_t mask_is_prob, int32_t dtype, void* stream) {
   CTDET_CHECK(dcol && x && om && dx && dom, "dcn_col2im_coord: null pointer");
+  CTDET_CHECK(dom_dtype == CTDET_DT_F32 || (dom_dtype == CTDET_DT_F16 && dtype == CTDET_DT_F16),
+              "dcn_col2im_coord: dom dtype %d with data dtype %d", dom_dtype, dtype);
   if (dtype == CTDET_DT_F32)
-    return launch_dcn_col2im_coord_f32((const float*)dcol, (const float*)x, x_stride, om, om_stride, dx, dom, B, H, W, Cin,
-                                       mask_is_prob, (hipStream_t)stream);
-  return launch_dcn_col2im_coord((const f16*)dcol, (const f16*)x, x_stride, om, om_stride, dx, dom, B, H, W, Cin,
-                                 mask_is_prob, (hipStream_t)stream);
+    return launch_dcn_col2im_coord_f32((const float*)dcol, (const float*)x, x_stride, om, om_stride, dx, (float*)dom, dom_stride,
+                                       B, H, W, Cin, mask_is_prob, (hipStream_t)stream);
+  return launch_dcn_col2im_coord((const f16*)dcol, (const f16*)x, x_stride, om, om_stride, dx, dom, dom_stride,
+                                 dom_dtype == CTDET_DT_F16, B, H, W, Cin, mask_is_prob, (hipStream_t)stream);
 }
 
 int32_t ctdet_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, const float* lr_dev,

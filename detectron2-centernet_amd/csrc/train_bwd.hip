@@ -316,7 +316,19 @@ struct WgradArgs {
   int B, H, W, Cin, in_stride, Cout, Ho, Wo, dy_stride, R, S, stride, pad, dil, K, M, msplit;
   float scale;   // multiplier applied to every partial sum before it is added to dw
   int lw, lh;    // log2(Wo), log2(Ho) when both are powers of two, else -1
+  // output layout: perm_rs == 0: dw[n][k], k = tap*Cin + c (tap-major).  perm_rs > 0: the parameter's own OIHW layout,
+  // dw[(n*cin_real + c)*perm_rs + tap] with k = tap*perm_cin + c, channels c >= cin_real (input padding) dropped -- the
+  // and rows n >= cout_real (output-channel padding of dy) dropped -- the kernel then accumulates straight into the
+  // optimizer's gradient buffer
+  int perm_rs, perm_cin, cin_real, cout_real;
 };
+
+template <typename A>
+__device__ __forceinline__ void wg_add(const A& a, int n, int k, float v) {
+  if (a.perm_rs == 0) { atomicAdd(a.dw + (long)n * a.K + k, v); return; }
+  const int tap = k / a.perm_cin, c = k - tap * a.perm_cin;
+  if (c < a.cin_real && n < a.cout_real) atomicAdd(a.dw + ((long)n * a.cin_real + c) * a.perm_rs + tap, v);
+}
 
 __device__ __forceinline__ f16x4 lds_tr_read(const f16* p) {
   const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
@@ -435,7 +447,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 32 + i * 16 + 4 * (lane >> 4) + r;
-        if (n < a.Cout) atomicAdd(a.dw + (long)n * a.K + kcol, acc[i][j][r] * a.scale);
+        if (n < a.Cout) wg_add(a, n, kcol, acc[i][j][r] * a.scale);
       }
     }
 }
@@ -599,6 +611,20 @@ __device__ __forceinline__ DcnGeom dcn_geom(const float* om, int tap, int b, int
   return g;
 }
 
+// d(offset), d(mask) of one (pixel, tap) into the dom row (f32 or f16, row stride dom_stride); tap 0 also clears the padding
+// channels 27 .. dom_stride-1, so the caller does not have to zero the buffer
+__device__ __forceinline__ void dom_store(void* dom, int dom_f16, long m, int dom_stride, int tap, float v_h, float v_w, float v_m) {
+  if (dom_f16) {
+    f16* d = (f16*)dom + m * dom_stride;
+    d[2 * tap] = (f16)v_h; d[2 * tap + 1] = (f16)v_w; d[18 + tap] = (f16)v_m;
+    if (tap == 0) for (int c = 27; c < dom_stride; ++c) d[c] = (f16)0.f;
+  } else {
+    float* d = (float*)dom + m * dom_stride;
+    d[2 * tap] = v_h; d[2 * tap + 1] = v_w; d[18 + tap] = v_m;
+    if (tap == 0) for (int c = 27; c < dom_stride; ++c) d[c] = 0.f;
+  }
+}
+
 // col[m][tap*Cin + c] = mask * bilinear(x)   (the `columns` of the reference, f16, tap-major)
 __global__ void __launch_bounds__(256) dcn_cols_kernel(const f16* __restrict__ x, int x_stride, const float* __restrict__ om,
                                                        int om_stride, f16* __restrict__ col, int B, int H, int W, int Cin, int mask_is_prob) {
@@ -636,8 +662,8 @@ __global__ void __launch_bounds__(256) dcn_cols_kernel(const f16* __restrict__ x
 // three per-(pixel,tap) dot products are wave reductions.
 __global__ void __launch_bounds__(256) dcn_col2im_coord_kernel(const f16* __restrict__ dcol, const f16* __restrict__ x,
                                                                int x_stride, const float* __restrict__ om, int om_stride,
-                                                               float* __restrict__ dx, float* __restrict__ dom, int B, int H,
-                                                               int W, int Cin, int mask_is_prob) {
+                                                               float* __restrict__ dx, void* __restrict__ dom, int dom_stride,
+                                                               int dom_f16, int B, int H, int W, int Cin, int mask_is_prob) {
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long nwork = (long)B * H * W * 9;
@@ -671,12 +697,8 @@ __global__ void __launch_bounds__(256) dcn_col2im_coord_kernel(const f16* __rest
       dh += __shfl_down(dh, o, 64);
       dwv += __shfl_down(dwv, o, 64);
     }
-    if (lane == 0) {
-      float* d = dom + m * om_stride;
-      d[2 * tap] = dh * g.mask;
-      d[2 * tap + 1] = dwv * g.mask;
-      d[18 + tap] = mask_is_prob ? val_dot : val_dot * g.mask * (1.f - g.mask);  // through the sigmoid of the mask logit
-    }
+    if (lane == 0)   // the mask logit's gradient goes through its sigmoid
+      dom_store(dom, dom_f16, m, dom_stride, tap, dh * g.mask, dwv * g.mask, mask_is_prob ? val_dot : val_dot * g.mask * (1.f - g.mask));
   }
 }
 
@@ -703,8 +725,8 @@ struct ColGeo {        // staged per (pixel, tap): 32 bytes
 
 __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __restrict__ dcol, const f16* __restrict__ x,
                                                                 int x_stride, const float* __restrict__ om, int om_stride,
-                                                                float* __restrict__ dx, float* __restrict__ dom, int B, int H,
-                                                                int W, int Cin, int mask_is_prob) {
+                                                                float* __restrict__ dx, void* __restrict__ dom, int dom_stride,
+                                                                int dom_f16, int B, int H, int W, int Cin, int mask_is_prob) {
   constexpr int TH = 8, TW = 16, MG = 4, WR = TH + 2 + 2 * MG, WC = TW + 2 + 2 * MG, NPX = WR * WC;  // 18 x 26 = 468
   // d(input) window, int32 fixed point, laid out [e = channel % 8][window pixel][q = channel / 8]: the 64 lanes (16
   // pixels x 4 groups) of one ds_add then touch 64 consecutive words
@@ -862,10 +884,7 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
     bw += __shfl_xor(bw, 16, 64); bw += __shfl_xor(bw, 32, 64);
     if (q == 0) {
       const float mk = geo[t * (TH * TW) + pl].mask;
-      float* o = dom + m * om_stride;
-      o[2 * t] = bh * mk;
-      o[2 * t + 1] = bw * mk;
-      o[18 + t] = mask_is_prob ? a : a * mk * (1.f - mk);   // through the sigmoid of the mask logit
+      dom_store(dom, dom_f16, m, dom_stride, t, bh * mk, bw * mk, mask_is_prob ? a : a * mk * (1.f - mk));  // through the sigmoid
     }
   }
 }
@@ -1089,7 +1108,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_win_kernel(const WgradArgs 
   for (int e = tid; e < 36 * 256; e += 256) {
     const int tile = e >> 8, t = tile >> 2, i = (tile >> 1) & 1, j = tile & 1, r = (e >> 6) & 3, ln = e & 63;
     const int n = n0 + i * 16 + 4 * (ln >> 4) + r;
-    if (n < a.Cout) atomicAdd(a.dw + (long)n * a.K + t * a.Cin + c0 + j * 16 + (ln & 15), red[e] * a.scale);
+    if (n < a.Cout) wg_add(a, n, t * a.Cin + c0 + j * 16 + (ln & 15), red[e] * a.scale);
   }
 }
 
@@ -1226,8 +1245,58 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_narrow_kernel(const WgradAr
     const int t = e >> 8, r = (e >> 6) & 3, ln = e & 63, col = ln & 15;
     const int n = 4 * (ln >> 4) + r, tr = t / NP, pr = t - tr * NP;
     const int ts = CIN == 8 ? 2 * pr + (col >> 3) : pr, c = CIN == 8 ? col & 7 : col;
-    if (n < a.Cout && ts < KS) atomicAdd(a.dw + (long)n * a.K + (tr * KS + ts) * CIN + c, red[e] * a.scale);
+    if (n < a.Cout && ts < KS) wg_add(a, n, (tr * KS + ts) * CIN + c, red[e] * a.scale);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradients into the parameters' layout, all layers of a bucket in one launch.  The weight-gradient kernels accumulate
+// tap-major [Cout][tap][Cin] (consecutive lanes = consecutive channels: the split-M partial sums arrive as coalesced
+// atomics; the same atomics at OIHW addresses, 4*taps bytes apart, cost the step 6 ms).  This pass adds each finished sum
+// to its place in the optimizer's flat OIHW gradient buffer: dst[(n*cin_real + c)*taps + tap] += src[(n*taps + tap)*cin_k + c]
+// -- what one autograd add kernel per parameter did before (~230 launches per step).  Up to GS_MAX tensors per launch,
+// descriptors by value.
+// ------------------------------------------------------------------------------------------------
+#define GS_MAX 24
+struct GradScatterArgs {
+  const float* src[GS_MAX]; float* dst[GS_MAX];
+  int cin_real[GS_MAX], cin_k[GS_MAX], taps[GS_MAX], nelem[GS_MAX], blk0[GS_MAX + 1];
+  int n;
+};
+__global__ void __launch_bounds__(256) grad_scatter_oihw_kernel(const GradScatterArgs a) {
+  int t = 0;
+  while (t + 1 < a.n && (int)blockIdx.x >= a.blk0[t + 1]) ++t;      // wave-uniform, n <= 24
+  const int i = ((int)blockIdx.x - a.blk0[t]) * 256 + threadIdx.x;  // element of dst: (n, c, tap)
+  if (i >= a.nelem[t]) return;
+  const int taps = a.taps[t], cr = a.cin_real[t];
+  const int tap = i % taps, nc = i / taps;
+  const int c = nc % cr, n = nc / cr;
+  a.dst[t][i] += a.src[t][((long)n * taps + tap) * a.cin_k[t] + c];
+}
+
+int launch_grad_scatter_oihw(const void* const* src, void* const* dst, const int* cout, const int* cin_real, const int* cin_k,
+                             const int* taps, int n, hipStream_t s) {
+  for (int base = 0; base < n; base += GS_MAX) {
+    GradScatterArgs a = {};
+    a.n = n - base < GS_MAX ? n - base : GS_MAX;
+    int blocks = 0;
+    for (int j = 0; j < a.n; ++j) {
+      const int k = base + j;
+      CTDET_CHECK(src[k] && dst[k] && cout[k] > 0 && cin_real[k] > 0 && cin_real[k] <= cin_k[k] && taps[k] > 0 &&
+                      (long)cout[k] * cin_k[k] * taps[k] < (1L << 31),
+                  "grad_scatter: bad descriptor %d", k);
+      a.src[j] = (const float*)src[k]; a.dst[j] = (float*)dst[k];
+      a.cin_real[j] = cin_real[k]; a.cin_k[j] = cin_k[k]; a.taps[j] = taps[k];
+      a.nelem[j] = cout[k] * cin_real[k] * taps[k];
+      a.blk0[j] = blocks;
+      blocks += (a.nelem[j] + 255) / 256;
+    }
+    a.blk0[a.n] = blocks;
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(grad_scatter_oihw_kernel, dim3(blocks), dim3(256), 0, s, a);
+    CTDET_LAUNCH_CHECK();
+  }
+  return 0;
 }
 
 static int device_cu_count() { return ctdet_device_cu_count(); }
@@ -1355,20 +1424,21 @@ int launch_dcn_cols(const f16* x, int x_stride, const float* om, int om_stride, 
 }
 
 int launch_dcn_col2im_coord(const f16* dcol, const f16* x, int x_stride, const float* om, int om_stride, float* dx,
-                            float* dom, int B, int H, int W, int Cin, int mask_is_prob, hipStream_t s) {
+                            void* dom, int dom_stride, int dom_f16, int B, int H, int W, int Cin, int mask_is_prob, hipStream_t s) {
+  CTDET_CHECK(dom_stride >= 27 && dom_stride <= 64, "dcn_col2im: dom_stride=%d", dom_stride);
   CTDET_CHECK(Cin % 8 == 0, "dcn_col2im: Cin=%d must be a multiple of 8", Cin);
   const long nwork = (long)B * H * W * 9;
   if (nwork == 0) return 0;
   if (H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && x_stride % 8 == 0 && !(ctdet_tuning_flags() & CTDET_TUNE_NO_COL2IM_WINDOW)) {
     hipLaunchKernelGGL(dcn_col2im_window_kernel, dim3((unsigned)(B * (H / 8) * (W / 16))), dim3(512), 0, s, dcol, x, x_stride,
-                       om, om_stride, dx, dom, B, H, W, Cin, mask_is_prob);
+                       om, om_stride, dx, dom, dom_stride, dom_f16, B, H, W, Cin, mask_is_prob);
     CTDET_LAUNCH_CHECK();
     return 0;
   }
   long nb = (nwork + 3) / 4;
   if (nb > 256 * 32) nb = 256 * 32;
   hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3((unsigned)nb), dim3(256), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
-                     B, H, W, Cin, mask_is_prob);
+                     dom_stride, dom_f16, B, H, W, Cin, mask_is_prob);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
@@ -1466,6 +1536,7 @@ struct WgradArgsF {
   const float* x; const float* dy; float* dw;
   int B, H, W, Cin, in_stride, Cout, Ho, Wo, dy_stride, R, S, stride, pad, dil, K, M, msplit;
   float scale;
+  int perm_rs, perm_cin, cin_real, cout_real;
 };
 __global__ void __launch_bounds__(256) conv_wgrad_f32_kernel(const WgradArgsF a) {
   __shared__ float sdy[16][17], sa[16][17];
@@ -1499,7 +1570,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_f32_kernel(const WgradArgsF a)
     for (int p = 0; p < 16; ++p) acc = fmaf(sdy[p][tn], sa[p][tk], acc);   // output element (n0 + tn, k0 + tk)
     __syncthreads();
   }
-  if (n0 + tn < a.Cout && k_ok && acc != 0.f) atomicAdd(a.dw + (long)(n0 + tn) * a.K + kl, acc * a.scale);
+  if (n0 + tn < a.Cout && k_ok && acc != 0.f) wg_add(a, n0 + tn, kl, acc * a.scale);
 }
 
 __global__ void __launch_bounds__(256) maxpool2x2_bwd_f32_kernel(const float* __restrict__ x, int x_stride,
@@ -1596,7 +1667,7 @@ __global__ void __launch_bounds__(256) dcn_cols_f32_kernel(const float* __restri
 // the generic coordinate / col2im kernel above for f32 columns and inputs (same wave-per-(pixel, tap) structure)
 __global__ void __launch_bounds__(256) dcn_col2im_coord_f32_kernel(const float* __restrict__ dcol, const float* __restrict__ x,
                                                                    int x_stride, const float* __restrict__ om, int om_stride,
-                                                                   float* __restrict__ dx, float* __restrict__ dom, int B,
+                                                                   float* __restrict__ dx, float* __restrict__ dom, int dom_stride, int B,
                                                                    int H, int W, int Cin, int mask_is_prob) {
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1631,12 +1702,8 @@ __global__ void __launch_bounds__(256) dcn_col2im_coord_f32_kernel(const float* 
       dh += __shfl_down(dh, o, 64);
       dwv += __shfl_down(dwv, o, 64);
     }
-    if (lane == 0) {
-      float* d = dom + m * om_stride;
-      d[2 * tap] = dh * g.mask;
-      d[2 * tap + 1] = dwv * g.mask;
-      d[18 + tap] = mask_is_prob ? val_dot : val_dot * g.mask * (1.f - g.mask);
-    }
+    if (lane == 0)
+      dom_store(dom, 0, m, dom_stride, tap, dh * g.mask, dwv * g.mask, mask_is_prob ? val_dot : val_dot * g.mask * (1.f - g.mask));
   }
 }
 
@@ -1689,7 +1756,7 @@ int launch_conv_wgrad_f32(const WgradArgs& h, hipStream_t s) {
   a.x = (const float*)h.x; a.dy = (const float*)h.dy; a.dw = h.dw;
   a.B = h.B; a.H = h.H; a.W = h.W; a.Cin = h.Cin; a.in_stride = h.in_stride; a.Cout = h.Cout; a.Ho = h.Ho; a.Wo = h.Wo;
   a.dy_stride = h.dy_stride; a.R = h.R; a.S = h.S; a.stride = h.stride; a.pad = h.pad; a.dil = h.dil; a.K = h.K; a.M = h.M;
-  a.scale = h.scale;
+  a.scale = h.scale; a.perm_rs = h.perm_rs; a.perm_cin = h.perm_cin; a.cin_real = h.cin_real; a.cout_real = h.cout_real;
   const int nkb = (a.K + 15) / 16, nnb = (a.Cout + 15) / 16;
   long ms = 4096 / ((long)nkb * nnb);
   if (ms < 1) ms = 1;
@@ -1738,13 +1805,14 @@ int launch_dcn_cols_f32(const float* x, int x_stride, const float* om, int om_st
 }
 
 int launch_dcn_col2im_coord_f32(const float* dcol, const float* x, int x_stride, const float* om, int om_stride, float* dx,
-                                float* dom, int B, int H, int W, int Cin, int mask_is_prob, hipStream_t s) {
+                                float* dom, int dom_stride, int B, int H, int W, int Cin, int mask_is_prob, hipStream_t s) {
+  CTDET_CHECK(dom_stride >= 27 && dom_stride <= 64, "dcn_col2im: dom_stride=%d", dom_stride);
   const long nwork = (long)B * H * W * 9;
   if (nwork == 0) return 0;
   long nb = (nwork + 3) / 4;
   if (nb > 256 * 32) nb = 256 * 32;
   hipLaunchKernelGGL(dcn_col2im_coord_f32_kernel, dim3((unsigned)nb), dim3(256), 0, s, dcol, x, x_stride, om, om_stride, dx,
-                     dom, B, H, W, Cin, mask_is_prob);
+                     dom, dom_stride, B, H, W, Cin, mask_is_prob);
   CTDET_LAUNCH_CHECK();
   return 0;
 }

@@ -36,7 +36,9 @@ class BucketedReducer:
         self.enabled = True   # False while a training step is captured / replayed as a graph: see reduce_all()
         if self.world > 1:
             for i, p in enumerate(optimizer.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                h = self._make_hook(i)
+                p.register_post_accumulate_grad_hook(h)
+                p._ctdet_grad_hook = h    # backward kernels that accumulate into the flat buffer themselves announce it here
 
     def _make_hook(self, i):
         b = self.bucket_of[i]
@@ -52,6 +54,10 @@ class BucketedReducer:
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
+        if self.opt.flat_grad.is_cuda:      # weight gradients still waiting in tap-major form for this range (ops_train.PENDING)
+            from .. import ops_train
+            base = self.opt.flat_grad.data_ptr()
+            ops_train.flush_param_grads(base + 4 * s, base + 4 * e)
         if self.comm is not None:
             # RCCL through the C ABI: ordered after the gradients produced so far, on a side stream so that the rest of
             # backward keeps running; finish() joins the streams

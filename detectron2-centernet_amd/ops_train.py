@@ -83,14 +83,19 @@ def bn_train_fwd(y, gamma, beta, running_mean, running_var, eps, momentum, res=N
     return z, mean, invstd, scale
 
 
-def bn_train_bwd(dz, z, y, mean, invstd, scale, relu=True, want_dres=False, grad_mult=None):
-    """dgamma / dbeta come back multiplied by grad_mult (default: PARAM_GRAD_MULT, what every parameter gradient carries)"""
+def bn_train_bwd(dz, z, y, mean, invstd, scale, relu=True, want_dres=False, grad_mult=None, into=None):
+    """dgamma / dbeta come back multiplied by grad_mult (default: PARAM_GRAD_MULT, what every parameter gradient carries).
+    into=(dgamma_slot, dbeta_slot): write them (Cc floats each; either may be None) straight into the parameters' gradient
+    slices -- each BatchNorm / bias parameter has one producer per step, so a plain store is the accumulation"""
     B, H, W, Cc = dz.shape
     dev = dz.device
     dy = torch.empty(B, H, W, Cc, dtype=dz.dtype, device=dev)
     dres = torch.empty(B, H, W, Cc, dtype=dz.dtype, device=dev) if want_dres else None
-    dgb = torch.empty(2, Cc, dtype=torch.float32, device=dev)   # written, not accumulated
-    dgamma, dbeta = dgb[0], dgb[1]
+    slots = [t if t is not None and t.numel() == Cc and t.is_contiguous() else None for t in (into or (None, None))]
+    dgamma, dbeta = slots
+    if dgamma is None or dbeta is None:
+        dgb = torch.empty(2, Cc, dtype=torch.float32, device=dev)   # written, not accumulated
+        dgamma, dbeta = (dgb[0] if dgamma is None else dgamma), (dgb[1] if dbeta is None else dbeta)
     gm = PARAM_GRAD_MULT if grad_mult is None else grad_mult
     with ops.prof_region("bn_train_bwd", flops=0.0, nbytes=float(B * H * W * Cc * 10)):
         rc = _lib.lib().ctdet_bn_train_bwd(_ptr(dz), _nhwc_stride(dz), _ptr(z), _nhwc_stride(z) if z is not None else 0,
@@ -102,8 +107,10 @@ def bn_train_bwd(dz, z, y, mean, invstd, scale, relu=True, want_dres=False, grad
     return dy, dres, dgamma, dbeta
 
 
-def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1, scale=None):
-    """scale * dW, f32 [Cout, R*S*Cin] (tap-major) for y = conv(x, W); x, dy f16 NHWC.  scale defaults to PARAM_GRAD_MULT."""
+def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1, scale=None, into=None):
+    """scale * dW, f32 [Cout, R*S*Cin] (tap-major) for y = conv(x, W); x, dy f16 NHWC.  scale defaults to PARAM_GRAD_MULT.
+    into=(grad, taps, cin_k): accumulate into `grad`, the parameter's own OIHW gradient [Cout_real, Cin_real, kh, kw] (its
+    slice of the optimizer's flat buffer), with k = tap*cin_k + c -- nothing is returned"""
     B, H, W, Cin = x.shape
     _, Ho, Wo, Cd = dy.shape
     assert Cd >= Cout
@@ -113,12 +120,76 @@ def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1, scale=None):
     d.R, d.S, d.stride, d.pad, d.dil = R, S, stride, pad, dil
     d.compute_dtype = dt_of(x)
     assert dy.dtype == x.dtype
-    dw = _zeros_f32((Cout, R * S * Cin), x.device)
+    sc = float(PARAM_GRAD_MULT if scale is None else scale)
     with ops.prof_region(f"conv_wgrad<{R}x{S}>", flops=2.0 * B * Ho * Wo * Cout * R * S * Cin, nbytes=0.0):
-        rc = _lib.lib().ctdet_conv_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
-                                         float(PARAM_GRAD_MULT if scale is None else scale), _stream())
+        if into is not None:
+            grad, taps, cin_k = into
+            assert grad.dtype == torch.float32 and grad.is_contiguous() and grad.dim() == 4
+            assert grad.shape[2] * grad.shape[3] == taps and grad.shape[0] <= Cout and grad.shape[1] <= cin_k
+            rc = _lib.lib().ctdet_conv_wgrad_oihw(C.byref(d), _ptr(x), _ptr(dy), _ptr(grad), sc, taps, cin_k, grad.shape[1],
+                                                  grad.shape[0], _stream())
+            dw = None
+        else:
+            dw = _zeros_f32((Cout, R * S * Cin), x.device)
+            rc = _lib.lib().ctdet_conv_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), sc, _stream())
     _lib.check(rc, "ctdet_conv_wgrad")
     return dw
+
+
+def grad_slot(p):
+    """the parameter's slice of the optimizer's flat gradient buffer when backward may accumulate into it directly (set up by
+    solver.FlatSGD), else None.  Writing there replaces `return dw` -> autograd's AccumulateGrad (`p.grad += dw`, one
+    elementwise kernel per parameter and step)."""
+    g = getattr(p, "_ctdet_flat_grad", None)
+    if g is None or p.grad is None or p.grad.data_ptr() != g.data_ptr():
+        return None
+    return g
+
+
+def grad_done(p):
+    """what AccumulateGrad's post hook would have announced (engine/reducer.py counts parameters per bucket)"""
+    h = getattr(p, "_ctdet_grad_hook", None)
+    if h is not None:
+        h(p)
+
+
+PENDING = []   # (slot, tap-major dw, taps, cin_k): finished weight gradients not yet added to their OIHW slots
+
+
+def flush_param_grads(ptr_lo=None, ptr_hi=None):
+    """adds the pending tap-major weight gradients (all, or those whose slot starts inside [ptr_lo, ptr_hi)) to the parameters'
+    gradients, 24 tensors per launch.  Runs by itself when a backward pass ends (queued on the autograd engine by the first
+    deferred gradient), and from the reducer before a bucket is exchanged."""
+    todo = [e for e in PENDING if ptr_lo is None or ptr_lo <= e[0].data_ptr() < ptr_hi]
+    if not todo:
+        return
+    PENDING[:] = [e for e in PENDING if not (ptr_lo is None or ptr_lo <= e[0].data_ptr() < ptr_hi)]
+    n = len(todo)
+    vp, i32 = C.c_void_p * n, C.c_int32 * n
+    rc = _lib.lib().ctdet_grad_scatter_oihw(vp(*[e[1].data_ptr() for e in todo]), vp(*[e[0].data_ptr() for e in todo]),
+                                            i32(*[e[0].shape[0] for e in todo]), i32(*[e[0].shape[1] for e in todo]),
+                                            i32(*[e[3] for e in todo]), i32(*[e[2] for e in todo]), n, _stream())
+    _lib.check(rc, "ctdet_grad_scatter_oihw")
+
+
+def wgrad_to_param(p, x, dy, Cout_k, R, S, stride, pad, taps, cin_k, scale=None):
+    """The weight gradient of parameter p (OIHW [Cout, Cin, kh, kw], kh*kw = taps; k = tap*cin_k + c in the kernel's order)
+    accumulated into p's slice of the optimizer's flat gradient buffer instead of being handed to autograd (whose
+    AccumulateGrad would launch one strided add per parameter).  1x1: the kernel writes the slot itself.  Other kernels:
+    tap-major partial sums as always (coalesced atomics), added to the slot by flush_param_grads.  False: p has no slot
+    (stand-alone use) -- the caller returns the gradient to autograd."""
+    slot = grad_slot(p)
+    if slot is None or scale is not None:
+        return False
+    if taps == 1:
+        conv_wgrad(x, dy, Cout_k, R, S, stride, pad, into=(slot, 1, cin_k))
+    else:
+        dw = conv_wgrad(x, dy, Cout_k, R, S, stride, pad)
+        if not PENDING:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_param_grads)
+        PENDING.append((slot, dw, taps, cin_k))
+    grad_done(p)
+    return True
 
 
 def maxpool2x2_bwd(x, dz):
@@ -150,13 +221,20 @@ def dcn_cols(x, om, mask_is_prob=False):
     return col
 
 
-def dcn_col2im_coord(dcol, x, om, mask_is_prob=False):
+def dcn_col2im_coord(dcol, x, om, mask_is_prob=False, dom_channels=None):
+    """dx (f32, atomically accumulated) and dom = d(offsets, mask logits).  dom_channels=None: f32, the shape of om;
+    dom_channels=C (f16 data): an f16 [B, H, W, C] tensor whose channels 27.. are zero -- directly the dY of the offset conv's
+    backward, without a cast or a channel pad in between"""
     B, H, W, Cin = x.shape
     dx = torch.zeros(B, H, W, Cin, dtype=torch.float32, device=x.device)
-    dom = torch.zeros_like(om)
+    if dom_channels is None or x.dtype == torch.float32:
+        dom = torch.empty(B, H, W, om.shape[3] if dom_channels is None else dom_channels, dtype=torch.float32, device=x.device)
+    else:
+        dom = torch.empty(B, H, W, dom_channels, dtype=torch.float16, device=x.device)
     with ops.prof_region("dcn_col2im", flops=0.0, nbytes=float(B * H * W * Cin * (18 + 2 + 4) + B * H * W * 27 * 8)):
         rc = _lib.lib().ctdet_dcn_col2im_coord(_ptr(dcol), _ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(dx),
-                                               _ptr(dom), B, H, W, Cin, int(mask_is_prob), dt_of(x), _stream())
+                                               _ptr(dom), dom.shape[3], dt_of(dom), B, H, W, Cin, int(mask_is_prob), dt_of(x),
+                                               _stream())
     _lib.check(rc, "ctdet_dcn_col2im_coord")
     return dx, dom
 
@@ -251,6 +329,7 @@ class ConvFn(torch.autograd.Function):
         y = ops.conv2d(x, p, act=ACT_RELU if relu else ACT_NONE,
                        out_dtype=torch.float32 if (out_f32 or f32) else torch.float16)
         ctx.cfg = (stride, pad, relu, weight.shape[0], bias is not None)
+        ctx.params = (weight, bias)
         ctx.save_for_backward(x, weight, y if relu else None)
         return y
 
@@ -263,12 +342,22 @@ class ConvFn(torch.autograd.Function):
             dy = dy.to(x.dtype)
         dy = _pad_c(dy.contiguous())          # channel count -> multiple of 8 (padded channels carry zeros)
         Cw = dy.shape[3]
+        direct = ctx.pgm is None                  # the training step's protocol: gradients go straight into the flat buffer
+        wparam, bparam = ctx.params
         dbias = None
         if relu or has_bias:
-            dy, _, _, db = bn_train_bwd(dy, _pad_c(y) if relu else None, None, None, None, None, relu=relu, grad_mult=ctx.pgm)
+            sb = grad_slot(bparam) if (direct and has_bias) else None
+            dy, _, _, db = bn_train_bwd(dy, _pad_c(y) if relu else None, None, None, None, None, relu=relu, grad_mult=ctx.pgm,
+                                        into=(None, sb) if sb is not None and sb.numel() == Cw else None)
             dbias = db[:Cout] if has_bias else None
-        dw = conv_wgrad(x, dy, Cw, R, S, stride, pad, scale=ctx.pgm)[:Cout]
-        dwt = _wgrad_to_oihw(dw, Cout, Cin, x.shape[3], R, S)
+            if sb is not None and sb.numel() == Cw:
+                grad_done(bparam)
+                dbias = None
+        if direct and wgrad_to_param(wparam, x, dy, Cw, R, S, stride, pad, R * S, x.shape[3]):
+            dwt = None
+        else:
+            dw = conv_wgrad(x, dy, Cw, R, S, stride, pad, scale=ctx.pgm)[:Cout]
+            dwt = _wgrad_to_oihw(dw, Cout, Cin, x.shape[3], R, S)
         dx = None
         if ctx.needs_input_grad[0]:
             wpad = weight if Cw == Cout else torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
@@ -366,15 +455,26 @@ class BNActFn(torch.autograd.Function):
         z, mean, invstd, scale = bn_train_fwd(y, gamma.detach(), beta.detach(), running_mean, running_var, eps, momentum,
                                               res=res, relu=relu)
         ctx.relu, ctx.has_res = relu, res is not None
+        ctx.params = (gamma, beta)
         ctx.save_for_backward(y, z, mean, invstd, scale)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         y, z, mean, invstd, scale = ctx.saved_tensors
+        gamma, beta = ctx.params
+        sg, sb = grad_slot(gamma), grad_slot(beta)
+        if sg is not None and sg.numel() != y.shape[3]:
+            sg = None
+        if sb is not None and sb.numel() != y.shape[3]:
+            sb = None
         dy, dres, dgamma, dbeta = bn_train_bwd(dz.contiguous(), z, y, mean, invstd, scale, relu=ctx.relu,
-                                               want_dres=ctx.has_res)
-        return dy, dgamma, dbeta, dres, None, None, None, None, None
+                                               want_dres=ctx.has_res, into=(sg, sb))
+        if sg is not None:
+            grad_done(gamma)
+        if sb is not None:
+            grad_done(beta)
+        return dy, None if sg is not None else dgamma, None if sb is not None else dbeta, dres, None, None, None, None, None
 
 
 class MaxPoolFn(torch.autograd.Function):
@@ -459,6 +559,7 @@ class DeformConvFn(torch.autograd.Function):
         om = ops.conv2d(x, p_off, out_dtype=torch.float32)
         p = ops.PackedConv(weight.detach(), None, bias, stride=1, pad=1, compute=comp, cout_align=None if f32 else 64)
         y = ops.dcnv2(x, om, p)
+        ctx.params = (w_off, b_off, weight, bias)
         ctx.save_for_backward(x, om, w_off, weight)
         return y
 
@@ -475,29 +576,42 @@ class DeformConvFn(torch.autograd.Function):
         wmat = weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
         if dyp.shape[3] != Cout:
             wmat = torch.nn.functional.pad(wmat, (0, 0, 0, 0, 0, 0, 0, dyp.shape[3] - Cout))
-        _, _, _, dbias = bn_train_bwd(dyp, None, None, None, None, None, relu=False)
-        dw = conv_wgrad(col, dyp, dyp.shape[3], 1, 1, 1, 0)[:Cout]
-        dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        p_woff, p_boff, p_w, p_b = ctx.params
+        sb = grad_slot(p_b) if p_b is not None else None
+        if sb is not None and sb.numel() != dyp.shape[3]:
+            sb = None
+        _, _, _, dbias = bn_train_bwd(dyp, None, None, None, None, None, relu=False, into=(None, sb))
+        if wgrad_to_param(p_w, col, dyp, dyp.shape[3], 1, 1, 1, 0, 9, Cin):   # k = tap*Cin + c of the columns
+            dwt = None
+        else:
+            dw = conv_wgrad(col, dyp, dyp.shape[3], 1, 1, 1, 0)[:Cout]
+            dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        if sb is not None:
+            grad_done(p_b)
         dcol = conv_dgrad(dyp, wmat, 1, 0, x.shape[1:3])
-        dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om)
-        # ---- offset / mask conv: bias and weight gradients from dom; its input gradient lands on top of dx32
-        dom_t = dom if x.dtype == torch.float32 else dom.to(x.dtype)      # [M, 28] (27 used + a zero pad channel)
+        # dom comes back in the data type and channel padding the offset conv's backward kernels take (f16: 32 channels)
         n_om = w_off.shape[0]
-        _, _, _, db_off = bn_train_bwd(_pad_c(dom_t), None, None, None, None, None, relu=False)
-        dw_off = conv_wgrad(x, _pad_c(dom_t), _pad_c(dom_t).shape[3], 3, 3, 1, 1)[:n_om]
-        dw_off_t = _wgrad_to_oihw(dw_off, n_om, Cin, x.shape[3], 3, 3)
-        Cw = _pad_c(dom_t).shape[3]
+        f32 = x.dtype == torch.float32
+        dx32, dom_p = dcn_col2im_coord(dcol.contiguous(), x, om, dom_channels=(n_om + 3) // 4 * 4 if f32 else (n_om + 7) // 8 * 8)
+        # ---- offset / mask conv: bias and weight gradients from dom; its input gradient lands on top of dx32
+        Cw = dom_p.shape[3]
+        _, _, _, db_off = bn_train_bwd(dom_p, None, None, None, None, None, relu=False)
+        if wgrad_to_param(p_woff, x, dom_p, Cw, 3, 3, 1, 1, 9, x.shape[3]):
+            dw_off_t = None
+        else:
+            dw_off = conv_wgrad(x, dom_p, Cw, 3, 3, 1, 1)[:n_om]
+            dw_off_t = _wgrad_to_oihw(dw_off, n_om, Cin, x.shape[3], 3, 3)
         wpad = torch.nn.functional.pad(w_off.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - n_om)) if Cw != n_om else w_off.detach()
-        if x.dtype == torch.float32:
+        if f32:
             wt = wpad.flip(2, 3).permute(1, 0, 2, 3).contiguous()
             pt = ops.PackedConv(wt, None, None, stride=1, pad=1, compute=F32)
         else:
             pt = ops.PackedConv(wpad, None, None, stride=1, pad=1, compute=F16, transposed=True)
-        dx = ops.conv2d(_pad_c(dom_t), pt, out=dx32 if pt.Cout_eff == Cin else None, residual=dx32 if pt.Cout_eff == Cin else None,
+        dx = ops.conv2d(dom_p, pt, out=dx32 if pt.Cout_eff == Cin else None, residual=dx32 if pt.Cout_eff == Cin else None,
                         out_dtype=torch.float32)
         if pt.Cout_eff != Cin:
             dx = dx[..., :Cin] + dx32
-        return dx.to(x.dtype), dw_off_t, db_off[:n_om], dwt, dbias[:Cout]
+        return dx.to(x.dtype), dw_off_t, db_off[:n_om], dwt, None if sb is not None else dbias[:Cout]
 
 
 class FocalLossFn(torch.autograd.Function):

@@ -55,6 +55,7 @@ class FlatSGD:
             self.flat_param[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + n].view_as(p.data)
             p.grad = self.flat_grad[off:off + n].view_as(p.data)
+            p._ctdet_flat_grad = p.grad      # ops_train.grad_slot: backward kernels accumulate here directly
             if self.runs and self.runs[-1][2] == lf and self.runs[-1][3] == wd:
                 self.runs[-1][1] = off + n
             else:
@@ -88,10 +89,12 @@ class FlatSGD:
     def zero_grad(self):
         self.flat_grad.zero_()
         if self._arena is not None:       # the weight-gradient accumulators of this backward pass: one fill for all of them
+            from .. import ops_train
+            ops_train.PENDING.clear()     # leftovers of a backward pass that raised
             self._arena.begin_step()
         for p, (off, n) in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
-                p.grad = self.flat_grad[off:off + n].view_as(p.data)
+                p.grad = p._ctdet_flat_grad = self.flat_grad[off:off + n].view_as(p.data)
 
     def step(self):
         ops.sgd_momentum_runs_(self.flat_param, self.flat_grad, self.flat_mom, self._run_end, self._run_lr_index,

@@ -246,6 +246,17 @@ int32_t ctdet_bn_train_bwd(const void* dz, int32_t dz_stride, const void* z, int
 /* weight gradient of a conv: dw f32 [Cout][R*S*Cin] (tap-major k) += scale * sum over pixels; dw must be zeroed by
  * the caller.  Geometry from the descriptor (out_stride = pixel stride of dy; compute_dtype = dtype of x and dy). */
 int32_t ctdet_conv_wgrad(const ctdet_conv_desc* d, const void* x, const void* dy, float* dw, float scale, void* stream);
+/* The same sums accumulated in the PARAMETER's layout: with k = tap*cin_k + c (taps*cin_k = R*S*Cin of the descriptor),
+ * dw[(n*cin_real + c)*taps + tap] += scale * sum, channels c >= cin_real and rows n >= cout_real (the channel padding of x
+ * and dy) dropped -- dw can be the OIHW weight's slice of an optimizer's flat gradient buffer, so no permute / add kernels follow the weight gradient.
+ * A 3x3 conv: taps = 9, cin_k = Cin; DCNv2's weight gradient as a 1x1 conv over the columns [M][9*Cin]: taps = 9, cin_k = Cin. */
+int32_t ctdet_conv_wgrad_oihw(const ctdet_conv_desc* d, const void* x, const void* dy, float* dw, float scale, int32_t taps,
+                              int32_t cin_k, int32_t cin_real, int32_t cout_real, void* stream);
+/* n finished tap-major weight gradients (ctdet_conv_wgrad's layout, [cout][taps][cin_k] f32) added into their parameters'
+ * OIHW gradients in one launch per 24 tensors: dst[i][(o*cin_real + c)*taps + t] += src[i][(o*taps + t)*cin_k + c].
+ * The six arrays are HOST arrays of length n (device pointers in src / dst). */
+int32_t ctdet_grad_scatter_oihw(const void* const* src, void* const* dst, const int32_t* cout, const int32_t* cin_real,
+                                const int32_t* cin_k, const int32_t* taps, int32_t n, void* stream);
 /* Interleave of the four output phases of a stride-2 3x3 conv's input gradient (f16 NHWC):
  * dst[b,y,x,c] = src[b,(y+1)/2,(x+1)/2,((y&1)*2+(x&1))*C + c]; src is the [B,Hs,Ws,>=4C] result of the 2x2 "phase" conv
  * over dY (ops_train.conv_dgrad), dst the [B,H,W,C] gradient (C % 8 == 0). */
@@ -259,13 +270,15 @@ int32_t ctdet_dwconvT_bwd(const void* x, int32_t x_stride, const void* dz, int32
                           int32_t dtype, void* stream);
 /* DCNv2 3x3/s1/p1 training pieces: columns [M][9*Cin] f16 (= modulated_deformable_im2col, kernel.cu:786-868) and the
  * backward through the sampler (col2im :871-949 + coordinate/mask gradients :952-1066): dcol [M][9*Cin] f16 ->
- * dx f32 dense [B*H*W][Cin] (+= atomics, zeroed by the caller), dom f32 [M][om_stride] (offset and mask-logit grads).
+ * dx f32 dense [B*H*W][Cin] (+= atomics, zeroed by the caller), dom [M][dom_stride] f32 or (f16 data only) f16: offset and
+ * mask-logit gradients in channels 0..26, zeros in the padding channels 27..dom_stride-1 -- every element is written, the
+ * caller does not clear it (a 32-channel f16 dom is directly the dY of the offset conv's backward).
  * mask_is_prob: channels 18..26 of om are sigmoid-ed masks (the reference's functional API) and dom carries d/d(mask). */
 int32_t ctdet_dcn_cols(const void* x, int32_t x_stride, const float* om, int32_t om_stride, void* col, int32_t B,
                        int32_t H, int32_t W, int32_t Cin, int32_t mask_is_prob, int32_t dtype, void* stream);
 int32_t ctdet_dcn_col2im_coord(const void* dcol, const void* x, int32_t x_stride, const float* om, int32_t om_stride,
-                               float* dx, float* dom, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t mask_is_prob,
-                               int32_t dtype, void* stream);
+                               float* dx, void* dom, int32_t dom_stride, int32_t dom_dtype, int32_t B, int32_t H, int32_t W,
+                               int32_t Cin, int32_t mask_is_prob, int32_t dtype, void* stream);
 
 /* ---- data-parallel exchange over RCCL / xGMI (one process per GPU) ---------------------------------------------
  * What DistributedDataParallel's reducer does over NCCL in the reference (detectron2/engine/defaults.py:279-285,
