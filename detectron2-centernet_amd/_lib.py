@@ -39,6 +39,7 @@ SIGNATURES = {
     "ctdet_global_avgpool": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ctdet_ese_scale": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_pack_weights": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_pack_weights_batch": (_i32, [_vp, _i32, _i32, _vp]),
     "ctdet_dwconvT_add": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_decode_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "ctdet_decode": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -97,6 +98,12 @@ def check(rc, what):
     if rc != 0:
         msg = lib().ctdet_last_error()
         raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+class PackDesc(C.Structure):
+    """mirrors ctdet_pack_desc"""
+    _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p)] + [(n, C.c_int32) for n in (
+        "O", "I", "R", "S", "chans_pad", "rows_pad", "Kpad", "korder", "transposed", "blk0")]
 
 
 class DlaBaseDesc(C.Structure):

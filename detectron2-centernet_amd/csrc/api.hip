@@ -52,6 +52,7 @@ struct WgradArgs {
   int perm_rs, perm_cin, cin_real, cout_real;
 };
 int launch_grad_scatter_oihw(const void* const*, void* const*, const int*, const int*, const int*, const int*, int, hipStream_t);
+int launch_pack_weights_batch(const void*, int, int, hipStream_t);
 size_t chan_reduce_workspace_bytes(int C);
 int launch_bn_train_fwd(const f16*, int, const f16*, int, f16*, int, int, int, const float*, const float*, float, float,
                         float*, float*, float*, float*, float*, float*, void*, int, hipStream_t);
@@ -278,6 +279,12 @@ int32_t ctdet_pack_weights(const float* w, void* packed, int32_t O, int32_t I, i
                            int32_t rows_pad, int32_t Kpad, int32_t korder, int32_t transposed, void* stream) {
   CTDET_CHECK(w && packed, "pack_weights: null pointer");
   return launch_pack_weights(w, packed, O, I, R, S, chans_pad, rows_pad, Kpad, korder, transposed, (hipStream_t)stream);
+}
+
+int32_t ctdet_pack_weights_batch(const ctdet_pack_desc* table_dev, int32_t n, int32_t total_blocks, void* stream) {
+  CTDET_CHECK(n >= 0 && total_blocks >= 0 && (n == 0 || table_dev), "pack_weights_batch: bad arguments");
+  static_assert(sizeof(ctdet_pack_desc) == 56, "ctdet_pack_desc layout");
+  return launch_pack_weights_batch(table_dev, n, total_blocks, (hipStream_t)stream);
 }
 
 int32_t ctdet_dwconvT_add(const void* x, const float* w, const void* skip, void* y, int32_t dtype, int32_t B,

@@ -402,6 +402,43 @@ int launch_ese_scale(const void* x, int x_stride, const float* sc, const void* i
   return 0;
 }
 
+// All conv weights of a model in one launch (training: every weight changes every step -- ~160 pack launches of a few
+// microseconds each otherwise).  The descriptor table lives in device memory; blk0 is the running block count.
+struct PackDesc {
+  const float* w; f16* out;
+  int O, I, R, S, chans_pad, rows_pad, Kpad, korder, transposed, blk0;
+};
+__global__ void __launch_bounds__(256) pack_weights_batch_kernel(const PackDesc* __restrict__ table, int n) {
+  int lo = 0, hi = n - 1;                         // last descriptor with blk0 <= blockIdx.x (block-uniform)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = table[lo];
+  const long idx = (long)((int)blockIdx.x - d.blk0) * 256 + threadIdx.x;
+  if (idx >= (long)d.rows_pad * d.Kpad) return;
+  const int rows = d.transposed ? d.I : d.O, chans = d.transposed ? d.O : d.I;
+  const int row = (int)(idx / d.Kpad), k = (int)(idx % d.Kpad);
+  const int RS = d.R * d.S;
+  int tap, c;
+  if (d.korder == 0) { tap = k / d.chans_pad; c = k - tap * d.chans_pad; }
+  else { const int chunk = k / (RS * 32), rem = k - chunk * (RS * 32); tap = rem >> 5; c = chunk * 32 + (rem & 31); }
+  float v = 0.f;
+  if (row < rows && tap < RS && c < chans) {
+    const int r = tap / d.S, s2 = tap - r * d.S;
+    if (!d.transposed) v = d.w[(((long)row * d.I + c) * d.R + r) * d.S + s2];
+    else v = d.w[(((long)c * d.I + row) * d.R + (d.R - 1 - r)) * d.S + (d.S - 1 - s2)];
+  }
+  d.out[idx] = (f16)v;
+}
+
+int launch_pack_weights_batch(const void* table_dev, int n, int total_blocks, hipStream_t s) {
+  if (n == 0 || total_blocks == 0) return 0;
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(total_blocks), dim3(256), 0, s, (const PackDesc*)table_dev, n);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_pack_weights(const float* w, void* out, int O, int I, int R, int S, int chans_pad, int rows_pad, int Kpad,
                         int korder, int transposed, hipStream_t s) {
   const int rows = transposed ? I : O, chans = transposed ? O : I;

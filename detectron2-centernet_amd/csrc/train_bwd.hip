@@ -326,6 +326,10 @@ struct WgradArgs {
 template <typename A>
 __device__ __forceinline__ void wg_add(const A& a, int n, int k, float v) {
   if (a.perm_rs == 0) { atomicAdd(a.dw + (long)n * a.K + k, v); return; }
+  if (a.perm_rs == 1) {   // 1x1: the parameter's layout is the kernel's, minus the channel padding
+    if (k < a.cin_real && n < a.cout_real) atomicAdd(a.dw + (long)n * a.cin_real + k, v);
+    return;
+  }
   const int tap = k / a.perm_cin, c = k - tap * a.perm_cin;
   if (c < a.cin_real && n < a.cout_real) atomicAdd(a.dw + ((long)n * a.cin_real + c) * a.perm_rs + tap, v);
 }

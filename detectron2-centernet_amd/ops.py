@@ -160,6 +160,57 @@ def round_up(a, b):
     return (a + b - 1) // b * b
 
 
+class PackPlan:
+    """The f16 operands of every conv weight a training step packs (forward and input-gradient forms), kept in persistent
+    buffers and refreshed by ONE kernel after the optimizer update (`run()`, called by solver.FlatSGD.step) instead of one
+    pack launch per layer, direction and step.  An entry is valid while the weight's version counter still has the value
+    `run()` (or the recording pack) saw; a stale or unknown weight is packed on the spot as before and (re)recorded."""
+
+    def __init__(self, flat_param):
+        """flat_param: the optimizer's parameter buffer -- only weights that live inside it are planned (their address is
+        stable and their version counter is the parameter's; a temporary could reuse an address with a fresh counter)"""
+        self.lo = flat_param.data_ptr()
+        self.hi = self.lo + flat_param.numel() * flat_param.element_size()
+        self.entries = {}        # key -> [weight, packed, args, version]
+        self.table = None        # device descriptor table, rebuilt when the set of entries changes
+        self.blocks = 0
+
+    def covers(self, weight):
+        return self.lo <= weight.data_ptr() < self.hi
+
+    def lookup(self, key, weight):
+        e = self.entries.get(key)
+        if e is not None and e[3] == weight._version:
+            return e[1]
+        return None
+
+    def record(self, key, weight, packed, args):
+        self.entries[key] = [weight, packed, args, weight._version]
+        self.table = None
+
+    def run(self):
+        if not self.entries:
+            return
+        es = list(self.entries.values())
+        if self.table is None:
+            arr = (_lib.PackDesc * len(es))()
+            blk = 0
+            for d, (w, wp, a, _) in zip(arr, es):
+                d.w, d.packed = w.data_ptr(), wp.data_ptr()
+                d.O, d.I, d.R, d.S, d.chans_pad, d.rows_pad, d.Kpad, d.korder, d.transposed = a
+                d.blk0 = blk
+                blk += (d.rows_pad * d.Kpad + 255) // 256
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.table, self.blocks = raw.to(es[0][1].device), blk
+        _lib.check(_lib.lib().ctdet_pack_weights_batch(_ptr(self.table), len(es), self.blocks, _stream()),
+                   "ctdet_pack_weights_batch")
+        for e in es:
+            e[3] = e[0]._version
+
+
+PACK_PLAN = None    # set by solver.FlatSGD on a GPU; None: every PackedConv packs for itself
+
+
 class PackedConv:
     """Weights of one conv-shaped contraction, packed for the kernels, plus its folded epilogue.
 
@@ -197,11 +248,16 @@ class PackedConv:
             tile = max(_lib.lib().ctdet_conv_cout_tile(self.Cout_eff), cout_align or 1)
             self.Kpad = round_up(K, 32)
             self.Cout_pad = round_up(self.Cout_eff, tile)
-            wp = torch.empty(self.Cout_pad, self.Kpad, dtype=torch.float16, device=dev)
             O, I = weight.shape[0], weight.shape[1]
-            rc = _lib.lib().ctdet_pack_weights(_ptr(weight.detach()), _ptr(wp), O, I, R, S, self.Cin, self.Cout_pad,
-                                               self.Kpad, self.korder, int(transposed), _stream())
-            _lib.check(rc, "ctdet_pack_weights")
+            args = (O, I, R, S, self.Cin, self.Cout_pad, self.Kpad, self.korder, int(transposed))
+            plan = PACK_PLAN if (PACK_PLAN is not None and PACK_PLAN.covers(weight)) else None
+            wp = plan.lookup(args + (weight.data_ptr(),), weight) if plan is not None else None
+            if wp is None:
+                wp = torch.empty(self.Cout_pad, self.Kpad, dtype=torch.float16, device=dev)
+                rc = _lib.lib().ctdet_pack_weights(_ptr(weight.detach()), _ptr(wp), *args, _stream())
+                _lib.check(rc, "ctdet_pack_weights")
+                if plan is not None:
+                    plan.record(args + (weight.data_ptr(),), weight, wp, args)
             self.w = wp
             self.scale = self._pad_vec(scale, 1.0, dev)
             self.bias = self._pad_vec(bias, 0.0, dev)

@@ -72,10 +72,11 @@ class FlatSGD:
         self.set_lr_factor(1.0)
         # zero-initialised scratch for the atomically accumulated weight gradients (ops_train.ZeroArena): a little larger
         # than the parameter count (channel padding), cleared together with the gradient buffer
-        self._arena = None
+        self._arena = self._packs = None
         if torch.device(device).type == "cuda":
             from .. import ops_train
             self._arena = ops_train.ARENA = ops_train.ZeroArena(int(total * 1.25) + (1 << 20), torch.device(device))
+            self._packs = ops.PACK_PLAN = ops.PackPlan(self.flat_param)
 
     def set_lr_factor(self, f):
         self._sched_factor = float(f)
@@ -102,6 +103,8 @@ class FlatSGD:
         self._first = False
         for p in self.params:  # raw-pointer update: tell autograd / the packed-weight caches the values changed
             torch.autograd.graph.increment_version(p)
+        if self._packs is not None:   # the f16 operands of every conv weight the last step used, in one launch
+            self._packs.run()
 
     def state_dict(self):
         return {"momentum": self.flat_mom.clone(), "first": self._first}

@@ -153,6 +153,14 @@ int32_t ctdet_ese_scale(const void* x, int32_t x_stride, const float* s, const v
  * flipped), i.e. dX = conv(dY, packed) -- what autograd of nn.Conv2d computes. */
 int32_t ctdet_pack_weights(const float* w, void* packed, int32_t O, int32_t I, int32_t R, int32_t S, int32_t chans_pad,
                            int32_t rows_pad, int32_t Kpad, int32_t korder, int32_t transposed, void* stream);
+/* n packs in one launch: a DEVICE table of descriptors with the arguments of ctdet_pack_weights; blk0 = number of
+ * 256-thread blocks of the descriptors before it (ceil(rows_pad*Kpad / 256) each), total_blocks their sum.  A training step
+ * re-packs every weight after the optimizer update with this call instead of one launch per layer and direction. */
+typedef struct ctdet_pack_desc {
+  const float* w; void* packed;
+  int32_t O, I, R, S, chans_pad, rows_pad, Kpad, korder, transposed, blk0;
+} ctdet_pack_desc;
+int32_t ctdet_pack_weights_batch(const ctdet_pack_desc* table_dev, int32_t n, int32_t total_blocks, void* stream);
 
 /* y = ConvTranspose2d(C, C, 2f, stride=f, padding=f/2, groups=C, bias=False)(x) + skip  (dla.py:162-177).
  * w is f32 [2f][2f][C] (the ConvTranspose2d weight [C,1,2f,2f] with the channel dim moved last); skip may be NULL. */

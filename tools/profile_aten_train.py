@@ -1,5 +1,5 @@
-"""Which Python lines launch the ATen kernels of one eager training step: python tools/profile_aten_train.py
-(torch.profiler with stacks; prints per ATen operator the source lines under detectron2_centernet_amd that called it)."""
+"""ATen kernels left in one eager training step: python tools/profile_aten_train.py
+(torch.profiler totals per operator, then the python call sites counted by wrapping the tensor constructors / casts)."""
 import collections
 import os
 import sys
@@ -21,6 +21,18 @@ batch = synthetic_batch(16, 512, 0, dev)
 for _ in range(3):
     trainer.run_step_tensors(*batch)
 torch.cuda.synchronize()
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    trainer.run_step_tensors(*batch)
+    torch.cuda.synchronize()
+rows = [(getattr(ev, "self_device_time_total", 0) or 0, ev.count, ev.key) for ev in prof.key_averages()]
+rows = sorted(r for r in rows if r[0] > 0 and r[2].startswith("aten::"))[::-1]
+print(f"ATen device time in one eager step: {sum(r[0] for r in rows) / 1000:.2f} ms over {sum(r[1] for r in rows)} operator calls")
+for t, n, k in rows[:12]:
+    print(f"{t / 1000:7.3f} ms {n:4d}x  {k}")
+print("python call sites that launch them (forward and custom backward functions; autograd's own accumulation is not listed):")
+
 import traceback  # noqa: E402
 
 sites = collections.Counter()
