@@ -75,7 +75,7 @@ int launch_depth_to_space2(const f16*, int, f16*, int, int, int, int, int, int, 
 int launch_dwconvT_bwd(const f16*, int, const f16*, int, const float*, f16*, int, float*, int, int, int, int, int,
                        hipStream_t);
 int launch_dcn_cols(const f16*, int, const float*, int, f16*, int, int, int, int, int, hipStream_t);
-int launch_dcn_col2im_coord(const f16*, const f16*, int, const float*, int, float*, void*, int, int, int, int, int, int, int,
+int launch_dcn_col2im_coord(const f16*, const f16*, int, const float*, int, float*, void*, int, int, int, int, int, int, int, int,
                             hipStream_t);
 
 static int fill_args(const ctdet_conv_desc* d, ConvArgs& a) {
@@ -467,15 +467,16 @@ int32_t ctdet_dcn_cols(const void* x, int32_t x_stride, const float* om, int32_t
 
 int32_t ctdet_dcn_col2im_coord(const void* dcol, const void* x, int32_t x_stride, const float* om, int32_t om_stride,
                                float* dx, void* dom, int32_t dom_stride, int32_t dom_dtype, int32_t B, int32_t H, int32_t W,
-                               int32_t Cin, int32_t mask_is_prob, int32_t dtype, void* stream) {
+                               int32_t Cin, int32_t mask_is_prob, int32_t dcol_chunked, int32_t dtype, void* stream) {
   CTDET_CHECK(dcol && x && om && dx && dom, "dcn_col2im_coord: null pointer");
   CTDET_CHECK(dom_dtype == CTDET_DT_F32 || (dom_dtype == CTDET_DT_F16 && dtype == CTDET_DT_F16),
               "dcn_col2im_coord: dom dtype %d with data dtype %d", dom_dtype, dtype);
+  CTDET_CHECK(!dcol_chunked || dtype == CTDET_DT_F16, "dcn_col2im_coord: the chunked dcol layout is an f16 layout");
   if (dtype == CTDET_DT_F32)
     return launch_dcn_col2im_coord_f32((const float*)dcol, (const float*)x, x_stride, om, om_stride, dx, (float*)dom, dom_stride,
                                        B, H, W, Cin, mask_is_prob, (hipStream_t)stream);
   return launch_dcn_col2im_coord((const f16*)dcol, (const f16*)x, x_stride, om, om_stride, dx, dom, dom_stride,
-                                 dom_dtype == CTDET_DT_F16, B, H, W, Cin, mask_is_prob, (hipStream_t)stream);
+                                 dom_dtype == CTDET_DT_F16, B, H, W, Cin, mask_is_prob, dcol_chunked, (hipStream_t)stream);
 }
 
 int32_t ctdet_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, const float* lr_dev,

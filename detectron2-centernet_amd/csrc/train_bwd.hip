@@ -667,7 +667,8 @@ __global__ void __launch_bounds__(256) dcn_cols_kernel(const f16* __restrict__ x
 __global__ void __launch_bounds__(256) dcn_col2im_coord_kernel(const f16* __restrict__ dcol, const f16* __restrict__ x,
                                                                int x_stride, const float* __restrict__ om, int om_stride,
                                                                float* __restrict__ dx, void* __restrict__ dom, int dom_stride,
-                                                               int dom_f16, int B, int H, int W, int Cin, int mask_is_prob) {
+                                                               int dom_f16, int B, int H, int W, int Cin, int mask_is_prob,
+                                                               int chunked) {
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long nwork = (long)B * H * W * 9;
@@ -680,9 +681,10 @@ __global__ void __launch_bounds__(256) dcn_col2im_coord_kernel(const f16* __rest
     const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride, mask_is_prob);  // wave-uniform
     float val_dot = 0.f, dh = 0.f, dwv = 0.f;
     if (g.inside) {
-      const f16* dcp = dcol + m * (9L * Cin) + (long)tap * Cin;
+      // dcol row of a pixel: [tap][Cin], or chunked [Cin/32][tap][32]
+      const f16* dcp = dcol + m * (9L * Cin) + (chunked ? tap * 32 : tap * Cin);
       for (int c = lane; c < Cin; c += 64) {
-        const float d = (float)dcp[c];
+        const float d = (float)dcp[chunked ? (c >> 5) * 288 + (c & 31) : c];
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = g.off[q] >= 0 ? (float)x[g.off[q] + c] : 0.f;
@@ -730,7 +732,8 @@ struct ColGeo {        // staged per (pixel, tap): 32 bytes
 __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __restrict__ dcol, const f16* __restrict__ x,
                                                                 int x_stride, const float* __restrict__ om, int om_stride,
                                                                 float* __restrict__ dx, void* __restrict__ dom, int dom_stride,
-                                                                int dom_f16, int B, int H, int W, int Cin, int mask_is_prob) {
+                                                                int dom_f16, int B, int H, int W, int Cin, int mask_is_prob,
+                                                                int chunked) {
   constexpr int TH = 8, TW = 16, MG = 4, WR = TH + 2 + 2 * MG, WC = TW + 2 + 2 * MG, NPX = WR * WC;  // 18 x 26 = 468
   // d(input) window, int32 fixed point, laid out [e = channel % 8][window pixel][q = channel / 8]: the 64 lanes (16
   // pixels x 4 groups) of one ds_add then touch 64 consecutive words
@@ -780,11 +783,13 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
   for (int chunk = 0; chunk < nch; ++chunk) {
     // ---- this lane's dcol vectors of the chunk, and the tile's largest magnitude (fixed-point scale) ----
     f16x8 dv[9];
-    const f16* dcp = dcol + m * (9L * Cin) + chunk * 32 + q * 8;
+    // chunked dcol ([Cin/32][tap][32] per pixel): the nine 64-byte pieces of this chunk are one contiguous 576-byte run
+    const f16* dcp = dcol + m * (9L * Cin) + (chunked ? chunk * 288 : chunk * 32) + q * 8;
+    const int tstep = chunked ? 32 : Cin;
     float amax = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      dv[t] = *(const f16x8*)(dcp + (long)t * Cin);
+      dv[t] = *(const f16x8*)(dcp + t * tstep);
 #pragma unroll
       for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)dv[t][e]));
     }
@@ -1428,21 +1433,23 @@ int launch_dcn_cols(const f16* x, int x_stride, const float* om, int om_stride, 
 }
 
 int launch_dcn_col2im_coord(const f16* dcol, const f16* x, int x_stride, const float* om, int om_stride, float* dx,
-                            void* dom, int dom_stride, int dom_f16, int B, int H, int W, int Cin, int mask_is_prob, hipStream_t s) {
+                            void* dom, int dom_stride, int dom_f16, int B, int H, int W, int Cin, int mask_is_prob, int chunked,
+                            hipStream_t s) {
   CTDET_CHECK(dom_stride >= 27 && dom_stride <= 64, "dcn_col2im: dom_stride=%d", dom_stride);
+  CTDET_CHECK(!chunked || Cin % 32 == 0, "dcn_col2im: the chunked dcol layout needs Cin %% 32 == 0 (Cin=%d)", Cin);
   CTDET_CHECK(Cin % 8 == 0, "dcn_col2im: Cin=%d must be a multiple of 8", Cin);
   const long nwork = (long)B * H * W * 9;
   if (nwork == 0) return 0;
   if (H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && x_stride % 8 == 0 && !(ctdet_tuning_flags() & CTDET_TUNE_NO_COL2IM_WINDOW)) {
     hipLaunchKernelGGL(dcn_col2im_window_kernel, dim3((unsigned)(B * (H / 8) * (W / 16))), dim3(512), 0, s, dcol, x, x_stride,
-                       om, om_stride, dx, dom, dom_stride, dom_f16, B, H, W, Cin, mask_is_prob);
+                       om, om_stride, dx, dom, dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
     CTDET_LAUNCH_CHECK();
     return 0;
   }
   long nb = (nwork + 3) / 4;
   if (nb > 256 * 32) nb = 256 * 32;
   hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3((unsigned)nb), dim3(256), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
-                     dom_stride, dom_f16, B, H, W, Cin, mask_is_prob);
+                     dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
   CTDET_LAUNCH_CHECK();
   return 0;
 }

@@ -221,7 +221,21 @@ def dcn_cols(x, om, mask_is_prob=False):
     return col
 
 
-def dcn_col2im_coord(dcol, x, om, mask_is_prob=False, dom_channels=None):
+def dcn_weight_matrix(weight, Cw=None, chunked=False):
+    """[Cw, 9*Cin, 1, 1] matrix W with d(columns) = dY . W: column index tap*Cin + c, or chunked (c/32)*288 + tap*32 + c%32 --
+    the layout dcn_col2im_coord(dcol_chunked=True) reads in contiguous runs"""
+    Cout, Cin = weight.shape[:2]
+    w = weight.detach()
+    if chunked:
+        wmat = w.reshape(Cout, Cin // 32, 32, 9).permute(0, 1, 3, 2).reshape(Cout, 9 * Cin, 1, 1)
+    else:
+        wmat = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
+    if Cw is not None and Cw != Cout:
+        wmat = torch.nn.functional.pad(wmat, (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
+    return wmat
+
+
+def dcn_col2im_coord(dcol, x, om, mask_is_prob=False, dom_channels=None, dcol_chunked=False):
     """dx (f32, atomically accumulated) and dom = d(offsets, mask logits).  dom_channels=None: f32, the shape of om;
     dom_channels=C (f16 data): an f16 [B, H, W, C] tensor whose channels 27.. are zero -- directly the dY of the offset conv's
     backward, without a cast or a channel pad in between"""
@@ -233,8 +247,8 @@ def dcn_col2im_coord(dcol, x, om, mask_is_prob=False, dom_channels=None):
         dom = torch.empty(B, H, W, dom_channels, dtype=torch.float16, device=x.device)
     with ops.prof_region("dcn_col2im", flops=0.0, nbytes=float(B * H * W * Cin * (18 + 2 + 4) + B * H * W * 27 * 8)):
         rc = _lib.lib().ctdet_dcn_col2im_coord(_ptr(dcol), _ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(dx),
-                                               _ptr(dom), dom.shape[3], dt_of(dom), B, H, W, Cin, int(mask_is_prob), dt_of(x),
-                                               _stream())
+                                               _ptr(dom), dom.shape[3], dt_of(dom), B, H, W, Cin, int(mask_is_prob),
+                                               int(dcol_chunked), dt_of(x), _stream())
     _lib.check(rc, "ctdet_dcn_col2im_coord")
     return dx, dom
 
@@ -534,14 +548,13 @@ class DCNFn(torch.autograd.Function):
             dy = dy[..., :Cout].contiguous()
         dyp = _pad_c(dy)
         col = dcn_cols(x, om, ctx.mask_is_prob)
-        wmat = weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
-        if dyp.shape[3] != Cout:
-            wmat = torch.nn.functional.pad(wmat, (0, 0, 0, 0, 0, 0, 0, dyp.shape[3] - Cout))
+        chunked = x.dtype == torch.float16 and Cin % 32 == 0
+        wmat = dcn_weight_matrix(weight, dyp.shape[3], chunked)
         _, _, _, dbias = bn_train_bwd(dyp, None, None, None, None, None, relu=False, grad_mult=ctx.pgm)
         dw = conv_wgrad(col, dyp, dyp.shape[3], 1, 1, 1, 0, scale=ctx.pgm)[:Cout]         # [Cout, 9*Cin]
         dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
         dcol = conv_dgrad(dyp, wmat, 1, 0, x.shape[1:3])                   # [M, 9*Cin]
-        dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om, ctx.mask_is_prob)
+        dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om, ctx.mask_is_prob, dcol_chunked=chunked)
         return dx32.to(x.dtype), dom, dwt, dbias[:Cout] if ctx.has_bias else None, None, None
 
 
@@ -573,9 +586,8 @@ class DeformConvFn(torch.autograd.Function):
         dyp = _pad_c(dy if dy.shape[3] == Cout else dy[..., :Cout].contiguous())
         # ---- main conv: dW, d(columns) -> scatter (d input, f32) + d(offset / mask logits)
         col = dcn_cols(x, om)
-        wmat = weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
-        if dyp.shape[3] != Cout:
-            wmat = torch.nn.functional.pad(wmat, (0, 0, 0, 0, 0, 0, 0, dyp.shape[3] - Cout))
+        chunked = x.dtype == torch.float16 and Cin % 32 == 0
+        wmat = dcn_weight_matrix(weight, dyp.shape[3], chunked)
         p_woff, p_boff, p_w, p_b = ctx.params
         sb = grad_slot(p_b) if p_b is not None else None
         if sb is not None and sb.numel() != dyp.shape[3]:
@@ -592,7 +604,8 @@ class DeformConvFn(torch.autograd.Function):
         # dom comes back in the data type and channel padding the offset conv's backward kernels take (f16: 32 channels)
         n_om = w_off.shape[0]
         f32 = x.dtype == torch.float32
-        dx32, dom_p = dcn_col2im_coord(dcol.contiguous(), x, om, dom_channels=(n_om + 3) // 4 * 4 if f32 else (n_om + 7) // 8 * 8)
+        dx32, dom_p = dcn_col2im_coord(dcol.contiguous(), x, om, dom_channels=(n_om + 3) // 4 * 4 if f32 else (n_om + 7) // 8 * 8,
+                                       dcol_chunked=chunked)
         # ---- offset / mask conv: bias and weight gradients from dom; its input gradient lands on top of dx32
         Cw = dom_p.shape[3]
         _, _, _, db_off = bn_train_bwd(dom_p, None, None, None, None, None, relu=False)

@@ -281,12 +281,15 @@ int32_t ctdet_dwconvT_bwd(const void* x, int32_t x_stride, const void* dz, int32
  * dx f32 dense [B*H*W][Cin] (+= atomics, zeroed by the caller), dom [M][dom_stride] f32 or (f16 data only) f16: offset and
  * mask-logit gradients in channels 0..26, zeros in the padding channels 27..dom_stride-1 -- every element is written, the
  * caller does not clear it (a 32-channel f16 dom is directly the dY of the offset conv's backward).
+ * dcol_chunked (f16, Cin % 32 == 0): a pixel's dcol row is [Cin/32][9][32] instead of [9][Cin] -- the order the scatter
+ * kernel consumes it in (one contiguous 576-byte run per 32-channel chunk); the producer gets it by permuting the rows of the
+ * weight matrix of the d(columns) contraction.
  * mask_is_prob: channels 18..26 of om are sigmoid-ed masks (the reference's functional API) and dom carries d/d(mask). */
 int32_t ctdet_dcn_cols(const void* x, int32_t x_stride, const float* om, int32_t om_stride, void* col, int32_t B,
                        int32_t H, int32_t W, int32_t Cin, int32_t mask_is_prob, int32_t dtype, void* stream);
 int32_t ctdet_dcn_col2im_coord(const void* dcol, const void* x, int32_t x_stride, const float* om, int32_t om_stride,
                                float* dx, void* dom, int32_t dom_stride, int32_t dom_dtype, int32_t B, int32_t H, int32_t W,
-                               int32_t Cin, int32_t mask_is_prob, int32_t dtype, void* stream);
+                               int32_t Cin, int32_t mask_is_prob, int32_t dcol_chunked, int32_t dtype, void* stream);
 
 /* ---- data-parallel exchange over RCCL / xGMI (one process per GPU) ---------------------------------------------
  * What DistributedDataParallel's reducer does over NCCL in the reference (detectron2/engine/defaults.py:279-285,

@@ -234,6 +234,19 @@ def test_dcn_col2im_window_fixed_point_vs_atomics(T, dev, scale):
     assert mx > 0
     assert (dx_w - dx_a).abs().max().item() <= mx * 2.0 ** -15
     assert (dom_w - dom_a).abs().max().item() <= dom_a.abs().max().item() * 1e-4
+    # the chunked dcol layout ([Cin/32][tap][32] per pixel) carries the same numbers: both kernels, the same results (dx up to
+    # the order of the f32 atomics that join neighbouring tiles);
+    # dom as the padded f16 tensor the offset conv's backward takes: the f32 values rounded once, zeros in the padding
+    dcol_c = dcol.view(B, H, W, 9, Cin // 32, 32).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 9 * Cin).contiguous()
+    dx_c, dom_c = ot.dcn_col2im_coord(dcol_c, x, om, dcol_chunked=True)
+    assert (dx_c - dx_w).abs().max().item() <= mx * 1e-6 and torch.equal(dom_c, dom_w)
+    with _lib.tuning(_lib.TUNE_NO_COL2IM_WINDOW):
+        dx_ca, dom_ca = ot.dcn_col2im_coord(dcol_c, x, om, dcol_chunked=True)
+    assert (dx_ca - dx_a).abs().max().item() <= mx * 1e-6 and torch.equal(dom_ca, dom_a)
+    _, dom_h = ot.dcn_col2im_coord(dcol, x, om, dom_channels=32)
+    assert dom_h.dtype == torch.float16 and dom_h.shape[3] == 32 and dom_h[..., 27:].abs().max().item() == 0
+    if scale <= 1.0:
+        assert torch.equal(dom_h[..., :27], dom_w[..., :27].half())
 
 
 def test_conv_bias_relu_fn(T, dev):
