@@ -57,6 +57,7 @@ class BucketedReducer:
         if self.opt.flat_grad.is_cuda:      # weight gradients still waiting in tap-major form for this range (ops_train.PENDING)
             from .. import ops_train
             base = self.opt.flat_grad.data_ptr()
+            ops_train.SIDE.join()           # weight gradients still in flight on the side stream
             ops_train.flush_param_grads(base + 4 * s, base + 4 * e)
         if self.comm is not None:
             # RCCL through the C ABI: ordered after the gradients produced so far, on a side stream so that the rest of

@@ -9,6 +9,8 @@ parameter gradient, so `param.grad` and the returned loss values are unscaled.
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -156,6 +158,54 @@ def grad_done(p):
 PENDING = []   # (slot, tap-major dw, taps, cin_k): finished weight gradients not yet added to their OIHW slots
 
 
+class SideLane:
+    """A second HIP stream for the weight-gradient branch of backward.  dX of a layer feeds the next layer's backward, dW feeds
+    nothing until the optimizer: the weight-gradient kernels (one workgroup per CU, atomics-bound) run here next to the
+    dX / BatchNorm chain instead of in front of it.  Captured into the training step's HIP graph as a parallel branch.
+    Operands are kept referenced until `join()`: a tensor freed on the main stream could be handed out again there while
+    this stream still reads it."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("CTDET_TRAIN_SIDE_STREAM", "0") == "1"
+        self.stream, self.keep, self.active = None, [], False
+
+    def run(self, fn, *operands):
+        if not self.enabled:
+            return fn()
+        main = torch.cuda.current_stream()
+        if self.stream is None or self.stream.device != main.device:
+            self.stream = torch.cuda.Stream(device=main.device)
+        self.stream.wait_stream(main)
+        with torch.cuda.stream(self.stream):
+            out = fn()
+        self.keep.append(operands)
+        self.active = True
+        return out
+
+    def join(self):
+        if self.active:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.keep.clear()
+            self.active = False
+
+
+SIDE = SideLane()
+_END_QUEUED = [False]
+
+
+def _end_of_backward():
+    _END_QUEUED[0] = False
+    SIDE.join()
+    flush_param_grads()
+
+
+def _queue_end_of_backward():
+    """once per backward pass: join the side stream and flush the deferred weight gradients when the pass ends"""
+    if not _END_QUEUED[0]:
+        _END_QUEUED[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+
+
 def flush_param_grads(ptr_lo=None, ptr_hi=None):
     """adds the pending tap-major weight gradients (all, or those whose slot starts inside [ptr_lo, ptr_hi)) to the parameters'
     gradients, 24 tensors per launch.  Runs by itself when a backward pass ends (queued on the autograd engine by the first
@@ -163,6 +213,7 @@ def flush_param_grads(ptr_lo=None, ptr_hi=None):
     todo = [e for e in PENDING if ptr_lo is None or ptr_lo <= e[0].data_ptr() < ptr_hi]
     if not todo:
         return
+    SIDE.join()
     PENDING[:] = [e for e in PENDING if not (ptr_lo is None or ptr_lo <= e[0].data_ptr() < ptr_hi)]
     n = len(todo)
     vp, i32 = C.c_void_p * n, C.c_int32 * n
@@ -172,21 +223,27 @@ def flush_param_grads(ptr_lo=None, ptr_hi=None):
     _lib.check(rc, "ctdet_grad_scatter_oihw")
 
 
-def wgrad_to_param(p, x, dy, Cout_k, R, S, stride, pad, taps, cin_k, scale=None):
+def wgrad_to_param(p, x, dy, Cout_k, R, S, stride, pad, taps, cin_k, scale=None, make_x=None, keep=()):
     """The weight gradient of parameter p (OIHW [Cout, Cin, kh, kw], kh*kw = taps; k = tap*cin_k + c in the kernel's order)
     accumulated into p's slice of the optimizer's flat gradient buffer instead of being handed to autograd (whose
     AccumulateGrad would launch one strided add per parameter).  1x1: the kernel writes the slot itself.  Other kernels:
     tap-major partial sums as always (coalesced atomics), added to the slot by flush_param_grads.  False: p has no slot
-    (stand-alone use) -- the caller returns the gradient to autograd."""
+    (stand-alone use) -- the caller returns the gradient to autograd.  make_x: the kernel's input is produced on the side stream
+    too (DCNv2: the sampled columns); keep: its operands."""
     slot = grad_slot(p)
     if slot is None or scale is not None:
         return False
-    if taps == 1:
-        conv_wgrad(x, dy, Cout_k, R, S, stride, pad, into=(slot, 1, cin_k))
-    else:
-        dw = conv_wgrad(x, dy, Cout_k, R, S, stride, pad)
-        if not PENDING:
-            torch.autograd.Variable._execution_engine.queue_callback(flush_param_grads)
+    _queue_end_of_backward()
+
+    def work():
+        xin = make_x() if make_x is not None else x
+        if taps == 1:
+            return conv_wgrad(xin, dy, Cout_k, R, S, stride, pad, into=(slot, 1, cin_k)), xin
+        return conv_wgrad(xin, dy, Cout_k, R, S, stride, pad), xin
+    dw, xin = SIDE.run(work, x, dy, *keep)
+    if make_x is not None:
+        SIDE.keep.append((xin,))
+    if taps != 1:
         PENDING.append((slot, dw, taps, cin_k))
     grad_done(p)
     return True
@@ -585,7 +642,6 @@ class DeformConvFn(torch.autograd.Function):
             dy = dy.to(x.dtype)
         dyp = _pad_c(dy if dy.shape[3] == Cout else dy[..., :Cout].contiguous())
         # ---- main conv: dW, d(columns) -> scatter (d input, f32) + d(offset / mask logits)
-        col = dcn_cols(x, om)
         chunked = x.dtype == torch.float16 and Cin % 32 == 0
         wmat = dcn_weight_matrix(weight, dyp.shape[3], chunked)
         p_woff, p_boff, p_w, p_b = ctx.params
@@ -593,9 +649,11 @@ class DeformConvFn(torch.autograd.Function):
         if sb is not None and sb.numel() != dyp.shape[3]:
             sb = None
         _, _, _, dbias = bn_train_bwd(dyp, None, None, None, None, None, relu=False, into=(None, sb))
-        if wgrad_to_param(p_w, col, dyp, dyp.shape[3], 1, 1, 1, 0, 9, Cin):   # k = tap*Cin + c of the columns
+        # k = tap*Cin + c of the columns, which are sampled on the weight-gradient stream as well
+        if wgrad_to_param(p_w, None, dyp, dyp.shape[3], 1, 1, 1, 0, 9, Cin, make_x=lambda: dcn_cols(x, om), keep=(x, om)):
             dwt = None
         else:
+            col = dcn_cols(x, om)
             dw = conv_wgrad(col, dyp, dyp.shape[3], 1, 1, 1, 0)[:Cout]
             dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
         if sb is not None:
