@@ -53,6 +53,7 @@ struct WgradArgs {
 };
 int launch_grad_scatter_oihw(const void* const*, void* const*, const int*, const int*, const int*, const int*, int, hipStream_t);
 int launch_pack_weights_batch(const void*, int, int, hipStream_t);
+bool dcn_offset_fused_ok(const ConvArgs& a);
 size_t chan_reduce_workspace_bytes(int C);
 int launch_bn_train_fwd(const f16*, int, const f16*, int, f16*, int, int, int, const float*, const float*, float, float,
                         float*, float*, float*, float*, float*, float*, void*, int, hipStream_t);
@@ -202,6 +203,29 @@ int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* of
     return launch_conv_f32(a, true, (hipStream_t)stream);
   }
   CTDET_CHECK(false, "dcnv2: bad compute dtype %d", d->compute_dtype);
+}
+
+int32_t ctdet_dcnv2_offset_supported(const ctdet_conv_desc* d) {
+  ConvArgs a;
+  if (fill_args(d, a) || d->compute_dtype != CTDET_DT_F16) return 0;
+  a.y = nullptr;
+  return dcn_offset_fused_ok(a) ? 1 : 0;
+}
+
+int32_t ctdet_dcnv2_offset_fwd(const ctdet_conv_desc* d, const void* x, const void* w_off_packed, const float* b_off,
+                               float* om_out, int32_t om_out_stride, const void* w_packed, const float* scale,
+                               const float* bias, void* y, void* stream) {
+  ConvArgs a;
+  int rc = fill_args(d, a);
+  if (rc) return rc;
+  if (a.M == 0) return 0;
+  CTDET_CHECK(x && w_off_packed && b_off && w_packed && y, "dcnv2_offset: null pointer");
+  CTDET_CHECK(d->compute_dtype == CTDET_DT_F16, "dcnv2_offset: f16 only");
+  CTDET_CHECK(!om_out || (om_out_stride >= 28 && om_out_stride % 4 == 0 && ((size_t)om_out & 15) == 0),
+              "dcnv2_offset: om_out needs a 16-byte aligned row of >= 28 floats (stride %d)", om_out_stride);
+  a.x = x; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = nullptr; a.y = y;
+  a.w_off = w_off_packed; a.b_off = b_off; a.om_out = om_out; a.om_out_stride = om_out_stride;
+  return launch_conv_f16(a, d->out_dtype, true, (hipStream_t)stream);
 }
 
 int32_t ctdet_preprocess(const void* img, int32_t img_dtype, void* out, int32_t out_dtype, int32_t B, int32_t H,

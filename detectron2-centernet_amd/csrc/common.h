@@ -60,6 +60,9 @@ struct ConvArgs {
   float clamp_lo, clamp_hi;
   int korder;           // 0 tap-major, 1 chunk-major (see ctdet_conv_desc)
   int in_dil;           // input dilation (zero-stuffed input): >1 only for the input-gradient of strided convs
+  // DCNv2 with its offset / mask conv computed in the same kernel (ctdet_dcnv2_offset_fwd): that conv's packed f16 weights
+  // (32 rows, chunk-major), its bias (32 f32), and optionally where to keep its f32 output for a backward pass
+  const void* w_off; const float* b_off; float* om_out; int om_out_stride;
 };
 
 // argument block of the fused CenterNet head kernel (conv_igemm.hip): per head 3x3 conv Cin->256 + bias + ReLU, then

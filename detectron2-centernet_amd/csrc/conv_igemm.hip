@@ -1170,7 +1170,12 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
 //   * one barrier per kernel ROW: its three weight taps are one ring stage (two stages, fetched a row ahead), operands of
 //     tap t+1 are read during the MFMAs of tap t.
 // ------------------------------------------------------------------------------------------
-template <typename TOut>
+// FUSED: the offset / mask conv (3x3/s1/p1, 27 couts in 32 packed rows, a.w_off / a.b_off) is computed here as well, from the
+// same LDS window, before the sampling: per 32-channel chunk nine taps of 4 MFMAs per wave into two accumulator tiles, then
+// the 128 x 32 f32 results go through LDS to the geometry stage (and to a.om_out if the caller wants them: training).  One
+// kernel and no 112-byte-per-pixel offset tensor instead of two kernels; the sampling pass then walks the chunks backwards,
+// starting on the window the offset conv finished with.
+template <typename TOut, bool FUSED>
 __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs a) {
   constexpr int BC = 64, TH = 8, TW = 16, BP = 128, MG = 4, TP = 2, TC = 4;
   constexpr int WR = TH + 2 + 2 * MG, WCU = TW + 2 + 2 * MG, WCP = 32;   // 18 rows x 26 used of 32 columns
@@ -1226,7 +1231,74 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
     }
   };
   issue_window(0);
-  issue_w(0, 0);
+  if constexpr (!FUSED) issue_w(0, 0);
+  // consumer mapping: lane (fr, q) = tile pixel (row 2*wave + fr/8, col 8p + fr%8), channels 8q..8q+7 of the chunk
+  const int fr = lane & 15, q = lane >> 4;
+  const int prow = 2 * wave + (fr >> 3), pcol = fr & 7;
+  float* const om_lds = (float*)geo;                     // FUSED: [128 pixels][32] f32, before the geometry records take the space
+  if constexpr (FUSED) {
+    constexpr int OSTG = 3 * 2048;                       // stage = 3 taps x 32 rows x 64 bytes
+    const int orow = (tid >> 2) & 31, otap = wave >> 1;  // waves 0-1: tap A (rows 0-15 / 16-31), waves 2-3: tap A+1
+    const f16* woptr = (const f16*)a.w_off + (long)orow * a.Kpad + (slotw ^ swz(orow)) * 8;
+    auto issue_wo = [&](int s, int st) {                 // row-step s = chunk*3 + kernel row of the chunk-major K order
+      dma16(woptr + (s * 3 + otap) * 32, ring + st * OSTG + otap * 2048 + (wave & 1) * 1024);
+      if (wave < 2) dma16(woptr + (s * 3 + 2) * 32, ring + st * OSTG + 2 * 2048 + (wave & 1) * 1024);
+    };
+    issue_wo(0, 0);
+    f32x4 oacc[TP][2];
+#pragma unroll
+    for (int p = 0; p < TP; ++p) oacc[p][0] = oacc[p][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // pixel fragments straight from the window: tap (tr, ts) of tile pixel (prow, 8p + pcol) is window pixel
+    // (prow + MG + tr, 8p + pcol + MG + ts); the slot swizzle flips with the row parity
+    unsigned pa[TP][2];
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const unsigned base = (unsigned)(((prow + MG) * WCP + 8 * p + pcol + MG) * 64);
+      pa[p][0] = base + (((unsigned)q << 4) ^ ((unsigned)(prow & 1) << 5));
+      pa[p][1] = pa[p][0] ^ 32u;
+    }
+    const char* fragO = ring + fr * 64 + ((q ^ swz(fr)) << 4);
+    for (int s = 0; s < ns; ++s) {
+      const int tr = s % 3, st = s & 1;
+      wait_vmcnt<0>();                                   // this row's offset-conv weights (and, tr == 0, the chunk's window)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + 1 < ns) issue_wo(s + 1, st ^ 1);
+#pragma unroll
+      for (int ts = 0; ts < 3; ++ts) {
+        const f16x8 w0 = *(const f16x8*)(fragO + st * OSTG + ts * 2048);
+        const f16x8 w1 = *(const f16x8*)(fragO + st * OSTG + ts * 2048 + 1024);
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+          const f16x8 px = *(const f16x8*)(win + pa[p][tr & 1] + tr * ROWB + ts * 64);
+          oacc[p][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, px, oacc[p][0], 0, 0, 0);
+          oacc[p][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, px, oacc[p][1], 0, 0, 0);
+        }
+      }
+      if (tr == 2 && s + 1 < ns) {                       // next chunk's window
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_window(s / 3 + 1);
+      }
+    }
+    // offsets / mask logits of the tile -> LDS (+ global for the caller): D rows = couts 16c + 4q + r, column = pixel
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const int px = prow * 16 + 8 * p + pcol;
+      const long m = (long)(b * a.H + ty0 + prow) * a.W + tx0 + 8 * p + pcol;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int co = 16 * c + 4 * q;
+        const f32x4 v = oacc[p][c] + *(const f32x4*)(a.b_off + co);
+        *(f32x4*)(om_lds + px * 32 + co) = v;
+        if (a.om_out && co < a.om_out_stride) *(f32x4*)(a.om_out + m * a.om_out_stride + co) = v;
+      }
+    }
+    __syncthreads();   // om tile complete; every wave is done with the offset-conv weight stages
+    issue_w((nch - 1) * 3, 0);                           // first row-step of the sampling pass: the last chunk
+  }
 
   if (tid < BC) {
     const int c = n0 + tid;
@@ -1237,7 +1309,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
   {
     const int gp = tid & 127, gh = tid >> 7;
     const int py = ty0 + (gp >> 4), pxx = tx0 + (gp & 15);
-    const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
+    const float* omrow = FUSED ? om_lds + gp * 32 : a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
     float oh[5], ow[5], om_[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -1245,6 +1317,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
       const bool on = t < 9;
       oh[i] = on ? omrow[2 * t] : 0.f; ow[i] = on ? omrow[2 * t + 1] : 0.f; om_[i] = on ? omrow[18 + t] : 0.f;
     }
+    if constexpr (FUSED) __syncthreads();                // the records below overwrite the om tile
     unsigned far_lo = 0, far_hi = 0;     // taps with a far sample among lanes 0-31 / 32-63 (= consumer waves 2*(w&1), +1)
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -1285,9 +1358,6 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
   }
   wait_vmcnt<0>();
   __syncthreads();
-  // ---- consumer mapping: lane (fr, q) blends tile pixel (row 2*wave + fr/8, col 8p + fr%8), channels 8q..8q+7 of the chunk
-  const int fr = lane & 15, q = lane >> 4;
-  const int prow = 2 * wave + (fr >> 3), pcol = fr & 7;
   const unsigned slow_taps = __builtin_amdgcn_readfirstlane(slowf[wave * 2] | slowf[wave * 2 + 1]);
   const unsigned q4 = (unsigned)q << 4;
   const char* georow = geo + (prow * 16 + pcol) * 16;
@@ -1346,18 +1416,21 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
   {
     u32x4 raw[TP][4];
     unsigned wts[TP][2];
-    gather(0, 0, raw, wts);
+    gather(0, FUSED ? nch - 1 : 0, raw, wts);
     blend(raw, wts, pf);
   }
-  auto tap = [&](int s, int chunk, auto tc) {
+  // i-th chunk of the sampling pass (FUSED walks them backwards: the offset conv left the last one's window in LDS)
+  auto chunk_at = [&](int i) { return FUSED ? nch - 1 - i : i; };
+  auto tap = [&](int s, int ci, auto tc) {               // s = 3*ci + kernel row: position in the pass
     constexpr int T = decltype(tc)::value, TS = T % 3;
     const int st = s & 1;
+    const int chunk = chunk_at(ci);
     if (TS == 0) {
       wait_vmcnt<0>();                                   // this row's weights (issued a row ago)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (s + 1 < ns) issue_w(s + 1, st ^ 1);
+      if (s + 1 < ns) issue_w(chunk_at((s + 1) / 3) * 3 + (s + 1) % 3, st ^ 1);
       frags(st, 0, wf);
     }
     f16x8 wfn[TC], pfn[TP];
@@ -1366,11 +1439,11 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
     if (TS < 2) frags(st, TS + 1, wfn);
     if (T < 8) {
       gather(T + 1, chunk, raw, wts);
-    } else if (chunk + 1 < nch) {                        // tap 8 was sampled during tap 7: the window is free
+    } else if (ci + 1 < nch) {                           // tap 8 was sampled during tap 7: the window is free
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      issue_window(chunk + 1);
+      issue_window(chunk_at(ci + 1));
     }
 #pragma unroll
     for (int p = 0; p < TP; ++p)
@@ -1378,11 +1451,11 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
       for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf[p], acc[p][c], 0, 0, 0);
     if (T < 8) {
       blend(raw, wts, pfn);
-    } else if (chunk + 1 < nch) {
+    } else if (ci + 1 < nch) {
       wait_vmcnt<0>();                                   // next chunk's window, behind this tap's MFMAs
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      gather(0, chunk + 1, raw, wts);
+      gather(0, chunk_at(ci + 1), raw, wts);
       blend(raw, wts, pfn);
     }
 #pragma unroll
@@ -1392,17 +1465,17 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
       for (int c = 0; c < TC; ++c) wf[c] = wfn[c];
     }
   };
-  for (int chunk = 0; chunk < nch; ++chunk) {
-    const int s = chunk * 3;
-    tap(s, chunk, std::integral_constant<int, 0>{});
-    tap(s, chunk, std::integral_constant<int, 1>{});
-    tap(s, chunk, std::integral_constant<int, 2>{});
-    tap(s + 1, chunk, std::integral_constant<int, 3>{});
-    tap(s + 1, chunk, std::integral_constant<int, 4>{});
-    tap(s + 1, chunk, std::integral_constant<int, 5>{});
-    tap(s + 2, chunk, std::integral_constant<int, 6>{});
-    tap(s + 2, chunk, std::integral_constant<int, 7>{});
-    tap(s + 2, chunk, std::integral_constant<int, 8>{});
+  for (int ci = 0; ci < nch; ++ci) {
+    const int s = ci * 3;
+    tap(s, ci, std::integral_constant<int, 0>{});
+    tap(s, ci, std::integral_constant<int, 1>{});
+    tap(s, ci, std::integral_constant<int, 2>{});
+    tap(s + 1, ci, std::integral_constant<int, 3>{});
+    tap(s + 1, ci, std::integral_constant<int, 4>{});
+    tap(s + 1, ci, std::integral_constant<int, 5>{});
+    tap(s + 2, ci, std::integral_constant<int, 6>{});
+    tap(s + 2, ci, std::integral_constant<int, 7>{});
+    tap(s + 2, ci, std::integral_constant<int, 8>{});
   }
 
   // epilogue: per cout-tile pair h a lane holds 8 consecutive couts (cout_of) of 2 pixels; scale/bias from LDS, 16-byte stores
@@ -1445,6 +1518,14 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
   }
 }
 
+// geometry the row-step kernel (and with it the fused offset conv) serves
+bool dcn_offset_fused_ok(const ConvArgs& a) {
+  return a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.in_dil == 1 && a.Cin % 32 == 0 && a.Kpad == a.K &&
+         a.korder == 1 && a.Cout_pad == 64 && a.H % 8 == 0 && a.W % 16 == 0 && a.H <= 65534 && a.W <= 65534 && !a.res &&
+         a.out_stride % 8 == 0 && ((size_t)a.y & 15) == 0 &&
+         !(ctdet_tuning_flags() & (CTDET_TUNE_DCN_MIXED | CTDET_TUNE_DCN_WINDOW_V1));
+}
+
 template <int BC, int WP, int WC_, typename TOut>
 static int launch_dcn_window(const ConvArgs& a, hipStream_t s) {
   const int nbx = a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16), nby = a.Cout_pad / BC;
@@ -1452,7 +1533,8 @@ static int launch_dcn_window(const ConvArgs& a, hipStream_t s) {
   const bool mixed = (ctdet_tuning_flags() & CTDET_TUNE_DCN_MIXED) != 0;
   if (BC == 64 && !mixed && a.H % 8 == 0 && a.W % 16 == 0 && a.H <= 65534 && a.W <= 65534 &&
       !(ctdet_tuning_flags() & CTDET_TUNE_DCN_WINDOW_V1)) {
-    hipLaunchKernelGGL((dcn_window_rows_kernel<TOut>), grid, dim3(256), 0, s, a);
+    if (a.w_off) hipLaunchKernelGGL((dcn_window_rows_kernel<TOut, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dcn_window_rows_kernel<TOut, false>), grid, dim3(256), 0, s, a);
     CTDET_LAUNCH_CHECK();
     return 0;
   }
@@ -1727,14 +1809,15 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   CTDET_CHECK(a.in_dil >= 1 && (!deform || a.in_dil == 1), "conv: bad in_dil %d", a.in_dil);
   if (deform && a.korder == 1) {
     // chunk-major weights: LDS-window kernel (3x3/s1/p1, map divisible by the 8x16 tile)
-    CTDET_CHECK(a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Cin % 32 == 0 && a.Kpad == a.K && a.om_stride % 4 == 0 && ((size_t)a.om & 15) == 0 && !a.res &&
+    CTDET_CHECK(a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Cin % 32 == 0 && a.Kpad == a.K && (a.w_off || (a.om_stride % 4 == 0 && ((size_t)a.om & 15) == 0)) && !a.res &&
                     a.out_stride % 8 == 0 && ((size_t)a.y & 15) == 0,
                 "dcnv2(window): unsupported geometry");
     // 64- or 128-cout tiles whatever Cout is: the packed rows are padded to a multiple of 64 (zero rows; nothing beyond
     // Cout is stored)
     CTDET_CHECK(a.Cout_pad % 64 == 0, "dcnv2(window): weight rows must be padded to a multiple of 64 (Cout=%d, packed %d)",
                 a.Cout, a.Cout_pad);
-    if (a.Cout > 64 && a.Cout_pad % 128 == 0) return launch_dcn_window<128, 2, 2, TOut>(a, s);
+    CTDET_CHECK(!a.w_off || dcn_offset_fused_ok(a), "dcnv2(offset conv fused): unsupported geometry (ctdet_dcnv2_offset_supported)");
+    if (!a.w_off && a.Cout > 64 && a.Cout_pad % 128 == 0) return launch_dcn_window<128, 2, 2, TOut>(a, s);
     return launch_dcn_window<64, 2, 2, TOut>(a, s);
   }
   CTDET_CHECK(!deform, "dcnv2: the f16 path takes chunk-major weights (korder 1, Cin %% 32 == 0); got korder %d, Cin %d",

@@ -111,9 +111,15 @@ class DCN(nn.Module):
     def hip_forward(self, x, ctx, bn=None, act=ACT_NONE):
         """x NHWC -> act(bn(dcn(x))) NHWC; the offset/mask conv writes f32 so sampling coordinates keep full
         precision even in f16 mode."""
-        om = hipnn.conv_module(x, self.conv_offset_mask, None, ACT_NONE, ctx=ctx, out_dtype=torch.float32)
         p = hipnn.packed(self, "dcn", ctx.compute, self.weight, bn, self.bias, self.stride, self.padding, self.dilation,
                          cout_align=64 if ctx.compute == F16 else None)
+        com = self.conv_offset_mask
+        if ctx.compute == F16 and x.shape[3] % 32 == 0:
+            # offset conv and deformable conv in one kernel where the geometry allows (64-cout layers on tile-divisible maps)
+            p_off = hipnn.packed(com, "conv", ctx.compute, com.weight, None, com.bias, com.stride[0], com.padding[0], com.dilation[0])
+            if ops.dcnv2_offset_supported(x, p_off, p):
+                return ops.dcnv2_offset(x, p_off, p, act=act)
+        om = hipnn.conv_module(x, com, None, ACT_NONE, ctx=ctx, out_dtype=torch.float32)
         return ops.dcnv2(x, om, p, act=act)
 
     def forward(self, x):

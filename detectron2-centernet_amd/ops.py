@@ -419,6 +419,46 @@ def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_pro
     return out
 
 
+def dcnv2_offset_supported(x, p_off, p):
+    """may `dcnv2_offset` serve this layer? (f16, 3x3/s1/p1 both convs, at most 64 couts packed to 64 rows, map divisible by
+    the 8x16 tile, Cin % 32 == 0, 27 offset / mask channels packed chunk-major into 32 rows)"""
+    if p.compute != F16 or p_off.compute != F16 or p.Cout_pad != 64 or p_off.Cout != 27 or p_off.Cout_pad != 32:
+        return False
+    if (p_off.R, p_off.S, p_off.stride, p_off.pad, p_off.dil, p_off.korder, p_off.Kpad) != (3, 3, 1, 1, 1, 1, p.Kpad):
+        return False
+    B, H, W, _ = x.shape
+    out = torch.empty(0, H, W, round_up(p.Cout_eff, 8), dtype=torch.float16, device=x.device)
+    d = p.desc(x[:0], out, ACT_NONE, None)
+    d.B = B
+    return bool(_lib.lib().ctdet_dcnv2_offset_supported(C.byref(d)))
+
+
+def dcnv2_offset(x, p_off, p, out=None, act=ACT_NONE, out_dtype=None, om_out=None):
+    """act(dcn(x, conv_offset_mask(x))) in one kernel (ctdet_dcnv2_offset_fwd): p_off = the packed 3x3 offset / mask conv with
+    its bias, p = the packed deformable conv.  om_out (f32 [B,H,W,>=28]) receives the offsets / mask logits if given."""
+    _require_cuda(x, out, om_out)
+    assert dt_of(x) == F16 and p.compute == F16 and p_off.bias is not None and p_off.scale is None
+    if out is None and p.Cout_eff % 8:
+        B, H, W, _ = x.shape
+        dt = out_dtype if out_dtype is not None else torch.float16
+        out = torch.empty(B, H, W, round_up(p.Cout_eff, 8), dtype=dt, device=x.device)[..., :p.Cout_eff]
+    out = _alloc_out(x, p, out, out_dtype)
+    if getattr(p_off, "bias32", None) is None:           # the kernel reads the bias of all 32 packed rows
+        p_off.bias32 = torch.nn.functional.pad(p_off.bias, (0, 32 - p_off.bias.shape[0])).contiguous()
+    d = p.desc(x, out, act, None)
+    prof = _Prof(p, d.B * d.Ho * d.Wo, True, d.out_dtype, x.shape, name=f"dcn_window_rows_kernel<128x64,offset conv fused>",
+                 flops=2.0 * d.B * d.Ho * d.Wo * p.K * (p.Cout + 27))
+    if prof.on:
+        prof.bytes -= d.B * d.Ho * d.Wo * 27 * 4      # no offset tensor is read
+    for _ in range(prof.reps()):
+        rc = _lib.lib().ctdet_dcnv2_offset_fwd(C.byref(d), _ptr(x), _ptr(p_off.w), _ptr(p_off.bias32), _ptr(om_out),
+                                               _nhwc_stride(om_out) if om_out is not None else 0, _ptr(p.w), _ptr(p.scale),
+                                               _ptr(p.bias), _ptr(out), _stream())
+    _lib.check(rc, "ctdet_dcnv2_offset_fwd")
+    prof.done()
+    return out
+
+
 def preprocess(images, mean, std, Hp, Wp, out_dtype=torch.float16, out=None, partial=False, border=0):
     """images: [B,3,H,W] uint8/float32 CHW on device -> normalised NHWC [B,Hp,Wp,8] (3 channels used).
     `out` may be a batch-slice of a larger padded buffer (ragged batches: one call per image).

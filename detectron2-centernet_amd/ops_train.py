@@ -626,9 +626,14 @@ class DeformConvFn(torch.autograd.Function):
         f32 = x.dtype == torch.float32
         comp = F32 if f32 else F16
         p_off = _fwd_pack(w_off, 1, 1, bias=b_off, compute=comp)
-        om = ops.conv2d(x, p_off, out_dtype=torch.float32)
         p = ops.PackedConv(weight.detach(), None, bias, stride=1, pad=1, compute=comp, cout_align=None if f32 else 64)
-        y = ops.dcnv2(x, om, p)
+        if not f32 and x.shape[3] % 32 == 0 and ops.dcnv2_offset_supported(x, p_off, p):
+            # one kernel for both convs; the offsets / mask logits are kept for the backward pass
+            om = torch.empty(x.shape[0], x.shape[1], x.shape[2], 28, dtype=torch.float32, device=x.device)
+            y = ops.dcnv2_offset(x, p_off, p, om_out=om)
+        else:
+            om = ops.conv2d(x, p_off, out_dtype=torch.float32)
+            y = ops.dcnv2(x, om, p)
         ctx.params = (w_off, b_off, weight, bias)
         ctx.save_for_backward(x, om, w_off, weight)
         return y

@@ -80,6 +80,18 @@ int32_t ctdet_conv1x1_cat_fwd(const ctdet_conv_desc* d, const void* const* xs, c
 int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* offset_mask, int32_t om_stride,
                         int32_t mask_is_prob, const void* w_packed, const float* scale, const float* bias, void* y, void* stream);
 
+/* DCNv2 together with the conv that produces its offsets and mask logits (the reference's DCN wrapper: conv_offset_mask 3x3 /
+ * s1 / p1, Cin -> 27, then modulated_deform_conv on the same input; detectron2/layers/deform_conv.py and the wrapper the
+ * CenterNet project uses) in ONE kernel: the offset conv is evaluated from the LDS window the sampling uses, its output never
+ * goes to memory unless om_out is given (f32 [M][om_out_stride], channels 0..27 written; a backward pass needs it).
+ * w_off_packed: ctdet_pack_weights of the [27,Cin,3,3] weight with rows_pad 32, chunk-major; b_off: 32 f32 (27 used).
+ * f16 compute, Cout <= 64 packed to 64 rows, maps divisible by 8x16, Cin % 32 == 0: ctdet_dcnv2_offset_supported(d) says
+ * whether a descriptor qualifies (otherwise: ctdet_conv2d_fwd + ctdet_dcnv2_fwd). */
+int32_t ctdet_dcnv2_offset_supported(const ctdet_conv_desc* d);
+int32_t ctdet_dcnv2_offset_fwd(const ctdet_conv_desc* d, const void* x, const void* w_off_packed, const float* b_off,
+                               float* om_out, int32_t om_out_stride, const void* w_packed, const float* scale,
+                               const float* bias, void* y, void* stream);
+
 /* CenterNet.preprocess_image (centernet.py:173-185) + ImageList.from_tensors padding
  * (detectron2/structures/image_list.py:58-130): img is [B,3,H,W] (u8 or f32, CHW, batch stride given in
  * elements), out is NHWC [B,Hp,Wp,out_stride] with channels 0..2 = (x/255 - mean)/std, the rest 0.

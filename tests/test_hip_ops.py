@@ -410,6 +410,41 @@ def test_dcnv2_window(ops, dev, case, variant):
     assert err <= 6e-3 * max(1.0, ref.abs().max().item()), f"max err {err}"
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 64, 1.0), (1, 8, 16, 128, 64, 0.3), (2, 16, 16, 64, 40, 4.0), (1, 24, 48, 256, 64, 2.0),
+                                  (3, 8, 32, 32, 16, 1.0)])
+def test_dcnv2_with_fused_offset_conv(ops, dev, case):
+    """ctdet_dcnv2_offset_fwd: the 3x3 offset / mask conv evaluated inside the DCNv2 kernel from the same LDS window.  Against
+    the two-kernel path on the same weights: offsets / mask logits (om_out) to f32 rounding of a different summation order,
+    the output to the f16 tolerance of the two-kernel path against the oracle; and against the oracle itself"""
+    B, H, W, Cin, Cout, off_scale = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = h16(torch.randn(B, Cin, H, W, generator=g))
+    w = h16(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    w_off = h16(torch.randn(27, Cin, 3, 3, generator=g) * (off_scale / (Cin * 9) ** 0.5))
+    b_off = torch.randn(27, generator=g) * 0.5
+    bias, scale = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5
+    om_ref = F.conv2d(x, w_off, b_off, 1, 1)
+    ref = O.dcnv2_forward(x, om_ref[:, :18], torch.sigmoid(om_ref[:, 18:]), w, None, 1, 1, 1)
+    ref = (ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)).relu()
+    pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=1, pad=1, compute=ops.F16, cout_align=64)
+    po = ops.PackedConv(w_off.to(dev), None, b_off.to(dev), stride=1, pad=1, compute=ops.F16)
+    xd = nhwc(x).half().to(dev)
+    assert ops.dcnv2_offset_supported(xd, po, pc)
+    om_out = torch.full((B, H, W, 28), float("nan"), device=dev)
+    y = ops.dcnv2_offset(xd, po, pc, act=ops.ACT_RELU, om_out=om_out)
+    om2 = ops.conv2d(xd, po, out_dtype=torch.float32)
+    y2 = ops.dcnv2(xd, om2, pc, act=ops.ACT_RELU)
+    assert (om_out[..., :27] - om2[..., :27]).abs().max().item() <= 2e-5 * max(1.0, om2.abs().max().item())
+    assert (nchw(om_out[..., :27].cpu()) - om_ref).abs().max().item() <= 1e-4 * max(1.0, om_ref.abs().max().item())
+    tol = 6e-3 * max(1.0, ref.abs().max().item())
+    assert (y.float() - y2.float()).abs().max().item() <= tol
+    assert (nchw(y[..., :Cout].float().cpu()) - ref).abs().max().item() <= tol
+    y3 = ops.dcnv2_offset(xd, po, pc, act=ops.ACT_RELU)          # without om_out
+    assert torch.equal(y3, y)
+    # geometry the fused kernel does not serve is reported as such
+    assert not ops.dcnv2_offset_supported(xd[:, :7], po, pc)
+
+
 @pytest.mark.parametrize("tdt", [torch.float16, torch.float32])
 def test_maxpool_and_dwconvT(ops, dev, tdt):
     g = torch.Generator().manual_seed(7)
