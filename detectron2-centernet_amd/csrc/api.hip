@@ -124,7 +124,7 @@ extern "C" {
 const char* ctdet_last_error(void) { return g_err; }
 int32_t ctdet_set_tuning_flags(uint32_t flags) { g_tuning.store(flags, std::memory_order_relaxed); return 0; }
 uint32_t ctdet_get_tuning_flags(void) { return g_tuning.load(std::memory_order_relaxed); }
-int32_t ctdet_abi_version(void) { return 2; }
+int32_t ctdet_abi_version(void) { return 3; }
 int32_t ctdet_conv_cout_tile(int32_t cout) {
   if (cout <= 16) return 16;
   if (cout <= 32) return 32;

@@ -44,6 +44,12 @@ def per_kernel(path, counter):
 
 def bench_name(mangled):
     """the kernel naming of bench.py's roofline record for the kernels it can be the dominant one of"""
+    m = re.search(r"dcn_window_rows_kernel(?:I|<)(DF16_|f|_Float16|float)[^a-zA-Z]*(Lb1|true)", mangled)
+    if m:
+        return "dcn_window_rows_kernel<128x64,offset conv fused>"
+    m = re.search(r"dcn_window_rows_kernel(?:I|<)(DF16_|f|_Float16|float)", mangled)
+    if m:
+        return f"dcn_window_kernel<128x64,{'f16' if m.group(1) in ('DF16_', '_Float16') else 'f32'}>"
     m = re.search(r"dcn_window_kernelILi(\d+)ELi\d+ELb[01]E(DF16_|f)", mangled)
     if m:
         return f"dcn_window_kernel<128x{m.group(1)},{'f16' if m.group(2) == 'DF16_' else 'f32'}>"
