@@ -33,6 +33,7 @@ class BucketedReducer:
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        self.calls = {}       # parameters announced in the current backward pass
         self.enabled = True   # False while a training step is captured / replayed as a graph: see reduce_all()
         if self.world > 1:
             for i, p in enumerate(optimizer.params):
@@ -46,6 +47,12 @@ class BucketedReducer:
         def hook(param):
             if not self.enabled:
                 return
+            # a parameter is announced by autograd's AccumulateGrad, by the backward wrapper that wrote its gradient into the
+            # flat buffer itself (ops_train.grad_done), or by both (autograd also visits the node when the function returned
+            # None): the first announcement of a pass counts
+            if i in self.calls:
+                return
+            self.calls[i] = 1
             self._ready[b] += 1
             if self._ready[b] == self.buckets[b][2] and not self._launched[b]:
                 self._launch(b)
@@ -72,6 +79,7 @@ class BucketedReducer:
 
     def prepare(self):
         """call before backward"""
+        self.calls = {}
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._handles = []
