@@ -344,6 +344,7 @@ __device__ __forceinline__ f16x4 lds_tr_read(const f16* p) {
 #define WG_BM 64            // pixels per K-loop step (two MFMA K slabs of 32)
 #define WG_LDA (WG_BK + 8)  // row padding (elements) to spread banks
 #define WG_LDY (WG_BN + 8)
+template <bool PERM>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
   __shared__ __attribute__((aligned(16))) f16 sA[WG_BM * WG_LDA];
   __shared__ __attribute__((aligned(16))) f16 sY[WG_BM * WG_LDY];
@@ -451,7 +452,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 32 + i * 16 + 4 * (lane >> 4) + r;
-        if (n < a.Cout) wg_add(a, n, kcol, acc[i][j][r] * a.scale);
+        if (n < a.Cout) {
+          if constexpr (PERM) wg_add(a, n, kcol, acc[i][j][r] * a.scale);
+          else atomicAdd(a.dw + (long)n * a.K + kcol, acc[i][j][r] * a.scale);
+        }
       }
     }
 }
@@ -1354,7 +1358,8 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
     while ((1 << a.lw) < a.Wo) ++a.lw;
     while ((1 << a.lh) < a.Ho) ++a.lh;
   }
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx * gy * split), dim3(256), 0, s, a);
+  if (a.perm_rs) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(gx * gy * split), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(gx * gy * split), dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
 }

@@ -99,6 +99,39 @@ def test_conv_wgrad_and_dgrad(T, dev, case):
     close(nchw(dx.float().cpu()), x.grad, 3e-3, "dX")
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 48, 3, 1, 1), (1, 8, 8, 256, 80, 1, 1, 0), (2, 10, 10, 32, 27, 3, 2, 1), (1, 16, 64, 16, 16, 3, 1, 1),
+                                  (2, 16, 32, 8, 16, 7, 1, 3)])
+def test_conv_wgrad_into_parameter_layout(T, dev, case):
+    """ctdet_conv_wgrad_oihw (every weight-gradient kernel) accumulating straight into an OIHW gradient that already holds
+    values, with padded input channels (3 real of 8) and padded dY channels dropped; and ctdet_grad_scatter_oihw, the batched
+    tap-major -> OIHW add the training step uses"""
+    ops, ot = T
+    B, H, W, Cin, Cout, k, s_, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    cin_real = 3 if Cin == 8 else Cin
+    x = h16(torch.randn(B, Cin, H, W, generator=g))
+    x[:, cin_real:] = 0
+    Ho, Wo = (H + 2 * p - k) // s_ + 1, (W + 2 * p - k) // s_ + 1
+    dy = h16(torch.randn(B, Cout, Ho, Wo, generator=g))
+    ref = torch.nn.grad.conv2d_weight(x[:, :cin_real], (Cout, cin_real, k, k), dy, stride=s_, padding=p)
+    Cw = (Cout + 7) // 8 * 8
+    dyp = torch.zeros(B, Ho, Wo, Cw)
+    dyp[..., :Cout] = nhwc(dy)
+    xd, dyd = nhwc(x).half().to(dev), dyp.half().to(dev)
+    prior = torch.randn(Cout, cin_real, k, k, generator=g)
+    slot = prior.clone().to(dev)
+    ot.conv_wgrad(xd, dyd, Cw, k, k, s_, p, scale=0.5, into=(slot, k * k, Cin))
+    close(slot.cpu() - prior, 0.5 * ref, 2e-3, "dW in the parameter's layout")
+    # the deferred form: tap-major sums, then one scatter launch for several tensors
+    dw = ot.conv_wgrad(xd, dyd, Cw, k, k, s_, p, scale=1.0)
+    slot2, slot3 = prior.clone().to(dev), torch.zeros_like(prior).to(dev)
+    ot.PENDING[:] = [(slot2, dw, k * k, Cin), (slot3, dw, k * k, Cin)]
+    ot.flush_param_grads()
+    assert not ot.PENDING
+    close(slot2.cpu() - prior, ref, 2e-3, "scatter onto a gradient")
+    close(slot3.cpu(), ref, 2e-3, "scatter onto zeros")
+
+
 @pytest.mark.parametrize("case", [(2, 16, 64, 64, 48, 3, 1), (2, 16, 32, 8, 16, 7, 3), (1, 8, 64, 16, 16, 3, 1), (2, 9, 20, 32, 16, 3, 1)])
 def test_conv_wgrad_reads_channel_slices(T, dev, case):
     """x and dy handed over as channel slices of wider NHWC buffers (pixel stride > channel count), as the DLA tree does
