@@ -552,3 +552,50 @@ def test_inference_on_dataset_loop(tmp_path, dev):
     assert all(1000 <= r["category_id"] < 1080 and len(r["bbox"]) == 4 and r["bbox"][2] > 0 for r in recs)
     t = inference_on_dataset.last_timing
     assert t["iters"] == 2 and t["compute_s_per_iter"] > 0
+
+
+def test_pack_plan_refreshes_weights_after_each_update(T, dev):
+    """solver.FlatSGD keeps the f16 operands of every conv weight it has seen packed in persistent buffers and refreshes all of
+    them with one launch after the update (ops.PackPlan): a PackedConv built after a step must hold exactly what a fresh pack of
+    the updated weight holds -- forward and input-gradient forms -- without launching a pack of its own; a weight changed
+    behind the plan's back (load_state_dict) is packed on the spot"""
+    ops, ot = T
+    from detectron2_centernet_amd.solver.build import FlatSGD
+
+    g = torch.Generator().manual_seed(11)
+    w1 = torch.nn.Parameter((torch.randn(64, 32, 3, 3, generator=g) / 17).to(dev))
+    w2 = torch.nn.Parameter((torch.randn(40, 64, 1, 1, generator=g) / 8).to(dev))
+    prev_plan, prev_arena = ops.PACK_PLAN, ot.ARENA
+    try:
+        opt = FlatSGD([(w1, 1.0, 0.0), (w2, 1.0, 0.0)], 0.1, 0.9)
+        plan = ops.PACK_PLAN
+        assert plan is not None and plan.covers(w1) and plan.covers(w2.detach())
+
+        def packs():
+            return (ops.PackedConv(w1, stride=1, pad=1, compute=ops.F16), ops.PackedConv(w1.detach(), stride=1, pad=1, compute=ops.F16, transposed=True),
+                    ops.PackedConv(w2, compute=ops.F16))
+
+        def fresh():
+            ops.PACK_PLAN = None
+            try:
+                return [p.w.clone() for p in packs()]
+            finally:
+                ops.PACK_PLAN = plan
+
+        first = packs()                       # recorded
+        assert len(plan.entries) == 3
+        for step in range(2):
+            opt.zero_grad()
+            w1.grad.copy_(torch.randn(w1.shape, generator=g).to(dev))
+            w2.grad.copy_(torch.randn(w2.shape, generator=g).to(dev))
+            opt.step()                        # SGD kernel + one batched re-pack
+            again = packs()
+            for a, b, f in zip(again, first, fresh()):
+                assert a.w.data_ptr() == b.w.data_ptr()        # the plan's persistent buffer, no new pack
+                assert torch.equal(a.w, f)
+        with torch.no_grad():
+            w1.mul_(2.0)                      # version bump the plan has not seen
+        p = ops.PackedConv(w1, stride=1, pad=1, compute=ops.F16)
+        assert torch.equal(p.w, fresh()[0])
+    finally:
+        ops.PACK_PLAN, ot.ARENA = prev_plan, prev_arena
