@@ -1291,7 +1291,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const int co = 16 * c + 4 * q;
-        const f32x4 v = oacc[p][c] + *(const f32x4*)(a.b_off + co);
+        const f32x4 v = co < 28 ? oacc[p][c] + *(const f32x4*)(a.b_off + co) : oacc[p][c];   // b_off: 28 floats (27 + pad)
         *(f32x4*)(om_lds + px * 32 + co) = v;
         if (a.om_out && co < a.om_out_stride) *(f32x4*)(a.om_out + m * a.om_out_stride + co) = v;
       }

@@ -443,15 +443,14 @@ def dcnv2_offset(x, p_off, p, out=None, act=ACT_NONE, out_dtype=None, om_out=Non
         dt = out_dtype if out_dtype is not None else torch.float16
         out = torch.empty(B, H, W, round_up(p.Cout_eff, 8), dtype=dt, device=x.device)[..., :p.Cout_eff]
     out = _alloc_out(x, p, out, out_dtype)
-    if getattr(p_off, "bias32", None) is None:           # the kernel reads the bias of all 32 packed rows
-        p_off.bias32 = torch.nn.functional.pad(p_off.bias, (0, 32 - p_off.bias.shape[0])).contiguous()
+    assert p_off.bias.shape[0] >= 28                     # Cout_eff floats: the kernel reads channels 0..27
     d = p.desc(x, out, act, None)
     prof = _Prof(p, d.B * d.Ho * d.Wo, True, d.out_dtype, x.shape, name=f"dcn_window_rows_kernel<128x64,offset conv fused>",
                  flops=2.0 * d.B * d.Ho * d.Wo * p.K * (p.Cout + 27))
     if prof.on:
         prof.bytes -= d.B * d.Ho * d.Wo * 27 * 4      # no offset tensor is read
     for _ in range(prof.reps()):
-        rc = _lib.lib().ctdet_dcnv2_offset_fwd(C.byref(d), _ptr(x), _ptr(p_off.w), _ptr(p_off.bias32), _ptr(om_out),
+        rc = _lib.lib().ctdet_dcnv2_offset_fwd(C.byref(d), _ptr(x), _ptr(p_off.w), _ptr(p_off.bias), _ptr(om_out),
                                                _nhwc_stride(om_out) if om_out is not None else 0, _ptr(p.w), _ptr(p.scale),
                                                _ptr(p.bias), _ptr(out), _stream())
     _lib.check(rc, "ctdet_dcnv2_offset_fwd")

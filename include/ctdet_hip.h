@@ -84,7 +84,7 @@ int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* of
  * s1 / p1, Cin -> 27, then modulated_deform_conv on the same input; detectron2/layers/deform_conv.py and the wrapper the
  * CenterNet project uses) in ONE kernel: the offset conv is evaluated from the LDS window the sampling uses, its output never
  * goes to memory unless om_out is given (f32 [M][om_out_stride], channels 0..27 written; a backward pass needs it).
- * w_off_packed: ctdet_pack_weights of the [27,Cin,3,3] weight with rows_pad 32, chunk-major; b_off: 32 f32 (27 used).
+ * w_off_packed: ctdet_pack_weights of the [27,Cin,3,3] weight with rows_pad 32, chunk-major; b_off: 28 f32 (27 used).
  * f16 compute, Cout <= 64 packed to 64 rows, maps divisible by 8x16, Cin % 32 == 0: ctdet_dcnv2_offset_supported(d) says
  * whether a descriptor qualifies (otherwise: ctdet_conv2d_fwd + ctdet_dcnv2_fwd). */
 int32_t ctdet_dcnv2_offset_supported(const ctdet_conv_desc* d);
