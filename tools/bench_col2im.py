@@ -11,6 +11,9 @@ from detectron2_centernet_amd import ops_train as ot  # noqa: E402
 B, H, W, Cin = [int(v) for v in sys.argv[1:5]]
 std = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
 dev = torch.device("cuda:0")
+if os.environ.get("TUNE"):       # ctdet_set_tuning_flags bits, e.g. TUNE=128: the LDS fixed-point scatter kernel
+    from detectron2_centernet_amd import _lib
+    _lib.lib().ctdet_set_tuning_flags(int(os.environ["TUNE"]))
 g = torch.Generator().manual_seed(0)
 x = torch.randn(B, H, W, Cin, generator=g).half().to(dev)
 dcol = torch.randn(B, H, W, 9 * Cin, generator=g).half().to(dev)
@@ -26,5 +29,4 @@ for _ in range(5):
     ot.dcn_col2im_coord(dcol, x, om)
 e1.record()
 torch.cuda.synchronize()
-print(f"col2im B{B} {H}x{W} Cin{Cin} off_std {std}: {e0.elapsed_time(e1) / 5 * 1000:.0f} us "
-      f"({'window' if not False else 'atomics'})")
+print(f"col2im B{B} {H}x{W} Cin{Cin} off_std {std} TUNE={os.environ.get('TUNE', '0')}: {e0.elapsed_time(e1) / 5 * 1000:.0f} us")
