@@ -1846,7 +1846,13 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
     switch (bc) {
       case 32: return launch_halo<32, 4, 1, TOut>(a, s);
       case 64: return launch_halo<64, 4, 1, TOut>(a, s);
-      case 128: return launch_halo<128, 2, 2, TOut>(a, s);
+      case 128: {
+        // fewer workgroups than the chip holds (2 per CU): 64-cout tiles double them.  Training batches on the 64^2 / 32^2
+        // levels: 128->128 @64^2, batch 16: 28.7 -> 24.2 us; 256->256 @32^2: 42.4 -> 27.7 us (32-cout tiles: no further gain)
+        const long wgs = (long)a.B * (a.H / 8) * (a.W / 32) * (a.Cout_pad / 128);
+        if (wgs < 512 && !(ctdet_tuning_flags() & CTDET_TUNE_NO_SMALL_GRID_TILES)) return launch_halo<64, 4, 1, TOut>(a, s);
+        return launch_halo<128, 2, 2, TOut>(a, s);
+      }
     }
   }
   if (uniform_k_ok(a)) {
@@ -1854,7 +1860,12 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
       case 16: return launch_uk<256, 16, 4, 1, TOut>(a, s);
       case 32: return big ? launch_uk<256, 32, 4, 1, TOut>(a, s) : launch_uk<128, 32, 4, 1, TOut>(a, s);
       case 64: return big ? launch_uk<256, 64, 4, 1, TOut>(a, s) : launch_uk<128, 64, 2, 2, TOut>(a, s);
-      case 128: return big ? launch_uk<256, 128, 2, 2, TOut>(a, s) : launch_uk<128, 128, 2, 2, TOut>(a, s);
+      case 128: {
+        const long wgs128 = ((long)a.M + 127) / 128 * (a.Cout_pad / 128);
+        if (!big && wgs128 < 512 && !(ctdet_tuning_flags() & CTDET_TUNE_NO_SMALL_GRID_TILES))   // as for the halo kernel
+          return launch_uk<128, 64, 2, 2, TOut>(a, s);
+        return big ? launch_uk<256, 128, 2, 2, TOut>(a, s) : launch_uk<128, 128, 2, 2, TOut>(a, s);
+      }
     }
   }
   switch (bc) {

@@ -52,6 +52,9 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
     bp = 256 if (big or bc == 16) else 128
     if (p.R == 3 and p.S == 3 and p.stride == 1 and p.pad == 1 and p.dil == 1 and p.in_dil == 1 and nsrc <= 1
             and p.korder == 1 and H % 8 == 0 and W % 32 == 0 and bc in (32, 64, 128)):
+        small = not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_SMALL_GRID_TILES)
+        if bc == 128 and small and (M // 256) * (p.Cout_pad // 128) < 512:
+            bc = 64                      # fewer workgroups than the chip holds: 64-cout tiles
         return f"conv3x3_halo_kernel<256x{bc},{o}>"
     Wo = (W + 2 * p.pad - p.dil * (p.S - 1) - 1) // p.stride + 1 if W else 0
     if p.Cin in (8, 16) and p.korder == 0 and nsrc <= 1 and Wo and Wo % 64 == 0 and p.Cout_pad <= 32:
@@ -62,6 +65,9 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
             return f"conv_win_kernel<{p.R}x{p.R},Cin{p.Cin},Cout{bc},s{p.stride},{o}>"
         return f"conv_smallc_kernel<Cout{bc},K{p.Kpad},{o}>"
     if p.Kpad == p.K and p.R * p.S <= 32 and p.in_dil == 1 and (p.korder == 1 or p.R * p.S == 1) and p.Cin % 32 == 0:
+        if (bc == 128 and not big and ((M + 127) // 128) * (p.Cout_pad // 128) < 512
+                and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_SMALL_GRID_TILES)):
+            bc = 64
         return f"conv_igemm_uk_kernel<{bp}x{bc},{'cat' if nsrc > 1 else 'conv'},{o}>"
     return f"conv_igemm_dma_kernel<{bp}x{bc},{o}>"
 

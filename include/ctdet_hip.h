@@ -52,7 +52,7 @@ int32_t ctdet_abi_version(void);
 enum ctdet_tuning {
   CTDET_TUNING_NO_HALO = 1, CTDET_TUNING_NO_WIN = 2, CTDET_TUNING_DCN_MIXED = 4, CTDET_TUNING_NO_WGRAD_WINDOW = 8,
   CTDET_TUNING_NO_COL2IM_WINDOW = 16, CTDET_TUNING_NO_F32_DCN_WINDOW = 32,
-  CTDET_TUNING_DCN_WINDOW_V1 = 64
+  CTDET_TUNING_DCN_WINDOW_V1 = 64, CTDET_TUNING_NO_SMALL_GRID_TILES = 128
 };
 int32_t ctdet_set_tuning_flags(uint32_t flags);
 uint32_t ctdet_get_tuning_flags(void);
