@@ -733,6 +733,9 @@ struct ColGeo {        // staged per (pixel, tap): 32 bytes
   float pad;
 };
 
+// NT = taps per workgroup: 9, or 3 with gridDim.y = 3 (one kernel row each) when the map has fewer tiles than the chip has
+// CUs -- every tap's scatter and its d(offset) / d(mask) entries are independent of the other taps'.
+template <int NT>
 __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __restrict__ dcol, const f16* __restrict__ x,
                                                                 int x_stride, const float* __restrict__ om, int om_stride,
                                                                 float* __restrict__ dx, void* __restrict__ dom, int dom_stride,
@@ -752,10 +755,12 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
   const int wy0 = ty0 - 1 - MG, wx0 = tx0 - 1 - MG;
   const f16* ximg = x + (long)b * H * W * x_stride;
   float* dximg = dx + (long)b * H * W * Cin;
+  const int t0 = blockIdx.y * NT;   // first tap of this workgroup
 
   // ---- geometry once per (pixel, tap) ----
-  for (int i = tid; i < 9 * TH * TW; i += 512) {
-    const int tap = i / (TH * TW), pl = i % (TH * TW);
+  for (int i = tid; i < NT * TH * TW; i += 512) {
+    const int tl = i / (TH * TW), tap = t0 + tl, pl = i % (TH * TW);
+    if (tap >= 9) break;               // NT = 5: the second workgroup owns taps 5..8
     const int py = ty0 + (pl >> 4), pxx = tx0 + (pl & 15);
     const float* omr = om + ((long)(b * H + py) * W + pxx) * om_stride;
     const int tr = tap / 3, ts = tap - tr * 3;
@@ -772,28 +777,29 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
       const bool inwin = wr >= 0 && wr + 1 < WR && wc >= 0 && wc + 1 < WC;
       g.off = inwin ? (unsigned)(wr * WC + wc) | 0x40000000u : ((unsigned)(h_low * W + w_low) & 0x3FFFFFFFu) | 0xC0000000u;
     }
-    geo[tap * (TH * TW) + pl] = g;
+    geo[tl * (TH * TW) + pl] = g;
   }
 
   const int fr = lane & 15, q = lane >> 4;
   const int prow = wave, pcol = fr;   // 8 waves = 8 tile rows; lane = (column, 8-channel group)
   const int pl = prow * 16 + pcol;
   const long m = ((long)(b * H + ty0 + prow) * W + tx0 + pcol);
-  float s_val[9], s_dh[9], s_dw[9];
+  float s_val[NT], s_dh[NT], s_dw[NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) s_val[t] = s_dh[t] = s_dw[t] = 0.f;
+  for (int t = 0; t < NT; ++t) s_val[t] = s_dh[t] = s_dw[t] = 0.f;
 
   const int nch = Cin / 32;
   for (int chunk = 0; chunk < nch; ++chunk) {
     // ---- this lane's dcol vectors of the chunk, and the tile's largest magnitude (fixed-point scale) ----
-    f16x8 dv[9];
+    f16x8 dv[NT];
     // chunked dcol ([Cin/32][tap][32] per pixel): the nine 64-byte pieces of this chunk are one contiguous 576-byte run
     const f16* dcp = dcol + m * (9L * Cin) + (chunked ? chunk * 288 : chunk * 32) + q * 8;
     const int tstep = chunked ? 32 : Cin;
     float amax = 0.f;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      dv[t] = *(const f16x8*)(dcp + t * tstep);
+    for (int t = 0; t < NT; ++t) {
+      if (t0 + t >= 9) { dv[t] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0}; continue; }
+      dv[t] = *(const f16x8*)(dcp + (t0 + t) * tstep);
 #pragma unroll
       for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)dv[t][e]));
     }
@@ -819,7 +825,8 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
     const float fscale = ldexpf(1.f, 19 - ex), finv = ldexpf(1.f, ex - 19);
     // ---- per tap: dots for d(offset)/d(mask), scatter of d(input) ----
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < NT; ++t) {
+      if (t0 + t >= 9) continue;
       const ColGeo g = geo[t * (TH * TW) + pl];
       if (!(g.off & 0x40000000u)) continue;            // sample outside the image: no contribution
       const f16x8 d = dv[t];
@@ -890,14 +897,15 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
   }
   // ---- d(offset), d(mask logit): reduce over the 4 channel-group lanes of a pixel ----
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
+  for (int t = 0; t < NT; ++t) {
+    if (t0 + t >= 9) continue;
     float a = s_val[t], bh = s_dh[t], bw = s_dw[t];
     a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
     bh += __shfl_xor(bh, 16, 64); bh += __shfl_xor(bh, 32, 64);
     bw += __shfl_xor(bw, 16, 64); bw += __shfl_xor(bw, 32, 64);
     if (q == 0) {
       const float mk = geo[t * (TH * TW) + pl].mask;
-      dom_store(dom, dom_f16, m, dom_stride, t, bh * mk, bw * mk, mask_is_prob ? a : a * mk * (1.f - mk));  // through the sigmoid
+      dom_store(dom, dom_f16, m, dom_stride, t0 + t, bh * mk, bw * mk, mask_is_prob ? a : a * mk * (1.f - mk));  // through the sigmoid
     }
   }
 }
@@ -1446,8 +1454,17 @@ int launch_dcn_col2im_coord(const f16* dcol, const f16* x, int x_stride, const f
   const long nwork = (long)B * H * W * 9;
   if (nwork == 0) return 0;
   if (H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && x_stride % 8 == 0 && !(ctdet_tuning_flags() & CTDET_TUNE_NO_COL2IM_WINDOW)) {
-    hipLaunchKernelGGL(dcn_col2im_window_kernel, dim3((unsigned)(B * (H / 8) * (W / 16))), dim3(512), 0, s, dcol, x, x_stride,
-                       om, om_stride, dx, dom, dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
+    const unsigned tiles = (unsigned)(B * (H / 8) * (W / 16));
+    const int ncu = ctdet_device_cu_count();    // one workgroup per CU at a time: with fewer tiles, split a tile's taps
+    if ((int)tiles * 3 <= ncu)
+      hipLaunchKernelGGL(dcn_col2im_window_kernel<3>, dim3(tiles, 3), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
+                         dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
+    else if ((int)tiles * 2 <= ncu)
+      hipLaunchKernelGGL(dcn_col2im_window_kernel<5>, dim3(tiles, 2), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
+                         dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
+    else
+      hipLaunchKernelGGL(dcn_col2im_window_kernel<9>, dim3(tiles), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
+                         dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
     CTDET_LAUNCH_CHECK();
     return 0;
   }

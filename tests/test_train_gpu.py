@@ -246,6 +246,29 @@ def test_dcn_training_fwd_bwd(T, dev, case):
     close(bd.grad.cpu(), bias.grad, 3e-3, "dcn dbias")
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 32, 64), (12, 32, 32, 32), (40, 32, 48, 32)])
+def test_dcn_col2im_window_tap_split_and_whole_tiles(T, dev, shape):
+    """the LDS-window scatter splits a tile's nine taps over 3 or 2 workgroups when the map has fewer tiles than the chip has
+    CUs (8 tiles -> 3 x 3 taps; 96 tiles -> 5 + 4 taps; 240 x 3 = 720 tiles -> one workgroup per tile): all three against the
+    global-atomics kernel"""
+    ops, ot = T
+    from detectron2_centernet_amd import _lib
+    B, H, W, Cin = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, H, W, Cin, generator=g).half().to(dev)
+    dcol = torch.randn(B, H, W, 9 * Cin, generator=g).half().to(dev)
+    om = torch.randn(B, H, W, 28, generator=g)
+    om[..., :18] *= 2.0
+    om = om.to(dev)
+    dx_w, dom_w = ot.dcn_col2im_coord(dcol, x, om)
+    with _lib.tuning(_lib.TUNE_NO_COL2IM_WINDOW):
+        dx_a, dom_a = ot.dcn_col2im_coord(dcol, x, om)
+    mx = dx_a.abs().max().item()
+    assert (dx_w - dx_a).abs().max().item() <= mx * 2.0 ** -15
+    assert (dom_w - dom_a).abs().max().item() <= dom_a.abs().max().item() * 1e-4
+    assert dom_w[..., 27:].abs().max().item() == 0
+
+
 @pytest.mark.parametrize("scale", [1e-6, 1.0, 3e3])
 def test_dcn_col2im_window_fixed_point_vs_atomics(T, dev, scale):
     """the LDS-window scatter accumulates d(input) in per-tile fixed point: against the f32-atomics kernel on the same
