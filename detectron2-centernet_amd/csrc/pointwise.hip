@@ -112,23 +112,36 @@ __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const T* __restrict__
 // included.  transposed != 0 packs the input-gradient form instead: rows = original input channels, k-channels =
 // original output channels, taps flipped (dX = conv(dY, W^T flipped)).  Replaces a chain of ~8 small torch kernels
 // per conv and training step (permute, pad, reshape, zeros, cast, copy).
-__global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ w, f16* __restrict__ out, int O, int I,
-                                                           int R, int S, int rows, int chans, int chans_pad, int rows_pad,
-                                                           int Kpad, int korder, int transposed) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)rows_pad * Kpad) return;
-  const int row = (int)(idx / Kpad), k = (int)(idx % Kpad);
+// element (row, k) of the packed operand.  transposed: 0 forward, 1 input-gradient (rows = I, channels = O, taps flipped),
+// 2 / 3: the operand of DCNv2's d(columns) contraction for a [O, I, 3, 3] weight -- a 1x1 conv from the O channels of dY to
+// 9*I column channels, row order tap-major (tap*I + c) or chunk-major ((c/32)*288 + tap*32 + c%32, what the scatter kernel
+// reads in contiguous runs): value w[o][c][tap], no permuted copy of the weight in between
+__device__ __forceinline__ float pack_value(const float* __restrict__ w, int O, int I, int R, int S, int chans_pad, int korder,
+                                            int transposed, int row, int k) {
+  if (transposed >= 2) {
+    if (row >= 9 * I || k >= O) return 0.f;
+    int tap, c;
+    if (transposed == 2) { tap = row / I; c = row - tap * I; }
+    else { const int chunk = row / 288, rem = row - chunk * 288; tap = rem >> 5; c = chunk * 32 + (rem & 31); }
+    return w[((long)k * I + c) * 9 + tap];
+  }
+  const int rows = transposed ? I : O, chans = transposed ? O : I;
   const int RS = R * S;
   int tap, c;
   if (korder == 0) { tap = k / chans_pad; c = k - tap * chans_pad; }
   else { const int chunk = k / (RS * 32), rem = k - chunk * (RS * 32); tap = rem >> 5; c = chunk * 32 + (rem & 31); }
-  float v = 0.f;
-  if (row < rows && tap < RS && c < chans) {
-    const int r = tap / S, s2 = tap - r * S;
-    if (!transposed) v = w[(((long)row * I + c) * R + r) * S + s2];
-    else v = w[(((long)c * I + row) * R + (R - 1 - r)) * S + (S - 1 - s2)];
-  }
-  out[idx] = (f16)v;
+  if (row >= rows || tap >= RS || c >= chans) return 0.f;
+  const int r = tap / S, s2 = tap - r * S;
+  if (!transposed) return w[(((long)row * I + c) * R + r) * S + s2];
+  return w[(((long)c * I + row) * R + (R - 1 - r)) * S + (S - 1 - s2)];
+}
+
+__global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ w, f16* __restrict__ out, int O, int I,
+                                                           int R, int S, int chans_pad, int rows_pad, int Kpad, int korder,
+                                                           int transposed) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)rows_pad * Kpad) return;
+  out[idx] = (f16)pack_value(w, O, I, R, S, chans_pad, korder, transposed, (int)(idx / Kpad), (int)(idx % Kpad));
 }
 
 // y[b,oy,ox,c] = skip[b,oy,ox,c] + sum_{ky,kx} x[b,iy,ix,c] * w[c,ky,kx],  oy = iy*f - f/2 + ky, k = 2f:
@@ -417,19 +430,7 @@ __global__ void __launch_bounds__(256) pack_weights_batch_kernel(const PackDesc*
   const PackDesc d = table[lo];
   const long idx = (long)((int)blockIdx.x - d.blk0) * 256 + threadIdx.x;
   if (idx >= (long)d.rows_pad * d.Kpad) return;
-  const int rows = d.transposed ? d.I : d.O, chans = d.transposed ? d.O : d.I;
-  const int row = (int)(idx / d.Kpad), k = (int)(idx % d.Kpad);
-  const int RS = d.R * d.S;
-  int tap, c;
-  if (d.korder == 0) { tap = k / d.chans_pad; c = k - tap * d.chans_pad; }
-  else { const int chunk = k / (RS * 32), rem = k - chunk * (RS * 32); tap = rem >> 5; c = chunk * 32 + (rem & 31); }
-  float v = 0.f;
-  if (row < rows && tap < RS && c < chans) {
-    const int r = tap / d.S, s2 = tap - r * d.S;
-    if (!d.transposed) v = d.w[(((long)row * d.I + c) * d.R + r) * d.S + s2];
-    else v = d.w[(((long)c * d.I + row) * d.R + (d.R - 1 - r)) * d.S + (d.S - 1 - s2)];
-  }
-  d.out[idx] = (f16)v;
+  d.out[idx] = (f16)pack_value(d.w, d.O, d.I, d.R, d.S, d.chans_pad, d.korder, d.transposed, (int)(idx / d.Kpad), (int)(idx % d.Kpad));
 }
 
 int launch_pack_weights_batch(const void* table_dev, int n, int total_blocks, hipStream_t s) {
@@ -441,12 +442,18 @@ int launch_pack_weights_batch(const void* table_dev, int n, int total_blocks, hi
 
 int launch_pack_weights(const float* w, void* out, int O, int I, int R, int S, int chans_pad, int rows_pad, int Kpad,
                         int korder, int transposed, hipStream_t s) {
-  const int rows = transposed ? I : O, chans = transposed ? O : I;
-  CTDET_CHECK(chans_pad >= chans && rows_pad >= rows && Kpad >= R * S * chans_pad, "pack_weights: padded sizes too small");
-  CTDET_CHECK(korder == 0 || (korder == 1 && chans_pad % 32 == 0), "pack_weights: chunk-major needs channels %% 32 == 0");
+  if (transposed >= 2) {
+    CTDET_CHECK(transposed <= 3 && R == 3 && S == 3 && korder == 0 && chans_pad >= O && Kpad >= chans_pad && rows_pad >= 9 * I &&
+                    (transposed == 2 || I % 32 == 0),
+                "pack_weights: the DCNv2 d(columns) operand needs a [O,I,3,3] weight, korder 0, rows_pad >= 9*I (chunk-major: I %% 32 == 0)");
+  } else {
+    const int rows = transposed ? I : O, chans = transposed ? O : I;
+    CTDET_CHECK(chans_pad >= chans && rows_pad >= rows && Kpad >= R * S * chans_pad, "pack_weights: padded sizes too small");
+    CTDET_CHECK(korder == 0 || (korder == 1 && chans_pad % 32 == 0), "pack_weights: chunk-major needs channels %% 32 == 0");
+  }
   const long total = (long)rows_pad * Kpad;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(nblk(total)), dim3(256), 0, s, w, (f16*)out, O, I, R, S, rows, chans, chans_pad,
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(nblk(total)), dim3(256), 0, s, w, (f16*)out, O, I, R, S, chans_pad,
                      rows_pad, Kpad, korder, transposed);
   CTDET_LAUNCH_CHECK();
   return 0;

@@ -231,7 +231,14 @@ class PackedConv:
         conv that maps dY to dX; f16 only.  cout_align: pad the packed rows to a multiple of this (the DCNv2 window kernel
         works on 64-cout tiles whatever Cout is)."""
         _require_cuda(weight)
-        if transposed:
+        # transposed = "dcn_cols" / "dcn_cols_chunked": the operand of DCNv2's d(columns) contraction for a [O, I, 3, 3] weight,
+        # a 1x1 conv from dY's O channels to 9*I column channels (ctdet_pack_weights transposed = 2 / 3)
+        dcn_mode = {"dcn_cols": 2, "dcn_cols_chunked": 3}[transposed] if isinstance(transposed, str) else 0
+        if dcn_mode:
+            assert compute == F16 and scale is None and bias is None and weight.dtype == torch.float32 and weight.is_contiguous()
+            assert tuple(weight.shape[2:]) == (3, 3) and not tap_major
+            Cin, Cout, R, S = weight.shape[0], 9 * weight.shape[1], 1, 1
+        elif transposed:
             assert compute == F16 and scale is None and bias is None
             Cin, Cout, R, S = weight.shape
         else:
@@ -255,7 +262,8 @@ class PackedConv:
             self.Kpad = round_up(K, 32)
             self.Cout_pad = round_up(self.Cout_eff, tile)
             O, I = weight.shape[0], weight.shape[1]
-            args = (O, I, R, S, self.Cin, self.Cout_pad, self.Kpad, self.korder, int(transposed))
+            args = (O, I, weight.shape[2], weight.shape[3], self.Cin, self.Cout_pad, self.Kpad, self.korder,
+                    dcn_mode if dcn_mode else int(bool(transposed)))
             plan = PACK_PLAN if (PACK_PLAN is not None and PACK_PLAN.covers(weight)) else None
             wp = plan.lookup(args + (weight.data_ptr(),), weight) if plan is not None else None
             if wp is None:

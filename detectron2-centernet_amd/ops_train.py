@@ -290,6 +290,20 @@ def dcn_weight_matrix(weight, Cw=None, chunked=False):
     return wmat
 
 
+def dcn_dcol(dyp, weight, chunked):
+    """d(columns) [B, H, W, 9*Cin] = dY . W of a DCNv2 layer (deform_conv_cuda.cu:1003-1009), rows tap-major or chunk-major.
+    f16: the operand is packed straight from the [Cout, Cin, 3, 3] parameter (a planned pack: no permuted copy per step);
+    f32: the permuted weight matrix through the generic input-gradient path."""
+    Cout, Cin = weight.shape[:2]
+    if dyp.dtype == torch.float32:
+        return conv_dgrad(dyp, dcn_weight_matrix(weight, dyp.shape[3], chunked), 1, 0, dyp.shape[1:3])
+    p = ops.PackedConv(weight.detach(), None, None, stride=1, pad=0, compute=F16, cin_pad=dyp.shape[3],
+                       transposed="dcn_cols_chunked" if chunked else "dcn_cols")
+    dcol = torch.empty(dyp.shape[0], dyp.shape[1], dyp.shape[2], p.Cout_eff, dtype=torch.float16, device=dyp.device)
+    ops.conv2d(dyp, p, out=dcol)
+    return dcol
+
+
 def dcn_col2im_coord(dcol, x, om, mask_is_prob=False, dom_channels=None, dcol_chunked=False):
     """dx (f32, atomically accumulated) and dom = d(offsets, mask logits).  dom_channels=None: f32, the shape of om;
     dom_channels=C (f16 data): an f16 [B, H, W, C] tensor whose channels 27.. are zero -- directly the dY of the offset conv's
@@ -356,8 +370,9 @@ def _conv_dgrad_s2_phases(dy, weight, in_hw):
     return dx if Cp == Cin else dx[..., :Cin]
 
 
-def conv_dgrad(dy, weight, stride, pad, in_hw):
+def conv_dgrad(dy, weight, stride, pad, in_hw, cin_pad=None):
     """dx of y = conv(x, weight): a conv over dy with the taps flipped and in/out channels swapped;
+    cin_pad (f16): dy carries that many channels (>= Cout, the extra ones zero) -- the operand gets zero columns for them;
     f16: 3x3 / stride 2 / pad 1 goes through the four-phase form, other strides read dy as zero-stuffed (in_dil);
     f32: always the zero-stuffed form on the f32 MFMA kernel."""
     Cout, Cin, R, S = weight.shape
@@ -369,9 +384,9 @@ def conv_dgrad(dy, weight, stride, pad, in_hw):
         ops.conv2d(dy, p, out=dx)
         return dx if p.Cout_eff == Cin else dx[..., :Cin]
     if stride == 2 and R == 3 and S == 3 and pad == 1 and dy.shape[3] % 8 == 0:
-        return _conv_dgrad_s2_phases(dy, weight, in_hw)
+        return _conv_dgrad_s2_phases(dy, weight, in_hw)     # pads the operand to dy's channel count itself
     p = ops.PackedConv(weight.detach(), None, None, stride=1, pad=R - 1 - pad, compute=F16, tap_major=stride > 1,
-                       transposed=True)
+                       transposed=True, cin_pad=cin_pad)
     p.in_dil = stride
     B = dy.shape[0]
     dx = torch.empty(B, in_hw[0], in_hw[1], p.Cout_eff, dtype=torch.float16, device=dy.device)
@@ -429,10 +444,13 @@ class ConvFn(torch.autograd.Function):
             dwt = _wgrad_to_oihw(dw, Cout, Cin, x.shape[3], R, S)
         dx = None
         if ctx.needs_input_grad[0]:
-            wpad = weight if Cw == Cout else torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
-            if x.shape[3] != Cin:             # input channels were padded (the 3 -> 8 channel image): so is dX
-                wpad = torch.nn.functional.pad(wpad.detach(), (0, 0, 0, 0, 0, x.shape[3] - Cin))
-            dx = conv_dgrad(dy, wpad, stride, pad, x.shape[1:3])
+            if x.shape[3] != Cin or x.dtype == torch.float32:
+                wpad = weight if Cw == Cout else torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
+                if x.shape[3] != Cin:         # input channels were padded (the 3 -> 8 channel image): so is dX
+                    wpad = torch.nn.functional.pad(wpad.detach(), (0, 0, 0, 0, 0, x.shape[3] - Cin))
+                dx = conv_dgrad(dy, wpad, stride, pad, x.shape[1:3])
+            else:                             # padded dY channels meet zero operand columns: no padded copy of the weight
+                dx = conv_dgrad(dy, weight, stride, pad, x.shape[1:3], cin_pad=Cw)
         return dx, dwt, dbias, None, None, None, None, None
 
 
@@ -604,11 +622,10 @@ class DCNFn(torch.autograd.Function):
         dyp = _pad_c(dy)
         col = dcn_cols(x, om, ctx.mask_is_prob)
         chunked = x.dtype == torch.float16 and Cin % 32 == 0
-        wmat = dcn_weight_matrix(weight, dyp.shape[3], chunked)
         _, _, _, dbias = bn_train_bwd(dyp, None, None, None, None, None, relu=False, grad_mult=ctx.pgm)
         dw = conv_wgrad(col, dyp, dyp.shape[3], 1, 1, 1, 0, scale=ctx.pgm)[:Cout]         # [Cout, 9*Cin]
         dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
-        dcol = conv_dgrad(dyp, wmat, 1, 0, x.shape[1:3])                   # [M, 9*Cin]
+        dcol = dcn_dcol(dyp, weight, chunked)                              # [M, 9*Cin]
         dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om, ctx.mask_is_prob, dcol_chunked=chunked)
         return dx32.to(x.dtype), dom, dwt, dbias[:Cout] if ctx.has_bias else None, None, None
 
@@ -646,7 +663,6 @@ class DeformConvFn(torch.autograd.Function):
         dyp = _pad_c(dy if dy.shape[3] == Cout else dy[..., :Cout].contiguous())
         # ---- main conv: dW, d(columns) -> scatter (d input, f32) + d(offset / mask logits)
         chunked = x.dtype == torch.float16 and Cin % 32 == 0
-        wmat = dcn_weight_matrix(weight, dyp.shape[3], chunked)
         p_woff, p_boff, p_w, p_b = ctx.params
         sb = grad_slot(p_b) if p_b is not None else None
         if sb is not None and sb.numel() != dyp.shape[3]:
@@ -661,7 +677,7 @@ class DeformConvFn(torch.autograd.Function):
             dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
         if sb is not None:
             grad_done(p_b)
-        dcol = conv_dgrad(dyp, wmat, 1, 0, x.shape[1:3])
+        dcol = dcn_dcol(dyp, weight, chunked)
         # dom comes back in the data type and channel padding the offset conv's backward kernels take (f16: 32 channels)
         n_om = w_off.shape[0]
         f32 = x.dtype == torch.float32
@@ -675,12 +691,12 @@ class DeformConvFn(torch.autograd.Function):
         else:
             dw_off = conv_wgrad(x, dom_p, Cw, 3, 3, 1, 1)[:n_om]
             dw_off_t = _wgrad_to_oihw(dw_off, n_om, Cin, x.shape[3], 3, 3)
-        wpad = torch.nn.functional.pad(w_off.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - n_om)) if Cw != n_om else w_off.detach()
         if f32:
+            wpad = torch.nn.functional.pad(w_off.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - n_om)) if Cw != n_om else w_off.detach()
             wt = wpad.flip(2, 3).permute(1, 0, 2, 3).contiguous()
             pt = ops.PackedConv(wt, None, None, stride=1, pad=1, compute=F32)
-        else:
-            pt = ops.PackedConv(wpad, None, None, stride=1, pad=1, compute=F16, transposed=True)
+        else:   # the padded dY channels meet zero operand columns: packed from the parameter itself (a planned pack)
+            pt = ops.PackedConv(w_off.detach(), None, None, stride=1, pad=1, compute=F16, transposed=True, cin_pad=Cw)
         dx = ops.conv2d(dom_p, pt, out=dx32 if pt.Cout_eff == Cin else None, residual=dx32 if pt.Cout_eff == Cin else None,
                         out_dtype=torch.float32)
         if pt.Cout_eff != Cin:

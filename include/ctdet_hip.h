@@ -162,7 +162,9 @@ int32_t ctdet_ese_scale(const void* x, int32_t x_stride, const float* s, const v
 /* Packs an f32 OIHW conv weight [O,I,R,S] (nn.Conv2d.weight as the reference stores it) into the f16 [rows_pad][Kpad]
  * operand of ctdet_conv2d_fwd / ctdet_dcnv2_fwd, zero padding included.  korder as in ctdet_conv_desc.  transposed = 0:
  * rows = O, channels = I (chans_pad >= I).  transposed = 1: the input-gradient operand (rows = I, channels = O, taps
- * flipped), i.e. dX = conv(dY, packed) -- what autograd of nn.Conv2d computes. */
+ * flipped), i.e. dX = conv(dY, packed) -- what autograd of nn.Conv2d computes.  transposed = 2 / 3 ([O,I,3,3] weights, korder 0):
+ * the operand of DCNv2's d(columns) contraction, a 1x1 conv from dY's O channels to 9*I column channels in tap-major /
+ * chunk-major row order (rows_pad >= 9*I, chans_pad >= O) -- see ctdet_dcn_col2im_coord's dcol_chunked. */
 int32_t ctdet_pack_weights(const float* w, void* packed, int32_t O, int32_t I, int32_t R, int32_t S, int32_t chans_pad,
                            int32_t rows_pad, int32_t Kpad, int32_t korder, int32_t transposed, void* stream);
 /* n packs in one launch: a DEVICE table of descriptors with the arguments of ctdet_pack_weights; blk0 = number of
