@@ -1175,7 +1175,10 @@ __global__ void __launch_bounds__(256, 2) dcn_window_kernel(const ConvArgs a) {
 // the 128 x 32 f32 results go through LDS to the geometry stage (and to a.om_out if the caller wants them: training).  One
 // kernel and no 112-byte-per-pixel offset tensor instead of two kernels; the sampling pass then walks the chunks backwards,
 // starting on the window the offset conv finished with.
-template <typename TOut, bool FUSED>
+// COLS: no contraction at all -- the sampled * mask operands are stored as the training backward's `columns` tensor
+// ([M][9*Cin] f16, tap-major; a.y), i.e. modulated_deformable_im2col (kernel.cu:786-868) with the gathers served from the LDS
+// window instead of 4 x 16 bytes per (pixel, tap, 8 channels) through L2.
+template <typename TOut, bool FUSED, bool COLS = false>
 __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs a) {
   constexpr int BC = 64, TH = 8, TW = 16, BP = 128, MG = 4, TP = 2, TC = 4;
   constexpr int WR = TH + 2 + 2 * MG, WCU = TW + 2 + 2 * MG, WCP = 32;   // 18 rows x 26 used of 32 columns
@@ -1231,7 +1234,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
     }
   };
   issue_window(0);
-  if constexpr (!FUSED) issue_w(0, 0);
+  if constexpr (!FUSED && !COLS) issue_w(0, 0);
   // consumer mapping: lane (fr, q) = tile pixel (row 2*wave + fr/8, col 8p + fr%8), channels 8q..8q+7 of the chunk
   const int fr = lane & 15, q = lane >> 4;
   const int prow = 2 * wave + (fr >> 3), pcol = fr & 7;
@@ -1300,7 +1303,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
     issue_w((nch - 1) * 3, 0);                           // first row-step of the sampling pass: the last chunk
   }
 
-  if (tid < BC) {
+  if (!COLS && tid < BC) {
     const int c = n0 + tid;
     sbuf[tid] = (a.scale && c < a.Cout) ? a.scale[c] : 1.f;
     sbuf[BC + tid] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
@@ -1425,7 +1428,14 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
     constexpr int T = decltype(tc)::value, TS = T % 3;
     const int st = s & 1;
     const int chunk = chunk_at(ci);
-    if (TS == 0) {
+    if constexpr (COLS) {                                // pf = sampled * mask of tap T: 8 channels of this lane's two pixels
+#pragma unroll
+      for (int p = 0; p < TP; ++p) {
+        const long m = (long)(b * a.H + ty0 + prow) * a.W + tx0 + 8 * p + pcol;
+        *(f16x8*)((f16*)a.y + m * (9L * a.Cin) + T * a.Cin + chunk * 32 + q * 8) = pf[p];
+      }
+    }
+    if (!COLS && TS == 0) {
       wait_vmcnt<0>();                                   // this row's weights (issued a row ago)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -1436,7 +1446,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
     f16x8 wfn[TC], pfn[TP];
     u32x4 raw[TP][4];
     unsigned wts[TP][2];
-    if (TS < 2) frags(st, TS + 1, wfn);
+    if (!COLS && TS < 2) frags(st, TS + 1, wfn);
     if (T < 8) {
       gather(T + 1, chunk, raw, wts);
     } else if (ci + 1 < nch) {                           // tap 8 was sampled during tap 7: the window is free
@@ -1445,10 +1455,12 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
       asm volatile("" ::: "memory");
       issue_window(chunk_at(ci + 1));
     }
+    if constexpr (!COLS) {
 #pragma unroll
-    for (int p = 0; p < TP; ++p)
+      for (int p = 0; p < TP; ++p)
 #pragma unroll
-      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf[p], acc[p][c], 0, 0, 0);
+        for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf[p], acc[p][c], 0, 0, 0);
+    }
     if (T < 8) {
       blend(raw, wts, pfn);
     } else if (ci + 1 < nch) {
@@ -1460,7 +1472,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
     }
 #pragma unroll
     for (int p = 0; p < TP; ++p) pf[p] = pfn[p];
-    if (TS < 2) {
+    if (!COLS && TS < 2) {
 #pragma unroll
       for (int c = 0; c < TC; ++c) wf[c] = wfn[c];
     }
@@ -1478,6 +1490,7 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
     tap(s + 2, ci, std::integral_constant<int, 8>{});
   }
 
+  if constexpr (COLS) return;
   // epilogue: per cout-tile pair h a lane holds 8 consecutive couts (cout_of) of 2 pixels; scale/bias from LDS, 16-byte stores
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
@@ -1516,6 +1529,19 @@ __global__ void __launch_bounds__(256, 2) dcn_window_rows_kernel(const ConvArgs 
       }
     }
   }
+}
+
+// `columns` of the DCNv2 backward from the LDS window (train_bwd.hip's launch_dcn_cols decides when)
+int launch_dcn_cols_window(const f16* x, int x_stride, const float* om, int om_stride, f16* col, int B, int H, int W, int Cin,
+                           int mask_is_prob, hipStream_t s) {
+  ConvArgs a = {};
+  a.x = x; a.y = col; a.om = om; a.om_stride = om_stride; a.mask_is_prob = mask_is_prob;
+  a.B = B; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.Cin = Cin; a.in_stride = x_stride; a.Cout = 64; a.Cout_pad = 64;
+  a.R = a.S = 3; a.stride = 1; a.pad = 1; a.dil = 1; a.in_dil = 1; a.K = a.Kpad = 9 * Cin; a.M = B * H * W; a.korder = 1;
+  const int nbx = B * (H / 8) * (W / 16);
+  hipLaunchKernelGGL((dcn_window_rows_kernel<f16, false, true>), dim3(8 * ((nbx + 7) / 8)), dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
 }
 
 // geometry the row-step kernel (and with it the fused offset conv) serves

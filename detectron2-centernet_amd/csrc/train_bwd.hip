@@ -1434,11 +1434,16 @@ int launch_dwconvT_bwd(const f16* x, int x_stride, const f16* dz, int dz_stride,
   return 0;
 }
 
+int launch_dcn_cols_window(const f16* x, int x_stride, const float* om, int om_stride, f16* col, int B, int H, int W, int Cin,
+                           int mask_is_prob, hipStream_t s);   // conv_igemm.hip: the sampling kernel's LDS window
 int launch_dcn_cols(const f16* x, int x_stride, const float* om, int om_stride, f16* col, int B, int H, int W, int Cin,
                     int mask_is_prob, hipStream_t s) {
   CTDET_CHECK(Cin % 8 == 0 && om_stride >= 27, "dcn_cols: bad shape");
   const long total = (long)B * H * W * 9 * (Cin / 8);
   if (total == 0) return 0;
+  if (H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && x_stride % 8 == 0 && om_stride % 4 == 0 && H <= 65534 && W <= 65534 &&
+      (((size_t)x | (size_t)col | (size_t)om) & 15) == 0 && !(ctdet_tuning_flags() & CTDET_TUNE_NO_COL2IM_WINDOW))
+    return launch_dcn_cols_window(x, x_stride, om, om_stride, col, B, H, W, Cin, mask_is_prob, s);
   hipLaunchKernelGGL(dcn_cols_kernel, dim3(nblk256(total)), dim3(256), 0, s, x, x_stride, om, om_stride, col, B, H, W, Cin,
                      mask_is_prob);
   CTDET_LAUNCH_CHECK();

@@ -246,6 +246,36 @@ def test_dcn_training_fwd_bwd(T, dev, case):
     close(bd.grad.cpu(), bias.grad, 3e-3, "dcn dbias")
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 1.0), (1, 24, 16, 128, 6.0), (3, 8, 48, 32, 0.0)])
+def test_dcn_cols_from_lds_window(T, dev, case):
+    """the backward's columns (modulated_deformable_im2col, kernel.cu:786-868) sampled from the forward kernel's LDS window
+    (packed-f16 blend, far samples per lane from global memory) against the per-element kernel with its f32 blend, and against
+    the oracle's bilinear sampling"""
+    ops, ot = T
+    from detectron2_centernet_amd import _lib
+    B, H, W, Cin, off_std = case
+    g = torch.Generator().manual_seed(int(sum(case[:4])))
+    x = h16(torch.randn(B, Cin, H, W, generator=g))
+    om = torch.randn(B, 27, H, W, generator=g)
+    om[:, :18] *= off_std
+    om[:, 0, 0, 0], om[:, 1, 0, 0], om[:, 4, 3, 5], om[:, 5, 3, 5] = -0.0, -1.0, 4.0, -4.0
+    xd = nhwc(x).half().to(dev)
+    omd = torch.zeros(B, H, W, 28)
+    omd[..., :27] = nhwc(om)
+    omd = omd.to(dev)
+    cols = ot.dcn_cols(xd, omd)
+    with _lib.tuning(_lib.TUNE_NO_COL2IM_WINDOW):
+        cols_ref = ot.dcn_cols(xd, omd)
+    scale = max(1.0, cols_ref.float().abs().max().item())
+    assert (cols.float() - cols_ref.float()).abs().max().item() <= 4e-3 * scale
+    # oracle: DCNv2 with an identity-like weight picking (tap t, channel c) reproduces column (t, c)
+    t, c = 4, 3
+    w = torch.zeros(1, Cin, 3, 3)
+    w[0, c, t // 3, t % 3] = 1.0
+    ref = O.dcnv2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, None, 1, 1, 1)[:, 0]
+    assert (cols[..., t * Cin + c].float().cpu() - ref).abs().max().item() <= 4e-3 * scale
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 32, 64), (12, 32, 32, 32), (40, 32, 48, 32)])
 def test_dcn_col2im_window_tap_split_and_whole_tiles(T, dev, shape):
     """the LDS-window scatter splits a tile's nine taps over 3 or 2 workgroups when the map has fewer tiles than the chip has
