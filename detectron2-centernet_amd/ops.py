@@ -709,11 +709,12 @@ def _dw_weight(weight, Cc, f, fresh=False):
     return hit[1]
 
 
-def dwconvT_add(x, weight, f, skip=None, out=None, fresh_weight=False):
-    """ConvTranspose2d(C,C,2f,stride=f,padding=f//2,groups=C)(x) + skip; weight f32 [C,1,2f,2f] or [C,2f,2f]."""
+def dwconvT_add(x, weight, f, skip=None, out=None, fresh_weight=False, prepared=None):
+    """ConvTranspose2d(C,C,2f,stride=f,padding=f//2,groups=C)(x) + skip; weight f32 [C,1,2f,2f] or [C,2f,2f];
+    prepared: its [2f,2f,C] f32 form if the caller already made it"""
     _require_cuda(x, weight, skip, out)
     B, H, W, Cc = x.shape
-    w = _dw_weight(weight, Cc, f, fresh_weight)
+    w = prepared if prepared is not None else _dw_weight(weight, Cc, f, fresh_weight)
     if out is None:
         out = torch.empty(B, H * f, W * f, Cc, dtype=x.dtype, device=x.device)
     rc = _lib.lib().ctdet_dwconvT_add(_ptr(x), _ptr(w), _ptr(skip), _ptr(out), dt_of(x), B, H, W, Cc, f,

@@ -256,15 +256,17 @@ def maxpool2x2_bwd(x, dz):
     return dx
 
 
-def dwconvT_bwd(x, dz, weight, f):
+def dwconvT_bwd(x, dz, weight, f, wk=None, raw=False):
+    """wk: the [2f, 2f, C] f32 form of `weight` if the caller already has it (the forward of the same step made it);
+    raw: return dw as the kernel accumulates it, [2f, 2f, C], instead of the parameter's [C, 1, 2f, 2f] view"""
     B, H, W, Cc = x.shape
-    w = weight.detach().reshape(Cc, 2 * f, 2 * f).to(torch.float32).permute(1, 2, 0).contiguous()
+    w = wk if wk is not None else weight.detach().reshape(Cc, 2 * f, 2 * f).to(torch.float32).permute(1, 2, 0).contiguous()
     dx = torch.empty(B, H, W, Cc, dtype=x.dtype, device=x.device)
-    dw = torch.zeros(2 * f, 2 * f, Cc, dtype=torch.float32, device=x.device)
+    dw = _zeros_f32((2 * f, 2 * f, Cc), x.device)
     rc = _lib.lib().ctdet_dwconvT_bwd(_ptr(x), _nhwc_stride(x), _ptr(dz), _nhwc_stride(dz), _ptr(w), _ptr(dx),
                                       _nhwc_stride(dx), _ptr(dw), B, H, W, Cc, f, dt_of(x), _stream())
     _lib.check(rc, "ctdet_dwconvT_bwd")
-    return dx, dw.permute(2, 0, 1).reshape(Cc, 1, 2 * f, 2 * f)
+    return dx, (dw if raw else dw.permute(2, 0, 1).reshape(Cc, 1, 2 * f, 2 * f))
 
 
 def dcn_cols(x, om, mask_is_prob=False):
@@ -580,14 +582,26 @@ class DwConvTAddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, skip, f):
         ctx.f = f
+        ctx.wparam = weight
+        ctx.wk = ops._dw_weight(weight, x.shape[3], f, True)      # [2f, 2f, C] f32: made once per step, used by both passes
         ctx.save_for_backward(x, weight)
-        return ops.dwconvT_add(x, weight, f, skip=skip, fresh_weight=True)
+        return ops.dwconvT_add(x, ctx.wk.permute(2, 0, 1), f, skip=skip, prepared=ctx.wk)
 
     @staticmethod
     def backward(ctx, dz):
         x, weight = ctx.saved_tensors
         dz = dz.contiguous()
-        dx, dw = dwconvT_bwd(x, dz, weight, ctx.f)
+        slot = grad_slot(ctx.wparam)
+        dx, dw = dwconvT_bwd(x, dz, weight, ctx.f, wk=ctx.wk, raw=slot is not None)
+        if slot is not None:
+            # tap-major [2f*2f][C] sums -> the [C, 1, 2f, 2f] gradient through the per-bucket scatter (as one "output channel"
+            # of C inputs), scaled like every parameter gradient
+            k2 = 4 * ctx.f * ctx.f
+            src = dw.view(k2, -1) * PARAM_GRAD_MULT
+            _queue_end_of_backward()
+            PENDING.append((slot.view(1, slot.shape[0], slot.shape[2], slot.shape[3]), src, k2, slot.shape[0]))
+            grad_done(ctx.wparam)
+            return dx, None, dz, None
         return dx, dw * PARAM_GRAD_MULT, dz, None
 
 
