@@ -424,7 +424,7 @@ def main():
     ap.add_argument("--task", default="infer", choices=["infer", "train"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64 infer / 16 train)")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "f32", "f16x3"])
     ap.add_argument("--config", default="dla34", choices=["dla34", "r50"],
                     help="dla34: BASELINE.json configs[1] (+[2]); r50: configs[4], ResNet-50 CenterNet 800x800 bs 8 per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -494,7 +494,7 @@ def main():
                                    f"{sum(len(o['instances']) for o in out) / max(1, len(out)):.0f} detections per image post-processed",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"replicas x{world}"},
         }
-        peak = MFMA_F16_PEAK_TFLOPS if args.precision == "f16" else FP32_PEAK_TFLOPS
+        peak = {"f16": MFMA_F16_PEAK_TFLOPS, "f32": FP32_PEAK_TFLOPS, "f16x3": MFMA_F16_PEAK_TFLOPS / 3.0}[args.precision]
         if rank == 0 and not args.no_roofline:
             result["roofline"] = roofline_record(roofline_pass(model, images), peak, with_traffic=headline)
         oracle_out = None

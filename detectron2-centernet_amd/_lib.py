@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libctdet_hip.so")
 
-F16, F32, U8 = 0, 1, 2
+F16, F32, U8, F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP = 0, 1, 2
 
 
@@ -42,6 +42,7 @@ SIGNATURES = {
     "ctdet_ese_scale": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_pack_weights": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_pack_weights_batch": (_i32, [_vp, _i32, _i32, _vp]),
+    "ctdet_split_weights": (_i32, [_vp, _vp, _i64, _vp]),
     "ctdet_dwconvT_add": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_decode_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "ctdet_decode": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),

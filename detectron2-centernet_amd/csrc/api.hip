@@ -53,6 +53,7 @@ struct WgradArgs {
 };
 int launch_grad_scatter_oihw(const void* const*, void* const*, const int*, const int*, const int*, const int*, int, hipStream_t);
 int launch_pack_weights_batch(const void*, int, int, hipStream_t);
+int launch_split_weights(const float*, void*, long, hipStream_t);
 bool dcn_offset_fused_ok(const ConvArgs& a);
 size_t chan_reduce_workspace_bytes(int C);
 int launch_bn_train_fwd(const f16*, int, const f16*, int, f16*, int, int, int, const float*, const float*, float, float,
@@ -124,7 +125,7 @@ extern "C" {
 const char* ctdet_last_error(void) { return g_err; }
 int32_t ctdet_set_tuning_flags(uint32_t flags) { g_tuning.store(flags, std::memory_order_relaxed); return 0; }
 uint32_t ctdet_get_tuning_flags(void) { return g_tuning.load(std::memory_order_relaxed); }
-int32_t ctdet_abi_version(void) { return 3; }
+int32_t ctdet_abi_version(void) { return 4; }
 int32_t ctdet_conv_cout_tile(int32_t cout) {
   if (cout <= 16) return 16;
   if (cout <= 32) return 32;
@@ -143,9 +144,9 @@ int32_t ctdet_conv2d_fwd(const ctdet_conv_desc* d, const void* x, const void* w_
   CTDET_CHECK(x && w_packed && y, "conv: null pointer");
   a.x = x; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
   if (d->compute_dtype == CTDET_DT_F16) return launch_conv_f16(a, d->out_dtype, false, (hipStream_t)stream);
-  if (d->compute_dtype == CTDET_DT_F32) {
-    CTDET_CHECK(d->out_dtype == CTDET_DT_F32, "conv(f32): output must be f32");
-    return launch_conv_f32(a, false, (hipStream_t)stream);
+  if (d->compute_dtype == CTDET_DT_F32 || d->compute_dtype == CTDET_DT_F16X3) {
+    CTDET_CHECK(d->out_dtype == CTDET_DT_F32, "conv(f32 / f16x3): output must be f32");
+    return launch_conv_f32(a, false, d->compute_dtype == CTDET_DT_F16X3, (hipStream_t)stream);
   }
   CTDET_CHECK(false, "conv: bad compute dtype %d", d->compute_dtype);
 }
@@ -161,7 +162,7 @@ int32_t ctdet_conv1x1_cat_fwd(const ctdet_conv_desc* d, const void* const* xs, c
   CTDET_CHECK(nsrc >= 1 && nsrc <= 4, "conv1x1_cat: nsrc=%d must be 1..4", nsrc);
   CTDET_CHECK(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0, "conv1x1_cat: only 1x1 stride-1 convs");
   a.korder = 0;
-  const int align = d->compute_dtype == CTDET_DT_F16 ? 8 : 1;
+  const int align = d->compute_dtype == CTDET_DT_F16 ? 8 : (d->compute_dtype == CTDET_DT_F16X3 ? 4 : 1);
   int cum = 0;
   for (int j = 0; j < 4; ++j) {
     if (j < nsrc) {
@@ -179,9 +180,9 @@ int32_t ctdet_conv1x1_cat_fwd(const ctdet_conv_desc* d, const void* const* xs, c
   if (nsrc == 1) { a.nsrc = 1; a.in_stride = strides[0]; }
   a.x = xs[0]; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
   if (d->compute_dtype == CTDET_DT_F16) return launch_conv_f16(a, d->out_dtype, false, (hipStream_t)stream);
-  if (d->compute_dtype == CTDET_DT_F32) {
-    CTDET_CHECK(d->out_dtype == CTDET_DT_F32, "conv1x1_cat(f32): output must be f32");
-    return launch_conv_f32(a, false, (hipStream_t)stream);
+  if (d->compute_dtype == CTDET_DT_F32 || d->compute_dtype == CTDET_DT_F16X3) {
+    CTDET_CHECK(d->out_dtype == CTDET_DT_F32, "conv1x1_cat(f32 / f16x3): output must be f32");
+    return launch_conv_f32(a, false, d->compute_dtype == CTDET_DT_F16X3, (hipStream_t)stream);
   }
   CTDET_CHECK(false, "conv1x1_cat: bad compute dtype %d", d->compute_dtype);
 }
@@ -198,9 +199,9 @@ int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* of
   a.x = x; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = nullptr; a.y = y;
   a.om = offset_mask; a.om_stride = om_stride; a.mask_is_prob = mask_is_prob;
   if (d->compute_dtype == CTDET_DT_F16) return launch_conv_f16(a, d->out_dtype, true, (hipStream_t)stream);
-  if (d->compute_dtype == CTDET_DT_F32) {
-    CTDET_CHECK(d->out_dtype == CTDET_DT_F32, "dcnv2(f32): output must be f32");
-    return launch_conv_f32(a, true, (hipStream_t)stream);
+  if (d->compute_dtype == CTDET_DT_F32 || d->compute_dtype == CTDET_DT_F16X3) {
+    CTDET_CHECK(d->out_dtype == CTDET_DT_F32, "dcnv2(f32 / f16x3): output must be f32");
+    return launch_conv_f32(a, true, d->compute_dtype == CTDET_DT_F16X3, (hipStream_t)stream);
   }
   CTDET_CHECK(false, "dcnv2: bad compute dtype %d", d->compute_dtype);
 }
@@ -303,6 +304,11 @@ int32_t ctdet_pack_weights(const float* w, void* packed, int32_t O, int32_t I, i
                            int32_t rows_pad, int32_t Kpad, int32_t korder, int32_t transposed, void* stream) {
   CTDET_CHECK(w && packed, "pack_weights: null pointer");
   return launch_pack_weights(w, packed, O, I, R, S, chans_pad, rows_pad, Kpad, korder, transposed, (hipStream_t)stream);
+}
+
+int32_t ctdet_split_weights(const float* w_packed_f32, void* w_split, int64_t n, void* stream) {
+  CTDET_CHECK(w_packed_f32 && w_split && n >= 0, "split_weights: bad arguments");
+  return launch_split_weights(w_packed_f32, w_split, (long)n, (hipStream_t)stream);
 }
 
 int32_t ctdet_pack_weights_batch(const ctdet_pack_desc* table_dev, int32_t n, int32_t total_blocks, void* stream) {

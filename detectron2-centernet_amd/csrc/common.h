@@ -9,6 +9,7 @@
 typedef _Float16 f16;
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // error plumbing (thread-local message, returned through ctdet_last_error()).
@@ -30,7 +31,7 @@ void ctdet_set_error(const char* fmt, ...);
     }                                                                 \
   } while (0)
 
-enum { CTDET_F16 = 0, CTDET_F32 = 1, CTDET_U8 = 2 };
+enum { CTDET_F16 = 0, CTDET_F32 = 1, CTDET_U8 = 2, CTDET_F16X3 = 3 };
 enum { CTDET_ACT_NONE = 0, CTDET_ACT_RELU = 1, CTDET_ACT_SIGMOID_CLAMP = 2 };
 
 // Kernel-side argument block for every conv-shaped contraction on the path
@@ -130,4 +131,4 @@ int ctdet_device_cu_count();
 // launchers implemented in the .hip files (return 0 or negative errno)
 int launch_conv_f16(const ConvArgs& a, int out_dtype, bool deform, hipStream_t s);
 int launch_head_fused(const HeadArgs& a, hipStream_t s);
-int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s);
+int launch_conv_f32(const ConvArgs& a, bool deform, bool split, hipStream_t s);

@@ -178,6 +178,63 @@ __device__ __forceinline__ void dma16(const void* g, char* lds_wave_base) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory", "m0");
 }
 
+// ------------------------------------------------------------------------------------------
+// f16x3 ("split") arithmetic of the f32-activation kernels (conv_f32.hip, SP = true): an f32 operand x is carried as
+// hi + lo, hi = f16(x), lo = f16(x - hi) (x - hi is exact in f32, so hi + lo reproduces x to ~2^-22 relative, 3e-8
+// absolute once lo reaches the f16 subnormals) and a product a*w runs on the f16 matrix pipe as
+// a_hi*w_hi + a_lo*w_hi + a_hi*w_lo with f32 accumulation; the dropped a_lo*w_lo is ~2^-22 of the product.  Exact f16
+// products, f32 sums: the error of a K-long dot product measures 6e-8 * sum|a w| (tools/split_probe.hip), the f32 MFMA
+// chain 1e-7.  Activations stay f32 in HBM and LDS (the f32 kernels' images unchanged); weights are split once at pack
+// time (ctdet_split_weights): each group of 4 consecutive k of a packed [Cout_pad][Kpad] f32 row becomes 16 bytes
+// {w_hi[4], w_lo[4]}, which IS the A fragment a lane reads with ds_read_b128.  Per 16-k step and (cout tile, pixel tile):
+//   acc += A . {a_hi[4], 0}         -> w_hi a_hi
+//   acc += A . {a_lo[4], a_hi[4]}   -> w_hi a_lo + w_lo a_hi
+// two v_mfma_f32_16x16x32_f16 of the same opcode on one accumulator (dependent issue needs no wait states; a 16x16x16
+// second product would cost 87 % of a 16x16x32 and mixes opcodes on one accumulator).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_b(const f32x4 x, f16x8& b1, f16x8& b2) {
+  const f16x4 hi = __builtin_convertvector(x, f16x4);
+  f32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = x[j] - (float)hi[j];
+  const f16x4 lo = __builtin_convertvector(r, f16x4);
+  const f16x4 z = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+  b1 = __builtin_shufflevector(hi, z, 0, 1, 2, 3, 4, 5, 6, 7);
+  b2 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// one 16-k step of one pixel tile against TC cout tiles: wf = the lanes' 16-byte weight fragments (4 f32 k, or the split
+// group), pf = 4 f32 k of the lane's pixel
+template <bool SP, int TC>
+__device__ __forceinline__ void mma_px(const f32x4 (&wf)[TC], const f32x4 pf, f32x4 (&acc)[TC]) {
+  if constexpr (SP) {
+    f16x8 b1, b2;
+    split_b(pf, b1, b2);
+#pragma unroll
+    for (int c = 0; c < TC; ++c)
+      acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[c]), b1, acc[c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < TC; ++c)
+      acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[c]), b2, acc[c], 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], pf[e], acc[c], 0, 0, 0);
+  }
+}
+
+// k-th weight of a packed row as f32 (scalar fallback kernels)
+template <bool SP>
+__device__ __forceinline__ float packed_w(const float* row, int k) {
+  if constexpr (SP) {
+    const f16* g = (const f16*)(row + (k & ~3));
+    return (float)g[k & 3] + (float)g[4 + (k & 3)];
+  } else {
+    return row[k];
+  }
+}
+
 // cout tile of a conv (= ctdet_conv_cout_tile): packed weight rows are padded to a multiple of it
 static inline int pick_bc(int cout) {
   if (cout <= 16) return 16;

@@ -11,9 +11,12 @@
 //   conv_direct_f32_kernel one thread per (pixel, cout): shapes the vector paths cannot take (Cin or strides not
 //                          multiples of 4 floats)
 // Weights: f32 [Cout_pad][Kpad], k = (r*S + s)*Cin + c, Kpad = roundup(K, 16), zero padded.
+// Every kernel has a second instantiation SP = true, the f16x3 ("split") mode: the same f32 activations, LDS images, DMA
+// schedule and epilogue, with each 16-k step contracted by two v_mfma_f32_16x16x32_f16 on hi/lo f16 halves (conv_common.h:
+// split_b / mma_px; weights pre-split by ctdet_split_weights) instead of four v_mfma_f32_16x16x4_f32.
 #include "conv_common.h"
 
-template <int BP, int BC, int WP, int WC_>
+template <int BP, int BC, int WP, int WC_, bool SP>
 __global__ void __launch_bounds__(256) conv_f32_mfma_kernel(const ConvArgs a) {
   constexpr int KS = 16, EPV = 4;            // k per LDS row (64 bytes), elements per 16-byte vector
   constexpr int TP = BP / WP / 16;
@@ -148,13 +151,18 @@ __global__ void __launch_bounds__(256) conv_f32_mfma_kernel(const ConvArgs a) {
     for (int c = 0; c < TC; ++c) wf[c] = *(const f32x4*)(base + BP * 64 + (wc * 16 * TC + 16 * c) * 64 + frag_off);
 #pragma unroll
     for (int p = 0; p < TP; ++p) pf[p] = *(const f32x4*)(base + (wp * 16 * TP + 16 * p) * 64 + frag_off);
+    if constexpr (SP) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int p = 0; p < TP; ++p) mma_px<true, TC>(wf, pf[p], acc[p]);
+    } else {
 #pragma unroll
-      for (int p = 0; p < TP; ++p)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int c = 0; c < TC; ++c)
-          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], pf[p][e], acc[p][c], 0, 0, 0);
+        for (int p = 0; p < TP; ++p)
+#pragma unroll
+          for (int c = 0; c < TC; ++c)
+            acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], pf[p][e], acc[p][c], 0, 0, 0);
+    }
     st_c = st_c == NST - 1 ? 0 : st_c + 1;
     st_l = st_l == NST - 1 ? 0 : st_l + 1;
   }
@@ -175,7 +183,7 @@ __global__ void __launch_bounds__(256) conv_f32_mfma_kernel(const ConvArgs a) {
 // the 128 accumulators of the 256x128 tile into 256 registers -> two workgroups per CU, so one workgroup's LDS-DMA
 // issue, barrier and fragment reads overlap the other's MFMAs.  k stays tap-major (the order of the packed weights).
 // ------------------------------------------------------------------------------------------
-template <int BP, int BC, int WP, int WC_, bool CAT>
+template <int BP, int BC, int WP, int WC_, bool CAT, bool SP>
 __global__ void __launch_bounds__(256, 2) conv_f32_uk_kernel(const ConvArgs a) {
   constexpr int KS = 16, EPV = 4;
   constexpr int TP = BP / WP / 16;
@@ -304,11 +312,7 @@ __global__ void __launch_bounds__(256, 2) conv_f32_uk_kernel(const ConvArgs a) {
 #pragma unroll
     for (int p = 0; p < TP; ++p) {
       const f32x4 pf = *(const f32x4*)(fragA + ST * STAGE + p * 1024);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int c = 0; c < TC; ++c)
-          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], pf[e], acc[p][c], 0, 0, 0);
+      mma_px<SP, TC>(wf, pf, acc[p]);
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -339,7 +343,7 @@ __global__ void __launch_bounds__(256, 2) conv_f32_uk_kernel(const ConvArgs a) {
 // corners of its (row, 4 channels) for the NEXT step before the MFMAs of the current one, blends after them and
 // writes the blended float4 where the LDS-DMA of the plain kernel would have put it; weights stream by LDS-DMA.
 // ------------------------------------------------------------------------------------------
-template <int BP, int BC, int WP, int WC_>
+template <int BP, int BC, int WP, int WC_, bool SP>
 __global__ void __launch_bounds__(256, 2) dcn_f32_mfma_kernel(const ConvArgs a) {
   constexpr int KS = 16, EPV = 4;
   constexpr int TP = BP / WP / 16;
@@ -463,13 +467,18 @@ __global__ void __launch_bounds__(256, 2) dcn_f32_mfma_kernel(const ConvArgs a) 
     for (int c = 0; c < TC; ++c) wf[c] = *(const f32x4*)(bW + (wc * 16 * TC + 16 * c) * 64 + frag_off);
 #pragma unroll
     for (int p = 0; p < TP; ++p) pf[p] = *(const f32x4*)(bA + (wp * 16 * TP + 16 * p) * 64 + frag_off);
+    if constexpr (SP) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int p = 0; p < TP; ++p) mma_px<true, TC>(wf, pf[p], acc[p]);
+    } else {
 #pragma unroll
-      for (int p = 0; p < TP; ++p)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int c = 0; c < TC; ++c)
-          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], pf[p][e], acc[p][c], 0, 0, 0);
+        for (int p = 0; p < TP; ++p)
+#pragma unroll
+          for (int c = 0; c < TC; ++c)
+            acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], pf[p][e], acc[p][c], 0, 0, 0);
+    }
     if (more) blend_store(smA + ((kt + 1) & 1) * ASTAGE);
   }
 
@@ -495,7 +504,7 @@ __global__ void __launch_bounds__(256, 2) dcn_f32_mfma_kernel(const ConvArgs a) 
 // (pixel, tap), staged in LDS.  Samples outside the window are gathered from global memory by the lanes concerned.
 // Weights stay tap-major in memory (k = tap*Cin + c): the K loop runs chunk-major and fetches the 64-byte piece it needs.
 // ------------------------------------------------------------------------------------------
-template <int BC>
+template <int BC, bool SP>
 __global__ void __launch_bounds__(256, 2) dcn_f32_window_kernel(const ConvArgs a) {
   constexpr int TH = 8, TW = 16, BP = 128, MG = 4;
   constexpr int WR = TH + 2 + 2 * MG, WCOLS = TW + 2 + 2 * MG;  // 18 x 26 window pixels
@@ -681,13 +690,18 @@ __global__ void __launch_bounds__(256, 2) dcn_f32_window_kernel(const ConvArgs a
       asm volatile("" ::: "memory");
       issue_window(chunk + 1);
     }
+    if constexpr (SP) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int p = 0; p < TP; ++p) mma_px<true, TC>(wf, pf[p], acc[p]);
+    } else {
 #pragma unroll
-      for (int p = 0; p < TP; ++p)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int c = 0; c < TC; ++c)
-          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], pf[p][e], acc[p][c], 0, 0, 0);
+        for (int p = 0; p < TP; ++p)
+#pragma unroll
+          for (int c = 0; c < TC; ++c)
+            acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], pf[p][e], acc[p][c], 0, 0, 0);
+    }
     if (T == 8 && chunk + 1 < nch) {
       wait_vmcnt<0>();                                             // next chunk's window, behind this tap's MFMAs
       __builtin_amdgcn_s_barrier();
@@ -729,7 +743,7 @@ __global__ void __launch_bounds__(256, 2) dcn_f32_window_kernel(const ConvArgs a
 // B fragment (4 channels of 16 consecutive pixels) with one ds_read_b128 at a compile-time offset.
 // Pixels must be contiguous in memory (in_stride == CIN); maps divisible by the tile.
 // ------------------------------------------------------------------------------------------
-template <int R, int CIN, int TC, int STRIDE, int TH, bool NOCHECK>
+template <int R, int CIN, int TC, int STRIDE, int TH, bool NOCHECK, bool SP>
 __global__ void __launch_bounds__(256) conv_f32_win_kernel(const ConvArgs a) {
   constexpr int TW = STRIDE == 1 ? 64 : 32;
   constexpr int WH = (TH - 1) * STRIDE + R, WW = (TW - 1) * STRIDE + R;
@@ -801,13 +815,18 @@ __global__ void __launch_bounds__(256) conv_f32_win_kernel(const ConvArgs a) {
       for (int kt = 0; kt < NK; ++kt) {
         const f32x4 pf0 = *(const f32x4*)(win + kaddr[kt] + toff);
         const f32x4 pf1 = *(const f32x4*)(win + kaddr[kt] + toff + 16 * STRIDE * PB);
+        if constexpr (SP) {
+          mma_px<true, TC>(wf[kt], pf0, acc[0]);
+          mma_px<true, TC>(wf[kt], pf1, acc[1]);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int c = 0; c < TC; ++c) {
-            acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kt][c][e], pf0[e], acc[0][c], 0, 0, 0);
-            acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kt][c][e], pf1[e], acc[1][c], 0, 0, 0);
-          }
+            for (int c = 0; c < TC; ++c) {
+              acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kt][c][e], pf0[e], acc[0][c], 0, 0, 0);
+              acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kt][c][e], pf1[e], acc[1][c], 0, 0, 0);
+            }
+        }
       }
       const int m = (b * a.Ho + ty0 + wave * RW + rr) * a.Wo + tx0 + tc * 16 + fr;
       epilogue_tiles<float, TC>(a, m, 0, q, acc[0]);
@@ -816,15 +835,15 @@ __global__ void __launch_bounds__(256) conv_f32_win_kernel(const ConvArgs a) {
   }
 }
 
-template <int R, int CIN, int TC, int STRIDE, int TH>
+template <int R, int CIN, int TC, int STRIDE, int TH, bool SP>
 static int launch_f32_win(const ConvArgs& a, hipStream_t s) {
   constexpr int TW = STRIDE == 1 ? 64 : 32;
   const int tiles = a.B * (a.Ho / TH) * (a.Wo / TW);
   // pad 0 (a pre-padded image: ops.preprocess border): the window never leaves the tensor -> no bounds checks
   if (a.pad == 0)
-    hipLaunchKernelGGL((conv_f32_win_kernel<R, CIN, TC, STRIDE, TH, true>), dim3(tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_f32_win_kernel<R, CIN, TC, STRIDE, TH, true, SP>), dim3(tiles), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((conv_f32_win_kernel<R, CIN, TC, STRIDE, TH, false>), dim3(tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_f32_win_kernel<R, CIN, TC, STRIDE, TH, false, SP>), dim3(tiles), dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
@@ -832,7 +851,7 @@ static int launch_f32_win(const ConvArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // Direct form: one thread per (pixel, cout), f32 FMA chain in k order (any Cin / stride).
 // ------------------------------------------------------------------------------------------
-template <bool DEFORM>
+template <bool DEFORM, bool SP>
 __global__ void __launch_bounds__(256) conv_direct_f32_kernel(const ConvArgs a) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const int CP = (a.Cout + 3) & ~3;
@@ -850,7 +869,7 @@ __global__ void __launch_bounds__(256) conv_direct_f32_kernel(const ConvArgs a) 
   float acc = 0.f;
   for (int tr = 0; tr < a.R; ++tr)
     for (int ts = 0; ts < a.S; ++ts) {
-      const float* wk = w + (tr * a.S + ts) * a.Cin;
+      const int kb = (tr * a.S + ts) * a.Cin;   // k of channel 0 of this tap in the packed row
       if constexpr (!DEFORM) {
         const int hn = hb + tr * a.dil, wn = wb + ts * a.dil;
         if (hn < 0 || wn < 0 || hn % idl || wn % idl) continue;
@@ -860,12 +879,12 @@ __global__ void __launch_bounds__(256) conv_direct_f32_kernel(const ConvArgs a) 
           int c = 0;
           for (int j = 0; j < a.nsrc; ++j) {
             const float* xp = (const float*)a.xs[j] + (long)m * a.xs_stride[j] - c;
-            for (; c < a.xs_cend[j]; ++c) acc = fmaf(xp[c], wk[c], acc);
+            for (; c < a.xs_cend[j]; ++c) acc = fmaf(xp[c], packed_w<SP>(w, kb + c), acc);
           }
           continue;
         }
         const float* xp = x + (long)(pix_base + hi * a.W + wi) * a.in_stride;
-        for (int c = 0; c < a.Cin; ++c) acc = fmaf(xp[c], wk[c], acc);
+        for (int c = 0; c < a.Cin; ++c) acc = fmaf(xp[c], packed_w<SP>(w, kb + c), acc);
       } else {
         DcnSample sp;
         dcn_setup(a, true, pix_base, hb, wb, tr, ts, a.om + (long)m * a.om_stride, sp);
@@ -875,7 +894,7 @@ __global__ void __launch_bounds__(256) conv_direct_f32_kernel(const ConvArgs a) 
           const float v3 = sp.off[2] >= 0 ? x[(long)sp.off[2] + c] : 0.f;
           const float v4 = sp.off[3] >= 0 ? x[(long)sp.off[3] + c] : 0.f;
           const float val = sp.wt[0] * v1 + sp.wt[1] * v2 + sp.wt[2] * v3 + sp.wt[3] * v4;
-          acc = fmaf(val * sp.mask, wk[c], acc);
+          acc = fmaf(val * sp.mask, packed_w<SP>(w, kb + c), acc);
         }
       }
     }
@@ -906,25 +925,25 @@ static bool f32_vector_ok(const ConvArgs& a, int bc) {
   return aligned16(a.x);
 }
 
-template <int BP, int BC, int WP, int WC_>
+template <int BP, int BC, int WP, int WC_, bool SP>
 static int launch_f32_mfma(const ConvArgs& a, int kind, hipStream_t s) {   // kind: 0 generic, 1 uniform-K
   const int nbx = (a.M + BP - 1) / BP, nby = a.Cout_pad / BC;
   dim3 grid(8 * ((nbx + 7) / 8) * nby);
   if (kind == 1 && a.nsrc > 1)
-    hipLaunchKernelGGL((conv_f32_uk_kernel<BP, BC, WP, WC_, true>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_f32_uk_kernel<BP, BC, WP, WC_, true, SP>), grid, dim3(256), 0, s, a);
   else if (kind == 1)
-    hipLaunchKernelGGL((conv_f32_uk_kernel<BP, BC, WP, WC_, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_f32_uk_kernel<BP, BC, WP, WC_, false, SP>), grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((conv_f32_mfma_kernel<BP, BC, WP, WC_>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_f32_mfma_kernel<BP, BC, WP, WC_, SP>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
 
-template <int BP, int BC, int WP, int WC_>
+template <int BP, int BC, int WP, int WC_, bool SP>
 static int launch_f32_dcn(const ConvArgs& a, hipStream_t s) {
   const int nbx = (a.M + BP - 1) / BP, nby = a.Cout_pad / BC;
   dim3 grid(8 * ((nbx + 7) / 8) * nby);
-  hipLaunchKernelGGL((dcn_f32_mfma_kernel<BP, BC, WP, WC_>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((dcn_f32_mfma_kernel<BP, BC, WP, WC_, SP>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
@@ -942,7 +961,8 @@ static bool f32_uniform_k_ok(const ConvArgs& a) {
   return a.Cin % 16 == 0;
 }
 
-int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s) {
+template <bool SP>
+static int launch_conv_f32_t(const ConvArgs& a, bool deform, hipStream_t s) {
   CTDET_CHECK((long)a.B * a.H * a.W * a.in_stride < (1L << 31), "conv: input too large for 32-bit element offsets");
   CTDET_CHECK(a.in_dil >= 1 && (!deform || a.in_dil == 1), "conv: bad in_dil %d", a.in_dil);
   CTDET_CHECK(a.Kpad >= a.K && a.Cout_pad >= a.Cout, "conv(f32): packed weights [%d][%d] too small for Cout=%d K=%d",
@@ -953,11 +973,11 @@ int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s) {
       a.in_stride == a.Cin && a.Cout_pad == bc && !a.res && a.Kpad == ((a.K + 15) & ~15)) {
     // the three narrow DLA base layers on tile-divisible maps
     if (a.R == 7 && a.Cin == 8 && bc == 16 && a.stride == 1 && a.Ho % 8 == 0 && a.Wo % 64 == 0 && (a.pad == 0 || a.pad == 3))
-      return launch_f32_win<7, 8, 1, 1, 8>(a, s);
+      return launch_f32_win<7, 8, 1, 1, 8, SP>(a, s);
     if (a.R == 3 && a.Cin == 16 && bc == 16 && a.stride == 1 && a.Ho % 8 == 0 && a.Wo % 64 == 0 && a.pad == 1)
-      return launch_f32_win<3, 16, 1, 1, 8>(a, s);
+      return launch_f32_win<3, 16, 1, 1, 8, SP>(a, s);
     if (a.R == 3 && a.Cin == 16 && bc == 32 && a.stride == 2 && a.Ho % 4 == 0 && a.Wo % 32 == 0 && a.pad == 1)
-      return launch_f32_win<3, 16, 2, 2, 4>(a, s);
+      return launch_f32_win<3, 16, 2, 2, 4, SP>(a, s);
   }
   if (vec) {
     const bool big = ((long)a.M + 255) / 256 * (a.Cout_pad / bc) >= 512;
@@ -966,33 +986,62 @@ int launch_conv_f32(const ConvArgs& a, bool deform, hipStream_t s) {
       // 64 couts per workgroup (128 would spill under two workgroups per CU); wider layers sample the window once per cout tile
       const int nbx = a.B * (a.H / 8) * (a.W / 16);
       dim3 grid(8 * ((nbx + 7) / 8) * (a.Cout_pad / 64));
-      hipLaunchKernelGGL((dcn_f32_window_kernel<64>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((dcn_f32_window_kernel<64, SP>), grid, dim3(256), 0, s, a);
       CTDET_LAUNCH_CHECK();
       return 0;
     }
     if (deform) {   // 128-pixel tiles: two or more workgroups per CU cover each other's gather latency
       switch (bc) {
-        case 16: return launch_f32_dcn<128, 16, 4, 1>(a, s);
-        case 32: return launch_f32_dcn<128, 32, 4, 1>(a, s);
-        case 64: return launch_f32_dcn<64, 64, 2, 2>(a, s);
-        case 128: return launch_f32_dcn<128, 128, 2, 2>(a, s);
+        case 16: return launch_f32_dcn<128, 16, 4, 1, SP>(a, s);
+        case 32: return launch_f32_dcn<128, 32, 4, 1, SP>(a, s);
+        case 64: return launch_f32_dcn<64, 64, 2, 2, SP>(a, s);
+        case 128: return launch_f32_dcn<128, 128, 2, 2, SP>(a, s);
       }
     }
     const int kind = f32_uniform_k_ok(a) ? 1 : 0;
     switch (bc) {
-      case 16: return launch_f32_mfma<256, 16, 4, 1>(a, kind, s);
-      case 32: return big ? launch_f32_mfma<256, 32, 4, 1>(a, kind, s) : launch_f32_mfma<128, 32, 4, 1>(a, kind, s);
-      case 64: return big ? launch_f32_mfma<256, 64, 4, 1>(a, kind, s) : launch_f32_mfma<128, 64, 2, 2>(a, kind, s);
-      case 128: return big ? launch_f32_mfma<256, 128, 2, 2>(a, kind, s) : launch_f32_mfma<128, 128, 2, 2>(a, kind, s);
+      case 16: return launch_f32_mfma<256, 16, 4, 1, SP>(a, kind, s);
+      case 32: return big ? launch_f32_mfma<256, 32, 4, 1, SP>(a, kind, s) : launch_f32_mfma<128, 32, 4, 1, SP>(a, kind, s);
+      case 64: return big ? launch_f32_mfma<256, 64, 4, 1, SP>(a, kind, s) : launch_f32_mfma<128, 64, 2, 2, SP>(a, kind, s);
+      case 128: return big ? launch_f32_mfma<256, 128, 2, 2, SP>(a, kind, s) : launch_f32_mfma<128, 128, 2, 2, SP>(a, kind, s);
     }
   }
   const int CP = (a.Cout + 3) & ~3;
   const long total = (long)a.M * CP;
   dim3 grid((unsigned)((total + 255) / 256));
   if (deform)
-    hipLaunchKernelGGL((conv_direct_f32_kernel<true>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_direct_f32_kernel<true, SP>), grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((conv_direct_f32_kernel<false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_direct_f32_kernel<false, SP>), grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_conv_f32(const ConvArgs& a, bool deform, bool split, hipStream_t s) {
+  return split ? launch_conv_f32_t<true>(a, deform, s) : launch_conv_f32_t<false>(a, deform, s);
+}
+
+// f32 packed weights [rows][Kpad] -> the split image of the same size: per group of 4 k {w_hi[4], w_lo[4]} (f16)
+__global__ void __launch_bounds__(256) split_weights_kernel(const f32x4* __restrict__ src, f16x8* __restrict__ dst, long groups) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= groups) return;
+  const f32x4 w = src[i];
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f16 h = (f16)w[j];
+    o[j] = h;
+    o[4 + j] = (f16)(w[j] - (float)h);
+  }
+  dst[i] = o;
+}
+
+int launch_split_weights(const float* src, void* dst, long n, hipStream_t s) {
+  CTDET_CHECK(n % 4 == 0 && (((size_t)src | (size_t)dst) & 15) == 0, "split_weights: needs 16-byte aligned buffers of a multiple of 4 floats");
+  if (n == 0) return 0;
+  const long groups = n / 4;
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, (const f32x4*)src, (f16x8*)dst,
+                     groups);
   CTDET_LAUNCH_CHECK();
   return 0;
 }

@@ -8,11 +8,12 @@ NHWC tensors.  Inference folds BatchNorm into the conv epilogue (the reference n
 import torch
 
 from .. import ops
-from ..ops import ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, F16, F32
+from ..ops import ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, F16, F16X3, F32
 
 
 class Ctx:
-    """numeric mode of one forward pass: F16 = f16 storage + f16 MFMA (f32 accumulate), F32 = exact f32."""
+    """numeric mode of one forward pass: F16 = f16 storage + f16 MFMA (f32 accumulate), F32 = exact f32, F16X3 = f32 storage,
+    contractions as three f16 products per term on the f16 matrix pipe (f32-grade results at several times the f32 rate)."""
 
     def __init__(self, compute):
         self.compute = compute

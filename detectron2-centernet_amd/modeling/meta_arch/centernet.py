@@ -21,7 +21,7 @@ from torch import nn
 from ... import ops
 from ...data.catalog import DatasetCatalog, MetadataCatalog
 from ...layers import hipnn
-from ...ops import ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, F16, F32
+from ...ops import ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, F16, F16X3, F32
 from ...structures import Boxes, ImageList, Instances
 from ..backbone import build_backbone
 from .build import META_ARCH_REGISTRY
@@ -176,8 +176,8 @@ class CenterNet(nn.Module):
         self.max_detections_per_image = cfg.TEST.DETECTIONS_PER_IMAGE
         precision                     = cfg.MODEL.CENTERNET.get("HIP_PRECISION", "f16")
         # fmt: on
-        assert precision in ("f16", "f32"), precision
-        self._ctx = hipnn.Ctx(F16 if precision == "f16" else F32)
+        assert precision in ("f16", "f32", "f16x3"), precision
+        self._ctx = hipnn.Ctx({"f16": F16, "f32": F32, "f16x3": F16X3}[precision])
 
         given_dataset = cfg.DATASETS.TRAIN[0]
         DatasetCatalog.get(given_dataset)

@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, F16, F32, U8, ConvDesc, HeadDesc
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, F16, F16X3, F32, U8, ConvDesc, HeadDesc
 
 _TORCH_DT = {F16: torch.float16, F32: torch.float32}
 
@@ -27,6 +27,9 @@ PROFILE_REP = 5   # each profiled launch is issued this many times back to back 
 def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
     """mirrors the kernel selection of launch_conv_f16_t() in csrc/conv_igemm.hip"""
     bc = _lib.lib().ctdet_conv_cout_tile(p.Cout_eff)
+    if p.compute == F16X3:       # the f32 kernels' split instantiations: same selection, tagged
+        p32 = _F32View(p)
+        return _kernel_name(p32, M, deform, out_dt, x_shape, nsrc).replace("_f32_", "_f16x3_", 1)
     if p.compute != F16:
         big = ((M + 255) // 256) * (p.Cout_pad // bc) >= 512
         if deform:
@@ -70,6 +73,15 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
             bc = 64
         return f"conv_igemm_uk_kernel<{bp}x{bc},{'cat' if nsrc > 1 else 'conv'},{o}>"
     return f"conv_igemm_dma_kernel<{bp}x{bc},{o}>"
+
+
+class _F32View:
+    """a PackedConv seen as its F32 twin (kernel selection of the F16X3 mode mirrors the F32 one)"""
+
+    def __init__(self, p):
+        self.__dict__.update(p.__dict__)
+        self.compute = F32
+        self.out_hw = p.out_hw
 
 
 class _Prof:
@@ -222,7 +234,8 @@ class PackedConv:
 
     weight: [Cout, Cin, R, S] (PyTorch OIHW, the reference's parameter layout).
     scale/bias: per-output-channel f32 epilogue (folded BatchNorm and/or conv bias) or None.
-    compute: F16 (MFMA) or F32 (exact).
+    compute: F16 (f16 tensors, f16 MFMA), F32 (f32 tensors, f32 MFMA: the reference's arithmetic) or F16X3 (f32 tensors,
+    every product as three f16 products on the f16 matrix pipe: ctdet_conv_desc in include/ctdet_hip.h).
     """
 
     def __init__(self, weight, scale=None, bias=None, stride=1, pad=0, dil=1, compute=F16, cin_pad=None,
@@ -300,6 +313,19 @@ class PackedConv:
             self.Cout_pad = round_up(self.Cout_eff, tile)
             wp = torch.zeros(self.Cout_pad, self.Kpad, dtype=torch.float32, device=dev)
             wp[:Cout, :K] = w
+            if compute == F16X3:   # same image, every group of 4 k as {w_hi[4], w_lo[4]} f16
+                # rows are first scaled by a power of two (exact) so that their largest weight lies in [1024, 2048): the lo
+                # halves of a row's significant weights then stay f16 normals (2^-22 of the row maximum instead of the 3e-8
+                # absolute floor of the f16 subnormals, which is 1e-6 of a typical 0.02 weight); the epilogue scale undoes it
+                amax = wp.abs().amax(dim=1)
+                e = torch.floor(torch.log2(amax.clamp_min(1e-30)))
+                pw = torch.where(amax > 0, torch.exp2(10.0 - e), torch.ones_like(amax))
+                wp = wp * pw[:, None]
+                inv = (1.0 / pw)[:self.Cout_eff]
+                scale = inv if scale is None else self._pad_vec(scale, 1.0, dev) * inv
+                ws = torch.empty_like(wp)
+                _lib.check(_lib.lib().ctdet_split_weights(_ptr(wp), _ptr(ws), wp.numel(), _stream()), "ctdet_split_weights")
+                wp = ws
         self.w = wp.contiguous()
 
         self.scale = self._pad_vec(scale, 1.0, dev)
@@ -314,6 +340,11 @@ class PackedConv:
         o = torch.full((self.Cout_eff,), fill, dtype=torch.float32, device=dev)
         o[:self.Cout] = v
         return o
+
+    @property
+    def act_dt(self):
+        """dtype enum of the activations this contraction takes"""
+        return F16 if self.compute == F16 else F32
 
     def out_hw(self, H, W):
         Ho = (H + 2 * self.pad - (self.dil * (self.R - 1) + 1)) // self.stride + 1
@@ -354,7 +385,7 @@ def _alloc_out(x, p, out, out_dtype):
 def conv2d(x, p, out=None, act=ACT_NONE, residual=None, out_dtype=None, clamp=(0.0, 1.0)):
     """y = act(conv(x) * scale + bias + residual); x NHWC. Returns the NHWC output buffer."""
     _require_cuda(x, residual, out)
-    assert dt_of(x) == p.compute, "input dtype must match the packed compute dtype"
+    assert dt_of(x) == p.act_dt, "input dtype must match the packed compute dtype"
     out = _alloc_out(x, p, out, out_dtype)
     if residual is not None:
         assert residual.dtype == out.dtype and residual.shape[:3] == out.shape[:3]
@@ -374,7 +405,7 @@ def conv1x1_cat(xs, p, out=None, act=ACT_NONE, residual=None, out_dtype=None):
     assert 1 <= len(xs) <= 4 and p.R == 1 and p.S == 1 and p.stride == 1 and p.pad == 0
     B, H, W, _ = xs[0].shape
     for t in xs:
-        assert tuple(t.shape[:3]) == (B, H, W) and dt_of(t) == p.compute
+        assert tuple(t.shape[:3]) == (B, H, W) and dt_of(t) == p.act_dt
     cins = [t.shape[3] for t in xs]
     assert sum(cins) == p.Cin, (cins, p.Cin)
     if out is None:
@@ -411,7 +442,7 @@ def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_pro
     """Modulated deformable conv: offset_mask is the raw f32 NHWC output of conv_offset_mask (>= 27 ch);
     with mask_is_prob the 9 mask channels already went through sigmoid."""
     _require_cuda(x, offset_mask, out)
-    assert dt_of(x) == p.compute and offset_mask.dtype == torch.float32
+    assert dt_of(x) == p.act_dt and offset_mask.dtype == torch.float32
     if p.compute == F16 and p.Cout_pad % 64:
         raise ValueError(f"dcnv2 (f16) works on 64-cout tiles: pack the weights with PackedConv(..., cout_align=64) "
                          f"(Cout={p.Cout}, packed rows {p.Cout_pad})")

@@ -19,7 +19,9 @@
 extern "C" {
 #endif
 
-enum ctdet_dtype { CTDET_DT_F16 = 0, CTDET_DT_F32 = 1, CTDET_DT_U8 = 2 };
+/* CTDET_DT_F16X3 is a COMPUTE mode only (ctdet_conv_desc.compute_dtype): tensors are f32, contractions run as three f16
+ * products per term on the f16 matrix pipe (see ctdet_conv_desc). */
+enum ctdet_dtype { CTDET_DT_F16 = 0, CTDET_DT_F32 = 1, CTDET_DT_U8 = 2, CTDET_DT_F16X3 = 3 };
 enum ctdet_act { CTDET_AC_NONE = 0, CTDET_AC_RELU = 1, CTDET_AC_SIGMOID_CLAMP = 2 };
 
 /* Geometry of one conv-shaped contraction.
@@ -28,7 +30,12 @@ enum ctdet_act { CTDET_AC_NONE = 0, CTDET_AC_RELU = 1, CTDET_AC_SIGMOID_CLAMP = 
  *   MFMA f16 x f16 -> f32 accumulate; y is out_dtype (f16 or f32).
  * compute_dtype F32 (the reference's own arithmetic): x, y f32, weights f32 packed [Cout_pad][Kpad], k tap-major,
  *   Kpad = roundup(R*S*Cin, 16), Cout_pad = roundup(Cout, tile); v_mfma_f32_16x16x4_f32 (bit-for-bit a k-ordered
- *   f32 fma chain) when Cin and the pixel strides are multiples of 4, a scalar f32 chain otherwise. */
+ *   f32 fma chain) when Cin and the pixel strides are multiples of 4, a scalar f32 chain otherwise.
+ * compute_dtype F16X3 (f32 tensors at the f16 matrix rate): x, y, residual f32 exactly as for F32; the weights are the F32
+ *   packed image passed through ctdet_split_weights (same size: each group of 4 k = {w_hi[4], w_lo[4]} f16, w_hi = f16(w),
+ *   w_lo = f16(w - w_hi)); the kernels split every activation the same way in registers and evaluate
+ *   a*w = a_hi*w_hi + a_lo*w_hi + a_hi*w_lo with v_mfma_f32_16x16x32_f16 and f32 accumulation (dropped term ~2^-22; a
+ *   K-long dot product is as accurate as the f32 chain).  Values must lie inside the f16 range (|x| < 65504). */
 typedef struct ctdet_conv_desc {
   int32_t B, H, W, Cin, in_stride;
   int32_t Cout, Ho, Wo, out_stride;
@@ -57,6 +64,11 @@ enum ctdet_tuning {
 int32_t ctdet_set_tuning_flags(uint32_t flags);
 uint32_t ctdet_get_tuning_flags(void);
 int32_t ctdet_conv_cout_tile(int32_t cout);
+
+/* f32 packed conv weights (the compute_dtype F32 image, n floats, n % 4 == 0, 16-byte aligned) -> the F16X3 image of the
+ * same size (see ctdet_conv_desc).  Replaces nothing in the reference (its convs are cuDNN fp32); it is the pack step of
+ * the F16X3 compute mode. */
+int32_t ctdet_split_weights(const float* w_packed_f32, void* w_split, int64_t n, void* stream);
 
 /* y = act(conv(x, w) * scale + bias + residual).  Replaces torch.nn.Conv2d (+BatchNorm2d eval +ReLU
  * +residual add) at detectron2/modeling/backbone/dla.py:59-73,86-94,212-220,249-259 and the head convs at

@@ -1,5 +1,7 @@
-"""f32 mode (the reference's own arithmetic) on the f32 matrix pipe: conv_f32_mfma_kernel / dcn_f32_mfma_kernel /
-the scalar fallback, through the C ABI, against torch's fp32 convolution and the DCNv2 oracle.
+"""The two f32-tensor modes through the C ABI against torch's fp32 convolution and the DCNv2 oracle: f32 (the reference's
+own arithmetic on the f32 matrix pipe: conv_f32_mfma_kernel / dcn_f32_mfma_kernel / the scalar fallback) and f16x3 (the
+same kernels' split instantiations: every product as a_hi*w_hi + a_lo*w_hi + a_hi*w_lo on the f16 matrix pipe with f32
+accumulation, include/ctdet_hip.h ctdet_conv_desc).  Every test runs in both modes with the SAME tolerance.
 
 Tolerance: 1e-5 of the output scale (f32 sums in a different order; north_star allows 1e-3 on fp32 values).
 """
@@ -21,6 +23,11 @@ def ops():
     return ops
 
 
+@pytest.fixture(params=["f32", "f16x3"])
+def comp(request, ops):
+    return {"f32": ops.F32, "f16x3": ops.F16X3}[request.param]
+
+
 def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
@@ -29,7 +36,7 @@ def nchw(t):
     return t.permute(0, 3, 1, 2).contiguous()
 
 
-def test_conv_f32_random_shapes(ops, dev):
+def test_conv_f32_random_shapes(ops, dev, comp):
     """every tile of the f32 MFMA kernel (16..128 couts, 128/256-pixel tiles), Cin below / not dividing the 16-k step,
     strides, dilation, ragged maps, residual; Cin % 4 != 0 takes the scalar kernel"""
     rng = np.random.RandomState(2026)
@@ -51,7 +58,7 @@ def test_conv_f32_random_shapes(ops, dev):
         scale = torch.rand(Cout, generator=g) + 0.5
         bias = torch.randn(Cout, generator=g)
         ref = F.conv2d(x, w, None, stride, pad, dil) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
-        pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=stride, pad=pad, dil=dil, compute=ops.F32)
+        pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=stride, pad=pad, dil=dil, compute=comp)
         res_d = None
         if use_res:
             res = torch.randn(ref.shape, generator=g)
@@ -69,13 +76,13 @@ def test_conv_f32_random_shapes(ops, dev):
             f"case {it}: B{B} {H}x{W} {Cin}->{Cout} k{k} s{stride} d{dil} res={use_res}: max err {err}"
 
 
-def test_conv_f32_slices_and_cat(ops, dev):
+def test_conv_f32_slices_and_cat(ops, dev, comp):
     """channel-slice input / output views and Root's multi-source 1x1 (dla.py:86-94) in f32"""
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 96, 12, 20, generator=g)
     w = torch.randn(32, 64, 3, 3, generator=g) / 24
     ref = F.conv2d(x[:, 16:80], w, None, 1, 1)
-    pc = ops.PackedConv(w.to(dev), None, None, stride=1, pad=1, compute=ops.F32)
+    pc = ops.PackedConv(w.to(dev), None, None, stride=1, pad=1, compute=comp)
     out = torch.zeros(2, 12, 20, 48, device=dev)
     ops.conv2d(nhwc(x).to(dev)[..., 16:80], pc, out=out[..., 8:40])
     assert (nchw(out[..., 8:40].cpu()) - ref).abs().max() < TOL * ref.abs().max()
@@ -89,23 +96,23 @@ def test_conv_f32_slices_and_cat(ops, dev):
         xs = [torch.randn(B, c, H, W, generator=g) for c in cins]
         w = torch.randn(Cout, sum(cins), 1, 1, generator=g) / sum(cins) ** 0.5
         ref = F.conv2d(torch.cat(xs, 1), w).relu()
-        pc = ops.PackedConv(w.to(dev), None, None, compute=ops.F32)
+        pc = ops.PackedConv(w.to(dev), None, None, compute=comp)
         y = ops.conv1x1_cat([nhwc(t).to(dev) for t in xs], pc, act=ops.ACT_RELU)
         err = (nchw(y[..., :Cout].cpu()) - ref).abs().max().item()
         assert err < TOL * max(1.0, ref.abs().max().item()), f"cat case {it}: {cins}->{Cout}: {err}"
 
 
-def test_conv_transpose_f32(ops, dev):
+def test_conv_transpose_f32(ops, dev, comp):
     """dense ConvTranspose2d 4x4 s2 p1 (centernet.py:268-293) in f32: the input is read as zero-stuffed in place"""
     g = torch.Generator().manual_seed(6)
     x = torch.randn(2, 32, 9, 11, generator=g)
     w = torch.randn(32, 24, 4, 4, generator=g) / 16
     ref = F.conv_transpose2d(x, w, None, stride=2, padding=1)
-    y = ops.conv_transpose2d(nhwc(x).to(dev), w.to(dev), None, None, 2, 1, ops.F32)
+    y = ops.conv_transpose2d(nhwc(x).to(dev), w.to(dev), None, None, 2, 1, comp)
     assert (nchw(y[..., :24].cpu()) - ref).abs().max() < TOL * ref.abs().max()
 
 
-def test_dcnv2_f32_random_shapes(ops, dev):
+def test_dcnv2_f32_random_shapes(ops, dev, comp):
     """DCNv2 on the f32 matrix pipe vs the oracle (deform_conv_cuda_kernel.cu:666-868 restated): partial tiles, every cout
     tile, offsets from zero to far outside the image, exact-integer and border coordinates; Cin % 16 != 0 -> scalar kernel"""
     rng = np.random.RandomState(77)
@@ -127,7 +134,7 @@ def test_dcnv2_f32_random_shapes(ops, dev):
         om[:, 3, 1, 1] = 0.5
         bias = torch.randn(Cout, generator=g)
         ref = O.dcnv2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, bias, 1, 1, 1).relu()
-        pc = ops.PackedConv(w.to(dev), None, bias.to(dev), stride=1, pad=1, compute=ops.F32)
+        pc = ops.PackedConv(w.to(dev), None, bias.to(dev), stride=1, pad=1, compute=comp)
         om_d = torch.zeros(B, H, W, 28)
         om_d[..., :27] = nhwc(om)
         y = ops.dcnv2(nhwc(x).to(dev), om_d.to(dev), pc, act=ops.ACT_RELU)
@@ -137,7 +144,7 @@ def test_dcnv2_f32_random_shapes(ops, dev):
 
 @pytest.mark.parametrize("case", [(7, 8, 16, 1, 3, 2, 32, 128), (7, 8, 16, 1, 0, 1, 16, 64), (3, 16, 16, 1, 1, 3, 24, 64),
                                   (3, 16, 32, 2, 1, 2, 32, 128)])
-def test_conv_f32_window_kernel(ops, dev, case):
+def test_conv_f32_window_kernel(ops, dev, case, comp):
     """conv_f32_win_kernel (the narrow DLA base layers in f32): stem 7x7 on the 8-channel image with its padding in the
     kernel (pad 3) or as a zero frame in memory (pad 0), level0 3x3 16->16, level1 3x3 16->32 stride 2 -- vs torch"""
     k, Cin, Cout, stride, pad, B, H, W = case
@@ -148,7 +155,7 @@ def test_conv_f32_window_kernel(ops, dev, case):
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
     scale, bias = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
     ref = (F.conv2d(x, w, None, stride, k // 2) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)).relu()
-    pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=stride, pad=pad, compute=ops.F32)
+    pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=stride, pad=pad, compute=comp)
     xin = nhwc(x)
     if pad == 0 and k > 1:      # zero frame in memory
         xin = F.pad(xin, (0, 0, k // 2, k // 2, k // 2, k // 2))
@@ -160,7 +167,7 @@ def test_conv_f32_window_kernel(ops, dev, case):
 
 @pytest.mark.parametrize("case", [(1, 8, 16, 16, 64, 0.0), (2, 16, 32, 32, 64, 0.7), (1, 24, 48, 64, 128, 2.0), (2, 8, 32, 16, 40, 5.0),
                                   (1, 16, 16, 128, 132, 30.0), (3, 40, 48, 64, 64, 3.0)])
-def test_dcnv2_f32_window_kernel(ops, dev, case):
+def test_dcnv2_f32_window_kernel(ops, dev, case, comp):
     """dcn_f32_window_kernel (8x16 tiles sampling an 18x26 LDS window; far samples from global memory) vs the oracle, and
     bit-for-bit against nothing less: the gather kernel (TUNE_NO_F32_DCN_WINDOW) must agree with it to f32 rounding"""
     from detectron2_centernet_amd import _lib
@@ -177,7 +184,7 @@ def test_dcnv2_f32_window_kernel(ops, dev, case):
     om[:, 8, 0, 5], om[:, 9, 0, 5] = -float(H), float(W) + 3   # outside the image: contributes 0
     bias = torch.randn(Cout, generator=g)
     ref = O.dcnv2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, bias, 1, 1, 1).relu()
-    pc = ops.PackedConv(w.to(dev), None, bias.to(dev), stride=1, pad=1, compute=ops.F32)
+    pc = ops.PackedConv(w.to(dev), None, bias.to(dev), stride=1, pad=1, compute=comp)
     om_d = torch.zeros(B, H, W, 28)
     om_d[..., :27] = nhwc(om)
     xd, omd = nhwc(x).to(dev), om_d.to(dev)
@@ -189,3 +196,19 @@ def test_dcnv2_f32_window_kernel(ops, dev, case):
     assert err <= 2e-5 * scale, f"{case}: window kernel vs oracle {err}"
     assert (y - y_gather).abs().max().item() <= 2e-5 * scale
     assert y[..., Cout:].abs().max().item() == 0 if y.shape[-1] > Cout else True
+
+
+def test_f16x3_small_and_large_magnitudes(ops, dev):
+    """operand scales from 1e-4 to 1e3.  Weight rows are scaled by a power of two at pack time, so their magnitude does not
+    matter; a small ACTIVATION's lo half reaches the f16 subnormals (spacing 6e-8), i.e. an absolute floor of 3e-8 per
+    element on top of the 2^-22 relative accuracy of the split: error measured against sum |x||w| in f64"""
+    g = torch.Generator().manual_seed(11)
+    for sx, sw in [(1e-4, 1.0), (1.0, 1e-4), (1e-3, 1e-3), (1.0, 1.0), (1e3, 1.0), (30.0, 30.0)]:
+        x = torch.randn(2, 64, 16, 32, generator=g) * sx
+        w = torch.randn(64, 64, 3, 3, generator=g) * sw
+        ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+        mag = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
+        pc = ops.PackedConv(w.to(dev), None, None, stride=1, pad=1, compute=ops.F16X3)
+        y = nchw(ops.conv2d(nhwc(x).to(dev), pc).cpu()).double()
+        rel = ((y - ref).abs() / mag).max().item()
+        assert rel < 5e-7 + 4e-8 / sx, f"scales {sx} {sw}: relative error {rel}"
