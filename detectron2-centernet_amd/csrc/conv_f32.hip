@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(256, 2) dcn_f32_window_kernel(const ConvArgs a
 }
 
 // ------------------------------------------------------------------------------------------
-// LDS-window form for the narrow layers of the DLA base in f32 (7x7 stem on the 8-channel padded image, level0 3x3
+// LDS-window form for the narrow layers of the DLA base in f32 (7x7 stem on the 4- or 8-channel padded image, level0 3x3
 // 16->16, level1 3x3 16->32 stride 2): with 8 or 16 input channels the im2col-on-the-fly kernels above fetch every
 // input pixel R*S times through L2 (26 GB for the stem at batch 64: 8.2 ms for 79 GFLOP).  Here a workgroup owns a
 // TH x TW output tile, brings the input window into LDS once, keeps ALL weights in registers and reads every MFMA
@@ -910,6 +910,8 @@ __global__ void __launch_bounds__(256) conv_direct_f32_kernel(const ConvArgs a) 
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+int launch_halo_split(const ConvArgs& a, hipStream_t s);   // conv_igemm.hip
+
 static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
 
 static bool f32_vector_ok(const ConvArgs& a, int bc) {
@@ -969,15 +971,24 @@ static int launch_conv_f32_t(const ConvArgs& a, bool deform, hipStream_t s) {
               a.Cout_pad, a.Kpad, a.Cout, a.K);
   const int bc = pick_bc(a.Cout);
   const bool vec = f32_vector_ok(a, bc) && (!deform || (a.Cin % 16 == 0 && a.nsrc <= 1));
-  if (vec && !deform && (a.Cin == 8 || a.Cin == 16) && a.in_dil == 1 && a.nsrc <= 1 && a.R == a.S && a.dil == 1 &&
+  if (vec && !deform && (a.Cin == 4 || a.Cin == 8 || a.Cin == 16) && a.in_dil == 1 && a.nsrc <= 1 && a.R == a.S && a.dil == 1 &&
       a.in_stride == a.Cin && a.Cout_pad == bc && !a.res && a.Kpad == ((a.K + 15) & ~15)) {
     // the three narrow DLA base layers on tile-divisible maps
     if (a.R == 7 && a.Cin == 8 && bc == 16 && a.stride == 1 && a.Ho % 8 == 0 && a.Wo % 64 == 0 && (a.pad == 0 || a.pad == 3))
       return launch_f32_win<7, 8, 1, 1, 8, SP>(a, s);
+    // the same stem on 4-channel pixels (3 used): K = 196 instead of 392, a 16-k step = four taps
+    if (a.R == 7 && a.Cin == 4 && bc == 16 && a.stride == 1 && a.Ho % 8 == 0 && a.Wo % 64 == 0 && (a.pad == 0 || a.pad == 3))
+      return launch_f32_win<7, 4, 1, 1, 8, SP>(a, s);
     if (a.R == 3 && a.Cin == 16 && bc == 16 && a.stride == 1 && a.Ho % 8 == 0 && a.Wo % 64 == 0 && a.pad == 1)
       return launch_f32_win<3, 16, 1, 1, 8, SP>(a, s);
     if (a.R == 3 && a.Cin == 16 && bc == 32 && a.stride == 2 && a.Ho % 4 == 0 && a.Wo % 32 == 0 && a.pad == 1)
       return launch_f32_win<3, 16, 2, 2, 4, SP>(a, s);
+  }
+  if constexpr (SP) {
+    if (vec && !deform) {                 // 3x3 / s1 / p1: the halo-resident kernel of conv_igemm.hip on f32 activations
+      const int rc = launch_halo_split(a, s);
+      if (rc <= 0) return rc;
+    }
   }
   if (vec) {
     const bool big = ((long)a.M + 255) / 256 * (a.Cout_pad / bc) >= 512;

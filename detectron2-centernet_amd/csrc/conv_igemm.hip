@@ -354,8 +354,15 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_uk_kernel(const ConvArgs a)
 // L2 once per cout tile instead of nine times.
 // LDS: halo[2] x {main [10 rows][32 px][64 B] swizzled like the tiles above, side [10][left,right][64 B]} + ring[3].
 // ------------------------------------------------------------------------------------------
-template <int BC, int WP, int WC_, typename TOut>
+// SP (the f16x3 mode of conv_f32.hip, TOut = float): the same kernel on f32 activations -- a chunk is 16 channels, again 64
+// bytes per window pixel, so the LDS images, the DMA schedule and every wait count are unchanged; the weights are the split
+// image of the tap-major f32 pack (the K loop fetches the 64-byte piece (tap, chunk) of every cout row, as the f32 DCNv2
+// window kernel does) and a K step is mma_px<true> (two f16 MFMAs per tile on hi / lo halves, conv_common.h).
+template <int BC, int WP, int WC_, typename TOut, bool SP = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const ConvArgs a) {
+  using TIn = std::conditional_t<SP, float, f16>;
+  constexpr int CH = SP ? 16 : 32, EPV = SP ? 4 : 8;   // channels per chunk (64 bytes), elements per 16-byte vector
+  static_assert(!SP || std::is_same<TOut, float>::value, "split mode stores f32");
   constexpr int TH = 8, TW = 32, BP = TH * TW;
   constexpr int TP = BP / WP / 16;      // 16-pixel tiles per wave
   constexpr int TC = BC / WC_ / 16;
@@ -378,49 +385,53 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const ConvArgs a) 
   const int ty0 = ((m_tile / tiles_x) % tiles_y) * TH;
   const int b = m_tile / (tiles_x * tiles_y);
   const int n0 = n_tile * BC;
-  const f16* zero = (const f16*)g_zero_page;
+  const TIn* zero = (const TIn*)g_zero_page;
   asm volatile("" : "+v"(zero));
-  const f16* ximg = (const f16*)a.x + (long)b * a.H * a.W * a.in_stride;
+  const TIn* ximg = (const TIn*)a.x + (long)b * a.H * a.W * a.in_stride;
 
   // ---- halo loader: 5 main pieces + 1 side piece per thread and chunk ----
   // main piece i of thread t: pid = t + 256 i -> halo row (t>>7) + 2i, pixel (t>>2)&31, slot t&3: rows two apart,
   // so one base pointer + a uniform row-pair stride suffice
   const int hslot = tid & 3, hpx = (tid >> 2) & 31, hr0 = tid >> 7;
   const int y0 = ty0 - 1 + hr0;
-  const f16* hp0 = ximg + ((long)y0 * a.W + tx0 + hpx) * a.in_stride + (hslot ^ swz(hpx)) * 8;
+  const TIn* hp0 = ximg + ((long)y0 * a.W + tx0 + hpx) * a.in_stride + (hslot ^ swz(hpx)) * EPV;
   const long row2 = 2L * a.W * a.in_stride;
   unsigned hmask = 0;
 #pragma unroll
   for (int i = 0; i < 5; ++i) hmask |= (y0 + 2 * i >= 0 && y0 + 2 * i < a.H) ? (1u << i) : 0u;
-  const f16* hps;
+  const TIn* hps;
   {
     const int side = (tid >> 2) & 1, hr = tid >> 3;   // [hr 0..9][side][slot], tid < 80
     const int y = ty0 - 1 + hr, x = side ? tx0 + TW : tx0 - 1;
     const bool ok = tid < 80 && y >= 0 && y < a.H && x >= 0 && x < a.W;
-    hps = ximg + ((long)(ok ? y : 0) * a.W + (ok ? x : 0)) * a.in_stride + hslot * 8;
+    hps = ximg + ((long)(ok ? y : 0) * a.W + (ok ? x : 0)) * a.in_stride + hslot * EPV;
     hmask |= ok ? 32u : 0u;
   }
   const int lrow = tid >> 2;
   const int gw = hslot ^ swz(lrow);
-  const f16* wptr[B_LD];
+  const TIn* wptr[B_LD];
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
     const int L = lrow + 64 * j;
     const int Lw = L % (16 * TC), wv = L / (16 * TC);
     const int tt = Lw >> 4, r = Lw & 15;
     const int cl = wv * 16 * TC + cout_of<TC>(tt, r >> 2, r & 3);
-    wptr[j] = (const f16*)a.w + (long)(n0 + (L < BC ? cl : 0)) * a.Kpad + gw * 8;
+    wptr[j] = (const TIn*)a.w + (long)(n0 + (L < BC ? cl : 0)) * a.Kpad + gw * EPV;
   }
   auto issue_halo = [&](int chunk, int hb) {
     char* dst = smem + hb * HBUF + wave * 1024;
-    const long coff = (long)chunk * 32;
+    const long coff = (long)chunk * CH;
 #pragma unroll
     for (int i = 0; i < 5; ++i) dma16((hmask & (1u << i)) ? hp0 + i * row2 + coff : zero, dst + i * 4096);
     dma16((hmask & 32u) ? hps + coff : zero, smem + hb * HBUF + HMAIN + wave * 1024);
   };
+  // K step kt = chunk * 9 + tap.  f16: packed chunk-major, step kt is the kt-th 32-k piece of a row; SP: packed tap-major
   auto issue_w = [&](int kt, int st) {
+    long koff;
+    if constexpr (SP) { const int ch = kt / 9, tp = kt - 9 * ch; koff = (long)tp * a.Cin + ch * CH; }
+    else koff = (long)kt * 32;
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) dma16(wptr[j] + (long)kt * 32, ring + st * WST + wave * 1024 + j * 4096);
+    for (int j = 0; j < B_LD; ++j) dma16(wptr[j] + koff, ring + st * WST + wave * 1024 + j * 4096);
   };
 
   // ---- fragment addressing: per lane one LDS base per (px-tile half e, tap column s) with the wave's first tile
@@ -449,7 +460,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const ConvArgs a) 
 #pragma unroll
     for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nch = a.Cin / 32, nk = nch * 9;
+  const int nch = a.Cin / CH, nk = nch * 9;
   issue_halo(0, 0);
   issue_w(0, 0);
   issue_w(1, 1);
@@ -469,9 +480,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const ConvArgs a) 
     if (T == 0 && chunk + 1 < nch) issue_halo(chunk + 1, HB ^ 1);
     if (kt + 2 < nk) issue_w(kt + 2, SL);
     const char* hbuf = smem + HB * HBUF;
-    f16x8 wf[TC];
+    f32x4 wf[TC];    // 16 bytes: 8 f16 k (f16 mode) / the split group of 4 k (SP)
 #pragma unroll
-    for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(fragB + ST * WST + c * 1024);
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f32x4*)(fragB + ST * WST + c * 1024);
 #pragma unroll
     for (int p = 0; p < TP; ++p) {
       const int e = p & 1, lr = p >> 1;
@@ -479,9 +490,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const ConvArgs a) 
       if (e == 0 && S_ == 0) off = abase[0][0] + (lr + R_) * estride0;
       else if (e == 1 && S_ == 2) off = abase[1][2] + (lr + R_) * estride1;
       else off = abase[e][S_] + (lr + R_) * 2048;
-      const f16x8 pf = *(const f16x8*)(hbuf + off);
+      const f32x4 pf = *(const f32x4*)(hbuf + off);
+      if constexpr (SP) {
+        mma_px<true, TC>(wf, pf, acc[p]);
+      } else {
 #pragma unroll
-      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf, acc[p][c], 0, 0, 0);
+        for (int c = 0; c < TC; ++c)
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[c]), __builtin_bit_cast(f16x8, pf),
+                                                             acc[p][c], 0, 0, 0);
+      }
     }
   };
   auto chunk_steps = [&](int kt, int chunk, auto hbc) {
@@ -512,13 +529,30 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_kernel(const ConvArgs a) 
   }
 }
 
-template <int BC, int WP, int WC_, typename TOut>
+template <int BC, int WP, int WC_, typename TOut, bool SP = false>
 static int launch_halo(const ConvArgs& a, hipStream_t s) {
   const int nbx = a.B * (a.H / 8) * (a.W / 32), nby = a.Cout_pad / BC;
   dim3 grid(8 * ((nbx + 7) / 8) * nby);
-  hipLaunchKernelGGL((conv3x3_halo_kernel<BC, WP, WC_, TOut>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<BC, WP, WC_, TOut, SP>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
+}
+
+// f16x3 mode (called from conv_f32.hip): 3x3 / s1 / p1 on f32 activations, tap-major split weights, Cin % 16 == 0, map
+// divisible by 8x32.  Returns 1 if the shape does not qualify (the caller then takes the uniform-K kernel).
+int launch_halo_split(const ConvArgs& a, hipStream_t s) {
+  const bool ok = a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.in_dil == 1 && a.nsrc <= 1 &&
+                  a.korder == 0 && a.Cin % 16 == 0 && a.Kpad == a.K && a.H % 8 == 0 && a.W % 32 == 0 && a.Ho == a.H &&
+                  a.Wo == a.W && a.in_stride % 4 == 0 && (((size_t)a.x) & 15) == 0 && !(ctdet_tuning_flags() & CTDET_TUNE_NO_HALO);
+  if (!ok) return 1;
+  switch (pick_bc(a.Cout)) {
+    case 32: return launch_halo<32, 4, 1, float, true>(a, s);
+    case 64: return launch_halo<64, 4, 1, float, true>(a, s);
+    // 128-cout layers run on 64-cout tiles too: with 128 accumulators the split operands no longer fit in 256 registers (54-81
+    // spilled, reloaded inside the K loop), and the spilling 256x128 instantiation measured 8-18 % slower than 256x64
+    case 128: return launch_halo<64, 4, 1, float, true>(a, s);
+  }
+  return 1;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const TIn* __restrict__
     *(f16x8*)o = r;
   } else {
     *(f32x4*)o = (f32x4){v[0], v[1], v[2], 0.f};
-    *(f32x4*)(o + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (out_stride >= 8) *(f32x4*)(o + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};   // f32 pixels may also be 4 channels wide
   }
 }
 
@@ -280,7 +280,8 @@ static inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
 int launch_preprocess(const void* img, int img_dtype, void* out, int out_dtype, int B, int H, int W, int Hp, int Wp,
                       long img_batch_stride, const float* mean, const float* stdv, int out_stride, int border,
                       hipStream_t s) {
-  CTDET_CHECK(out_stride >= 8 && out_stride % 8 == 0, "preprocess: out_stride=%d must be a multiple of 8", out_stride);
+  CTDET_CHECK((out_stride >= 8 && out_stride % 8 == 0) || (out_stride == 4 && out_dtype == CTDET_F32),
+              "preprocess: out_stride=%d must be a multiple of 8 (or 4 for f32 output)", out_stride);
   CTDET_CHECK(Hp >= H && Wp >= W && border >= 0, "preprocess: padded size smaller than image");
   const long total = (long)B * Hp * Wp;
   if (total == 0) return 0;

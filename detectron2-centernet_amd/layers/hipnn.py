@@ -41,7 +41,8 @@ def packed(owner, key, compute, weight, bn=None, conv_bias=None, stride=1, pad=0
     if bn is not None:
         tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
     ver = _versions(*tensors)
-    hit = cache.get((key, compute))
+    ckey = (key, compute) if cin_pad is None else (key, compute, cin_pad)
+    hit = cache.get(ckey)
     if hit is not None and hit[0] == ver:
         return hit[1]
     if bn is not None:
@@ -52,7 +53,7 @@ def packed(owner, key, compute, weight, bn=None, conv_bias=None, stride=1, pad=0
         scale, bias = None, (conv_bias.detach().float() if conv_bias is not None else None)
     p = ops.PackedConv(weight, scale, bias, stride=stride, pad=pad, dil=dil, compute=compute, cin_pad=cin_pad,
                        tap_major=tap_major, cout_align=cout_align)
-    cache[(key, compute)] = (ver, p)
+    cache[ckey] = (ver, p)
     return p
 
 

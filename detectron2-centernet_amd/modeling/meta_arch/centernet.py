@@ -81,7 +81,9 @@ class _EvalEngine:
         # otherwise: normalised input with a 3-pixel zero frame (the 7x7 stem's padding), cleared once, interior rewritten
         # per call
         self.border = int(getattr(model.backbone, "stem_border", 3))      # VoVNet's 3x3 stem pads in the kernel: 0
-        self.xpad = None if self.fused_base else torch.zeros(B, Hp + 2 * self.border, Wp + 2 * self.border, 8,
+        # f32 tensors (f32 / f16x3 modes), DLA-34: 4-channel pixels (3 used) halve the 7x7 stem's K
+        xch = 4 if (model._ctx.dtype == torch.float32 and model.backbone_type == "dla34") else 8
+        self.xpad = None if self.fused_base else torch.zeros(B, Hp + 2 * self.border, Wp + 2 * self.border, xch,
                                                              dtype=model._ctx.dtype, device=dev)
         self.l1 = torch.empty(B, Hp // 2, Wp // 2, 32, dtype=torch.float16, device=dev) if self.fused_base else None
         self.l1p = torch.empty(B, Hp // 4, Wp // 4, 32, dtype=torch.float16, device=dev) if self.fused_base else None

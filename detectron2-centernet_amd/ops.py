@@ -28,6 +28,12 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
     """mirrors the kernel selection of launch_conv_f16_t() in csrc/conv_igemm.hip"""
     bc = _lib.lib().ctdet_conv_cout_tile(p.Cout_eff)
     if p.compute == F16X3:       # the f32 kernels' split instantiations: same selection, tagged
+        H, W = (x_shape[1], x_shape[2]) if x_shape is not None else (0, 0)
+        if (not deform and p.R == 3 and p.S == 3 and p.stride == 1 and p.pad == 1 and p.dil == 1 and p.in_dil == 1 and nsrc <= 1
+                and p.Cin % 16 == 0 and p.Kpad == p.K and H and H % 8 == 0 and W % 32 == 0 and bc in (32, 64, 128)
+                and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_HALO)):
+            bc = min(bc, 64)
+            return f"conv3x3_halo_kernel<256x{bc},f16x3>"
         p32 = _F32View(p)
         return _kernel_name(p32, M, deform, out_dt, x_shape, nsrc).replace("_f32_", "_f16x3_", 1)
     if p.compute != F16:
@@ -40,9 +46,9 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
             return f"dcn_f32_window_kernel<8x16,{p.Cout_pad}>" if win else f"dcn_f32_mfma_kernel<128x{bc}>"
         bp = 256 if (big or bc == 16) else 128
         H, W = (x_shape[1], x_shape[2]) if x_shape is not None else (0, 0)
-        if p.Cin in (8, 16) and p.R == p.S and p.dil == 1 and nsrc <= 1 and H:
+        if p.Cin in (4, 8, 16) and p.R == p.S and p.dil == 1 and nsrc <= 1 and H:
             Ho, Wo = p.out_hw(H, W)
-            if ((p.R, p.Cin, bc, p.stride) in ((7, 8, 16, 1), (3, 16, 16, 1)) and Ho % 8 == 0 and Wo % 64 == 0) or \
+            if ((p.R, p.Cin, bc, p.stride) in ((7, 4, 16, 1), (7, 8, 16, 1), (3, 16, 16, 1)) and Ho % 8 == 0 and Wo % 64 == 0) or \
                     ((p.R, p.Cin, bc, p.stride) == (3, 16, 32, 2) and Ho % 4 == 0 and Wo % 32 == 0):
                 return f"conv_f32_win_kernel<{p.R}x{p.R},Cin{p.Cin},Cout{bc},s{p.stride}>"
         uk = p.R * p.S <= 32 and p.in_dil == 1 and p.Kpad == p.K and p.Cin % 16 == 0
@@ -515,6 +521,7 @@ def preprocess(images, mean, std, Hp, Wp, out_dtype=torch.float16, out=None, par
             out = torch.zeros(B, Hp + 2 * border, Wp + 2 * border, 8, dtype=out_dtype, device=images.device)
         else:
             out = torch.empty(B, Hp, Wp, 8, dtype=out_dtype, device=images.device)
+    assert out.shape[3] % 8 == 0 or (out.shape[3] == 4 and out.dtype == torch.float32)
     assert tuple(out.shape[1:3]) == (Hp + 2 * border, Wp + 2 * border)
     m = (C.c_float * 3)(*[float(v) for v in mean])
     s = (C.c_float * 3)(*[float(v) for v in std])

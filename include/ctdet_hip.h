@@ -108,7 +108,8 @@ int32_t ctdet_dcnv2_offset_fwd(const ctdet_conv_desc* d, const void* x, const vo
  * (detectron2/structures/image_list.py:58-130): img is [B,3,H,W] (u8 or f32, CHW, batch stride given in
  * elements), out is NHWC [B,Hp,Wp,out_stride] with channels 0..2 = (x/255 - mean)/std, the rest 0.
  * border > 0: out is [B,Hp+2*border,Wp+2*border,out_stride] whose zero frame the caller cleared once; only the
- * interior is written (the 7x7 stem then runs as a pad-0 conv with no bounds checks). */
+ * interior is written (the 7x7 stem then runs as a pad-0 conv with no bounds checks).  out_stride: a multiple of 8, or 4
+ * with f32 output (4-channel pixels halve the stem's K). */
 int32_t ctdet_preprocess(const void* img, int32_t img_dtype, void* out, int32_t out_dtype, int32_t B, int32_t H,
                          int32_t W, int32_t Hp, int32_t Wp, int64_t img_batch_stride, const float* mean3,
                          const float* std3, int32_t out_stride, int32_t border, void* stream);

@@ -25,6 +25,7 @@ ap.add_argument("--f32out", action="store_true")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--tap-major", action="store_true")
 ap.add_argument("--f32", action="store_true", help="the f32 (reference precision) kernels")
+ap.add_argument("--f16x3", action="store_true", help="f32 tensors, split f16 products (the f16x3 mode)")
 ap.add_argument("--tune", type=int, default=0, help="ctdet_set_tuning_flags bits (see _lib.TUNE_*)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -33,10 +34,11 @@ if a.tune:
     _lib.lib().ctdet_set_tuning_flags(a.tune)
 g = torch.Generator().manual_seed(0)
 x = torch.randn(a.B, a.H, a.W, a.cin, generator=g).half().to(dev)
-if a.f32:
+if a.f32 or a.f16x3:
+    a.f32 = True
     x = x.float()
 w = (torch.randn(a.cout, a.cin, a.k, a.k, generator=g) / (a.cin * a.k * a.k) ** 0.5).to(dev)
-p = ops.PackedConv(w, None, None, stride=a.stride, pad=a.k // 2, compute=ops.F32 if a.f32 else ops.F16,
+p = ops.PackedConv(w, None, None, stride=a.stride, pad=a.k // 2, compute=ops.F16X3 if a.f16x3 else (ops.F32 if a.f32 else ops.F16),
                    tap_major=a.tap_major and not a.dcn)
 od = torch.float32 if (a.f32out or a.f32) else torch.float16
 if a.dcn:

@@ -1,6 +1,7 @@
 """Dev tool: one line per conv-shaped launch of the bench workload's eval forward (instrumented eager pass, every
 launch repeated ops.PROFILE_REP times between one HIP event pair): time, TFLOP/s, algorithmic GB/s and the fraction of
-max(MFMA time, HBM time) at 2.5 PFLOP/s / 8 TB/s.  usage: python3 tools/layer_table.py [batch]"""
+max(MFMA time, HBM time) at 2.5 PFLOP/s (f16; f16x3: a third of it; f32: 157.3 TFLOP/s) / 8 TB/s.
+usage: python3 tools/layer_table.py [batch] [f16|f32|f16x3]"""
 import os
 import sys
 
@@ -12,8 +13,10 @@ from detectron2_centernet_amd import ops  # noqa: E402
 from detectron2_centernet_amd.modeling.meta_arch.centernet import _EvalEngine  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+PREC = sys.argv[2] if len(sys.argv) > 2 else "f16"
+PEAK = {"f16": 2.5e15, "f32": 157.3e12, "f16x3": 2.5e15 / 3}[PREC]
 dev = torch.device("cuda:0")
-model, cfg = bench.build_model("f16", dev)
+model, cfg = bench.build_model(PREC, dev)
 model.eval()
 images = bench.synthetic_images(B, 512, 0, dev)
 eng = _EvalEngine(model, B, 512, 512, 512, 512, images.dtype, use_graph=False)
@@ -30,7 +33,7 @@ ideal = 0.0
 print(f"{'us':>8} {'TF/s':>7} {'GB/s':>7} {'frac':>5}  kernel / layer")
 for name, flops, e0, e1, nbytes, info, reps in ops.PROFILE:
     ms = e0.elapsed_time(e1) / reps
-    t_roof = max(flops / 2.5e15, nbytes / 8e12) * 1e3
+    t_roof = max(flops / PEAK, nbytes / 8e12) * 1e3
     tot += ms
     ideal += t_roof
     print(f"{ms*1e3:8.1f} {flops/ms/1e9:7.1f} {nbytes/ms/1e6:7.0f} {t_roof/ms:5.2f}  {name}  [{info}]")
