@@ -538,6 +538,275 @@ static int launch_halo(const ConvArgs& a, hipStream_t s) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// f16x3 mode of the halo-resident 3x3 convolution, second form ("pair" weights, ctdet_conv_desc.korder 2).  The SP
+// instantiation above splits every pixel fragment in registers once per tap (nine times per window pixel and chunk: 40 VALU
+// per 32 MFMAs) and spends four MFMAs per 32 k-products' worth of work.  Here
+//   * the f32 window of a 16-channel chunk is converted IN PLACE, once, to the split form: every 16-byte piece (4 f32
+//     channels of a pixel) becomes {hi[4], lo[4]} f16.  A thread converts exactly the pieces its own LDS-DMAs fetched, two
+//     steps before they are first read, so the pass needs no barrier of its own;
+//   * two taps share an MFMA: the B operands are H = {hi(tap t), hi(tap t+1)} and L = {lo(t), lo(t+1)} -- four ds_read_b64
+//     straight from the converted window, no VALU -- and the weights come packed per tap pair as X = {w_hi(t), w_hi(t+1)},
+//     Y = {w_lo(t), w_lo(t+1)} (ops.PackedConv._pack_pairs).  acc += X.H + Y.H + X.L: three 16x16x32 MFMAs per 32
+//     k-products instead of four.  The nine taps are five pairs with a zero tenth tap (15 MFMAs per tile and chunk, was 18);
+//   * a step's MFMAs start right behind its barrier: their operands are read DURING the previous step -- the weight
+//     fragments into a second register set (the barrier of step k vouches for the weights of step k+1), the pixel fragments
+//     of tile p into the registers the MFMAs of tile p have just released -- and the step's LDS-DMAs are issued between its
+//     MFMAs.  With the reads and DMA issue in front of the MFMAs the kernel ran at the SUM of its skeleton (DMA issue,
+//     barrier, LDS reads: 132 us on 128->128 @64^2, batch 64, measured with the MFMAs removed) and its MFMA time (137 us):
+//     a wave parks ~500 cycles per step on LDS latency and the barrier, and its SIMD partner is often parked with it.
+// LDS: halo[2] as above + a 3-stage ring of {X image, Y image} (BCL rows x 64 B each).
+// ------------------------------------------------------------------------------------------
+template <int BC, int WP, int WC_>
+__global__ void __launch_bounds__(256, 2) conv3x3_halo_pair_kernel(const ConvArgs a) {
+  constexpr int TH = 8, TW = 32, BP = TH * TW;
+  constexpr int TP = BP / WP / 16;      // 16-pixel tiles per wave
+  constexpr int TC = BC / WC_ / 16;
+  constexpr int ROWS_W = TH / WP;       // tile rows per wave
+  constexpr int BCL = BC < 64 ? 64 : BC;
+  constexpr int W_LD = BCL / 64;        // DMA rounds per image (X or Y) and stage
+  constexpr int HMAIN = 10 * 32 * 64, HSIDE = 4096, HBUF = HMAIN + HSIDE;
+  constexpr int WIMG = BCL * 64, WST = 2 * WIMG, NST = 3;
+  static_assert(WP * WC_ == 4 && TP == 2 * ROWS_W, "wave layout");
+  static_assert(2 * HBUF + NST * WST <= 81920, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) char smem[2 * HBUF + NST * WST];
+  char* const ring = smem + 2 * HBUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave / WC_, wc = wave % WC_;
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  int m_tile, n_tile;
+  if (!tile_of_block(a.B * tiles_y * tiles_x, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int tx0 = (m_tile % tiles_x) * TW;
+  const int ty0 = ((m_tile / tiles_x) % tiles_y) * TH;
+  const int b = m_tile / (tiles_x * tiles_y);
+  const int n0 = n_tile * BC;
+  const float* zero = (const float*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+  const float* ximg = (const float*)a.x + (long)b * a.H * a.W * a.in_stride;
+
+  // ---- halo loader (as conv3x3_halo_kernel): 5 main pieces + 1 side piece per thread and chunk ----
+  const int hslot = tid & 3, hpx = (tid >> 2) & 31, hr0 = tid >> 7;
+  const int y0 = ty0 - 1 + hr0;
+  const float* hp0 = ximg + ((long)y0 * a.W + tx0 + hpx) * a.in_stride + (hslot ^ swz(hpx)) * 4;
+  const long row2 = 2L * a.W * a.in_stride;
+  unsigned hmask = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) hmask |= (y0 + 2 * i >= 0 && y0 + 2 * i < a.H) ? (1u << i) : 0u;
+  const float* hps;
+  {
+    const int side = (tid >> 2) & 1, hr = tid >> 3;   // [hr 0..9][side][slot], tid < 80
+    const int y = ty0 - 1 + hr, x = side ? tx0 + TW : tx0 - 1;
+    const bool ok = tid < 80 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    hps = ximg + ((long)(ok ? y : 0) * a.W + (ok ? x : 0)) * a.in_stride + hslot * 4;
+    hmask |= ok ? 32u : 0u;
+  }
+  const int lrow = tid >> 2;
+  const int gw = hslot ^ swz(lrow);
+  const float* wptr[W_LD];             // packed row (X image of step 0) of the cout this thread stages, + its k group
+#pragma unroll
+  for (int j = 0; j < W_LD; ++j) {
+    const int L = lrow + 64 * j;
+    const int Lw = L % (16 * TC), wv = L / (16 * TC);
+    const int tt = Lw >> 4, r = Lw & 15;
+    const int cl = wv * 16 * TC + cout_of<TC>(tt, r >> 2, r & 3);
+    wptr[j] = (const float*)a.w + (long)(n0 + (L < BC ? cl : 0)) * a.Kpad + gw * 4;
+  }
+  auto issue_halo = [&](int chunk, int hb) {
+    char* dst = smem + hb * HBUF + wave * 1024;
+    const long coff = (long)chunk * 16;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dma16((hmask & (1u << i)) ? hp0 + i * row2 + coff : zero, dst + i * 4096);
+    dma16((hmask & 32u) ? hps + coff : zero, smem + hb * HBUF + HMAIN + wave * 1024);
+  };
+  // K step kt = chunk * 5 + pair: 32 floats of every packed row = X (16) then Y (16)
+  auto issue_w = [&](int kt, int st) {
+#pragma unroll
+    for (int j = 0; j < W_LD; ++j) {
+      dma16(wptr[j] + (long)kt * 32, ring + st * WST + wave * 1024 + j * 4096);
+      dma16(wptr[j] + (long)kt * 32 + 16, ring + st * WST + WIMG + wave * 1024 + j * 4096);
+    }
+  };
+  // the thread's own six pieces of halo buffer hb: 4 f32 -> {hi[4], lo[4]} f16, in place
+  auto convert = [&](int hb) {
+    char* base = smem + hb * HBUF + wave * 1024 + lane * 16;
+    f32x4 v[6];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] = *(const f32x4*)(base + i * 4096);
+    v[5] = *(const f32x4*)(base + HMAIN);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const f16x4 hi = __builtin_convertvector(v[i], f16x4);
+      f32x4 r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = v[i][j] - (float)hi[j];
+      const f16x4 lo = __builtin_convertvector(r, f16x4);
+      *(f16x8*)(base + (i < 5 ? i * 4096 : HMAIN)) = __builtin_shufflevector(hi, lo, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+
+  // ---- fragment addressing (as conv3x3_halo_kernel) ----
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int row0 = wp * ROWS_W;
+  int abase[2][3];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+      const int X = 16 * e + l15 + s2 - 1;
+      if (X < 0) abase[e][s2] = HMAIN + kg * 16 + row0 * 128;
+      else if (X > 31) abase[e][s2] = HMAIN + 64 + kg * 16 + row0 * 128;
+      else abase[e][s2] = X * 64 + ((kg ^ swz(X)) << 4) + row0 * 2048;
+    }
+  const int estride0 = (l15 == 0) ? 128 : 2048;    // row stride of this lane for (e=0, s=0)
+  const int estride1 = (l15 == 15) ? 128 : 2048;   // ... for (e=1, s=2)
+  const int fr_off = l15 * 64 + ((kg ^ swz(l15)) << 4);
+  const char* fragB = ring + (wc * 16 * TC) * 64 + fr_off;
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  typedef unsigned long long u64;
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  // window offset of this lane's fragment of pixel tile p for tap T
+  auto tap_off = [&](int p, int T) {
+    const int R_ = T / 3, S_ = T % 3;
+    const int e = p & 1, lr = p >> 1;
+    if (e == 0 && S_ == 0) return abase[0][0] + (lr + R_) * estride0;
+    if (e == 1 && S_ == 2) return abase[1][2] + (lr + R_) * estride1;
+    return abase[e][S_] + (lr + R_) * 2048;
+  };
+  // operands of a K step: X / Y weight fragments (two register sets) and H / L pixel fragments
+  f16x8 xf[2][TC], yf[2][TC], hf[TP], lf[TP];
+  auto load_w = [&](auto parc, int st) {
+    constexpr int PAR = decltype(parc)::value;
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+      xf[PAR][c] = *(const f16x8*)(fragB + st * WST + c * 1024);
+      yf[PAR][c] = *(const f16x8*)(fragB + st * WST + WIMG + c * 1024);
+    }
+  };
+  // pixel fragments of tile p for pair PR (taps 2*PR, 2*PR+1; tap 9: zero weights, tap 8's pixels) from halo buffer hb
+  auto load_px = [&](int p, auto prc, int hb) {
+    constexpr int PR = decltype(prc)::value;
+    constexpr int T0 = 2 * PR, T1 = PR == 4 ? 8 : 2 * PR + 1;
+    const char* hbuf = smem + hb * HBUF;
+    const char* p0 = hbuf + tap_off(p, T0);
+    const char* p1 = hbuf + tap_off(p, T1);
+    u64x2 hq, lq;
+    hq[0] = *(const u64*)(p0); hq[1] = *(const u64*)(p1);
+    lq[0] = *(const u64*)(p0 + 8); lq[1] = *(const u64*)(p1 + 8);
+    hf[p] = __builtin_bit_cast(f16x8, hq);
+    lf[p] = __builtin_bit_cast(f16x8, lq);
+  };
+
+  const int nch = a.Cin / 16, nk = nch * 5;      // nk >= 5: the three prologue stages exist
+  issue_halo(0, 0);
+  issue_w(0, 0);
+  issue_w(1, 1);
+  issue_w(2, 2);
+  wait_vmcnt<6 * W_LD>();               // the window of chunk 0 (older than the weight stages)
+  convert(0);
+  wait_vmcnt<4 * W_LD>();               // weights(0)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  load_w(std::integral_constant<int, 0>{}, 0);
+#pragma unroll
+  for (int p = 0; p < TP; ++p) load_px(p, std::integral_constant<int, 0>{}, 0);
+
+  // K step kt (pair PR of `chunk`, ring stage st = kt % 3, weight fragments in register set PAR): behind one barrier the
+  // reads of the next step's weight fragments, then tile by tile the MFMAs and, into the registers they release, the next
+  // step's pixel fragments; the DMAs of step kt + 3 (into the stage this step's weights came from) go out behind tile 0
+  auto kstep = [&](int kt, int chunk, int st, auto prc, auto hbc, auto parc) {
+    constexpr int PR = decltype(prc)::value, HB = decltype(hbc)::value, PAR = decltype(parc)::value;
+    using NextPR = std::integral_constant<int, (PR + 1) % 5>;
+    constexpr int NHB = PR == 4 ? (HB ^ 1) : HB;
+    // weights(kt + 1) have landed once only what was queued behind them is still in flight: weights(kt + 2) and, in the
+    // step after a halo prefetch (PR == 1), its 6 pieces
+    if (kt + 2 < nk) { if (PR == 1 && chunk + 1 < nch) wait_vmcnt<2 * W_LD + 6>(); else wait_vmcnt<2 * W_LD>(); }
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 1 < nk) load_w(std::integral_constant<int, PAR ^ 1>{}, st == 2 ? 0 : st + 1);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[PAR][c], hf[p], acc[p][c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yf[PAR][c], hf[p], acc[p][c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[PAR][c], lf[p], acc[p][c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);            // tile p's MFMAs are issued before its operand registers are reloaded
+      if (kt + 1 < nk) load_px(p, NextPR{}, NHB);
+      if (p == 0) {                                 // DMA issue behind the first MFMAs
+        if (PR == 0 && chunk + 1 < nch) issue_halo(chunk + 1, HB ^ 1);
+        if (kt + 3 < nk) issue_w(kt + 3, st);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the next chunk's window has landed (this step's wait left only weight stages in flight): split this thread's own
+    // pieces of it; the barrier of step PR == 3 publishes them, the end of step PR == 4 reads the first operands from them
+    if (PR == 2 && chunk + 1 < nch) convert(HB ^ 1);
+  };
+  auto next_stage = [](int st) { return st == NST - 1 ? 0 : st + 1; };
+  // the five steps of a chunk; P0 = weight register set of its first step (a chunk is an odd number of steps, so the two
+  // chunks of the loop body start on opposite sets)
+  auto chunk_steps = [&](int chunk, int st0, auto hbc, auto p0c) {
+    constexpr int P0 = decltype(p0c)::value;
+    const int kt = chunk * 5;
+    int st = st0;
+    kstep(kt + 0, chunk, st, std::integral_constant<int, 0>{}, hbc, std::integral_constant<int, P0>{}); st = next_stage(st);
+    kstep(kt + 1, chunk, st, std::integral_constant<int, 1>{}, hbc, std::integral_constant<int, P0 ^ 1>{}); st = next_stage(st);
+    kstep(kt + 2, chunk, st, std::integral_constant<int, 2>{}, hbc, std::integral_constant<int, P0>{}); st = next_stage(st);
+    kstep(kt + 3, chunk, st, std::integral_constant<int, 3>{}, hbc, std::integral_constant<int, P0 ^ 1>{}); st = next_stage(st);
+    kstep(kt + 4, chunk, st, std::integral_constant<int, 4>{}, hbc, std::integral_constant<int, P0>{});
+  };
+  int chunk = 0, st0 = 0;                 // st0 = (chunk * 5) % 3
+  for (; chunk + 1 < nch; chunk += 2) {
+    chunk_steps(chunk, st0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    st0 = (st0 + 2) % 3;
+    chunk_steps(chunk + 1, st0, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    st0 = (st0 + 2) % 3;
+  }
+  if (chunk < nch) chunk_steps(chunk, st0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+
+  const int q = lane >> 4;
+  const int cb = n0 + wc * 16 * TC;
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int y = ty0 + row0 + (p >> 1), x = tx0 + 16 * (p & 1) + l15;
+    const int m = (b * a.H + y) * a.W + x;
+    epilogue_tiles<float, TC>(a, m, cb, q, acc[p]);
+  }
+}
+
+template <int BC, int WP, int WC_>
+static int launch_halo_pair_t(const ConvArgs& a, hipStream_t s) {
+  const int nbx = a.B * (a.H / 8) * (a.W / 32), nby = a.Cout_pad / BC;
+  dim3 grid(8 * ((nbx + 7) / 8) * nby);
+  hipLaunchKernelGGL((conv3x3_halo_pair_kernel<BC, WP, WC_>), grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+// korder 2 (pair-packed split weights, Kpad = Cin / 16 * 160): only this kernel reads them
+int launch_halo_pair(const ConvArgs& a, hipStream_t s) {
+  CTDET_CHECK(a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.in_dil == 1 && a.nsrc <= 1 &&
+                  a.Cin % 16 == 0 && a.Kpad == a.Cin / 16 * 160 && a.H % 8 == 0 && a.W % 32 == 0 && a.Ho == a.H && a.Wo == a.W &&
+                  a.in_stride % 4 == 0 && (((size_t)a.x | (size_t)a.w) & 15) == 0,
+              "conv(f16x3, pair weights): needs 3x3/s1/p1, Cin %% 16 == 0 and a map divisible by 8x32 (Cin=%d, %dx%d, Kpad=%d)",
+              a.Cin, a.H, a.W, a.Kpad);
+  // 64-cout tiles also for the 128-cout layers: with 128 accumulators the two operand register sets do not fit
+  if (pick_bc(a.Cout) <= 32) return launch_halo_pair_t<32, 4, 1>(a, s);
+  return launch_halo_pair_t<64, 4, 1>(a, s);
+}
+
 // f16x3 mode (called from conv_f32.hip): 3x3 / s1 / p1 on f32 activations, tap-major split weights, Cin % 16 == 0, map
 // divisible by 8x32.  Returns 1 if the shape does not qualify (the caller then takes the uniform-K kernel).
 int launch_halo_split(const ConvArgs& a, hipStream_t s) {

@@ -33,7 +33,7 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
                 and p.Cin % 16 == 0 and p.Kpad == p.K and H and H % 8 == 0 and W % 32 == 0 and bc in (32, 64, 128)
                 and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_HALO)):
             bc = min(bc, 64)
-            return f"conv3x3_halo_kernel<256x{bc},f16x3>"
+            return f"conv3x3_halo_pair_kernel<256x{max(bc, 32)},f16x3>"
         p32 = _F32View(p)
         return _kernel_name(p32, M, deform, out_dt, x_shape, nsrc).replace("_f32_", "_f16x3_", 1)
     if p.compute != F16:
@@ -329,6 +329,8 @@ class PackedConv:
                 wp = wp * pw[:, None]
                 inv = (1.0 / pw)[:self.Cout_eff]
                 scale = inv if scale is None else self._pad_vec(scale, 1.0, dev) * inv
+                if (R, S, stride, pad, dil) == (3, 3, 1, 1, 1) and self.Cin % 16 == 0 and not transposed:
+                    self._wp_scaled = wp          # kept until the first plain-conv use builds the pair image from it
                 ws = torch.empty_like(wp)
                 _lib.check(_lib.lib().ctdet_split_weights(_ptr(wp), _ptr(ws), wp.numel(), _stream()), "ctdet_split_weights")
                 wp = ws
@@ -336,6 +338,32 @@ class PackedConv:
 
         self.scale = self._pad_vec(scale, 1.0, dev)
         self.bias = self._pad_vec(bias, 0.0, dev)
+
+    w_pair = None      # F16X3, 3x3 / s1 / p1: the tap-pair image of the halo-resident kernel (ctdet_conv_desc.korder 2),
+    _wp_scaled = None  # built on the first conv2d() that can use it (a DCNv2 weight never does)
+
+    def _pack_pairs(self, wp):
+        """wp: the scaled tap-major f32 image [Cout_pad, 9*Cin] -> pair image viewed as f32 [Cout_pad', Cin/16*160]: per row and
+        16-channel chunk five 128-byte steps {X, Y}; X = for q in 0..3 {w_hi[tap 2s][4q..4q+3], w_hi[tap 2s+1][4q..4q+3]},
+        Y likewise from w_lo; tap 9 is zero.  Rows are padded to a multiple of 32 (the narrowest tile of the kernel)."""
+        rows = round_up(self.Cout_pad, 32)
+        nch = self.Cin // 16
+        w = torch.zeros(rows, 10, self.Cin, dtype=torch.float32, device=wp.device)
+        w[:wp.shape[0], :9] = wp.reshape(wp.shape[0], 9, self.Cin)
+        hi = w.to(torch.float16)
+        lo = (w - hi.float()).to(torch.float16)
+        hl = torch.stack([hi, lo], 0).reshape(2, rows, 5, 2, nch, 4, 4)     # [X/Y, row, pair, tap of pair, chunk, q, j]
+        img = hl.permute(1, 4, 2, 0, 5, 3, 6).contiguous()                  # [row, chunk, pair, X/Y, q, tap of pair, j]
+        return img.reshape(rows, nch * 320).view(torch.float32)
+
+    def pair_ok(self, x):
+        """may the halo pair kernel take this input? (mirrors launch_halo_pair in csrc/conv_igemm.hip)"""
+        ok = ((self.w_pair is not None or self._wp_scaled is not None) and self.in_dil == 1 and x.shape[1] % 8 == 0
+              and x.shape[2] % 32 == 0 and _nhwc_stride(x) % 4 == 0 and x.data_ptr() % 16 == 0
+              and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_HALO))
+        if ok and self.w_pair is None:
+            self.w_pair, self._wp_scaled = self._pack_pairs(self._wp_scaled), None
+        return ok
 
     def _pad_vec(self, v, fill, dev):
         if v is None:
@@ -357,7 +385,7 @@ class PackedConv:
         Wo = (W + 2 * self.pad - (self.dil * (self.S - 1) + 1)) // self.stride + 1
         return Ho, Wo
 
-    def desc(self, x, out, act, residual, clamp=(0.0, 1.0)):
+    def desc(self, x, out, act, residual, clamp=(0.0, 1.0), allow_pair=False):
         B, H, W, Cx = x.shape
         assert Cx == self.Cin, f"conv expects {self.Cin} input channels, got {Cx}"
         if self.in_dil > 1:
@@ -375,6 +403,8 @@ class PackedConv:
         d.clamp_lo, d.clamp_hi = clamp
         d.korder = self.korder
         d.in_dil = self.in_dil
+        if allow_pair and self.pair_ok(x):
+            d.korder, d.Kpad, d.Cout_pad = 2, self.w_pair.shape[1], self.w_pair.shape[0]
         return d
 
 
@@ -395,10 +425,11 @@ def conv2d(x, p, out=None, act=ACT_NONE, residual=None, out_dtype=None, clamp=(0
     out = _alloc_out(x, p, out, out_dtype)
     if residual is not None:
         assert residual.dtype == out.dtype and residual.shape[:3] == out.shape[:3]
-    d = p.desc(x, out, act, residual, clamp)
+    d = p.desc(x, out, act, residual, clamp, allow_pair=True)
     prof = _Prof(p, d.B * d.Ho * d.Wo, False, d.out_dtype, x.shape)
+    w = p.w_pair if d.korder == 2 else p.w
     for _ in range(prof.reps()):
-        rc = _lib.lib().ctdet_conv2d_fwd(C.byref(d), _ptr(x), _ptr(p.w), _ptr(p.scale), _ptr(p.bias), _ptr(residual),
+        rc = _lib.lib().ctdet_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w), _ptr(p.scale), _ptr(p.bias), _ptr(residual),
                                          _ptr(out), _stream())
     _lib.check(rc, "ctdet_conv2d_fwd")
     prof.done()
@@ -460,6 +491,7 @@ def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_pro
         out = torch.empty(B, H, W, round_up(p.Cout_eff, 8), dtype=dt, device=x.device)[..., :p.Cout_eff]
     out = _alloc_out(x, p, out, out_dtype)
     assert tuple(offset_mask.shape[:3]) == tuple(out.shape[:3])
+    p._wp_scaled = None          # a deformable conv's weights: no pair image will be needed
     d = p.desc(x, out, act, None)
     prof = _Prof(p, d.B * d.Ho * d.Wo, True, d.out_dtype, x.shape)
     for _ in range(prof.reps()):

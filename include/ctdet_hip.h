@@ -48,6 +48,10 @@ typedef struct ctdet_conv_desc {
   int32_t korder;       /* f16 packing order of k: 0 = tap-major  k = (r*S+s)*Cin + c;
                            1 = chunk-major k = ((c/32)*R*S + r*S+s)*32 + c%32 (needs Cin % 32 == 0; keeps the taps
                            of one 32-channel chunk adjacent in time => L2-friendly; not for ctdet_dcnv2_fwd) */
+                        /* 2 (F16X3, 3x3 / stride 1 / pad 1, Cin % 16 == 0, maps divisible by 8x32; ctdet_conv2d_fwd only):
+                           "pair" packing for the halo-resident kernel -- per cout row, per 16-channel chunk, five tap pairs
+                           (taps 2s, 2s+1; the tenth tap is zero), each 128 bytes: X = for q = 0..3 {w_hi[tap 2s][4q..4q+3],
+                           w_hi[tap 2s+1][4q..4q+3]} f16, then Y = the same of w_lo; Kpad = Cin / 16 * 160 (4-byte units) */
   int32_t in_dil;       /* 0/1 = none.  >1: the input is read as if zero-stuffed by this factor (input-gradient of a
                            strided conv expressed as a conv over dY); Ho/Wo may then exceed the formula by < in_dil */
 } ctdet_conv_desc;
