@@ -1,22 +1,24 @@
 #!/usr/bin/env python
 """Benchmark of the CenterNet DLA-34 hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--task infer|train] [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--task infer|train] [--batch B] [--precision f16x3|f16|f32]
 
 N = 1 workload (BASELINE.json configs[1]): DLA-34 CenterNet inference, batch 64, 512x512 synthetic uint8
 images resident in HBM; one step = the whole eval forward of the meta-architecture (preprocess, backbone, heads,
-sigmoid+clamp, peak-NMS, top-K decode, threshold + detector_postprocess, Instances).  For N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank runs the same per-GPU batch on its own shard of images
-(weak scaling, no data-path collective for inference); the timed region is bracketed by barrier +
-torch.cuda.synchronize and the maximum over ranks is reported.
+sigmoid+clamp, peak-NMS, top-K decode, threshold + detector_postprocess, Instances).  For N > 1 every rank (one per GPU:
+started by torch.distributed.run, or by this script itself when it is called with --gpus N and no WORLD_SIZE) runs the
+same per-GPU batch on its own shard of images (weak scaling, no data-path collective for inference); the timed region
+is bracketed by barrier + torch.cuda.synchronize and the maximum over ranks is reported.
 
-Prints ONE JSON line (rank 0): the f16 inference throughput (`value`), the roofline of the dominant kernel
-(measured live with HIP events around every launch in an instrumented eager pass, plus the decode's HBM rate),
-the CPU baseline (the oracle's port of the reference arithmetic timed on this host's cores, bounded sample),
-`accuracy` (this dtype's heat-map error and top-K agreement against the fp32 oracle on the CPU sample), `f32`
-(the same workload at the reference's own precision on the f32 matrix pipe, with its roofline against 157.3
-TFLOP/s and its accuracy) and `train` (BASELINE.json's training half: bs 16 per GPU, whole step, data parallel
-over RCCL when N > 1, with its dominant kernel's roofline and a CPU train-step baseline).
+Prints ONE JSON line (rank 0).  The headline (`value`, `dtype`) is the mode that meets north_star's parity bar at the
+highest rate: f16x3 -- f32 tensors, every product as three f16 products on the f16 matrix pipe (heat map within 1e-5 of
+the fp32 oracle).  With it: the roofline of the dominant kernel (measured live with HIP events around every launch in an
+instrumented eager pass, plus the decode's HBM rate), the CPU baseline (the oracle's port of the reference arithmetic
+timed on this host's cores, bounded sample), `accuracy` (heat-map error and top-K agreement against the fp32 oracle on
+the CPU sample), the sub-records `f16` (f16 storage: the fastest mode, whose error exceeds the 1e-3 bar -- reported, not
+the headline) and `f32` (the reference's own arithmetic on the f32 matrix pipe), each with its roofline and accuracy,
+and `train` / `train_f32` (BASELINE.json's training half: bs 16 per GPU, whole step, data parallel over RCCL when N > 1,
+with the dominant kernel's roofline and a CPU train-step baseline).
 """
 import argparse
 import json
@@ -134,6 +136,8 @@ def build_model(precision, device, seed=0, calibrate=True, config="dla34"):
         else:   # the calibration pass runs on the f16 training kernels: take the statistics from an f16 twin (same seed)
             twin, _ = build_model("f16", device, seed, calibrate=True)
             model.load_state_dict(twin.state_dict())
+            twin._engines = {}
+            del twin
     return model, cfg
 
 
@@ -190,10 +194,10 @@ def cpu_sample_images(size, n_images=2):
     return [torch.randint(0, 256, (3, size, size), generator=g, dtype=torch.uint8) for _ in range(n_images)]
 
 
-def cpu_baseline(model, cfg, size, n_images=2, warm=2, reps=5, budget_s=40.0):
+def cpu_baseline(model, cfg, size, n_images=2, warm=2, reps=5, budget_s=60.0):
     """the oracle (CPU port of the reference arithmetic: torch-CPU convs + the DCNv2 restatement + decode) on a
     bounded sample: BASELINE.json configs[0] = 2 synthetic 512x512 images, forward + decode; `warm` untimed runs,
-    then up to `reps` timed ones (fewer if `budget_s` of CPU time is used up first; at least 3).
+    then `reps` timed ones (BASELINE.md section 3 asks for >= 5; the run stops early only past `budget_s` of CPU time).
     Returns (record, oracle outputs of the sample) -- the outputs feed the `accuracy` records."""
     from oracle import model_ref as MR
 
@@ -207,7 +211,7 @@ def cpu_baseline(model, cfg, size, n_images=2, warm=2, reps=5, budget_s=40.0):
             out = MR.centernet_inference(sd, imgs, cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, thresh=0.0)
             if i >= warm:
                 times.append(time.perf_counter() - t0)
-            if len(times) >= 3 and time.perf_counter() - t_start > budget_s:
+            if len(times) >= reps or (len(times) >= 3 and time.perf_counter() - t_start > budget_s):
                 break
     times.sort()
     med = times[len(times) // 2]
@@ -217,7 +221,7 @@ def cpu_baseline(model, cfg, size, n_images=2, warm=2, reps=5, budget_s=40.0):
     return rec, out
 
 
-def cpu_train_baseline(model, cfg, size, n_images=1, warm=1, reps=2, budget_s=30.0):
+def cpu_train_baseline(model, cfg, size, n_images=1, warm=1, reps=3, budget_s=60.0):
     """CPU train step of the oracle port (targets + forward in train mode + losses + autograd backward; no optimizer
     update) on a bounded sample of the bs-16 workload: `n_images` images per step."""
     from oracle import ctdet_oracle as O
@@ -238,7 +242,7 @@ def cpu_train_baseline(model, cfg, size, n_images=1, warm=1, reps=2, budget_s=30
         sum(MR.centernet_losses(z, targets, [1.0]).values()).backward()
         if i >= warm:
             times.append(time.perf_counter() - t0)
-        if len(times) >= 1 and time.perf_counter() - t_start > budget_s:
+        if len(times) >= reps or (len(times) >= 2 and time.perf_counter() - t_start > budget_s):
             break
     times.sort()
     med = times[len(times) // 2]
@@ -405,7 +409,8 @@ def train_roofline(model, cfg, B, size, rank, device):
     model.zero_grad(set_to_none=True)
     name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
     if a["flops"] > 0:
-        ach, peak, unit, bound = a["flops"] / (a["ms"] * 1e-3) / 1e12, MFMA_F16_PEAK_TFLOPS, "TFLOP/s", "mfma"
+        mfma_peak = MFMA_F16_PEAK_TFLOPS if model._ctx.dtype == torch.float16 else FP32_PEAK_TFLOPS
+        ach, peak, unit, bound = a["flops"] / (a["ms"] * 1e-3) / 1e12, mfma_peak, "TFLOP/s", "mfma"
     else:
         ach, peak, unit, bound = a["bytes"] / (a["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
     return {"bound": bound, "kernel": name, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
@@ -416,6 +421,67 @@ def train_roofline(model, cfg, B, size, rank, device):
                            for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}}
 
 
+PEAKS = {"f16": MFMA_F16_PEAK_TFLOPS, "f32": FP32_PEAK_TFLOPS, "f16x3": MFMA_F16_PEAK_TFLOPS / 3.0}
+MODE_NOTES = {
+    "f16x3": "f32 tensors; every product as a_hi*w_hi + a_lo*w_hi + a_hi*w_lo on the f16 matrix pipe, f32 accumulation "
+             "(f32-grade results); roofline peak = 2.5 PFLOP/s / 3 products",
+    "f16": "f16 activations and weights, f32 accumulation: the fastest mode; its heat-map error is above north_star's 1e-3, "
+           "so it is reported here and is not the headline",
+    "f32": "the reference's own arithmetic (fp32 in, fp32 accumulate) on the f32 matrix pipe; peak 157.3 TFLOP/s: "
+           "64x3x512x512 needs >= 26.9 ms per step",
+}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU, rendezvous on 127.0.0.1) and
+    relay rank 0's line; non-zero exit if any rank fails.  Runs BEFORE this process touches the GPU.  With fewer visible GPUs
+    than ranks the ranks share devices and the timing reduction goes over gloo (a rehearsal: the line says so)."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ndev = torch.cuda.device_count()       # does not initialise the GPU on this image
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if ndev < n:
+            env.setdefault("CTDET_BENCH_BACKEND", "gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"bench.py --gpus {n}: rank exit codes {rcs}")
+    line = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+    if not line or json.loads(line[-1]).get("n_gpus") != n:
+        raise SystemExit(f"bench.py --gpus {n}: fewer than {n} ranks joined")
+
+
+def infer_record(precision, state, images, steps, warmup, dist, backend, device, world, config, with_roofline, headline,
+                 oracle_out, size):
+    """one precision of the inference workload: timed serving loop, roofline of its kernels, accuracy against the oracle"""
+    model, cfg = build_model(precision, device, calibrate=state is None, config=config)
+    if state is not None:
+        model.load_state_dict(state)      # the same weights and calibrated BatchNorm statistics in every mode
+    model.eval()
+    B = images.shape[0]
+    elapsed, out = timed_infer(model, images, steps, warmup, dist, backend, device)
+    assert len(out) == B
+    rec = {"value": world * B * steps / elapsed, "unit": "images/s", "ms_per_step": 1000.0 * elapsed / steps, "steps": steps,
+           "warmup": warmup, "dtype": precision, "note": MODE_NOTES[precision],
+           "detections_per_image": sum(len(o["instances"]) for o in out) / max(1, len(out))}
+    if with_roofline:
+        rec["roofline"] = roofline_record(roofline_pass(model, images, passes=2 if headline else 1), PEAKS[precision],
+                                          with_traffic=headline)
+    return rec, model, cfg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -424,20 +490,24 @@ def main():
     ap.add_argument("--task", default="infer", choices=["infer", "train"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64 infer / 16 train)")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--precision", default="f16", choices=["f16", "f32", "f16x3"])
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16", "f32"],
+                    help="headline mode (default f16x3: the fastest mode inside north_star's 1e-3 parity bar)")
     ap.add_argument("--config", default="dla34", choices=["dla34", "r50"],
                     help="dla34: BASELINE.json configs[1] (+[2]); r50: configs[4], ResNet-50 CenterNet 800x800 bs 8 per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-f32", action="store_true", help="skip the reference-precision (f32) sub-record")
-    ap.add_argument("--no-train", action="store_true", help="skip the training sub-record")
+    ap.add_argument("--no-f32", action="store_true", help="skip the f32 sub-records (inference and training)")
+    ap.add_argument("--no-f16", action="store_true", help="skip the f16 inference sub-record")
+    ap.add_argument("--no-train", action="store_true", help="skip the training sub-records")
     ap.add_argument("--require-graph", action="store_true", help="fail if the training step did not replay as a HIP graph")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
@@ -456,94 +526,101 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        world = dist.get_world_size()      # the ranks that actually joined
 
     if args.config == "r50":
         args.size = 800 if args.size == 512 else args.size
         args.batch = args.batch or 8
-        args.no_f32, args.no_cpu_baseline = True, True
-    model, cfg = build_model(args.precision, device, config=args.config)
+        args.no_f32 = args.no_f16 = args.no_cpu_baseline = True
+        if args.precision == "f16x3":
+            args.precision = "f16"          # the ResNet config is the MFMA / xGMI stress case: its throughput mode
 
     if args.task == "train":
         from detectron2_centernet_amd.engine.bench_train import run_train_bench
+        model, cfg = build_model("f32" if args.precision == "f32" else "f16", device, config=args.config)
         result = run_train_bench(model, cfg, args, args.batch or 16, rank, world, device, dist)
         if args.require_graph and world == 1 and result["config"]["graph_state"] != "captured":
             raise SystemExit(f"training step did not replay as a HIP graph: {result['config']['graph_state']}")
     else:
         B = args.batch or 64
         headline = B == 64 and args.size == 512 and args.config == "dla34"
-        model.eval()
         images = synthetic_images(B, args.size, rank, device)
-        elapsed, out = timed_infer(model, images, args.steps, args.warmup, dist, backend, device)
-        assert len(out) == B
+        solo = rank == 0 and world == 1
+        rec, model, cfg = infer_record(args.precision, None, images, args.steps, args.warmup, dist, backend, device, world,
+                                       args.config, rank == 0 and not args.no_roofline, headline, None, args.size)
         result = {
             "metric": "images/sec at 512x512 (infer bs=64)" if headline else
                       f"images/sec at {args.size}x{args.size} (infer bs={B})",
-            "value": world * B * args.steps / elapsed,
+            "value": rec["value"],
             "unit": "images/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / args.steps,
+            "ms_per_step": rec["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": f"{'DLA-34' if args.config == 'dla34' else 'ResNet-50'} CenterNet eval forward+decode, {B}x3x{args.size}x{args.size} uint8 per GPU, "
-                                   "80 classes, K=100, random-init weights, DCN offsets ~N(0,1px), "
-                                   f"{sum(len(o['instances']) for o in out) / max(1, len(out)):.0f} detections per image post-processed",
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"replicas x{world}"},
+                                   "80 classes, K=100, random-init weights (BatchNorm statistics calibrated), DCN offsets ~N(0,1px), "
+                                   f"{rec['detections_per_image']:.0f} detections per image post-processed",
+                       "precision": MODE_NOTES[args.precision],
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"replicas x{world}",
+                       "ranks_share_devices": backend != "nccl" and world > 1},
         }
-        peak = {"f16": MFMA_F16_PEAK_TFLOPS, "f32": FP32_PEAK_TFLOPS, "f16x3": MFMA_F16_PEAK_TFLOPS / 3.0}[args.precision]
-        if rank == 0 and not args.no_roofline:
-            result["roofline"] = roofline_record(roofline_pass(model, images), peak, with_traffic=headline)
+        if "roofline" in rec:
+            result["roofline"] = rec["roofline"]
         oracle_out = None
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if solo and not args.no_cpu_baseline:
             result["cpu_baseline"], oracle_out = cpu_baseline(model, cfg, args.size)
-            # the same two images through the HIP engine: error of this dtype against the reference's fp32 arithmetic
+            # the same two images through the HIP engine: error of this mode against the reference's fp32 arithmetic
             result["accuracy"] = accuracy_vs_oracle(model, cpu_sample_images(args.size), oracle_out)
         state = {k: v.clone() for k, v in model.state_dict().items()}
         model._engines = {}
         del model
         torch.cuda.empty_cache()
 
-        # ---- reference precision: the same workload with f32 activations / weights on the f32 matrix pipe
-        if rank == 0 and world == 1 and args.precision == "f16" and not args.no_f32:
-            m32, _ = build_model("f32", device, calibrate=False)   # same seed: the same weights ...
-            m32.load_state_dict(state)                                # ... and the same calibrated BatchNorm statistics
-            m32.eval()
-            st32, wu32 = max(3, args.steps // 5), 2
-            el32, _ = timed_infer(m32, images, st32, wu32, None, backend, device)
-            rec = {"value": B * st32 / el32, "unit": "images/s", "ms_per_step": 1000.0 * el32 / st32, "steps": st32,
-                   "warmup": wu32, "dtype": "f32", "note": "the reference's own arithmetic (fp32 in, fp32 accumulate); peak = "
-                   "157.3 TFLOP/s f32 MFMA: 64x3x512x512 needs >= 26.9 ms per step"}
-            if not args.no_roofline:
-                rec["roofline"] = roofline_record(roofline_pass(m32, images, passes=1), FP32_PEAK_TFLOPS, with_traffic=False)
-            if oracle_out is not None:
-                rec["accuracy"] = accuracy_vs_oracle(m32, cpu_sample_images(args.size), oracle_out)
-            result["f32"] = rec
-            m32._engines = {}
-            del m32
-            torch.cuda.empty_cache()
+        # ---- the other modes on the same workload and weights (single-GPU runs only)
+        if solo and args.config == "dla34":
+            for mode, skip, st, wu in (("f16", args.no_f16, max(5, args.steps // 2), 3),
+                                       ("f32", args.no_f32, max(10, args.steps // 5), 2)):
+                if skip or mode == args.precision:
+                    continue
+                sub, m, _ = infer_record(mode, state, images, st, wu, None, backend, device, 1, args.config,
+                                         not args.no_roofline, False, oracle_out, args.size)
+                if oracle_out is not None:
+                    sub["accuracy"] = accuracy_vs_oracle(m, cpu_sample_images(args.size), oracle_out)
+                result[mode] = sub
+                m._engines = {}
+                del m
+                torch.cuda.empty_cache()
 
         # ---- the training half of BASELINE.json's metric (train bs=16/GPU): every rank, data parallel when world > 1
         if (headline or args.config == "r50") and not args.no_train:
             from detectron2_centernet_amd.engine.bench_train import run_train_bench
 
-            tm, tcfg = build_model("f16", device, config=args.config)
             tB = 16 if args.config == "dla34" else B
-            targs = argparse.Namespace(steps=max(5, args.steps // 2), warmup=max(4, args.warmup // 2), size=args.size)
-            tr = run_train_bench(tm, tcfg, targs, tB, rank, world, device, dist)
-            rec = {k: tr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "scaling")}
-            rec["graph_state"] = tr["config"]["graph_state"]
-            rec["config"] = tr["config"]
-            if args.require_graph and world == 1 and rec["graph_state"] != "captured":
-                raise SystemExit(f"training step did not replay as a HIP graph: {rec['graph_state']}")
-            if rank == 0 and not args.no_roofline:
-                rec["roofline"] = train_roofline(tm, tcfg, tB, args.size, rank, device)
-            if rank == 0 and world == 1 and not args.no_cpu_baseline:
-                rec["cpu_baseline"] = cpu_train_baseline(tm, tcfg, args.size)
-            result["train"] = rec
+            for key, prec, skip in (("train", "f16", False), ("train_f32", "f32", args.no_f32 or args.config != "dla34")):
+                if skip:
+                    continue
+                tm, tcfg = build_model(prec, device, config=args.config)
+                few = prec == "f32"
+                targs = argparse.Namespace(steps=max(5, args.steps // (5 if few else 2)), warmup=3 if few else max(4, args.warmup // 2),
+                                           size=args.size)
+                tr = run_train_bench(tm, tcfg, targs, tB, rank, world, device, dist)
+                trec = {k: tr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "scaling")}
+                trec["graph_state"] = tr["config"]["graph_state"]
+                trec["config"] = tr["config"]
+                if args.require_graph and world == 1 and trec["graph_state"] != "captured":
+                    raise SystemExit(f"training step ({prec}) did not replay as a HIP graph: {trec['graph_state']}")
+                if rank == 0 and not args.no_roofline:
+                    trec["roofline"] = train_roofline(tm, tcfg, tB, args.size, rank, device)
+                if solo and not args.no_cpu_baseline and key == "train":
+                    trec["cpu_baseline"] = cpu_train_baseline(tm, tcfg, args.size)
+                result[key] = trec
+                del tm
+                torch.cuda.empty_cache()
 
     if rank == 0:
         print(json.dumps(result))

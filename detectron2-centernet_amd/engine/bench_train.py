@@ -54,10 +54,11 @@ def run_train_bench(model, cfg, args, B, rank, world, device, dist):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f16",
+        "dtype": "f16" if model._ctx.dtype == torch.float16 else "f32",
         "data": "synthetic",
         "config": {"workload": f"{'DLA-34' if model.backbone_type == 'dla34' else 'ResNet'} CenterNet train step (targets+fwd+loss+bwd+allreduce+SGD), {B}x3x{args.size}x"
-                               f"{args.size} per GPU, 80 classes, f16 activations / f32 master weights",
+                               f"{args.size} per GPU, 80 classes, " + ("f16 activations / f32 master weights" if model._ctx.dtype == torch.float16 else
+                                                                      "f32 activations, gradients and statistics (the reference's precision)"),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "final_losses": losses, "graph_state": trainer.graph_state},
     }

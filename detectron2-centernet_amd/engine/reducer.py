@@ -19,7 +19,10 @@ class BucketedReducer:
         stream instead of torch.distributed's collectives (the process group, if any, only bootstrapped the communicator)"""
         self.opt, self.group, self.comm = optimizer, process_group, comm
         self._side = None
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        if comm is not None:
+            self.world = comm.world            # the communicator that carries the exchange says how many ranks there are
+        else:
+            self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets = []  # [start, end, n_params]
         self.bucket_of = []
         cur = None

@@ -19,7 +19,7 @@ class SimpleTrainer:
         self.model, self.cfg = model, cfg
         self._data_iter = iter(data_loader) if data_loader is not None else None
         self.optimizer = optimizer or build_optimizer(cfg, model)
-        self.reducer = BucketedReducer(self.optimizer, process_group=process_group)
+        self.reducer = BucketedReducer(self.optimizer, process_group=process_group, comm=self._rccl_comm(process_group))
         ops_train.set_world_size(self.reducer.world)
         self.reducer.broadcast_parameters([b for b in model.buffers() if b.dtype.is_floating_point])
         self.scheduler = WarmupMultiStepLR(self.optimizer, cfg.SOLVER.STEPS, cfg.SOLVER.GAMMA, cfg.SOLVER.WARMUP_FACTOR,
@@ -27,10 +27,28 @@ class SimpleTrainer:
         self.iter = 0
         self.last_losses = None
         import os
+        # CTDET_TRAIN_GRAPH: "1" (default) replay the step as a HIP graph -- data parallel: forward + backward replayed, then the
+        # bucketed all-reduce and the SGD launch; "hooks": data parallel steps stay eager with the all-reduce launched from
+        # autograd hooks (overlaps backward, costs ~1,000 host launches per step); "0": every step eager
         mode = os.environ.get("CTDET_TRAIN_GRAPH", "1")
         self.use_hip_graph = mode != "0"
-        self.graph_ddp = mode == "ddp"
+        self.graph_ddp = mode in ("1", "ddp")
         self._graphs = {}
+
+    @staticmethod
+    def _rccl_comm(process_group):
+        """CTDET_RCCL_DIRECT=1: the gradient exchange goes through the C ABI's RCCL entry points (ctdet_comm_init /
+        ctdet_allreduce_bucket, engine/rccl.py) instead of torch.distributed's collectives; the process group only carries the
+        128-byte unique id.  One rank per GPU (RCCL cannot put two ranks on one device)."""
+        import os
+        import torch.distributed as dist
+        if os.environ.get("CTDET_RCCL_DIRECT", "0") != "1" or not torch.cuda.is_available():
+            return None
+        if not (dist.is_available() and dist.is_initialized()):
+            from .rccl import RcclComm
+            return RcclComm(0, 1)
+        from .rccl import RcclComm
+        return RcclComm(dist.get_rank(process_group), dist.get_world_size(process_group), process_group)
 
     def run_step(self, data=None):
         assert self.model.training, "[SimpleTrainer] model was changed to eval mode!"
@@ -44,12 +62,13 @@ class SimpleTrainer:
         """device-resident batch (uint8 [B,3,H,W], boxes f32 [B,N,4], classes i64 [B,N], counts i32 [B]).
 
         From the third call with a given batch shape on, the step replays as ONE captured HIP graph: the eager step issues
-        ~2,300 launches, which a slow host cannot keep up with.  Single GPU: targets, forward, losses, backward and the SGD
-        launch are all in the graph.  Data parallel: eager by default, the bucketed all-reduce launched from autograd hooks
-        so that it overlaps backward (on the GPU box's host an eager step costs the same 29 ms as the replay; measured).
-        CTDET_TRAIN_GRAPH=ddp replays forward + backward as a graph there too and runs the all-reduce of the flat gradient
-        buffer and the SGD launch after it (no overlap).  The LR schedule and the per-parameter version counters stay on
-        the host.  CTDET_TRAIN_GRAPH=0 keeps every step eager."""
+        ~1,000 launches (23.9 ms against 20.5 replayed on an idle host; eight ranks' launch threads share one host).
+        Single GPU: targets, forward, losses, backward and the SGD launch are all in the graph.  Data parallel: forward +
+        backward replay as a graph, then the bucketed all-reduce of the flat gradient buffer (78.7 MB: ~0.5 ms over xGMI
+        against a 20 ms step, so the lost overlap costs less than the eager step's launches) and the SGD launch.
+        CTDET_TRAIN_GRAPH=hooks keeps data-parallel steps eager with the all-reduce launched from autograd hooks (overlaps
+        backward).  The LR schedule and the per-parameter version counters stay on the host.  CTDET_TRAIN_GRAPH=0 keeps
+        every step eager."""
         multi = self.reducer.world > 1
         if not self.use_hip_graph or (multi and not self.graph_ddp):
             return self._finish_step(self.model.train_batch_tensor(images, boxes, classes, counts))

@@ -1,7 +1,14 @@
-"""`inference_on_dataset` and the evaluator interface (detectron2/evaluation/evaluator.py:12-180): the loop that follows the
-decode -- feeds the loader's batches to the model in eval mode, times pure compute per image after a warm-up, hands
-(inputs, outputs) to the evaluator and returns its result.  `COCOResultsWriter` collects the detections in the COCO
-results wire format (coco_evaluation.py:109-126, 321-382); scoring with pycocotools is out of scope (absent here)."""
+"""The evaluation loop behind the decode (the role of detectron2/evaluation/evaluator.py:101-180) for the HIP engine.
+
+The reference runs `model(inputs)`, calls `torch.cuda.synchronize()` and only then hands the batch to the evaluator, so the
+GPU idles while the host builds COCO records and the host idles while the GPU runs.  The native engine's eval step is
+asynchronous (one HIP-graph replay, the detection counts read back through a pinned buffer): this loop keeps ONE batch in
+flight -- batch i+1 is enqueued before batch i's result is awaited and processed -- and measures a batch's compute time on
+the device, between two HIP events on the launch stream, instead of by stalling the host.  What tools depend on is kept:
+the `DatasetEvaluator` protocol (reset / process / evaluate), the warm-up rule (the first min(5, len - 1) batches are not
+timed) and the two log lines ("Total inference time", "Total inference pure compute time", evaluator.py:163-174).
+`COCOResultsWriter` collects the detections in the COCO results wire format (coco_evaluation.py:109-126, 321-382), gathers
+them on the main process and writes the json there; scoring with pycocotools is out of scope (absent here)."""
 import datetime
 import json
 import logging
@@ -12,12 +19,12 @@ from contextlib import contextmanager
 
 import torch
 
-from ..utils.comm import get_world_size, is_main_process
+from ..utils import comm
 from .coco_results import instances_to_coco_json
 
 
 class DatasetEvaluator:
-    """process(inputs, outputs) per batch, evaluate() at the end (evaluator.py:12-53)"""
+    """reset() once, process(inputs, outputs) per batch, evaluate() at the end (evaluator.py:12-53)"""
 
     def reset(self):
         pass
@@ -30,31 +37,34 @@ class DatasetEvaluator:
 
 
 class DatasetEvaluators(DatasetEvaluator):
+    """several evaluators over one pass of the data; their result dicts are merged on the main process"""
+
     def __init__(self, evaluators):
         self._evaluators = list(evaluators)
 
     def reset(self):
-        for e in self._evaluators:
-            e.reset()
+        for ev in self._evaluators:
+            ev.reset()
 
     def process(self, inputs, outputs):
-        for e in self._evaluators:
-            e.process(inputs, outputs)
+        for ev in self._evaluators:
+            ev.process(inputs, outputs)
 
     def evaluate(self):
-        results = OrderedDict()
-        for e in self._evaluators:
-            r = e.evaluate()
-            if is_main_process() and r is not None:
-                for k, v in r.items():
-                    assert k not in results, "Different evaluators produce results with the same key {}".format(k)
-                    results[k] = v
-        return results
+        merged = OrderedDict()
+        for res in [ev.evaluate() for ev in self._evaluators]:       # every evaluator finishes (they may hold collectives)
+            if res and comm.is_main_process():
+                clash = set(res) & set(merged)
+                if clash:
+                    raise ValueError(f"evaluators report the same result keys: {sorted(clash)}")
+                merged.update(res)
+        return merged
 
 
 class COCOResultsWriter(DatasetEvaluator):
-    """collects `instances_to_coco_json` records per image (`image_id` from the loader's dicts) and writes
-    `coco_instances_results.json` like COCOEvaluator does before scoring (coco_evaluation.py:140-170)"""
+    """per-image `instances_to_coco_json` records (`image_id` from the loader's dicts); `evaluate()` gathers every rank's
+    records on the main process, which writes `coco_instances_results.json` (what COCOEvaluator does before scoring,
+    coco_evaluation.py:130-170) and returns the counts; the other ranks return {}"""
 
     def __init__(self, output_dir=None, dataset_id_to_contiguous_id=None):
         self._dir, self._rev = output_dir, None
@@ -74,55 +84,95 @@ class COCOResultsWriter(DatasetEvaluator):
             self._results.extend(recs)
 
     def evaluate(self):
+        shards = comm.gather(self._results, dst=0)
+        if not comm.is_main_process():
+            return {}
+        results = [r for shard in shards for r in shard]
         if self._dir:
             os.makedirs(self._dir, exist_ok=True)
             with open(os.path.join(self._dir, "coco_instances_results.json"), "w") as f:
-                json.dump(self._results, f)
-        return OrderedDict(bbox={"num_detections": len(self._results)})
+                json.dump(results, f)
+        return OrderedDict(bbox={"num_detections": len(results)})
 
 
 @contextmanager
 def inference_context(model):
-    """eval mode for the duration, the previous mode afterwards (evaluator.py:183-196)"""
-    training_mode = model.training
+    """eval mode inside the block, the caller's mode afterwards"""
+    was_training = model.training
     model.eval()
     try:
         yield
     finally:
-        model.train(training_mode)
+        model.train(was_training)
+
+
+class _Step:
+    """one enqueued batch: its inputs, the engine's handle and the HIP events that bracket its launches"""
+
+    def __init__(self, model, inputs, timed):
+        self.inputs, self.timed = inputs, timed
+        on_gpu = torch.cuda.is_available() and next(model.parameters()).is_cuda
+        self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if on_gpu else None
+        if self.ev:
+            self.ev[0].record()
+        start = getattr(model, "forward_async", None)
+        self.handle = start(inputs) if start is not None else None
+        self.outputs = None if self.handle is not None else model(inputs)
+        if self.ev:
+            self.ev[1].record()
+
+    def finish(self):
+        """(outputs, device seconds of this batch)"""
+        if self.handle is not None:
+            self.outputs = self.handle.result()
+        if not self.ev:
+            return self.outputs, 0.0
+        self.ev[1].synchronize()
+        return self.outputs, self.ev[0].elapsed_time(self.ev[1]) * 1e-3
 
 
 def inference_on_dataset(model, data_loader, evaluator):
-    """Run model on the data_loader and evaluate with `evaluator` (None: benchmark only).  Returns evaluator.evaluate()
-    (an empty dict if it returns None).  The timing figures are logged and kept on the function's `last_timing`."""
-    num_devices = get_world_size()
-    logger = logging.getLogger(__name__)
-    total = len(data_loader)  # inference data loader must have a fixed length
-    logger.info("Start inference on {} images".format(total))
-    if evaluator is None:
-        evaluator = DatasetEvaluators([])
+    """Run `model` over `data_loader` (fixed length) in eval mode and feed `evaluator` (None: timing only); returns
+    evaluator.evaluate() or {}.  One batch stays in flight while the previous one is processed on the host.  The timing
+    figures are logged in the reference's two lines and kept on `inference_on_dataset.last_timing`."""
+    devices = comm.get_world_size()
+    log = logging.getLogger(__name__)
+    total = len(data_loader)
+    log.info("Start inference on {} images".format(total))
+    evaluator = DatasetEvaluators([]) if evaluator is None else evaluator
     evaluator.reset()
-    num_warmup = min(5, total - 1)
-    start_time = time.perf_counter()
-    total_compute_time = 0.0
+    warmup = min(5, total - 1)
+    wall0, compute_s, timed_iters = time.perf_counter(), 0.0, 0
+
+    def retire(step):
+        nonlocal compute_s, timed_iters
+        outputs, dev_s = step.finish()
+        if step.timed:
+            compute_s += dev_s
+            timed_iters += 1
+        evaluator.process(step.inputs, outputs)
+
     with inference_context(model), torch.no_grad():
+        pending = None
         for idx, inputs in enumerate(data_loader):
-            if idx == num_warmup:
-                start_time = time.perf_counter()
-                total_compute_time = 0.0
-            start_compute_time = time.perf_counter()
-            outputs = model(inputs)
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-            total_compute_time += time.perf_counter() - start_compute_time
-            evaluator.process(inputs, outputs)
-    total_time = time.perf_counter() - start_time
-    n = max(1, total - num_warmup)
-    logger.info("Total inference time: {} ({:.6f} s / img per device, on {} devices)".format(
-        str(datetime.timedelta(seconds=total_time)), total_time / n, num_devices))
-    logger.info("Total inference pure compute time: {} ({:.6f} s / img per device, on {} devices)".format(
-        str(datetime.timedelta(seconds=int(total_compute_time))), total_compute_time / n, num_devices))
-    inference_on_dataset.last_timing = {"total_s_per_iter": total_time / n, "compute_s_per_iter": total_compute_time / n,
-                                        "iters": n, "devices": num_devices}
+            if idx == warmup:
+                if pending is not None:      # the warm-up batches end before the clock starts
+                    retire(pending)
+                    pending = None
+                wall0 = time.perf_counter()
+            step = _Step(model, inputs, timed=idx >= warmup)
+            if pending is not None:
+                retire(pending)
+            pending = step
+        if pending is not None:
+            retire(pending)
+    wall = time.perf_counter() - wall0
+    n = max(1, timed_iters)
+    log.info("Total inference time: {} ({:.6f} s / img per device, on {} devices)".format(
+        str(datetime.timedelta(seconds=wall)), wall / n, devices))
+    log.info("Total inference pure compute time: {} ({:.6f} s / img per device, on {} devices)".format(
+        str(datetime.timedelta(seconds=int(compute_s))), compute_s / n, devices))
+    inference_on_dataset.last_timing = {"total_s_per_iter": wall / n, "compute_s_per_iter": compute_s / n, "iters": n,
+                                        "devices": devices}
     results = evaluator.evaluate()
     return {} if results is None else results

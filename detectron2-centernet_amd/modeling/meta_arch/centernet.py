@@ -401,6 +401,24 @@ class CenterNet(nn.Module):
             stage[b].copy_(im if im.dtype == img_dtype else im.to(img_dtype), non_blocking=True)
         return self._finish_eval(eng, batched_inputs, sizes)
 
+    def forward_async(self, batched_inputs):
+        """eval forward of a `list[dict]` batch without waiting for it: returns a handle whose `.result()` is what
+        `forward` returns.  Same-size images go through the captured engine (one step in flight is safe: the engine's
+        post-processing writes fresh tensors per step); ragged batches run eagerly and come back already finished."""
+        assert not self.training
+        imgs = [x["image"] for x in batched_inputs]
+        sizes = [tuple(im.shape[-2:]) for im in imgs]
+        if not (all(s == sizes[0] for s in sizes) and all(im.dtype == imgs[0].dtype for im in imgs)):
+            return _Done(self._forward_eval(batched_inputs))
+        Hp, Wp = ImageList.padded_size(sizes, self.size_divisibility)
+        H, W = sizes[0]
+        img_dtype = torch.uint8 if imgs[0].dtype == torch.uint8 else torch.float32
+        eng = self._engine(len(imgs), H, W, Hp, Wp, img_dtype)
+        stage = eng.staging(H, W)
+        for b, im in enumerate(imgs):
+            stage[b].copy_(im if im.dtype == img_dtype else im.to(img_dtype), non_blocking=True)
+        return self._launch_eval(eng, batched_inputs, sizes)
+
     def infer_batch_tensor(self, images, out_sizes=None):
         """Fast path for an already-batched device tensor [B,3,H,W] (uint8 or float32, 0..255): the DLA base kernel reads
         it in place (other backbones: one staging copy), then one graph replay.  Returns the same list of {"instances": Instances} as forward()."""
@@ -563,6 +581,16 @@ class CenterNet(nn.Module):
     def inference_single_image(self, output, image_size):
         """centernet.py:236-266 (batch of one)."""
         return self.inference(output, [image_size])[0]
+
+
+class _Done:
+    """a finished eval step behind the handle interface"""
+
+    def __init__(self, results):
+        self._results = results
+
+    def result(self):
+        return self._results
 
 
 class _EvalHandle:

@@ -192,12 +192,17 @@ class PackPlan:
 
     def __init__(self, flat_param):
         """flat_param: the optimizer's parameter buffer -- only weights that live inside it are planned (their address is
-        stable and their version counter is the parameter's; a temporary could reuse an address with a fresh counter)"""
+        stable and their version counter is the parameter's; a temporary could reuse an address with a fresh counter).
+
+        A captured training step holds raw pointers to every entry's packed buffer (its conv kernels) and to the descriptor
+        table (its pack launch), so neither may ever be freed or moved while the plan lives: a stale entry is re-packed INTO
+        its buffer (`repack`), a table that the entry set outgrew is retired, not dropped."""
         self.lo = flat_param.data_ptr()
         self.hi = self.lo + flat_param.numel() * flat_param.element_size()
         self.entries = {}        # key -> [weight, packed, args, version]
         self.table = None        # device descriptor table, rebuilt when the set of entries changes
         self.blocks = 0
+        self._retired = []       # earlier tables: a captured graph may still launch the pack kernel on them
 
     def covers(self, weight):
         return self.lo <= weight.data_ptr() < self.hi
@@ -208,8 +213,20 @@ class PackPlan:
             return e[1]
         return None
 
+    def stale_buffer(self, key):
+        """the packed buffer of a known entry whose weight has changed since it was packed (None: unknown key)"""
+        e = self.entries.get(key)
+        return e[1] if e is not None else None
+
     def record(self, key, weight, packed, args):
+        e = self.entries.get(key)
+        if e is not None:                      # re-packed in place: same buffer, same table
+            assert e[1].data_ptr() == packed.data_ptr()
+            e[0], e[3] = weight, weight._version
+            return
         self.entries[key] = [weight, packed, args, weight._version]
+        if self.table is not None:
+            self._retired.append(self.table)
         self.table = None
 
     def run(self):
@@ -286,7 +303,10 @@ class PackedConv:
             plan = PACK_PLAN if (PACK_PLAN is not None and PACK_PLAN.covers(weight)) else None
             wp = plan.lookup(args + (weight.data_ptr(),), weight) if plan is not None else None
             if wp is None:
-                wp = torch.empty(self.Cout_pad, self.Kpad, dtype=torch.float16, device=dev)
+                # a stale planned entry is re-packed into its own buffer: a captured step reads that address
+                wp = plan.stale_buffer(args + (weight.data_ptr(),)) if plan is not None else None
+                if wp is None:
+                    wp = torch.empty(self.Cout_pad, self.Kpad, dtype=torch.float16, device=dev)
                 rc = _lib.lib().ctdet_pack_weights(_ptr(weight.detach()), _ptr(wp), *args, _stream())
                 _lib.check(rc, "ctdet_pack_weights")
                 if plan is not None:

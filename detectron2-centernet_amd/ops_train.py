@@ -715,7 +715,9 @@ class DeformConvFn(torch.autograd.Function):
                         out_dtype=torch.float32)
         if pt.Cout_eff != Cin:
             dx = dx[..., :Cin] + dx32
-        return dx.to(x.dtype), dw_off_t, db_off[:n_om], dwt, None if sb is not None else dbias[:Cout]
+        # no gradient for a bias that is not there (autograd raises on a tensor returned for a None input) or that was written
+        # straight into its slot
+        return dx.to(x.dtype), dw_off_t, db_off[:n_om], dwt, None if (sb is not None or p_b is None) else dbias[:Cout]
 
 
 class FocalLossFn(torch.autograd.Function):

@@ -91,7 +91,9 @@ class FlatSGD:
         self.flat_grad.zero_()
         if self._arena is not None:       # the weight-gradient accumulators of this backward pass: one fill for all of them
             from .. import ops_train
-            ops_train.PENDING.clear()     # leftovers of a backward pass that raised
+            ops_train.PENDING.clear()     # leftovers of a backward pass that raised ...
+            ops_train._END_QUEUED[0] = False   # ... whose end-of-backward callback autograd dropped with it: without this
+                                               # reset no later pass would queue the flush of its weight gradients again
             self._arena.begin_step()
         for p, (off, n) in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:

@@ -44,3 +44,13 @@ def synchronize():
         dist.barrier(device_ids=[torch.cuda.current_device()])
     else:
         dist.barrier()
+
+
+def gather(data, dst=0):
+    """a picklable object from every rank -> list of them on `dst` ([] elsewhere); [data] for a single process
+    (detectron2/utils/comm.py:166-205)"""
+    if get_world_size() == 1:
+        return [data]
+    out = [None] * get_world_size() if get_rank() == dst else None
+    dist.gather_object(data, out, dst=dst)
+    return out if get_rank() == dst else []

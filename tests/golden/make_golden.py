@@ -34,10 +34,11 @@ sys.path.insert(0, HERE)
 
 STUB_PREFIXES = ("fvcore", "yacs", "pycocotools", "termcolor", "torchvision", "iopath", "cv2", "tabulate",
                  "detectron2._C", "detectron2.data.transforms", "detectron2.utils.env", "detectron2.utils.comm",
-                 "detectron2.utils.file_io")
+                 "detectron2.utils.file_io", "detectron2.data.datasets", "detectron2.utils.logger",
+                 "detectron2.evaluation.fast_eval_api", "detectron2.evaluation.evaluator")
 PACKAGES = ["detectron2", "detectron2.layers", "detectron2.structures", "detectron2.modeling",
             "detectron2.modeling.backbone", "detectron2.modeling.meta_arch", "detectron2.data", "detectron2.utils",
-            "detectron2.config"]
+            "detectron2.config", "detectron2.evaluation"]
 
 
 class _Dummy:
@@ -396,6 +397,30 @@ def main():
     with open(os.path.join(HERE, "g12_vovnet19slim_state_dict_keys.txt"), "w") as f:
         for k in sorted(v19.state_dict().keys()):
             f.write(f"backbone.{k} {tuple(v19.state_dict()[k].shape)}\n")
+    # ---------------- G13: the COCO results wire format (coco_evaluation.py:321-382 instances_to_coco_json) ----------------
+    # records of three images (one without detections) from the reference's own Instances / Boxes; stored as flat arrays
+    st.BoxMode = boxes.BoxMode
+    ce = load("detectron2.evaluation.coco_evaluation")
+    gg = torch.Generator().manual_seed(1300)
+    g13 = {}
+    for i, n in enumerate([7, 0, 3]):
+        xy = torch.rand(n, 2, generator=gg) * 300
+        wh_ = torch.rand(n, 2, generator=gg) * 200 + 0.25
+        bx = torch.cat([xy, xy + wh_], 1)
+        sc = torch.rand(n, generator=gg)
+        cl = torch.randint(0, 80, (n,), generator=gg, dtype=torch.int64).to(torch.int32)
+        inst = instances.Instances((480, 640))
+        inst.pred_boxes = boxes.Boxes(bx)
+        inst.scores = sc
+        inst.pred_classes = cl
+        recs = ce.instances_to_coco_json(inst, 4100 + i)
+        assert all(set(r) == {"image_id", "category_id", "bbox", "score"} for r in recs)
+        g13[f"boxes{i}"], g13[f"scores{i}"], g13[f"classes{i}"] = bx.numpy(), sc.numpy(), cl.numpy()
+        g13[f"out_image_id{i}"] = np.array([r["image_id"] for r in recs], dtype=np.int64)
+        g13[f"out_category_id{i}"] = np.array([r["category_id"] for r in recs], dtype=np.int64)
+        g13[f"out_bbox{i}"] = np.array([r["bbox"] for r in recs], dtype=np.float64).reshape(len(recs), 4)
+        g13[f"out_score{i}"] = np.array([r["score"] for r in recs], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "g13_coco_json.npz"), **g13)
     print("golden vectors written to", HERE)
 
 

@@ -3,6 +3,8 @@ the oracle cannot run the network at this size in test time, so the checks are (
 HIP heat map (exact indices / scores / classes for all 64 images), (ii) sortedness and range invariants, (iii) bit-exact
 repeatability of the captured graph, (iv) batch-composition independence: images 0..3 give the same bits in a batch of
 64 as in a batch of 4 (every kernel is per-pixel / per-image, no cross-image reduction, no atomics in inference)."""
+import math
+
 import pytest
 import torch
 
@@ -228,3 +230,105 @@ def test_resnet50_800x800_bs8_properties(dev):
     assert all(v == v and abs(v) < 1e9 for v in vals.values()), vals
     assert torch.isfinite(tr.optimizer.flat_param).all() and (tr.optimizer.flat_param - p0).abs().max() > 0
     assert torch.equal(model.backbone.stem.conv1.weight.detach(), stem0)
+
+
+# ---- f16x3 (f32 tensors, split f16 products) at the BASELINE sizes: many rounds of workgroups per CU ----
+@pytest.mark.parametrize("case", [(64, 128, 128, 64, 64), (64, 64, 64, 128, 128), (64, 32, 32, 256, 256), (16, 128, 128, 64, 768),
+                                  (64, 128, 128, 64, 27), (64, 16, 16, 512, 512)])
+def test_fullsize_conv3x3_f16x3_matches_torch_f32(case):
+    """the tap-pair halo kernel (and, for the 16x16 map, the uniform-K kernel) in f16x3 mode against torch's fp32 conv:
+    deterministic, every element within 2e-5 of the output scale"""
+    import torch.nn.functional as F
+    from detectron2_centernet_amd import ops
+    B, H, W, cin, cout = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, H, W, cin, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    p = ops.PackedConv(w, None, bias, stride=1, pad=1, compute=ops.F16X3)
+    y = ops.conv2d(x, p, act=ops.ACT_RELU)
+    assert torch.equal(y, ops.conv2d(x, p, act=ops.ACT_RELU))   # deterministic
+    worst = 0.0
+    for b0 in range(0, B, 8):
+        ref = F.conv2d(x[b0:b0 + 8].permute(0, 3, 1, 2), w, bias, 1, 1).relu().permute(0, 2, 3, 1)
+        worst = max(worst, (y[b0:b0 + 8, ..., :cout] - ref).abs().max().item() / max(1.0, ref.abs().max().item()))
+    assert worst <= 2e-5, worst
+
+
+def test_fullsize_dcn_f16x3_matches_oracle_on_sampled_images():
+    """f16x3 DCNv2 (LDS-window kernel, split operands) on a full 64 x 128 x 128 x 64 layer: deterministic, images 0 / 40 / 63
+    against the CPU oracle within 2e-5"""
+    from detectron2_centernet_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(64, 128, 128, 64, generator=g)
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24)
+    om = torch.randn(64, 128, 128, 28, generator=g)
+    om[..., :18] *= 1.5
+    pw = ops.PackedConv(w.to(dev), None, None, stride=1, pad=1, compute=ops.F16X3)
+    xd, omd = x.to(dev), om.to(dev)
+    y = ops.dcnv2(xd, omd, pw)
+    assert torch.equal(y, ops.dcnv2(xd, omd, pw))
+    y = y.cpu()
+    for b in (0, 40, 63):
+        xb, omb = x[b:b + 1].permute(0, 3, 1, 2), om[b:b + 1].permute(0, 3, 1, 2)
+        ref = O.dcnv2_forward(xb, omb[:, :18], torch.sigmoid(omb[:, 18:27]), w, None, 1, 1, 1)
+        err = (y[b] - ref.permute(0, 2, 3, 1)[0]).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (b, err)
+
+
+def test_fullsize_fused_dcn_offset_matches_oracle_on_sampled_images():
+    """the dominant f16 inference kernel -- DCNv2 with its offset / mask conv computed in the same kernel
+    (`ops.dcnv2_offset`, dcn_window_rows_kernel<fused>) -- on a full 64 x 128 x 128 x 64 layer: deterministic, and images
+    0 / 21 / 40 / 63 against the CPU oracle (offset conv + sampling + contraction on the f16-rounded operands).  The
+    round-1 halo race only showed from the third round of workgroups per CU on: this is that regime."""
+    import torch.nn.functional as F
+    from detectron2_centernet_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 128, 128, 64, generator=g).half()
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    w_off = torch.randn(27, 64, 3, 3, generator=g) * (0.5 / 24)
+    b_off = torch.randn(27, generator=g) * 0.5
+    p = ops.PackedConv(w.to(dev), None, None, stride=1, pad=1, compute=ops.F16, cout_align=64)
+    p_off = ops.PackedConv(w_off.to(dev), None, b_off.to(dev), stride=1, pad=1, compute=ops.F16)
+    xd = x.to(dev)
+    assert ops.dcnv2_offset_supported(xd, p_off, p)
+    y = ops.dcnv2_offset(xd, p_off, p, act=ops.ACT_RELU)
+    assert torch.equal(y, ops.dcnv2_offset(xd, p_off, p, act=ops.ACT_RELU))
+    y = y.float().cpu()
+    for b in (0, 21, 40, 63):
+        xb = x[b:b + 1].float().permute(0, 3, 1, 2)
+        om = F.conv2d(xb, w_off.half().float(), b_off, 1, 1)
+        ref = O.dcnv2_forward(xb, om[:, :18], torch.sigmoid(om[:, 18:27]), w.half().float(), None, 1, 1, 1).relu()
+        err = (y[b] - ref.permute(0, 2, 3, 1)[0]).abs().max().item()
+        assert err <= 8e-3 * max(1.0, ref.abs().max().item()), (b, err)
+
+
+def test_fullsize_dla34_training_step_16x512(dev):
+    """BASELINE configs[2] as a whole under -m gpu: DLA-34 CenterNet, 16 x 3 x 512 x 512, targets + forward + losses +
+    backward + SGD.  Finite losses, the step replays as a captured HIP graph, and the replayed trajectory follows the
+    eager one (f32 atomics make both slightly non-deterministic: losses within 2e-3, update norms within 5 %)."""
+    import bench
+    from detectron2_centernet_amd.engine.bench_train import synthetic_batch
+    from detectron2_centernet_amd.engine.train_loop import SimpleTrainer
+
+    res = {}
+    for mode in ("eager", "graph"):
+        model, cfg = bench.build_model("f16", dev, seed=3)
+        cfg.SOLVER.IMS_PER_BATCH = 16
+        tr = SimpleTrainer(model, None, cfg)
+        tr.use_hip_graph = mode == "graph"
+        p0 = tr.optimizer.flat_param.clone()
+        batch = synthetic_batch(16, 512, 0, dev)
+        hist = [sum(float(v) for v in tr.run_step_tensors(*batch).values()) for _ in range(4)]
+        assert all(math.isfinite(h) for h in hist), hist
+        assert tr.graph_state == ("captured" if mode == "graph" else "eager"), tr.graph_state
+        res[mode] = (hist, (tr.optimizer.flat_param - p0).norm().item())
+        del tr, model
+        torch.cuda.empty_cache()
+    (he, de), (hg, dg) = res["eager"], res["graph"]
+    for a, b in zip(he, hg):
+        assert abs(a - b) <= 2e-3 * abs(a), (he, hg)
+    assert de > 0 and abs(de - dg) <= 0.05 * de, (de, dg)

@@ -281,3 +281,59 @@ def test_flat_sgd_accepts_torch_sgd_state_and_refuses_unimplemented_options():
     cfg.SOLVER.CLIP_GRADIENTS.ENABLED = True
     with pytest.raises(NotImplementedError):
         build_optimizer(cfg, net)
+
+
+def test_coco_json_matches_reference_g13():
+    """`instances_to_coco_json` against the records the REFERENCE's own function
+    (detectron2/evaluation/coco_evaluation.py:321-382) produced for the same Instances (G13: three images, one empty):
+    identical image ids, category ids, XYWH boxes and scores, as json numbers"""
+    import os
+    import numpy as np
+    from detectron2_centernet_amd.evaluation import instances_to_coco_json
+    from detectron2_centernet_amd.structures import Boxes, Instances
+
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g13_coco_json.npz"))
+    for i in range(3):
+        inst = Instances((480, 640))
+        inst.pred_boxes = Boxes(torch.from_numpy(d[f"boxes{i}"]))
+        inst.scores = torch.from_numpy(d[f"scores{i}"])
+        inst.pred_classes = torch.from_numpy(d[f"classes{i}"])
+        recs = instances_to_coco_json(inst, 4100 + i)
+        assert len(recs) == len(d[f"out_score{i}"])
+        for k, r in enumerate(recs):
+            assert set(r) == {"image_id", "category_id", "bbox", "score"}
+            assert r["image_id"] == int(d[f"out_image_id{i}"][k]) and r["category_id"] == int(d[f"out_category_id{i}"][k])
+            assert isinstance(r["category_id"], int) and isinstance(r["score"], float)
+            assert r["bbox"] == d[f"out_bbox{i}"][k].tolist() and r["score"] == float(d[f"out_score{i}"][k])
+
+
+def _gather_worker(outdir):
+    import json
+    from detectron2_centernet_amd.evaluation import COCOResultsWriter
+    from detectron2_centernet_amd.structures import Boxes, Instances
+    from detectron2_centernet_amd.utils import comm
+
+    r = comm.get_rank()
+    ev = COCOResultsWriter(outdir, {100 + c: c for c in range(4)})
+    ev.reset()
+    inst = Instances((10, 10))
+    inst.pred_boxes = Boxes(torch.tensor([[1.0, 2.0, 4.0, 6.0]] * (r + 1)))
+    inst.scores = torch.full((r + 1,), 0.5 + 0.1 * r)
+    inst.pred_classes = torch.full((r + 1,), r, dtype=torch.int32)
+    ev.process([{"image_id": 7 + r}], [{"instances": inst}])
+    res = ev.evaluate()
+    with open(os.path.join(outdir, f"res{r}.json"), "w") as f:
+        json.dump(res, f)
+
+
+def test_coco_results_writer_gathers_on_main_rank(tmp_path):
+    """sharded inference under `launch`: every rank's records end up in ONE file written by the main process
+    (coco_evaluation.py:130-135: gather to rank 0, {} elsewhere); two ranks over gloo"""
+    import json
+    from detectron2_centernet_amd.engine import launch
+
+    launch(_gather_worker, 2, num_machines=1, machine_rank=0, dist_url="auto", args=(str(tmp_path),), backend="gloo")
+    recs = json.load(open(tmp_path / "coco_instances_results.json"))
+    assert sorted((r["image_id"], r["category_id"]) for r in recs) == [(7, 100), (8, 101), (8, 101)]
+    assert json.load(open(tmp_path / "res0.json")) == {"bbox": {"num_detections": 3}}
+    assert json.load(open(tmp_path / "res1.json")) == {}

@@ -46,7 +46,34 @@ VERSION: 2
 """
 
 
-def make_model(tmp_path, precision, seed=0):
+# heat-map tolerance of each mode against the fp32 oracle on a CALIBRATED network (a random-init DLA-34 with untouched
+# running statistics collapses to a constant heat map on which any error bound holds trivially: every e2e test below
+# calibrates BatchNorm and asserts that the oracle's map is not degenerate).  f32 / f16x3 carry north_star's parity
+# (1e-3 allowed, ~5e-6 measured); f16 is the throughput mode whose error is reported, bounded loosely here.
+HM_TOL = {"f32": 1e-5, "f16x3": 5e-5, "f16": 2e-2}
+MIN_HM_STD = 3e-3
+
+
+def calibrate(model, seed):
+    """running statistics of every BatchNorm = batch statistics of synthetic images (bench.calibrate_batchnorm runs on the
+    f16 training kernels: other modes take them from an f16 twin with the same weights)"""
+    import bench
+
+    if model._ctx.dtype == torch.float16:
+        bench.calibrate_batchnorm(model, seed, n_images=2, size=256)
+        return
+    import copy
+    import detectron2_centernet_amd.ops as ops
+    from detectron2_centernet_amd.layers import hipnn
+
+    twin = copy.deepcopy(model)
+    twin._ctx = hipnn.Ctx(ops.F16)
+    twin._engines = {}
+    bench.calibrate_batchnorm(twin, seed, n_images=2, size=256)
+    model.load_state_dict(twin.state_dict())
+
+
+def make_model(tmp_path, precision, seed=0, calibrated=True):
     from detectron2_centernet_amd.config import get_cfg
     from detectron2_centernet_amd.data.catalog import register_synthetic
     from detectron2_centernet_amd.modeling import build_model
@@ -60,6 +87,8 @@ def make_model(tmp_path, precision, seed=0):
     torch.manual_seed(seed)
     model = build_model(cfg)
     randomize(model, seed)
+    if calibrated:
+        calibrate(model, seed)
     return model.eval(), cfg
 
 
@@ -86,7 +115,7 @@ def images(B, H, W, seed=1234):
     return torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8)
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16"])
 def test_heads_match_oracle(tmp_path, dev, precision):
     import detectron2_centernet_amd.ops as ops
 
@@ -103,16 +132,17 @@ def test_heads_match_oracle(tmp_path, dev, precision):
         err = (g - ref[k]).abs().max().item()
         scale = ref[k].abs().max().item()
         print(precision, k, "max err", err, "ref max", scale)
-        if precision == "f32":
+        if precision != "f16":
             assert err <= 2e-4 * max(1.0, scale), (k, err)
     p_ref = torch.clamp(torch.sigmoid(ref["hm"]), 1e-4, 1 - 1e-4)
+    assert p_ref.std().item() > MIN_HM_STD, "degenerate heat map: the comparison would be meaningless"
     p_got = torch.clamp(torch.sigmoid(hm.float().cpu().permute(0, 3, 1, 2)), 1e-4, 1 - 1e-4)
     perr = (p_got - p_ref).abs().max().item()
     print(precision, "heatmap (post-sigmoid) max err", perr)
-    assert perr <= (1e-3 if precision == "f16" else 1e-5)
+    assert perr <= HM_TOL[precision]
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16"])
 def test_eval_forward_end_to_end(tmp_path, dev, precision):
     model, cfg = make_model(tmp_path, precision, seed=3)
     model.score_threshold = 0.0  # every top-K entry passes (scores >= 1e-4 after the clamp)
@@ -139,18 +169,20 @@ def test_eval_forward_end_to_end(tmp_path, dev, precision):
         assert torch.equal(inst.scores, inst2.scores) and torch.equal(inst.pred_boxes.tensor, inst2.pred_boxes.tensor)
     # the full CPU oracle agrees on the heatmap within the mode's tolerance
     res, hm_ref, _ = MR.centernet_inference(sd, [i for i in img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, thresh=0.0)
+    assert hm_ref.std().item() > MIN_HM_STD, "degenerate heat map: the comparison would be meaningless"
     perr = (hm_c - hm_ref).abs().max().item()
     print(precision, "e2e heatmap max err", perr)
-    assert perr <= (1e-3 if precision == "f16" else 1e-5)
+    assert perr <= HM_TOL[precision]
 
 
+@pytest.mark.parametrize("precision", ["f16", "f16x3"])
 @pytest.mark.parametrize("case", [(1, 97, 131, "u8"), (2, 160, 96, "f32"), (3, 33, 33, "u8"), (2, 224, 352, "u8")])
-def test_eval_odd_sizes_match_oracle(tmp_path, dev, case):
-    """whole f16 eval forward on sizes that are not multiples of 32 (padding inside the fused base kernel, partial DCN /
-    decode tiles, maps where the fused heads do not apply) against the CPU oracle: heat map within 1e-3, decode of the
-    HIP heat map bit-exact"""
+def test_eval_odd_sizes_match_oracle(tmp_path, dev, case, precision):
+    """whole eval forward on sizes that are not multiples of 32 (padding inside the fused base kernel, partial DCN /
+    decode tiles, maps where the fused heads / the halo kernels do not apply) against the CPU oracle: heat map within the
+    mode's tolerance, decode of the HIP heat map bit-exact"""
     B, H, W, kind = case
-    model, cfg = make_model(tmp_path, "f16", seed=5)
+    model, cfg = make_model(tmp_path, precision, seed=5)
     model.score_threshold = 0.0
     img = images(B, H, W, seed=H + W)
     if kind == "f32":
@@ -162,7 +194,8 @@ def test_eval_odd_sizes_match_oracle(tmp_path, dev, case):
     res, hm_ref, _ = MR.centernet_inference(cpu_state_dict(model), [i for i in img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD,
                                             thresh=0.0)
     assert hm.shape == hm_ref.shape
-    assert (hm - hm_ref).abs().max().item() <= 1e-3
+    assert hm_ref.std().item() > MIN_HM_STD, "degenerate heat map: the comparison would be meaningless"
+    assert (hm - hm_ref).abs().max().item() <= HM_TOL[precision]
     rb, rs, rc, ri = O.ctdet_decode(hm, wh, reg, down_ratio=4, K=100)
     boxes, scores, classes, inds = [t.cpu() for t in eng.dec]
     assert torch.equal(scores, rs) and torch.equal(classes, rc) and torch.equal(inds.long(), ri)
@@ -297,20 +330,21 @@ def _topk_vs_oracle(model, cfg, img, K=100):
     return hm, sc, cl, ind.long(), hm_ref, rs, rc, ri
 
 
-def test_f32_topk_indices_equal_fp32_oracle(dev):
-    """north_star: bit-exact peak indices / top-K against the reference CPU path.  The f32 engine (f32 MFMA, exact f32
-    arithmetic) on a BatchNorm-calibrated network (O(1) activations, spread-out heat map) must return the SAME
-    (class, position) at every rank whose score is separated from its neighbours by more than the summation-order noise;
-    the heat map itself within 1e-5 (north_star allows 1e-3)."""
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_f32_topk_indices_equal_fp32_oracle(dev, precision):
+    """north_star: bit-exact peak indices / top-K against the reference CPU path.  The two f32-tensor engines (f32 MFMA:
+    exact f32 arithmetic; f16x3: the same sums from three f16 products per term) on a BatchNorm-calibrated network (O(1)
+    activations, spread-out heat map) must return the SAME (class, position) at every rank whose score is separated from its
+    neighbours by more than the summation-order noise; the heat map itself within 1e-5 / 5e-5 (north_star allows 1e-3)."""
     import bench
 
-    model, cfg = bench.build_model("f32", dev, seed=5)
+    model, cfg = bench.build_model(precision, dev, seed=5)
     model.eval()
     K = 100
     hm, sc, cl, ind, hm_ref, rs, rc, ri = _topk_vs_oracle(model, cfg, images(2, 256, 256, seed=21), K)
     err = (hm - hm_ref).abs().max().item()
     assert hm_ref.std().item() > 3e-3, "degenerate heat map: the comparison would be meaningless"
-    assert err <= 1e-5, err
+    assert err <= HM_TOL[precision], err
     margin = 2 * max(err, 1e-7)        # two scores further apart than twice the largest error cannot swap
     gap_prev = torch.cat([torch.full((2, 1), 1.0), rs[:, :K - 1] - rs[:, 1:K]], dim=1)   # to the better neighbour
     gap_next = rs[:, :K] - rs[:, 1:K + 1]                                                # to the worse neighbour
@@ -318,8 +352,8 @@ def test_f32_topk_indices_equal_fp32_oracle(dev):
     assert safe.float().mean().item() > 0.5, "too few tie-free ranks for the test to mean anything"
     same = (cl == rc[:, :K]) & (ind == ri[:, :K])
     assert bool(same[safe].all()), f"{int((~same[safe]).sum())} tie-free ranks differ from the fp32 oracle"
-    assert (sc - rs[:, :K]).abs().max().item() <= 1e-5
-    print("f32: hm err", err, "tie-free ranks", float(safe.float().mean()), "rank agreement", float(same.float().mean()))
+    assert (sc - rs[:, :K]).abs().max().item() <= HM_TOL[precision]
+    print(precision, ": hm err", err, "tie-free ranks", float(safe.float().mean()), "rank agreement", float(same.float().mean()))
 
 
 def test_f16_topk_agreement_reported(dev):
@@ -462,3 +496,34 @@ def test_out_of_image_boxes_do_not_reach_memory(dev):
     want = pred.view(-1, 2)[5].abs().sum() / (2 + 1e-4)
     assert torch.allclose(loss[0], want, rtol=1e-5)
     assert int((grad != 0).sum()) == 2
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_reference_dla34_state_dict_through_checkpointer(tmp_path, dev, precision):
+    """a checkpoint in the reference's layout -- {"model": state_dict} with the reference DLA34's own
+    key names and shapes (G8, listed from the reference module) and DistributedDataParallel's `module.` prefix -- loaded
+    through DetectionCheckpointer into the HIP model must reproduce what the REFERENCE's DLA34 computed with those weights
+    (G7: its three ida_up outputs for the golden input; DCN slots = the oracle's DCNv2 on the reference side)."""
+    import os
+    import numpy as np
+    import test_oracle_golden as TG
+    from detectron2_centernet_amd.checkpoint import DetectionCheckpointer
+
+    sd, _shapes = TG._golden_state_dict()
+    ckpt = {"model": {"module.backbone." + k: v for k, v in sd.items()}, "iteration": 1234}
+    path = str(tmp_path / "reference_format.pth")
+    torch.save(ckpt, path)
+    model, _cfg = make_model(tmp_path, precision, seed=2, calibrated=False)
+    rest = DetectionCheckpointer(model).resume_or_load(path, resume=False)
+    assert rest.get("iteration") == 1234
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_dla34.npz"))
+    x = torch.from_numpy(d["x"]).to(dev)
+    with torch.no_grad():
+        y = model.backbone(x)
+    assert len(y) == 3
+    for i, m in enumerate(y):
+        ref = torch.from_numpy(d[f"y{i}"])
+        got = m.float().cpu()
+        assert got.shape == ref.shape
+        err = (got - ref).abs().max().item()
+        assert ref.std().item() > 0.1 and err <= 1e-4 * max(1.0, ref.abs().max().item()), (i, err)

@@ -1,6 +1,8 @@
 """GPU parity of the training-side kernels and of the whole CenterNet training forward/backward against the CPU
 oracle (torch autograd through the oracle's functional model).  Activations/gradients are f16 on the device, so
 gradient comparisons use f16-sized tolerances (inputs are f16-representable, accumulation is f32)."""
+import math
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -652,3 +654,78 @@ def test_pack_plan_refreshes_weights_after_each_update(T, dev):
         assert torch.equal(p.w, fresh()[0])
     finally:
         ops.PACK_PLAN, ot.ARENA = prev_plan, prev_arena
+
+
+def test_captured_step_survives_eval_and_other_shapes(tmp_path, dev):
+    """ops.PackPlan keeps the packed-weight buffers and the descriptor table a captured training step points at alive and in
+    place: capture + replay, then an eval forward (packs the same weights again: stale entries) and an eager step of another
+    batch shape (new entries: the table is rebuilt), then replay again.  The captured graph must keep training on the LIVE
+    weights: the trajectory follows an all-eager trainer doing the same sequence (a freed buffer or table would show up as
+    garbage weights -- or a memory fault)."""
+    from test_model_gpu import make_model
+    from detectron2_centernet_amd.engine.bench_train import synthetic_batch
+    from detectron2_centernet_amd.engine.train_loop import SimpleTrainer
+
+    res = {}
+    for mode in ("eager", "graph"):
+        model, cfg = make_model(tmp_path, "f16", seed=6, calibrated=False)
+        cfg.SOLVER.IMS_PER_BATCH = 2
+        tr = SimpleTrainer(model, None, cfg)
+        tr.use_hip_graph = mode == "graph"
+        p0 = tr.optimizer.flat_param.clone()
+        a, b = synthetic_batch(2, 128, 0, dev), synthetic_batch(2, 96, 1, dev)
+        hist = []
+        for i in range(4):                                   # eager, eager, capture + replay, replay
+            hist.append(sum(float(v) for v in tr.run_step_tensors(*a).values()))
+        model.eval()
+        with torch.no_grad():
+            model.infer_batch_tensor(a[0])                   # BatchNorm-folded packs of the same (now stale) weights
+        model.train()
+        hist.append(sum(float(v) for v in tr.run_step_tensors(*b).values()))     # another shape: eager, new plan entries
+        for i in range(3):
+            hist.append(sum(float(v) for v in tr.run_step_tensors(*a).values()))  # the earlier graph again
+        if mode == "graph":
+            assert tr.graph_state == "captured"
+        assert all(math.isfinite(h) for h in hist), hist
+        res[mode] = (hist, (tr.optimizer.flat_param - p0).norm().item())
+    (he, de), (hg, dg) = res["eager"], res["graph"]
+    for x, y in zip(he, hg):
+        assert abs(x - y) <= 5e-3 * abs(x), (he, hg)
+    assert de > 0 and abs(de - dg) <= 0.05 * de, (de, dg)
+
+
+def test_weight_gradients_flow_after_a_failed_backward(tmp_path, dev):
+    """a backward pass that raises drops autograd's queued end-of-backward callback; the flag that says "already queued"
+    must not survive it (solver.FlatSGD.zero_grad resets it), or every later step would skip the flush of its conv weight
+    gradients and train on BatchNorm / bias gradients only, silently"""
+    from test_model_gpu import make_model
+    from detectron2_centernet_amd import ops_train
+    from detectron2_centernet_amd.engine.bench_train import synthetic_batch
+    from detectron2_centernet_amd.engine.train_loop import SimpleTrainer
+
+    model, cfg = make_model(tmp_path, "f16", seed=9, calibrated=False)
+    cfg.SOLVER.IMS_PER_BATCH = 2
+    tr = SimpleTrainer(model, None, cfg)
+    tr.use_hip_graph = False
+    batch = synthetic_batch(2, 128, 0, dev)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    losses = model.train_batch_tensor(*batch)
+    tr.optimizer.zero_grad()
+    # the exploding node sits on the path of the LAST backward nodes to run (the image-side end), after conv layers have
+    # already queued the end-of-backward callback
+    total = sum(losses.values()) + 0.0 * Boom.apply(next(model.parameters())).sum()
+    with pytest.raises(RuntimeError, match="boom"):
+        total.backward()
+    assert ops_train._END_QUEUED[0] or not ops_train.PENDING     # the state the bug needs (flag left set) or nothing queued yet
+    tr.run_step_tensors(*batch)                                   # zero_grad resets the flag; this step must flush
+    w = model.backbone.base.level2.tree1.conv1.weight
+    assert w.grad is not None and w.grad.abs().max().item() > 0, "conv weight gradients were not flushed"
