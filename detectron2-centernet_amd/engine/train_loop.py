@@ -27,12 +27,14 @@ class SimpleTrainer:
         self.iter = 0
         self.last_losses = None
         import os
-        # CTDET_TRAIN_GRAPH: "1" (default) replay the step as a HIP graph -- data parallel: forward + backward replayed, then the
-        # bucketed all-reduce and the SGD launch; "hooks": data parallel steps stay eager with the all-reduce launched from
-        # autograd hooks (overlaps backward, costs ~1,000 host launches per step); "0": every step eager
+        # CTDET_TRAIN_GRAPH: "1" (default): a single-GPU step replays as one HIP graph; data-parallel steps stay eager with the
+        # bucketed all-reduce launched from autograd hooks (overlaps backward).  "ddp": data-parallel steps replay forward +
+        # backward as a graph, then the all-reduce and the SGD launch -- EXPERIMENTAL: in the two-ranks-on-one-GPU gloo rehearsal
+        # of `bench.py --gpus 2` this path corrupted the hm head in 3 of 6 runs (graph replay next to gloo's worker threads; not
+        # reproduced outside bench.py's flow, cause not found), the hooks path in 0 of 6, so it is not the default.  "0": eager.
         mode = os.environ.get("CTDET_TRAIN_GRAPH", "1")
         self.use_hip_graph = mode != "0"
-        self.graph_ddp = mode in ("1", "ddp")
+        self.graph_ddp = mode == "ddp"
         self._graphs = {}
 
     @staticmethod
@@ -63,12 +65,11 @@ class SimpleTrainer:
 
         From the third call with a given batch shape on, the step replays as ONE captured HIP graph: the eager step issues
         ~1,000 launches (23.9 ms against 20.5 replayed on an idle host; eight ranks' launch threads share one host).
-        Single GPU: targets, forward, losses, backward and the SGD launch are all in the graph.  Data parallel: forward +
-        backward replay as a graph, then the bucketed all-reduce of the flat gradient buffer (78.7 MB: ~0.5 ms over xGMI
-        against a 20 ms step, so the lost overlap costs less than the eager step's launches) and the SGD launch.
-        CTDET_TRAIN_GRAPH=hooks keeps data-parallel steps eager with the all-reduce launched from autograd hooks (overlaps
-        backward).  The LR schedule and the per-parameter version counters stay on the host.  CTDET_TRAIN_GRAPH=0 keeps
-        every step eager."""
+        Single GPU: targets, forward, losses, backward and the SGD launch are all in the graph.  Data parallel: eager, the
+        bucketed all-reduce launched from autograd hooks so that it overlaps backward.  CTDET_TRAIN_GRAPH=ddp replays forward
+        + backward as a graph there too and runs the all-reduce of the flat gradient buffer and the SGD launch after it
+        (experimental, see __init__).  The LR schedule and the per-parameter version counters stay on the host.
+        CTDET_TRAIN_GRAPH=0 keeps every step eager."""
         multi = self.reducer.world > 1
         if not self.use_hip_graph or (multi and not self.graph_ddp):
             return self._finish_step(self.model.train_batch_tensor(images, boxes, classes, counts))

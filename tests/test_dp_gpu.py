@@ -77,43 +77,21 @@ def test_two_rank_step_equals_single_rank_step(tmp_path):
     assert torch.equal(r0["param"], r1["param"])
 
 
-def _graph_steps(outfile):
-    import bench
-    from detectron2_centernet_amd.engine.bench_train import synthetic_batch
-    from detectron2_centernet_amd.engine.train_loop import SimpleTrainer
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE starts two ranks itself (before touching the GPU) and
+    rank 0 prints ONE line with n_gpus == 2; with fewer GPUs than ranks the ranks share the device and the line says so"""
+    import json
+    import subprocess
+    import sys
 
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(0)
-    model, cfg = bench.build_model("f16", dev, seed=5, calibrate=False)
-    model.train()
-    cfg.SOLVER.IMS_PER_BATCH = 2
-    tr = SimpleTrainer(model, None, cfg)
-    batch = synthetic_batch(2, 128, 0, dev)
-    hist = [sum(float(v) for v in tr.run_step_tensors(*batch).values()) for _ in range(5)]
-    torch.cuda.synchronize()
-    torch.save({"param": tr.optimizer.flat_param.cpu(), "hist": hist, "world": tr.reducer.world, "state": tr.graph_state}, outfile)
-
-
-def _graph_worker(outdir):
-    from detectron2_centernet_amd.utils import comm
-
-    _graph_steps(os.path.join(outdir, f"g_rank{comm.get_rank()}.pt"))
-
-
-def test_two_rank_graph_replay_step(tmp_path):
-    """the DEFAULT data-parallel step: forward + backward replayed as a captured HIP graph on every rank, then the bucketed
-    all-reduce of the flat gradient buffer and the SGD launch (CTDET_TRAIN_GRAPH=1).  Two ranks with the same batch must
-    stay identical to each other and follow the single-process captured step."""
-    from detectron2_centernet_amd.engine import launch
-
-    os.environ.pop("CTDET_TRAIN_GRAPH", None)
-    _graph_steps(str(tmp_path / "g_single.pt"))
-    launch(_graph_worker, 2, num_machines=1, machine_rank=0, dist_url="auto", args=(str(tmp_path),), backend="gloo")
-    ref = torch.load(tmp_path / "g_single.pt")
-    r0, r1 = torch.load(tmp_path / "g_rank0.pt"), torch.load(tmp_path / "g_rank1.pt")
-    assert ref["world"] == 1 and r0["world"] == 2 and r0["state"] == r1["state"] == ref["state"] == "captured"
-    assert torch.equal(r0["param"], r1["param"])
-    for a, b in zip(ref["hist"], r0["hist"]):
-        assert abs(a - b) <= 5e-3 * abs(a), (ref["hist"], r0["hist"])
-    d_ref = (ref["param"] - r0["param"]).abs().max().item()
-    assert d_ref <= 1e-3, d_ref
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "CTDET_BENCH_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-f32", "--no-f16", "--no-train", "--no-roofline"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dtype"] == "f16x3" and rec["value"] > 0
+    assert rec["config"]["ranks_share_devices"] == (torch.cuda.device_count() < 2)
