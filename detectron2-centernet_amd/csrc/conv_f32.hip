@@ -736,6 +736,255 @@ __global__ void __launch_bounds__(256, 2) dcn_f32_window_kernel(const ConvArgs a
 }
 
 // ------------------------------------------------------------------------------------------
+// f16x3 mode of the LDS-window DCNv2 above, re-cut for instruction count: the SP instantiation of dcn_f32_window_kernel
+// issues 58 VALU per (pixel tile, tap) -- 4,181 per wave on a 64->64 tile against 576 MFMAs -- and is bound by vector issue
+// (SQ counters: vector ALU 267 us of issue per SIMD in a 507 us launch, matrix pipe 147 us, LDS array 50 % busy).  Here
+//   * the geometry stage stores the four bilinear weights ALREADY multiplied by the mask (f32: the split keeps them exact
+//     to 2^-22) and the window byte offset with the row-parity swizzle folded in; the consumer's address is one v_xor with
+//     its channel-group bits, the blend 16 FMAs per 4 channels (was: 6 for the weights + 20 + 9 of address arithmetic);
+//   * far samples (outside the +-4 px window) re-derive their coordinates from the offsets in the wave-uniform slow path
+//     instead of carrying a second LDS table;
+//   * the split of a sampled fragment feeds the MFMAs directly: b1 = {hi, 0}, b2 = {lo, hi} (conv_common.h).
+// Same tile (8x16 pixels x 64 couts), window (18x26 pixels, 16-channel chunks of f32), ring (a stage = the three taps of a
+// kernel row) and barriers as dcn_f32_window_kernel.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) dcn_split_window_kernel(const ConvArgs a) {
+  constexpr int BC = 64, TH = 8, TW = 16, BP = 128, MG = 4;
+  constexpr int WR = TH + 2 + 2 * MG, WCOLS = TW + 2 + 2 * MG;  // 18 x 26 window pixels
+  constexpr int NPIECE = WR * WCOLS * 4;                        // 1872 16-byte pieces
+  constexpr int W_LD = (NPIECE + 255) / 256;                    // 8 DMA rounds; the last one only on waves 0-1
+  constexpr int WINB = ((NPIECE + 63) / 64) * 1024;             // 30720
+  constexpr int GEOW = 9 * BP * 16, GEOC = 9 * BP * 4;          // {w1 m, w2 m, w3 m, w4 m} and the window code per (tap, pixel)
+  constexpr int TP = 2, TC = BC / 16;                           // wave = 32 pixels (2 tile rows) x all BC couts
+  constexpr int WST = BC * 64, NST = 2, STG = 3 * WST;          // a stage = the three taps of a kernel row
+  static_assert(WINB + GEOW + GEOC + NST * STG <= 81920, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) char smem[WINB + GEOW + GEOC + NST * STG];
+  char* const win = smem;
+  char* const geow = smem + WINB;
+  char* const geoc = smem + WINB + GEOW;
+  char* const ring = smem + WINB + GEOW + GEOC;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  int m_tile, n_tile;
+  if (!tile_of_block(a.B * tiles_y * tiles_x, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int tx0 = (m_tile % tiles_x) * TW;
+  const int ty0 = ((m_tile / tiles_x) % tiles_y) * TH;
+  const int b = m_tile / (tiles_x * tiles_y);
+  const int n0 = n_tile * BC;
+  const float* zero = (const float*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+  const float* ximg = (const float*)a.x + (long)b * a.H * a.W * a.in_stride;
+  const int wy0 = ty0 - 1 - MG, wx0 = tx0 - 1 - MG;  // image coordinates of window pixel (0,0)
+  const int nch = a.Cin / 16;
+
+  // ---- loaders (as dcn_f32_window_kernel)
+  const int lrow = tid >> 2, slotw = tid & 3;
+  const int gwk = slotw ^ swz(lrow);
+  const float* wptr;
+  {
+    const int tt = lrow >> 4, r = lrow & 15;
+    wptr = (const float*)a.w + (long)(n0 + cout_of<TC>(tt, r >> 2, r & 3)) * a.Kpad + gwk * 4;
+  }
+  auto issue_w = [&](int chunk, int tr, int st) {      // step (chunk, kernel row tr): 3 taps x 16 channels of every cout
+#pragma unroll
+    for (int ts = 0; ts < 3; ++ts)
+      dma16(wptr + (tr * 3 + ts) * a.Cin + chunk * 16, ring + st * STG + ts * WST + wave * 1024);
+  };
+  int wofs[W_LD];
+#pragma unroll
+  for (int i = 0; i < W_LD; ++i) {
+    const int pid = tid + 256 * i;
+    const int pw = pid >> 2, sl = pid & 3;
+    const int wr = pw / WCOLS, wcn = pw - wr * WCOLS;
+    const int y = wy0 + wr, x = wx0 + wcn;
+    const bool ok = pid < NPIECE && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    // slot sl of a pixel in an odd window row holds channel group sl^2 (conflict-free corner reads over two rows)
+    wofs[i] = ok ? (y * a.W + x) * a.in_stride + (sl ^ (2 * (wr & 1))) * 4 : -1;
+  }
+  auto issue_window = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < W_LD; ++i) {
+      if (i < W_LD - 1 || (wave * 64 + 256 * i) * 16 < WINB)  // wave-uniform: the last round ends with the window
+        dma16(wofs[i] >= 0 ? ximg + wofs[i] + chunk * 16 : zero, win + (wave * 64 + 256 * i) * 16);
+    }
+  };
+  issue_window(0);
+  issue_w(0, 0, 0);
+
+  // ---- sampling geometry, once per (pixel, tap): thread = pixel gp, taps gh, gh+2, ...
+  {
+    const int gp = tid & 127, gh = tid >> 7;
+    const int py = ty0 + (gp >> 4), pxx = tx0 + (gp & 15);
+    const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int t = 2 * i + gh;
+      if (t < 9) {
+        const int tr = t / 3, ts = t - 3 * tr;
+        const float h_im = (float)(py - 1 + tr) + omrow[2 * t], w_im = (float)(pxx - 1 + ts) + omrow[2 * t + 1];
+        const float mraw = omrow[18 + t];
+        const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W;     // kernel.cu:852
+        const float mk = valid ? (a.mask_is_prob ? mraw : ctdet_sigmoid_exact(mraw)) : 0.f;           // invalid: contributes 0
+        const float fh = floorf(h_im), fw = floorf(w_im);
+        const int h_low = (int)fh, w_low = (int)fw;
+        const float lh = valid ? h_im - fh : 0.f, lw = valid ? w_im - fw : 0.f, hh = 1.f - lh, hw = 1.f - lw;
+        const int wr = h_low - wy0, wcn = w_low - wx0;  // window coordinates of corner (h_low, w_low)
+        // every in-image corner of a valid sample inside the window => the out-of-image ones are too (1 px outside the
+        // image, where the window is zero-filled): the window read then IS the guarded read of kernel.cu:683-693
+        const bool inside = wr >= 0 && wr + 1 < WR && wcn >= 0 && wcn + 1 < WCOLS;
+        const bool oow = valid && !inside;
+        // window byte offset of corner 1 for channel group 0, the row parity in bit 5 (group g sits at (g << 4) ^ (parity << 5))
+        const unsigned code = (valid && inside) ? ((unsigned)((wr * WCOLS + wcn) * 64) | ((unsigned)(wr & 1) << 5)) : (oow ? 0x80000000u : 0u);
+        f32x4 gv;
+        gv[0] = hh * hw * mk; gv[1] = hh * lw * mk; gv[2] = lh * hw * mk; gv[3] = lh * lw * mk;
+        *(f32x4*)(geow + (t * BP + gp) * 16) = gv;
+        *(unsigned*)(geoc + (t * BP + gp) * 4) = code;
+      }
+    }
+  }
+  wait_vmcnt<0>();
+  __syncthreads();
+  // ---- consumer mapping: lane (fr, q) samples tile pixel (row 2*wave + fr/8, col 8p + fr%8), channels 4q..4q+3 of the chunk
+  const int fr = lane & 15, q = lane >> 4;
+  const int prow = 2 * wave + (fr >> 3), pcol = fr & 7;
+  const unsigned q4 = (unsigned)q << 4;
+
+  // sampling of tap t in two halves, so that the MFMAs of the previous tap can be issued between them: `gather` starts the
+  // LDS reads (weights, window code, the four corner fragments of both pixel tiles), `blend` turns them into split operands
+  struct Raw { f32x4 w[TP], v[TP][4]; };
+  auto gather = [&](int t, int chunk, Raw& r) {
+    unsigned code[TP];
+    unsigned far = 0;
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const int px = prow * 16 + 8 * p + pcol;
+      r.w[p] = *(const f32x4*)(geow + (t * BP + px) * 16);
+      code[p] = *(const unsigned*)(geoc + (t * BP + px) * 4);
+      far |= code[p] >> 31;
+    }
+    const bool any_far = __builtin_amdgcn_ballot_w64(far != 0) != 0;      // wave-uniform
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const unsigned A = (code[p] & 0xFFFFu) ^ q4;
+      const char* c0p = win + A;
+      const char* c2p = win + (A ^ 32u) + WCOLS * 64;       // next window row: the other slot swizzle
+      r.v[p][0] = *(const f32x4*)(c0p); r.v[p][1] = *(const f32x4*)(c0p + 64);
+      r.v[p][2] = *(const f32x4*)(c2p); r.v[p][3] = *(const f32x4*)(c2p + 64);
+      if (any_far) {                                          // rare: the lanes concerned re-derive the sample from the offsets
+        const bool out = code[p] >> 31;
+        const int py = ty0 + prow, pxx = tx0 + 8 * p + pcol, tr = t / 3, ts = t - 3 * (t / 3);
+        const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
+        const float h_im = (float)(py - 1 + tr) + omrow[2 * t], w_im = (float)(pxx - 1 + ts) + omrow[2 * t + 1];
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const bool r0 = out && h_low >= 0, r1 = out && h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
+        const long o0 = ((long)h_low * a.W + w_low) * a.in_stride, o2 = o0 + (long)a.W * a.in_stride;
+        const float* base = ximg + chunk * 16 + q * 4;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 g1 = (r0 && c0) ? *(const f32x4*)(base + o0) : z;
+        const f32x4 g2 = (r0 && c1) ? *(const f32x4*)(base + o0 + a.in_stride) : z;
+        const f32x4 g3 = (r1 && c0) ? *(const f32x4*)(base + o2) : z;
+        const f32x4 g4 = (r1 && c1) ? *(const f32x4*)(base + o2 + a.in_stride) : z;
+        if (out) { r.v[p][0] = g1; r.v[p][1] = g2; r.v[p][2] = g3; r.v[p][3] = g4; }
+      }
+    }
+  };
+  auto blend = [&](const Raw& r, f16x8 (&b1)[TP], f16x8 (&b2)[TP]) {
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      f32x4 val;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        val[e] = r.w[p][0] * r.v[p][0][e] + r.w[p][1] * r.v[p][1][e] + r.w[p][2] * r.v[p][2][e] + r.w[p][3] * r.v[p][3][e];
+      split_b(val, b1[p], b2[p]);
+    }
+  };
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const char* fragB = ring + fr * 64 + ((q ^ swz(fr)) << 4);
+  auto frags = [&](int st, int ts, f16x8 (&wf)[TC]) {
+#pragma unroll
+    for (int c = 0; c < TC; ++c) wf[c] = *(const f16x8*)(fragB + st * STG + ts * WST + c * 1024);
+  };
+  f16x8 b1[TP], b2[TP], wf[TC];
+  {
+    Raw r0;
+    gather(0, 0, r0);
+    blend(r0, b1, b2);
+  }
+  const int ns = nch * 3;
+
+  auto tap = [&](int s, int chunk, auto tc) {
+    constexpr int T = decltype(tc)::value, TS = T % 3;
+    const int st = s & 1;
+    if (TS == 0) {
+      wait_vmcnt<0>();                                             // this row's weights (issued a row ago)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + 1 < ns) issue_w(T == 6 ? chunk + 1 : chunk, T == 6 ? 0 : T / 3 + 1, st ^ 1);
+      frags(st, 0, wf);
+    }
+    f16x8 wfn[TC];
+    Raw raw;
+    if (TS < 2) frags(st, TS + 1, wfn);
+    if (T < 8) {
+      gather(T + 1, chunk, raw);                                   // LDS reads in flight behind the MFMAs below
+    } else if (chunk + 1 < nch) {                                  // tap 8 was sampled during tap 7: the window is free
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_window(chunk + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], b1[p], acc[p][c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], b2[p], acc[p][c], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);                             // the operands above are consumed: b1 / b2 may be rewritten
+    if (T < 8) {
+      blend(raw, b1, b2);
+    } else if (chunk + 1 < nch) {
+      wait_vmcnt<0>();                                             // next chunk's window, behind this tap's MFMAs
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      gather(0, chunk + 1, raw);
+      blend(raw, b1, b2);
+    }
+    if (TS < 2) {
+#pragma unroll
+      for (int c = 0; c < TC; ++c) wf[c] = wfn[c];
+    }
+  };
+  for (int chunk = 0; chunk < nch; ++chunk) {
+    const int s = chunk * 3;
+    tap(s, chunk, std::integral_constant<int, 0>{});
+    tap(s, chunk, std::integral_constant<int, 1>{});
+    tap(s, chunk, std::integral_constant<int, 2>{});
+    tap(s + 1, chunk, std::integral_constant<int, 3>{});
+    tap(s + 1, chunk, std::integral_constant<int, 4>{});
+    tap(s + 1, chunk, std::integral_constant<int, 5>{});
+    tap(s + 2, chunk, std::integral_constant<int, 6>{});
+    tap(s + 2, chunk, std::integral_constant<int, 7>{});
+    tap(s + 2, chunk, std::integral_constant<int, 8>{});
+  }
+
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int m = (b * a.H + ty0 + prow) * a.W + tx0 + 8 * p + pcol;
+    epilogue_tiles<float, TC>(a, m, n0, q, acc[p]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // LDS-window form for the narrow layers of the DLA base in f32 (7x7 stem on the 4- or 8-channel padded image, level0 3x3
 // 16->16, level1 3x3 16->32 stride 2): with 8 or 16 input channels the im2col-on-the-fly kernels above fetch every
 // input pixel R*S times through L2 (26 GB for the stem at batch 64: 8.2 ms for 79 GFLOP).  Here a workgroup owns a
@@ -1003,7 +1252,10 @@ static int launch_conv_f32_t(const ConvArgs& a, bool deform, hipStream_t s) {
       // 64 couts per workgroup (128 would spill under two workgroups per CU); wider layers sample the window once per cout tile
       const int nbx = a.B * (a.H / 8) * (a.W / 16);
       dim3 grid(8 * ((nbx + 7) / 8) * (a.Cout_pad / 64));
-      hipLaunchKernelGGL((dcn_f32_window_kernel<64, SP>), grid, dim3(256), 0, s, a);
+      if (SP && !(ctdet_tuning_flags() & CTDET_TUNE_DCN_WINDOW_V1))
+        hipLaunchKernelGGL(dcn_split_window_kernel, grid, dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL((dcn_f32_window_kernel<64, SP>), grid, dim3(256), 0, s, a);
       CTDET_LAUNCH_CHECK();
       return 0;
     }
