@@ -928,11 +928,9 @@ __global__ void __launch_bounds__(256, 2) dcn_split_window_kernel(const ConvArgs
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (s + 1 < ns) issue_w(T == 6 ? chunk + 1 : chunk, T == 6 ? 0 : T / 3 + 1, st ^ 1);
-      frags(st, 0, wf);
     }
-    f16x8 wfn[TC];
     Raw raw;
-    if (TS < 2) frags(st, TS + 1, wfn);
+    frags(st, TS, wf);                                             // this tap's weight fragments
     if (T < 8) {
       gather(T + 1, chunk, raw);                                   // LDS reads in flight behind the MFMAs below
     } else if (chunk + 1 < nch) {                                  // tap 8 was sampled during tap 7: the window is free
@@ -958,10 +956,6 @@ __global__ void __launch_bounds__(256, 2) dcn_split_window_kernel(const ConvArgs
       asm volatile("" ::: "memory");
       gather(0, chunk + 1, raw);
       blend(raw, b1, b2);
-    }
-    if (TS < 2) {
-#pragma unroll
-      for (int c = 0; c < TC; ++c) wf[c] = wfn[c];
     }
   };
   for (int chunk = 0; chunk < nch; ++chunk) {
