@@ -1028,6 +1028,23 @@ __global__ void __launch_bounds__(256) conv_f32_win_kernel(const ConvArgs a) {
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt) wf[kt][c] = *(const f32x4*)(wr + kt * 16);
   }
+  // SP: with 16 or 32 couts a split in registers per fragment (10 VALU for 2 * TC MFMAs) makes the kernel vector-issue bound.
+  // Instead the window is split ONCE, in place (every thread the pieces its own DMAs fetched: no barrier of its own), each
+  // 16-byte piece becoming {hi[4], lo[4]}; a fragment read then IS the B operand of both products, with the weights held as
+  //   wa = {w_lo, w_hi} -> wa . {hi, lo} = w_lo hi + w_hi lo      wb = {w_hi, 0} -> wb . {hi, lo} = w_hi hi
+  // (the packed group is {w_hi, w_lo}): two MFMAs per tile and K step, no VALU in the loop.
+  f16x8 wa[SP ? NK : 1][TC], wb[SP ? NK : 1][TC];
+  if constexpr (SP) {
+    const f16x4 z4 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) {
+        const f16x8 raw = __builtin_bit_cast(f16x8, wf[kt][c]);
+        wa[kt][c] = __builtin_shufflevector(raw, raw, 4, 5, 6, 7, 0, 1, 2, 3);
+        wb[kt][c] = __builtin_shufflevector(__builtin_shufflevector(raw, raw, 0, 1, 2, 3), z4, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+  }
   // per K step: LDS byte address of this lane's k-group for tile pixel (row 0 of the wave, column fr)
   int kaddr[NK];
 #pragma unroll
@@ -1039,6 +1056,19 @@ __global__ void __launch_bounds__(256) conv_f32_win_kernel(const ConvArgs a) {
     kaddr[kt] = ((wave * RW * STRIDE + tr) * WW + fr * STRIDE + ts) * PB + (tail ? 0 : (G - tap * GPT) * 16);
   }
   wait_vmcnt<0>();
+  if constexpr (SP) {
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+      char* pc = win + (tid + 256 * i) * 16;
+      const f32x4 v = *(const f32x4*)pc;
+      const f16x4 hi = __builtin_convertvector(v, f16x4);
+      f32x4 r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = v[j] - (float)hi[j];
+      const f16x4 lo = __builtin_convertvector(r, f16x4);
+      *(f16x8*)pc = __builtin_shufflevector(hi, lo, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  }
   __syncthreads();
 
   // two pixel tiles at a time: two independent accumulator chains per cout tile (a 16x16x4 f32 MFMA has 40 cycles of
@@ -1059,8 +1089,17 @@ __global__ void __launch_bounds__(256) conv_f32_win_kernel(const ConvArgs a) {
         const f32x4 pf0 = *(const f32x4*)(win + kaddr[kt] + toff);
         const f32x4 pf1 = *(const f32x4*)(win + kaddr[kt] + toff + 16 * STRIDE * PB);
         if constexpr (SP) {
-          mma_px<true, TC>(wf[kt], pf0, acc[0]);
-          mma_px<true, TC>(wf[kt], pf1, acc[1]);
+          const f16x8 h0 = __builtin_bit_cast(f16x8, pf0), h1 = __builtin_bit_cast(f16x8, pf1);
+#pragma unroll
+          for (int c = 0; c < TC; ++c) {
+            acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[kt][c], h0, acc[0][c], 0, 0, 0);
+            acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[kt][c], h1, acc[1][c], 0, 0, 0);
+          }
+#pragma unroll
+          for (int c = 0; c < TC; ++c) {
+            acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[kt][c], h0, acc[0][c], 0, 0, 0);
+            acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[kt][c], h1, acc[1][c], 0, 0, 0);
+          }
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)

@@ -734,16 +734,27 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_pair_kernel(const ConvArg
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt + 1 < nk) load_w(std::integral_constant<int, PAR ^ 1>{}, st == 2 ? 0 : st + 1);
+    // two pixel tiles at a time, their products interleaved: the three MFMAs that accumulate into one tile are 2 * TC
+    // instructions apart (a dependent MFMA issued TC = 2..4 instructions after its predecessor waits for it)
 #pragma unroll
-    for (int p = 0; p < TP; ++p) {
+    for (int p = 0; p < TP; p += 2) {
 #pragma unroll
-      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[PAR][c], hf[p], acc[p][c], 0, 0, 0);
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yf[PAR][c], hf[p], acc[p][c], 0, 0, 0);
+        for (int c = 0; c < TC; ++c)
+          acc[p + u][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[PAR][c], hf[p + u], acc[p + u][c], 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < TC; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[PAR][c], lf[p], acc[p][c], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);            // tile p's MFMAs are issued before its operand registers are reloaded
-      if (kt + 1 < nk) load_px(p, NextPR{}, NHB);
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+          acc[p + u][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yf[PAR][c], hf[p + u], acc[p + u][c], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+          acc[p + u][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[PAR][c], lf[p + u], acc[p + u][c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);            // these tiles' MFMAs are issued before their operand registers are reloaded
+      if (kt + 1 < nk) { load_px(p, NextPR{}, NHB); load_px(p + 1, NextPR{}, NHB); }
       if (p == 0) {                                 // DMA issue behind the first MFMAs
         if (PR == 0 && chunk + 1 < nch) issue_halo(chunk + 1, HB ^ 1);
         if (kt + 3 < nk) issue_w(kt + 3, st);
