@@ -421,6 +421,49 @@ def main():
         g13[f"out_bbox{i}"] = np.array([r["bbox"] for r in recs], dtype=np.float64).reshape(len(recs), 4)
         g13[f"out_score{i}"] = np.array([r["score"] for r in recs], dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, "g13_coco_json.npz"), **g13)
+    # ---------------- G14: dataset-dict annotations -> Instances (detection_utils.py:256-287, 362-384, 456-483) ----------------
+    # the reference's own transform_instance_annotations / annotations_to_instances / filter_empty_instances on XYWH and XYXY
+    # annotations (boxes leaving the image, degenerate after clipping, crowd flags ignored here as in the functions) under a
+    # duck-typed affine transform (x' = sx x + tx, y' = sy y + ty on the 4 corners: what fvcore's ScaleTransform / crop do);
+    # the transform classes themselves are fvcore's (absent), so only `apply_box` is supplied
+    class _Affine:
+        def __init__(self, sx, sy, tx, ty):
+            self.sx, self.sy, self.tx, self.ty = sx, sy, tx, ty
+
+        def apply_box(self, box):
+            b = np.asarray(box, dtype=np.float64).reshape(-1, 4)
+            idxs = np.array([(0, 1), (2, 1), (0, 3), (2, 3)]).flatten()
+            c = b[:, idxs].reshape(-1, 2)
+            c = c * [self.sx, self.sy] + [self.tx, self.ty]
+            c = c.reshape(-1, 4, 2)
+            return np.concatenate((c.min(axis=1), c.max(axis=1)), axis=1)
+
+    rng = np.random.RandomState(1400)
+    g14 = {}
+    for i, (sx, sy, tx, ty, hw) in enumerate([(1.5, 1.5, 0.0, 0.0, (720, 960)), (0.6, 0.75, -40.0, -25.0, (200, 300)),
+                                               (-1.0, 1.0, 639.0, 0.0, (480, 640))]):
+        n = 9
+        xywh = np.concatenate([rng.uniform(-30, 600, (n, 2)), rng.uniform(0.0, 220, (n, 2))], 1)
+        xywh[2, 2:] = 0.0                      # empty box
+        xywh[5, :2] = [5000.0, 5000.0]         # far outside: empty after clipping
+        modes = [boxes.BoxMode.XYWH_ABS if k % 2 == 0 else boxes.BoxMode.XYXY_ABS for k in range(n)]
+        raw = [xywh[k] if modes[k] == boxes.BoxMode.XYWH_ABS else np.concatenate([xywh[k, :2], xywh[k, :2] + xywh[k, 2:]])
+               for k in range(n)]
+        cats = rng.randint(0, 80, n)
+        annos = [{"bbox": raw[k].tolist(), "bbox_mode": modes[k], "category_id": int(cats[k])} for k in range(n)]
+        tr = _Affine(sx, sy, tx, ty)
+        out = [du.transform_instance_annotations(dict(a), tr, hw) for a in annos]
+        inst = du.annotations_to_instances(out, hw)
+        kept = du.filter_empty_instances(inst)
+        g14[f"bbox{i}"] = np.array(raw, dtype=np.float64)
+        g14[f"mode{i}"] = np.array([int(m) for m in modes], dtype=np.int64)
+        g14[f"cat{i}"] = cats.astype(np.int64)
+        g14[f"affine{i}"] = np.array([sx, sy, tx, ty, hw[0], hw[1]], dtype=np.float64)
+        g14[f"out_bbox{i}"] = np.array([o["bbox"] for o in out], dtype=np.float64)
+        g14[f"inst_boxes{i}"] = inst.gt_boxes.tensor.numpy()
+        g14[f"kept_boxes{i}"] = kept.gt_boxes.tensor.numpy()
+        g14[f"kept_classes{i}"] = kept.gt_classes.numpy()
+    np.savez_compressed(os.path.join(HERE, "g14_annotations.npz"), **g14)
     print("golden vectors written to", HERE)
 
 

@@ -196,3 +196,39 @@ def test_mapped_batches_of_unequal_sizes_train_and_infer(tmp_path):
         out = model([{"image": d["image"], "height": d["height"], "width": d["width"]} for d in batch])
     assert len(out) == 3 and out[0]["instances"].image_size == (batch[0]["height"], batch[0]["width"])
     DatasetCatalog.remove(name)
+
+
+def test_annotations_to_instances_match_reference_g14():
+    """`transform_instance_annotations` -> `annotations_to_instances` -> `filter_empty_instances` against
+    what the REFERENCE's own functions (detectron2/data/detection_utils.py:256-287, 362-384, 456-483) returned for the same
+    annotations (G14: XYWH / XYXY boxes, boxes leaving the image, empty boxes) under the same affine box transform (scale,
+    crop shift, horizontal flip): transformed + clipped boxes, the Instances tensor, and which instances survive"""
+    import os
+    from detectron2_centernet_amd.data import detection_utils as du
+    from detectron2_centernet_amd.data import transforms as T
+    from detectron2_centernet_amd.structures import BoxMode
+
+    class Affine(T.Transform):
+        def __init__(self, sx, sy, tx, ty):
+            self.sx, self.sy, self.tx, self.ty = sx, sy, tx, ty
+
+        def apply_coords(self, coords):
+            return np.asarray(coords, dtype=np.float64) * [self.sx, self.sy] + [self.tx, self.ty]
+
+        def apply_image(self, img):
+            return img
+
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g14_annotations.npz"))
+    for i in range(3):
+        sx, sy, tx, ty, h, w = d[f"affine{i}"]
+        hw = (int(h), int(w))
+        annos = [{"bbox": d[f"bbox{i}"][k].tolist(), "bbox_mode": BoxMode(int(d[f"mode{i}"][k])), "category_id": int(d[f"cat{i}"][k])}
+                 for k in range(len(d[f"cat{i}"]))]
+        out = [du.transform_instance_annotations(dict(a), Affine(sx, sy, tx, ty), hw) for a in annos]
+        assert np.array_equal(np.array([o["bbox"] for o in out]), d[f"out_bbox{i}"]), i
+        assert all(o["bbox_mode"] == BoxMode.XYXY_ABS for o in out)
+        inst = du.annotations_to_instances(out, hw)
+        assert np.array_equal(inst.gt_boxes.tensor.numpy(), d[f"inst_boxes{i}"])
+        kept = du.filter_empty_instances(inst)
+        assert np.array_equal(kept.gt_boxes.tensor.numpy(), d[f"kept_boxes{i}"])
+        assert np.array_equal(kept.gt_classes.numpy(), d[f"kept_classes{i}"])
