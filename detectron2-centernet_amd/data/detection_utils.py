@@ -41,8 +41,9 @@ def check_image_size(dataset_dict, image):
 
 
 def _xyxy(annotation):
-    return np.asarray(BoxMode.convert(np.asarray(annotation["bbox"], dtype=np.float64), annotation["bbox_mode"],
-                                      BoxMode.XYXY_ABS), dtype=np.float64).reshape(4)
+    # the stored object (a json list, or an array from an earlier transform) goes to BoxMode.convert as it is: the
+    # reference's conversion of a list runs in float32 (structures/boxes.py)
+    return np.asarray(BoxMode.convert(annotation["bbox"], annotation["bbox_mode"], BoxMode.XYXY_ABS), dtype=np.float64).reshape(4)
 
 
 def transform_instance_annotations(annotation, transforms, image_size):

@@ -13,11 +13,20 @@ class BoxMode:
 
     @staticmethod
     def convert(box, from_mode, to_mode):
+        """the reference's arithmetic (structures/boxes.py:41-129), including its dtypes: a list / tuple (what a COCO json
+        annotation holds) goes through `torch.tensor`, i.e. float32 -- all four numbers are rounded, not only the two that
+        change --, an ndarray keeps its dtype, a tensor is cloned; same mode: the input object itself (pinned by G14)"""
         import numpy as np
         if from_mode == to_mode:
             return box
         single = isinstance(box, (list, tuple))
-        arr = np.array(box, dtype=np.float64).reshape(-1, 4) if not isinstance(box, torch.Tensor) else box.clone().reshape(-1, 4)
+        is_numpy = isinstance(box, np.ndarray)
+        if single:
+            arr = torch.tensor(box)[None, :]
+        elif is_numpy:
+            arr = torch.from_numpy(np.asarray(box)).clone().reshape(-1, 4)
+        else:
+            arr = box.clone().reshape(-1, 4)
         if from_mode == BoxMode.XYWH_ABS and to_mode == BoxMode.XYXY_ABS:
             arr[:, 2] += arr[:, 0]
             arr[:, 3] += arr[:, 1]
@@ -28,7 +37,9 @@ class BoxMode:
             raise NotImplementedError(f"BoxMode conversion {from_mode} -> {to_mode}")
         if single:
             return type(box)(arr.flatten().tolist())
-        return arr if not isinstance(box, np.ndarray) or box.ndim == 2 else arr.reshape(box.shape)
+        if is_numpy:
+            return arr.numpy() if box.ndim == 2 else arr.numpy().reshape(box.shape)
+        return arr
 
 
 class Boxes:

@@ -222,7 +222,7 @@ def test_annotations_to_instances_match_reference_g14():
     for i in range(3):
         sx, sy, tx, ty, h, w = d[f"affine{i}"]
         hw = (int(h), int(w))
-        annos = [{"bbox": d[f"bbox{i}"][k].tolist(), "bbox_mode": BoxMode(int(d[f"mode{i}"][k])), "category_id": int(d[f"cat{i}"][k])}
+        annos = [{"bbox": d[f"bbox{i}"][k].tolist(), "bbox_mode": int(d[f"mode{i}"][k]), "category_id": int(d[f"cat{i}"][k])}
                  for k in range(len(d[f"cat{i}"]))]
         out = [du.transform_instance_annotations(dict(a), Affine(sx, sy, tx, ty), hw) for a in annos]
         assert np.array_equal(np.array([o["bbox"] for o in out]), d[f"out_bbox{i}"]), i
