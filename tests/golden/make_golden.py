@@ -35,10 +35,11 @@ sys.path.insert(0, HERE)
 STUB_PREFIXES = ("fvcore", "yacs", "pycocotools", "termcolor", "torchvision", "iopath", "cv2", "tabulate",
                  "detectron2._C", "detectron2.data.transforms", "detectron2.utils.env", "detectron2.utils.comm",
                  "detectron2.utils.file_io", "detectron2.data.datasets", "detectron2.utils.logger",
-                 "detectron2.evaluation.fast_eval_api", "detectron2.evaluation.evaluator")
+                 "detectron2.evaluation.fast_eval_api", "detectron2.evaluation.evaluator", "onnx",
+                 "detectron2.modeling.meta_arch.retinanet", "detectron2.export.patcher")
 PACKAGES = ["detectron2", "detectron2.layers", "detectron2.structures", "detectron2.modeling",
             "detectron2.modeling.backbone", "detectron2.modeling.meta_arch", "detectron2.data", "detectron2.utils",
-            "detectron2.config", "detectron2.evaluation"]
+            "detectron2.config", "detectron2.evaluation", "detectron2.export"]
 
 
 class _Dummy:
@@ -464,6 +465,38 @@ def main():
         g14[f"kept_boxes{i}"] = kept.gt_boxes.tensor.numpy()
         g14[f"kept_classes{i}"] = kept.gt_classes.numpy()
     np.savez_compressed(os.path.join(HERE, "g14_annotations.npz"), **g14)
+    # ---------------- G15: the serving split of the export path (export/meta_modeling.py:151-201) ----------------
+    # the reference's own CenterNetModel.inference ({images} -> {hm after sigmoid + clamp, wh, reg}) on a ResNet-18 CenterNet
+    # assembled from the reference's modules: G10's backbone + deconv layers and heads built as centernet.py:111-134 builds
+    # them (HEAD_CONV 64), name-keyed weights.  The wrapped model subclasses the reference CenterNet (the function asserts
+    # the type) without running its constructor, which needs a dataset and the network.
+    sys.modules["detectron2.modeling.meta_arch"].CenterNet = cn.CenterNet
+    sys.modules["detectron2.modeling"].meta_arch = sys.modules["detectron2.modeling.meta_arch"]
+    mm = load("detectron2.export.meta_modeling")
+
+    class _Wrapped(cn.CenterNet):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.backbone, self.deconv_layers, self.backbone_type = r18, deconv18, "resnet"
+            self.heads = {"HM": 80, "WH": 2, "REG": 2}
+            for head, classes in self.heads.items():
+                self.__setattr__(head.lower(), torch.nn.Sequential(
+                    torch.nn.Conv2d(256, 64, kernel_size=3, padding=1, bias=True), torch.nn.ReLU(inplace=True),
+                    torch.nn.Conv2d(64, classes, kernel_size=1, stride=1, padding=0, bias=True)))
+
+    wm = _Wrapped().eval()
+    heads_sd = {k: v for k, v in wm.state_dict().items() if k.split(".")[0] in ("hm", "wh", "reg")}
+    wm.load_state_dict(fill_state_dict(heads_sd, seed=15), strict=False)
+    em = mm.CenterNetModel.__new__(mm.CenterNetModel)
+    torch.nn.Module.__init__(em)
+    em._wrapped_model = wm
+    gg = torch.Generator().manual_seed(1000)
+    x = torch.randn(1, 3, 64, 96, generator=gg)          # G10's input
+    with torch.no_grad():
+        res = em.inference({"images": x})
+    assert em.get_input_names() == ["images", "im_info"]
+    np.savez_compressed(os.path.join(HERE, "g15_export_split.npz"), x=x.numpy(), hm=res["hm"].numpy(), wh=res["wh"].numpy(),
+                        reg=res["reg"].numpy(), output_names=np.array(em.get_output_names()))
     print("golden vectors written to", HERE)
 
 
