@@ -45,7 +45,7 @@ SIGNATURES = {
     "ctdet_split_weights": (_i32, [_vp, _vp, _i64, _vp]),
     "ctdet_dwconvT_add": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_decode_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
-    "ctdet_decode": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ctdet_decode": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctdet_postprocess": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctdet_decode_status": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_gaussian_targets": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -28,7 +28,7 @@ int launch_pack_weights(const float*, void*, int, int, int, int, int, int, int, 
 int launch_dwconvT_add(const void*, const float*, const void*, void*, int, int, int, int, int, int, int, int, int,
                        hipStream_t);
 size_t decode_workspace_bytes(int B, int H, int W, int C, int K);
-int decode_status_words(int H, int W, int C, int K, long* ws_words);
+int decode_status_words(int H, int W, int C, int K, long* ws_words, int* below_word);
 int launch_decode(const DecArgs&, hipStream_t);
 int launch_postprocess(const float*, const float*, const int*, int, int, int, float, const float*, float*, float*, int*,
                        int*, hipStream_t);
@@ -126,7 +126,7 @@ extern "C" {
 const char* ctdet_last_error(void) { return g_err; }
 int32_t ctdet_set_tuning_flags(uint32_t flags) { g_tuning.store(flags, std::memory_order_relaxed); return 0; }
 uint32_t ctdet_get_tuning_flags(void) { return g_tuning.load(std::memory_order_relaxed); }
-int32_t ctdet_abi_version(void) { return 4; }
+int32_t ctdet_abi_version(void) { return 5; }
 int32_t ctdet_conv_cout_tile(int32_t cout) {
   if (cout <= 16) return 16;
   if (cout <= 32) return 32;
@@ -332,12 +332,15 @@ size_t ctdet_decode_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C, 
 
 int32_t ctdet_decode(const float* heat, int32_t heat_stride, const float* wh, int32_t wh_stride, const float* reg,
                      int32_t reg_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t K, float down_ratio,
-                     void* workspace, float* boxes, float* scores, int32_t* classes, int32_t* inds, void* stream) {
+                     float heat_floor, void* workspace, float* boxes, float* scores, int32_t* classes, int32_t* inds,
+                     void* stream) {
   CTDET_CHECK(heat && wh && workspace && boxes && scores && classes, "decode: null pointer");
   CTDET_CHECK(B >= 0 && H > 0 && W > 0, "decode: bad shape B=%d H=%d W=%d", B, H, W);
+  CTDET_CHECK(heat_floor >= 0.f && heat_floor < 1.f, "decode: heat_floor %g outside [0, 1)", (double)heat_floor);
   DecArgs a;
   a.heat = heat; a.wh = wh; a.reg = reg; a.heat_stride = heat_stride; a.wh_stride = wh_stride; a.reg_stride = reg_stride;
   a.B = B; a.H = H; a.W = W; a.C = C; a.K = K; a.down_ratio = down_ratio;
+  memcpy(&a.floor_bits, &heat_floor, 4);
   a.ws = (uint32_t*)workspace; a.boxes = boxes; a.scores = scores; a.classes = classes; a.inds = inds;
   return launch_decode(a, (hipStream_t)stream);
 }
@@ -353,7 +356,8 @@ int32_t ctdet_postprocess(const float* boxes, const float* scores, const int32_t
 
 int32_t ctdet_decode_status(const void* workspace, int32_t B, int32_t H, int32_t W, int32_t C, int32_t K, void* stream) {
   long words = 0;
-  const int flag = decode_status_words(H, W, C, K, &words);
+  int below = 0;
+  const int flag = decode_status_words(H, W, C, K, &words, &below);
   for (int b = 0; b < B; ++b) {
     uint32_t st[16];
     hipError_t e = hipMemcpyAsync(st, (const char*)workspace + (size_t)words * 4 * b, sizeof(st), hipMemcpyDeviceToHost,
@@ -363,6 +367,10 @@ int32_t ctdet_decode_status(const void* workspace, int32_t B, int32_t H, int32_t
     if (st[flag]) {
       ctdet_set_error("decode: image %d overflowed the candidate buffer", b);
       return -75;
+    }
+    if (st[below]) {
+      ctdet_set_error("decode: image %d holds positive heat values below the promised heat_floor", b);
+      return -22;
     }
   }
   return 0;

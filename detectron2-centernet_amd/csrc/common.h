@@ -105,6 +105,7 @@ struct DecArgs {
   int heat_stride, wh_stride, reg_stride;   // pixel strides (elements)
   int B, H, W, C, K;
   float down_ratio;
+  uint32_t floor_bits;                      // bits of the promised lower bound of the heat values (0 = none)
   uint32_t* ws;
   float* boxes; float* scores; int* classes; int* inds;
 };

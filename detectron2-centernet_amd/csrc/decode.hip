@@ -17,6 +17,14 @@
 // candidate list per image (tens of KB) in which dec_final_kernel (one workgroup per image) repeats the same select,
 // sorts the <= K-1 + DEC_CAP finalists and assembles the boxes.  HBM traffic: the heat map once (halo rows come from
 // L2) + ~1 % for the candidates; the first version read it two to three times in 15 launches.
+//
+// Clamp floor (DecArgs::floor_bits, ctdet_decode's heat_floor): the map `_sigmoid` hands over (centernet.py:13-15) is
+// clamped to [1e-4, 1 - 1e-4], and a trained network's background sits exactly ON the lower clamp -- a plateau of several
+// hundred thousand tied "peaks" per image that rank below every other peak and among themselves by flat index.  With the
+// floor given, the tile pass leaves them out (its lists hold the few real peaks only) and dec_final_kernel, if an image
+// has fewer than K peaks above the floor, takes the floor peaks of lowest flat index straight from the map -- the same
+// entries in the same order the canonical rule selects.  A positive value below the floor breaks the caller's promise
+// and is reported through the status word (ctdet_decode_status: -EINVAL).
 #include "common.h"
 
 #define DEC_CAP 2048            // max uncertain candidates carried to the final sort
@@ -28,7 +36,7 @@
 #define DEC_LDS_TILE (60 * 1024)
 // per-image workspace (uint32 words): [0] candidate count, [1] overflow flag, [16..) candidates (u64)
 #define DEC_ST_WORDS 16
-enum { ST_NCAND = 0, ST_OVERFLOW = 1 };
+enum { ST_NCAND = 0, ST_OVERFLOW = 1, ST_BELOW_FLOOR = 2 };
 
 __device__ __forceinline__ int dec_d0(uint32_t bits) {
   const int d = ((int)bits - 0x38000000) >> 15;
@@ -231,6 +239,8 @@ __global__ void __launch_bounds__(DEC_TNT, 4) dec_tile_kernel(DecArgs a, int CW,
   // exact equality with the window maximum, positive values only.  The centre values stay in registers.
   f32x4 ctr[TH];
   uint32_t pk = 0;
+  bool below = false;
+  const float floorv = __uint_as_float(a.floor_bits);     // 0.0f when no floor is promised: excludes nothing new
   const bool interior = has_col && px >= 1 && px <= DEC_TW;
   if (interior) {
     f32x4 h[TH + 2];
@@ -248,9 +258,11 @@ __global__ void __launch_bounds__(DEC_TNT, 4) dec_tile_kernel(DecArgs a, int CW,
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float m = fmaxf(fmaxf(h[r][e], h[r + 1][e]), h[r + 2][e]);
-        if (ctr[r][e] == m && ctr[r][e] > 0.f) pk |= 1u << (r * 4 + e);
+        if (ctr[r][e] == m && ctr[r][e] > floorv) pk |= 1u << (r * 4 + e);
+        below |= ctr[r][e] > 0.f && ctr[r][e] < floorv;
       }
   }
+  if (below) a.ws[(long)b * ws_words + ST_BELOW_FLOOR] = 1;
   __syncthreads();     // every thread has read its neighbours: the tile image may be overwritten
   // ---- compact list of the tile's peaks in LDS (over the tile image): score bits + position (local channel << 7 | row
   // << 4 | column).  Later passes cost per PEAK, not per element.
@@ -361,24 +373,73 @@ __global__ void __launch_bounds__(1024) dec_final_kernel(DecArgs a, long ws_word
     }
   }
   const int HW = a.H * a.W;
-  // fewer positive peaks than K: the reference's topk (centernet.py:408-424) then returns entries of the NMS-ed map that
-  // are exactly 0 -- in canonical order the non-peak positions of lowest flat index.  Rare (tiny maps): a serial fill.
+  // fewer peaks (above the floor) than K.  What the reference's topk (centernet.py:408-424) returns next, in canonical
+  // order: first the peaks that sit on the clamp floor, lowest flat index first (a trained map's background: the first
+  // chunk of class 0 has them all); then, if the map runs out of those too (tiny maps), entries of the NMS-ed map that
+  // are exactly 0 -- the non-peak positions of lowest flat index.  Both straight from the heat map.
   uint32_t* fill = lh;                      // the histogram is free now: [0, 2K) flags, [2048, 2048 + K) the fill list
+  uint32_t nfloor = 0;                      // leading entries of the fill list that are floor peaks
   if (n < (uint32_t)a.K) {
-    const uint32_t span = 2u * (uint32_t)a.K < (uint32_t)a.C * HW ? 2u * (uint32_t)a.K : (uint32_t)a.C * HW;
-    for (uint32_t c = t; c < span; c += 1024) {
-      uint32_t is_peak = 0;
-      for (uint32_t i = 0; i < n; ++i) is_peak |= (0xFFFFFFFFu - (uint32_t)keys[i]) == c ? 1u : 0u;
-      fill[c] = is_peak;
-    }
+    __shared__ uint32_t sh_got, wcnt[16];
+    const float* hb = a.heat + (long)b * HW * a.heat_stride;
+    const uint32_t total = (uint32_t)a.C * (uint32_t)HW, need = (uint32_t)a.K - n;
+    const int lane = t & 63, wv = t >> 6;
+    // value at canon position c and whether it is a 3x3 peak (positive, equal to the window maximum)
+    auto probe = [&](uint32_t c, float& v) -> bool {
+      const int cls = (int)(c / (uint32_t)HW), pix = (int)(c % (uint32_t)HW);
+      const int x = pix % a.W, y = pix / a.W;
+      v = hb[(long)pix * a.heat_stride + cls];
+      if (!(v > 0.f)) return false;
+      bool peak = true;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = y + dy, xx = x + dx;
+          if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
+          peak &= hb[(long)(yy * a.W + xx) * a.heat_stride + cls] <= v;
+        }
+      return peak;
+    };
+    if (t == 0) sh_got = 0;
     __syncthreads();
-    if (t == 0) {
-      uint32_t got = 0;
-      for (uint32_t c = 0; c < span && n + got < (uint32_t)a.K; ++c)
-        if (!fill[c]) fill[2048 + got++] = c;
-      for (; n + got < (uint32_t)a.K; ++got) fill[2048 + got] = 0;      // map smaller than K positions
+    if (a.floor_bits) {
+      for (uint32_t base = 0; base < total; base += 1024) {
+        const uint32_t c = base + (uint32_t)t;
+        bool on = false;
+        if (c < total) {
+          const int cls = (int)(c / (uint32_t)HW), pix = (int)(c % (uint32_t)HW);
+          float v = hb[(long)pix * a.heat_stride + cls];
+          if (__float_as_uint(v) == a.floor_bits) on = probe(c, v);
+        }
+        const unsigned long long m = __ballot(on);
+        if (lane == 0) wcnt[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = sh_got, all = 0;
+        for (int w = 0; w < 16; ++w) { const uint32_t q = wcnt[w]; all += q; if (w < wv) before += q; }
+        if (on) {
+          const uint32_t pos = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (pos < need) fill[2048 + pos] = c;
+        }
+        __syncthreads();
+        if (t == 0) sh_got += all;
+        __syncthreads();
+        if (sh_got >= need) break;
+      }
     }
-    __syncthreads();
+    const uint32_t got_f = sh_got < need ? sh_got : need;
+    nfloor = got_f;
+    if (got_f < need) {
+      // fewer than K peaks in the whole map: of its first 2K positions at least K are not peaks
+      const uint32_t span = 2u * (uint32_t)a.K < total ? 2u * (uint32_t)a.K : total;
+      for (uint32_t c = t; c < span; c += 1024) { float v; fill[c] = probe(c, v) ? 1u : 0u; }
+      __syncthreads();
+      if (t == 0) {
+        uint32_t got = got_f;
+        for (uint32_t c = 0; c < span && got < need; ++c)
+          if (!fill[c]) fill[2048 + got++] = c;
+        for (; got < need; ++got) fill[2048 + got] = 0;      // map smaller than K positions
+      }
+      __syncthreads();
+    }
   }
   for (int k = t; k < a.K; k += 1024) {
     const uint64_t key = k < NS ? keys[k] : 0ull;
@@ -392,6 +453,7 @@ __global__ void __launch_bounds__(1024) dec_final_kernel(DecArgs a, long ws_word
       const uint32_t canon = fill[2048 + k - n];
       cls = (int)(canon / HW);
       ind = (int)(canon % HW);
+      if ((uint32_t)k - n < nfloor) score = __uint_as_float(a.floor_bits);
     }
     const int x = ind % a.W, y = ind / a.W;
     const long pix = (long)b * HW + ind;
@@ -471,7 +533,11 @@ static long dec_ws_words(int H, int W, int C, int K) { return DEC_ST_WORDS + 2 *
 size_t decode_workspace_bytes(int B, int H, int W, int C, int K) {
   return (size_t)B * dec_ws_words(H, W, C, K) * sizeof(uint32_t);
 }
-int decode_status_words(int H, int W, int C, int K, long* ws_words) { *ws_words = dec_ws_words(H, W, C, K); return ST_OVERFLOW; }
+int decode_status_words(int H, int W, int C, int K, long* ws_words, int* below_word) {
+  *ws_words = dec_ws_words(H, W, C, K);
+  *below_word = ST_BELOW_FLOOR;
+  return ST_OVERFLOW;
+}
 
 int launch_decode(const DecArgs& a, hipStream_t s) {
   CTDET_CHECK(a.C >= 1 && a.heat_stride >= a.C, "decode: C=%d / heat_stride=%d invalid", a.C, a.heat_stride);

@@ -136,7 +136,8 @@ class _EvalEngine:
             x = ops.preprocess(self.images, m._mean_host, m._std_host, self.Hp, self.Wp, out=self.xpad, border=self.border)
             self.out = m._network_outputs(x, apply_sigmoid=True, prepadded=self.border > 0)
         hm, wh, reg = self.out
-        self.dec = ops.decode(hm, wh, reg, m.topk_candidates, m.backbone.down_ratio)
+        # the head kernel's epilogue has just clamped hm to [1e-4, 1 - 1e-4]: the decode may skip the floor plateau
+        self.dec = ops.decode(hm, wh, reg, m.topk_candidates, m.backbone.down_ratio, heat_floor=ops.SIGMOID_CLAMP_FLOOR)
 
     def _post(self):
         """threshold / rescale / clip / compact into FRESH output tensors: runs after the captured part, outside the graph, so
@@ -462,7 +463,8 @@ class CenterNet(nn.Module):
             ops.preprocess(im.unsqueeze(0).contiguous(), self._mean_host, self._std_host, Hp, Wp, out=x[b:b + 1],
                            partial=True)
         hm, wh, reg = self._network_outputs(x, apply_sigmoid=True)
-        boxes, scores, classes, _ = ops.decode(hm, wh, reg, self.topk_candidates, self.backbone.down_ratio)
+        boxes, scores, classes, _ = ops.decode(hm, wh, reg, self.topk_candidates, self.backbone.down_ratio,
+                                               heat_floor=ops.SIGMOID_CLAMP_FLOOR)
         params = torch.empty(B, 4, dtype=torch.float32)
         out_sizes = []
         for b, (inp, size) in enumerate(zip(batched_inputs, sizes)):

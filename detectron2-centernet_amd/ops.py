@@ -823,9 +823,14 @@ class DecodeWorkspace:
         self.buf = torch.empty(n // 4, dtype=torch.int32, device=device)
 
 
-def decode(heat, wh, reg, K, down_ratio, workspace=None, check_status=False):
+SIGMOID_CLAMP_FLOOR = 1e-4     # `_sigmoid`'s lower clamp (centernet.py:13-15); the head kernels' epilogue writes exactly this f32
+
+
+def decode(heat, wh, reg, K, down_ratio, workspace=None, check_status=False, heat_floor=0.0):
     """Batched ctdet_decode. heat f32 NHWC [B,H,W,C] (may be the channel slice [..., :C] of a wider buffer: padded head
-    outputs are decoded in place); wh/reg f32 NHWC (2 channels, may be slices).
+    outputs are decoded in place); wh/reg f32 NHWC (2 channels, may be slices).  heat_floor: a lower bound of the positive
+    heat values the caller vouches for (SIGMOID_CLAMP_FLOOR for a clamped map; same results, the background plateau is
+    skipped).
     Returns boxes [B,K,4], scores [B,K], classes [B,K] (int32), inds [B,K] (int32)."""
     _require_cuda(heat, wh, reg)
     assert heat.dtype == torch.float32
@@ -840,7 +845,7 @@ def decode(heat, wh, reg, K, down_ratio, workspace=None, check_status=False):
     with prof_region("decode", nbytes=float(B * H * W * Cc * 4), info=f"{B}x{H}x{W}x{Cc} K={K}"):
         rc = _lib.lib().ctdet_decode(_ptr(heat), _nhwc_stride(heat), _ptr(wh), _nhwc_stride(wh), _ptr(reg),
                                      _nhwc_stride(reg) if reg is not None else 0, B, H, W, Cc, K, float(down_ratio),
-                                     _ptr(workspace.buf), _ptr(boxes), _ptr(scores), _ptr(classes), _ptr(inds), _stream())
+                                     float(heat_floor), _ptr(workspace.buf), _ptr(boxes), _ptr(scores), _ptr(classes), _ptr(inds), _stream())
     _lib.check(rc, "ctdet_decode")
     if check_status:
         _lib.check(_lib.lib().ctdet_decode_status(_ptr(workspace.buf), B, H, W, Cc, K, _stream()), "ctdet_decode_status")

@@ -202,11 +202,17 @@ int32_t ctdet_dwconvT_add(const void* x, const float* w, const void* skip, void*
 /* Batched ctdet_decode (centernet.py:399-458): heat f32 NHWC [B,H,W,heat_stride] (already sigmoid+clamp; the first C
  * channels are classes, any C >= 1), wh/reg f32 with pixel strides; outputs boxes [B,K,4] f32, scores [B,K] f32, classes
  * [B,K] i32, inds [B,K] i32 (spatial index y*W+x; may be NULL).  Order: score desc, ties by c*H*W+y*W+x asc.  reg may
- * be NULL.  The heat map is read once; workspace: ctdet_decode_workspace_bytes of the same B, H, W, C, K. */
+ * be NULL.  The heat map is read once; workspace: ctdet_decode_workspace_bytes of the same B, H, W, C, K.
+ * heat_floor: a lower bound the caller promises for every positive heat value -- 1e-4f for the map `_sigmoid` clamps
+ * (centernet.py:13-15) -- or 0 for none.  Results are the same either way; with the bound, the plateau a trained
+ * network's background forms exactly on the clamp is skipped by the selection passes and only consulted (lowest flat index
+ * first, which is the tie rule) when an image has fewer than K peaks above it.  A positive value below a non-zero
+ * heat_floor is reported by ctdet_decode_status. */
 size_t ctdet_decode_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C, int32_t K);
 int32_t ctdet_decode(const float* heat, int32_t heat_stride, const float* wh, int32_t wh_stride, const float* reg,
                      int32_t reg_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t K, float down_ratio,
-                     void* workspace, float* boxes, float* scores, int32_t* classes, int32_t* inds, void* stream);
+                     float heat_floor, void* workspace, float* boxes, float* scores, int32_t* classes, int32_t* inds,
+                     void* stream);
 /* CenterNet.inference_single_image (centernet.py:251-261) + detector_postprocess
  * (detectron2/modeling/postprocessing.py:11-72, structures/boxes.py:184-213,271-278) for a whole batch:
  * keep k < max_det with score > score_thresh, scale boxes by (scale_x, scale_y), clip to (out_w, out_h), drop
@@ -216,7 +222,8 @@ int32_t ctdet_postprocess(const float* boxes, const float* scores, const int32_t
                           float* out_scores, int32_t* out_classes, int32_t* counts, void* stream);
 /* reads back the per-image status words of the last decode on this workspace (device->host copy + sync):
  * returns 0 if every image decoded exactly, -75 (EOVERFLOW) if a candidate buffer overflowed (cannot happen for a
- * workspace of the queried size).  Test/diagnostic helper, not on the hot path. */
+ * workspace of the queried size), -22 (EINVAL) if a positive heat value lay below the promised heat_floor.
+ * Test/diagnostic helper, not on the hot path. */
 int32_t ctdet_decode_status(const void* workspace, int32_t B, int32_t H, int32_t W, int32_t C, int32_t K, void* stream);
 
 /* gen_heatmap + gaussian_radius + draw_umich_gaussian, batched on device

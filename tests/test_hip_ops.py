@@ -576,6 +576,61 @@ def test_decode_plateau_and_sparse(ops, dev):
     assert c[0, :2].tolist() == [3, 0] and i[0, :2].tolist() == [8 * W + 9, 3 * W + 3]
 
 
+def _trained_like(B, C, H, W, n_blobs, seed):
+    """a map like a trained network's: background exactly on the 1e-4 clamp, a few Gaussian-ish blobs above it"""
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(B, C, H, W, generator=g) - 14.0
+    for b in range(B):
+        for _ in range(n_blobs):
+            c, y, x = int(torch.randint(0, C, (1,), generator=g)), int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, W, (1,), generator=g))
+            amp = float(torch.rand(1, generator=g)) * 8 + 6
+            for dy in range(-2, 3):
+                for dx in range(-2, 3):
+                    if 0 <= y + dy < H and 0 <= x + dx < W:
+                        logits[b, c, y + dy, x + dx] += amp * 0.5 ** (dy * dy + dx * dx) + 0.01 * float(torch.rand(1, generator=g))
+    return torch.clamp(torch.sigmoid(logits), 1e-4, 1 - 1e-4)
+
+
+@pytest.mark.parametrize("shape,n_blobs,K", [((2, 80, 128, 128), 300, 100), ((2, 80, 128, 128), 12, 100), ((3, 20, 24, 40), 5, 100),
+                                             ((1, 4, 9, 7), 2, 100), ((2, 4, 5, 5), 0, 60), ((1, 80, 128, 128), 0, 100)])
+def test_decode_with_clamp_floor_equals_plain_decode(ops, dev, shape, n_blobs, K):
+    """heat_floor = 1e-4 on trained-like maps (background exactly on the clamp): same scores / classes / indices / boxes as
+    the oracle's plain canonical decode and as the kernel without the promise -- more than K real peaks (the floor is never
+    consulted), fewer than K (the floor peaks of lowest flat index fill the rest; blobs touching the first rows make some of
+    those positions non-peaks), tiny maps that run out of floor peaks too (zeros of the NMS-ed map follow), no peak at all"""
+    B, C, H, W = shape
+    heat = _trained_like(B, C, H, W, n_blobs, seed=sum(shape) + n_blobs)
+    if n_blobs:   # one blob next to flat index 0 so that the fill has to step over non-peak floor cells
+        heat[0, 0, 0, 1] = 0.3
+    assert (heat == 1e-4).float().mean() > 0.5
+    g = torch.Generator().manual_seed(1)
+    wh = torch.rand(B, 2, H, W, generator=g) * 20
+    reg = torch.rand(B, 2, H, W, generator=g)
+    rb, rs, rc, ri = O.ctdet_decode(heat, wh, reg, down_ratio=4, K=K)
+    whreg = torch.cat([nhwc(wh), nhwc(reg)], dim=3).to(dev)
+    hm = nhwc(heat).to(dev)
+    for floor in (1e-4, 0.0):
+        b, s, c, i = ops.decode(hm, whreg[..., 0:2], whreg[..., 2:4], K, 4.0, check_status=True, heat_floor=floor)
+        assert torch.equal(s.cpu(), rs), f"floor {floor}: scores differ"
+        assert torch.equal(c.cpu(), rc), f"floor {floor}: classes differ"
+        assert torch.equal(i.cpu().long(), ri), f"floor {floor}: peak indices differ"
+        assert torch.allclose(b.cpu(), rb, atol=1e-4, rtol=1e-6)
+
+
+def test_decode_clamp_floor_on_spread_maps_and_broken_promise(ops, dev):
+    """maps that never touch the floor decode the same with the promise; a positive value below the promised floor is
+    reported by the status call"""
+    heat = _rand_heat(2, 80, 64, 64, seed=5)
+    wh = torch.ones(2, 2, 64, 64)
+    whreg = torch.cat([nhwc(wh), nhwc(torch.zeros(2, 2, 64, 64))], dim=3).to(dev)
+    rb, rs, rc, ri = O.ctdet_decode(heat, wh, torch.zeros(2, 2, 64, 64), down_ratio=4, K=100)
+    b, s, c, i = ops.decode(nhwc(heat).to(dev), whreg[..., 0:2], whreg[..., 2:4], 100, 4.0, check_status=True, heat_floor=1e-4)
+    assert torch.equal(s.cpu(), rs) and torch.equal(c.cpu(), rc) and torch.equal(i.cpu().long(), ri)
+    heat[1, 3, 10, 10] = 5e-5
+    with pytest.raises(RuntimeError, match="below the promised heat_floor"):
+        ops.decode(nhwc(heat).to(dev), whreg[..., 0:2], whreg[..., 2:4], 100, 4.0, check_status=True, heat_floor=1e-4)
+
+
 def test_decode_big_tie_block(ops, dev):
     """a constant heatmap (every cell a peak, all equal) needs the deep radix levels: top-K = first K flat indices."""
     B, C, H, W = 2, 8, 32, 32

@@ -75,7 +75,7 @@ def test_vovnet_pool_and_ese_kernels(dev, tdt):
     assert (nchw(out.float().cpu()) - (ref + idn)).abs().max() <= tol * (ref + idn).abs().max()
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16"])
 def test_vovnet19_slim_centernet_eval_matches_oracle(tmp_path, dev, precision):
     import sys
     from detectron2_centernet_amd.config import get_cfg
@@ -112,11 +112,79 @@ def test_vovnet19_slim_centernet_eval_matches_oracle(tmp_path, dev, precision):
     hm_ref = torch.clamp(torch.sigmoid(z["hm"]), 1e-4, 1 - 1e-4)
     err = (hm - hm_ref).abs().max().item()
     print(precision, "vovnet19-slim heatmap err", err)
-    assert err <= (1e-5 if precision == "f32" else 1e-3)
-    assert (wh - z["wh"]).abs().max().item() <= (2e-4 if precision == "f32" else 2e-2) * max(1.0, z["wh"].abs().max().item())
+    assert err <= (1e-3 if precision == "f16" else 5e-5)
+    assert (wh - z["wh"]).abs().max().item() <= (2e-2 if precision == "f16" else 2e-4) * max(1.0, z["wh"].abs().max().item())
     rb, rs, rc, _ = O.ctdet_decode(hm, wh, reg, down_ratio=4, K=100)
     for b in range(2):
         inst = out[b]["instances"]
         bb, ss, cc = O.inference_single_image(rb[b], rs[b], rc[b], 100, 0.0)
         bb, keep = O.detector_postprocess(bb, (90, 120), 90, 120)
         assert torch.equal(inst.scores.cpu(), ss[keep]) and torch.equal(inst.pred_classes.cpu(), cc[keep])
+
+
+V39_YAML = """
+_BASE_: "./Base-CenterNet.yaml"
+MODEL:
+  BACKBONE:
+    NAME: "build_vovnet_backbone"
+  WEIGHTS: "/autox-sz/users/chenxiaoniu/models/vovnet39_ese_detectron2.pth"
+  VOVNET:
+    OUT_FEATURES: ["stage2", "stage3", "stage4", "stage5"]
+  CENTERNET:
+    FOCAL_LOSS_ALPHA: [1]
+DATASETS:
+  TRAIN: ("bulb_train",)
+  TEST: ("bulb_val",)
+INPUT:
+  FORMAT: "RGB"
+  MIN_SIZE_TRAIN: (640, 672, 704, 736, 768, 800)
+SOLVER:
+  IMS_PER_BATCH: 24
+  BASE_LR: 2.5e-4
+  STEPS: (136500, 273000)
+  MAX_ITER: 364000
+  CHECKPOINT_PERIOD: 3640
+TEST:
+  EVAL_PERIOD: 1820
+OUTPUT_DIR: "./output/centernet-vovnet39-bulb"
+VERSION: 2
+"""
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_vovnet39_centernet_eval_matches_oracle(tmp_path, dev, precision):
+    """`ctdet_vovnet2_39_1x.yaml` (text unchanged): VoVNet-39-eSE (the default CONV_BODY: 5 concat layers per block, 1/1/2/2
+    blocks, 256-channel heads on stage4 -> two deconv stages) through the HIP kernels against the oracle whose VoVNet code is
+    pinned to the reference module by G12; heat map within 5e-5, decode of the HIP heat map bit-exact"""
+    import sys
+    from detectron2_centernet_amd.config import get_cfg
+    from detectron2_centernet_amd.data.catalog import register_synthetic
+    from detectron2_centernet_amd.modeling import build_model
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from weights import fill_state_dict
+
+    (tmp_path / "Base-CenterNet.yaml").write_text(BASE)
+    (tmp_path / "ctdet_vovnet2_39_1x.yaml").write_text(V39_YAML)
+    cfg = get_cfg()
+    cfg.merge_from_file(str(tmp_path / "ctdet_vovnet2_39_1x.yaml"))
+    cfg.MODEL.CENTERNET.HIP_PRECISION = precision
+    register_synthetic("bulb_train", num_classes=80)
+    model = build_model(cfg).eval()
+    assert model.backbone_type == "vovnet" and cfg.MODEL.VOVNET.CONV_BODY == "V-39-eSE"
+    sd = fill_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, seed=39)
+    model.load_state_dict({k: v.to(model.device) for k, v in sd.items()})
+    g = torch.Generator().manual_seed(7)
+    img = torch.randint(0, 256, (2, 3, 96, 128), generator=g, dtype=torch.uint8)
+    model.score_threshold = 0.0
+    model([{"image": img[b]} for b in range(2)])
+    eng = next(iter(model._engines.values()))
+    hm, wh, reg = [t.float().cpu().permute(0, 3, 1, 2) for t in eng.out]
+    x, _ = O.preprocess([i for i in img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 16)
+    with torch.no_grad():
+        z = MR.centernet_vovnet_forward({k: v.float() for k, v in sd.items()}, x, body="V-39-eSE")
+    hm_ref = torch.clamp(torch.sigmoid(z["hm"]), 1e-4, 1 - 1e-4)
+    assert hm_ref.std().item() > 3e-3
+    assert (hm - hm_ref).abs().max().item() <= 5e-5
+    rb, rs, rc, ri = O.ctdet_decode(hm, wh, reg, down_ratio=4, K=100)
+    boxes, scores, classes, inds = [t.cpu() for t in eng.dec]
+    assert torch.equal(scores, rs) and torch.equal(classes, rc) and torch.equal(inds.long(), ri)

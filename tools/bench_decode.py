@@ -11,16 +11,17 @@ ws = ops.DecodeWorkspace(B, 128, 128, 80, 100, dev)
 
 
 def run(name, hm):
-    for _ in range(2):
-        ops.decode(hm, whreg[..., :2], whreg[..., 2:], 100, 4.0, workspace=ws)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        ops.decode(hm, whreg[..., :2], whreg[..., 2:], 100, 4.0, workspace=ws)
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 10 * 1000
-    print(f"decode bs{B} {name:28s}: {us:6.0f} us  = {hm.numel() * 4 / us / 1e3:6.0f} GB/s of heat-map reads")
+    for floor in (ops.SIGMOID_CLAMP_FLOOR, 0.0):     # the model's call (clamp floor promised) / the plain call
+        for _ in range(2):
+            ops.decode(hm, whreg[..., :2], whreg[..., 2:], 100, 4.0, workspace=ws, heat_floor=floor)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.decode(hm, whreg[..., :2], whreg[..., 2:], 100, 4.0, workspace=ws, heat_floor=floor)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 10 * 1000
+        print(f"decode bs{B} {name:28s} heat_floor={floor:<6g}: {us:6.0f} us  = {hm.numel() * 4 / us / 1e3:6.0f} GB/s of heat-map reads", flush=True)
 
 
 clamp = lambda t: torch.clamp(torch.sigmoid(t), 1e-4, 1 - 1e-4)
