@@ -168,6 +168,13 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// All of this wave's LDS operations have completed.  Through the builtin, not inline asm: the compiler's own waitcnt
+// bookkeeping then KNOWS the counter is zero.  With an asm wait it still counts fragments that were read before a barrier
+// for use behind it as in flight, and puts s_waitcnt lgkmcnt(n) in front of the MFMAs that consume them -- n chosen so
+// that they wait for the reads issued AFTER the barrier (the next step's operands): the register double buffer is undone.
+// Encoding (gfx9): vmcnt 63 and expcnt 7 = "don't wait", lgkmcnt 0.
+__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+
 // One 16-byte-per-lane global->LDS DMA (global_load_lds_dwordx4: LDS address = M0 + lane*16).  Issued through inline
 // asm on purpose: the compiler's waitcnt pass treats every LDS read as possibly aliasing every outstanding
 // __builtin_amdgcn_global_load_lds and puts s_waitcnt vmcnt(0) in front of it, which serialises the multi-stage

@@ -681,27 +681,38 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_pair_kernel(const ConvArg
     return abase[e][S_] + (lr + R_) * 2048;
   };
   // operands of a K step: X / Y weight fragments (two register sets) and H / L pixel fragments
-  f16x8 xf[2][TC], yf[2][TC], hf[TP], lf[TP];
-  auto load_w = [&](auto parc, int st) {
+  static_assert(TP == 4, "two pixel-tile pairs per wave");
+  typedef __attribute__((address_space(3))) const volatile u64 lds_u64;
+  f16x8 xf[2][TC], yf[2][TC];
+  u64x2 hq[TP], lq[TP];
+  // weight fragment j of ring stage st into register set PAR: j = 2 * c + (0: X, 1: Y)
+  auto load_w1 = [&](auto parc, int st, int j) {
     constexpr int PAR = decltype(parc)::value;
-#pragma unroll
-    for (int c = 0; c < TC; ++c) {
-      xf[PAR][c] = *(const f16x8*)(fragB + st * WST + c * 1024);
-      yf[PAR][c] = *(const f16x8*)(fragB + st * WST + WIMG + c * 1024);
-    }
+    const int c = j >> 1;
+    if (j & 1) yf[PAR][c] = *(const f16x8*)(fragB + st * WST + WIMG + c * 1024);
+    else xf[PAR][c] = *(const f16x8*)(fragB + st * WST + c * 1024);
   };
-  // pixel fragments of tile p for pair PR (taps 2*PR, 2*PR+1; tap 9: zero weights, tap 8's pixels) from halo buffer hb
-  auto load_px = [&](int p, auto prc, int hb) {
+  // piece q of the pixel fragments of tile p for pair PR (taps 2*PR, 2*PR+1; tap 9: zero weights, tap 8's pixels) from halo
+  // buffer hb: q = 0, 1 the hi halves of the two taps (H), q = 2, 3 the lo halves (L).  Separate 8-byte reads (volatile: not
+  // merged into one 16-byte read of a tap whose halves then have to be moved apart, with a wait for the data in the
+  // middle of the MFMA stream)
+  auto load_px1 = [&](int p, auto prc, int hb, int q) {
     constexpr int PR = decltype(prc)::value;
     constexpr int T0 = 2 * PR, T1 = PR == 4 ? 8 : 2 * PR + 1;
-    const char* hbuf = smem + hb * HBUF;
-    const char* p0 = hbuf + tap_off(p, T0);
-    const char* p1 = hbuf + tap_off(p, T1);
-    u64x2 hq, lq;
-    hq[0] = *(const u64*)(p0); hq[1] = *(const u64*)(p1);
-    lq[0] = *(const u64*)(p0 + 8); lq[1] = *(const u64*)(p1 + 8);
-    hf[p] = __builtin_bit_cast(f16x8, hq);
-    lf[p] = __builtin_bit_cast(f16x8, lq);
+    const char* src = smem + hb * HBUF + tap_off(p, (q & 1) ? T1 : T0) + (q >> 1) * 8;
+    if (q >> 1) lq[p][q & 1] = *(lds_u64*)src;
+    else hq[p][q & 1] = *(lds_u64*)src;
+  };
+  // MFMA i (0 .. 6 * TC) of the tile pair (p, p + 1): three groups of 2 * TC -- kinds[g] = 0: X.H, 1: Y.H, 2: X.L -- each
+  // over (tile u, cout tile c); consecutive MFMAs write different accumulators, the three that accumulate into one tile are
+  // 2 * TC instructions apart
+  auto mfma1 = [&](auto parc, int p, int i, int k0, int k1, int k2) {
+    constexpr int PAR = decltype(parc)::value;
+    const int g = i / (2 * TC), w = i % (2 * TC), u = w / TC, c = w % TC;
+    const int kind = g == 0 ? k0 : (g == 1 ? k1 : k2);
+    const f16x8 wfrag = kind == 1 ? yf[PAR][c] : xf[PAR][c];
+    const f16x8 pfrag = __builtin_bit_cast(f16x8, kind == 2 ? lq[p + u] : hq[p + u]);
+    acc[p + u][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfrag, pfrag, acc[p + u][c], 0, 0, 0);
   };
 
   const int nch = a.Cin / 16, nk = nch * 5;      // nk >= 5: the three prologue stages exist
@@ -712,58 +723,73 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_pair_kernel(const ConvArg
   wait_vmcnt<6 * W_LD>();               // the window of chunk 0 (older than the weight stages)
   convert(0);
   wait_vmcnt<4 * W_LD>();               // weights(0)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wait_lgkm0();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  load_w(std::integral_constant<int, 0>{}, 0);
 #pragma unroll
-  for (int p = 0; p < TP; ++p) load_px(p, std::integral_constant<int, 0>{}, 0);
+  for (int j = 0; j < 2 * TC; ++j) load_w1(std::integral_constant<int, 0>{}, 0, j);
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_px1(p, std::integral_constant<int, 0>{}, 0, q);
 
-  // K step kt (pair PR of `chunk`, ring stage st = kt % 3, weight fragments in register set PAR): behind one barrier the
-  // reads of the next step's weight fragments, then tile by tile the MFMAs and, into the registers they release, the next
-  // step's pixel fragments; the DMAs of step kt + 3 (into the stage this step's weights came from) go out behind tile 0
+  // K step kt (pair PR of `chunk`, ring stage st = kt % 3, weight fragments in register set PAR).  Behind one barrier, the
+  // step's 12 * TC MFMAs in 4 * TC slots of three; in front of every slot ONE or two LDS reads of the next step's operands,
+  // pinned there with sched_barriers -- the eight weight reads of a step issued in one burst behind the barrier (eight waves
+  // of the CU at the same moment: 64 ds_read_b128 = 256 LDS cycles) fill the LDS queue, and a wave whose read is not
+  // accepted cannot issue the MFMAs behind it either.  Slot plan (TC = 4): tile pair (0, 1): the 2 * TC weight fragments
+  // of step kt + 1 into the other register set; tile pair (2, 3), whose products run X.L first: the pixel fragments of tiles
+  // 0 and 1 (their registers are free), then the L fragments of tiles 2 and 3; behind the last MFMA only the four H reads
+  // of tiles 2 and 3 are left.  The DMAs of step kt + 3 (into the stage this step's weights came from) go out between the
+  // pairs.  The operand reads are unconditional (behind the last step they fetch stale LDS that nothing uses); only the
+  // DMA issue and the wait counts know about the last chunk, through scalar branches outside the MFMA slots.
   auto kstep = [&](int kt, int chunk, int st, auto prc, auto hbc, auto parc) {
     constexpr int PR = decltype(prc)::value, HB = decltype(hbc)::value, PAR = decltype(parc)::value;
     using NextPR = std::integral_constant<int, (PR + 1) % 5>;
+    using NextPar = std::integral_constant<int, PAR ^ 1>;
     constexpr int NHB = PR == 4 ? (HB ^ 1) : HB;
+    const bool last = chunk + 1 == nch;
     // weights(kt + 1) have landed once only what was queued behind them is still in flight: weights(kt + 2) and, in the
     // step after a halo prefetch (PR == 1), its 6 pieces
-    if (kt + 2 < nk) { if (PR == 1 && chunk + 1 < nch) wait_vmcnt<2 * W_LD + 6>(); else wait_vmcnt<2 * W_LD>(); }
+    if (!last) { if (PR == 1) wait_vmcnt<2 * W_LD + 6>(); else wait_vmcnt<2 * W_LD>(); }
+    else if (PR < 3) wait_vmcnt<2 * W_LD>();
     else wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_lgkm0();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + 1 < nk) load_w(std::integral_constant<int, PAR ^ 1>{}, st == 2 ? 0 : st + 1);
-    // two pixel tiles at a time, their products interleaved: the three MFMAs that accumulate into one tile are 2 * TC
-    // instructions apart (a dependent MFMA issued TC = 2..4 instructions after its predecessor waits for it)
+    const int nst = st == 2 ? 0 : st + 1;
+    constexpr int SLOTS = 2 * TC;
 #pragma unroll
-    for (int p = 0; p < TP; p += 2) {
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      load_w1(NextPar{}, nst, sl);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int c = 0; c < TC; ++c)
-          acc[p + u][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[PAR][c], hf[p + u], acc[p + u][c], 0, 0, 0);
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int c = 0; c < TC; ++c)
-          acc[p + u][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yf[PAR][c], hf[p + u], acc[p + u][c], 0, 0, 0);
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int c = 0; c < TC; ++c)
-          acc[p + u][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[PAR][c], lf[p + u], acc[p + u][c], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);            // these tiles' MFMAs are issued before their operand registers are reloaded
-      if (kt + 1 < nk) { load_px(p, NextPR{}, NHB); load_px(p + 1, NextPR{}, NHB); }
-      if (p == 0) {                                 // DMA issue behind the first MFMAs
-        if (PR == 0 && chunk + 1 < nch) issue_halo(chunk + 1, HB ^ 1);
-        if (kt + 3 < nk) issue_w(kt + 3, st);
-      }
+      for (int i = 3 * sl; i < 3 * sl + 3; ++i) mfma1(parc, 0, i, 0, 1, 2);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (PR == 0 && !last) issue_halo(chunk + 1, HB ^ 1);
+    if (!last || PR < 2) issue_w(kt + 3, st);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      if (sl < TC) {                 // 8 reads for tiles 0, 1 over the first TC slots
+#pragma unroll
+        for (int r = sl * (8 / TC); r < (sl + 1) * (8 / TC); ++r) load_px1(r >> 2, NextPR{}, NHB, r & 3);
+      } else {                       // the 4 L reads of tiles 2, 3 over the other TC slots (X.L of this pair ran first)
+#pragma unroll
+        for (int r = (sl - TC) * 4 / TC; r < (sl - TC + 1) * 4 / TC; ++r) load_px1(2 + (r >> 1), NextPR{}, NHB, 2 + (r & 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 3 * sl; i < 3 * sl + 3; ++i) mfma1(parc, 2, i, 2, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) load_px1(2 + (r >> 1), NextPR{}, NHB, r & 1);
     // the next chunk's window has landed (this step's wait left only weight stages in flight): split this thread's own
     // pieces of it; the barrier of step PR == 3 publishes them, the end of step PR == 4 reads the first operands from them
-    if (PR == 2 && chunk + 1 < nch) convert(HB ^ 1);
+    if (PR == 2 && !last) convert(HB ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto next_stage = [](int st) { return st == NST - 1 ? 0 : st + 1; };
   // the five steps of a chunk; P0 = weight register set of its first step (a chunk is an odd number of steps, so the two

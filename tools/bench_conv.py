@@ -22,7 +22,7 @@ ap.add_argument("--dcn", action="store_true")
 ap.add_argument("--window", action="store_true")
 ap.add_argument("--off-std", type=float, default=1.0)
 ap.add_argument("--f32out", action="store_true")
-ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--reps", type=int, default=1000, help="timed launches; short runs (tens of launches) measure the clock ramp, not the kernel")
 ap.add_argument("--tap-major", action="store_true")
 ap.add_argument("--f32", action="store_true", help="the f32 (reference precision) kernels")
 ap.add_argument("--f16x3", action="store_true", help="f32 tensors, split f16 products (the f16x3 mode)")
@@ -48,7 +48,7 @@ if a.dcn:
     f = lambda: ops.dcnv2(x, om, p, act=ops.ACT_RELU, out_dtype=od)
 else:
     f = lambda: ops.conv2d(x, p, act=ops.ACT_RELU, out_dtype=od)
-for _ in range(3):
+for _ in range(200):
     y = f()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
