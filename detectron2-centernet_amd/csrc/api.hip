@@ -131,6 +131,7 @@ int32_t ctdet_conv_cout_tile(int32_t cout) {
   if (cout <= 16) return 16;
   if (cout <= 32) return 32;
   if (cout <= 64) return 64;
+  if (cout <= 128) return 128;          // = pick_bc (conv_common.h)
   if (cout % 128 == 0) return 128;
   if (cout % 64 == 0) return 64;
   return 32;

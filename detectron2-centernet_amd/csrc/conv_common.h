@@ -247,6 +247,7 @@ static inline int pick_bc(int cout) {
   if (cout <= 16) return 16;
   if (cout <= 32) return 32;
   if (cout <= 64) return 64;
+  if (cout <= 128) return 128;          // 80 classes: one padded 128-cout tile reads the input once, three 32-cout tiles three times
   if (cout % 128 == 0) return 128;
   if (cout % 64 == 0) return 64;
   return 32;

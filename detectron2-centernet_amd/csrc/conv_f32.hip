@@ -748,16 +748,19 @@ __global__ void __launch_bounds__(256, 2) dcn_f32_window_kernel(const ConvArgs a
 // Same tile (8x16 pixels x 64 couts), window (18x26 pixels, 16-channel chunks of f32), ring (a stage = the three taps of a
 // kernel row) and barriers as dcn_f32_window_kernel.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) dcn_split_window_kernel(const ConvArgs a) {
-  constexpr int BC = 64, TH = 8, TW = 16, BP = 128, MG = 4;
+template <int TP, int BC>
+__global__ void __launch_bounds__(512 / TP, 2) dcn_split_window_kernel(const ConvArgs a) {
+  constexpr int TH = 8, TW = 16, BP = 128, MG = 4;
+  constexpr int NT = 512 / TP;                                  // TP = 2: 4 waves of 32 pixels, TP = 1: 8 waves of 16
+  static_assert(BC * 4 == NT, "one weight piece per thread and tap");
   constexpr int WR = TH + 2 + 2 * MG, WCOLS = TW + 2 + 2 * MG;  // 18 x 26 window pixels
   constexpr int NPIECE = WR * WCOLS * 4;                        // 1872 16-byte pieces
-  constexpr int W_LD = (NPIECE + 255) / 256;                    // 8 DMA rounds; the last one only on waves 0-1
+  constexpr int W_LD = (NPIECE + NT - 1) / NT;                  // DMA rounds; the last one ends with the window
   constexpr int WINB = ((NPIECE + 63) / 64) * 1024;             // 30720
   constexpr int GEOW = 9 * BP * 16, GEOC = 9 * BP * 4;          // {w1 m, w2 m, w3 m, w4 m} and the window code per (tap, pixel)
-  constexpr int TP = 2, TC = BC / 16;                           // wave = 32 pixels (2 tile rows) x all BC couts
+  constexpr int TC = BC / 16;                                   // wave = 16 * TP pixels x all BC couts
   constexpr int WST = BC * 64, NST = 2, STG = 3 * WST;          // a stage = the three taps of a kernel row
-  static_assert(WINB + GEOW + GEOC + NST * STG <= 81920, "two workgroups per CU");
+  static_assert(WINB + GEOW + GEOC + NST * STG <= (TP == 2 ? 81920 : 163840), "two workgroups (TP = 2) / one (TP = 1) per CU");
   __shared__ __attribute__((aligned(16))) char smem[WINB + GEOW + GEOC + NST * STG];
   char* const win = smem;
   char* const geow = smem + WINB;
@@ -795,7 +798,7 @@ __global__ void __launch_bounds__(256, 2) dcn_split_window_kernel(const ConvArgs
   int wofs[W_LD];
 #pragma unroll
   for (int i = 0; i < W_LD; ++i) {
-    const int pid = tid + 256 * i;
+    const int pid = tid + NT * i;
     const int pw = pid >> 2, sl = pid & 3;
     const int wr = pw / WCOLS, wcn = pw - wr * WCOLS;
     const int y = wy0 + wr, x = wx0 + wcn;
@@ -806,21 +809,22 @@ __global__ void __launch_bounds__(256, 2) dcn_split_window_kernel(const ConvArgs
   auto issue_window = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < W_LD; ++i) {
-      if (i < W_LD - 1 || (wave * 64 + 256 * i) * 16 < WINB)  // wave-uniform: the last round ends with the window
-        dma16(wofs[i] >= 0 ? ximg + wofs[i] + chunk * 16 : zero, win + (wave * 64 + 256 * i) * 16);
+      if (i < W_LD - 1 || (wave * 64 + NT * i) * 16 < WINB)  // wave-uniform: the last round ends with the window
+        dma16(wofs[i] >= 0 ? ximg + wofs[i] + chunk * 16 : zero, win + (wave * 64 + NT * i) * 16);
     }
   };
   issue_window(0);
   issue_w(0, 0, 0);
 
-  // ---- sampling geometry, once per (pixel, tap): thread = pixel gp, taps gh, gh+2, ...
+  // ---- sampling geometry, once per (pixel, tap): thread = pixel gp, taps gh, gh + NT/128, ...
   {
+    constexpr int GS = NT / 128;
     const int gp = tid & 127, gh = tid >> 7;
     const int py = ty0 + (gp >> 4), pxx = tx0 + (gp & 15);
     const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int t = 2 * i + gh;
+    for (int i = 0; i < (9 + GS - 1) / GS; ++i) {
+      const int t = GS * i + gh;
       if (t < 9) {
         const int tr = t / 3, ts = t - 3 * tr;
         const float h_im = (float)(py - 1 + tr) + omrow[2 * t], w_im = (float)(pxx - 1 + ts) + omrow[2 * t + 1];
@@ -846,9 +850,10 @@ __global__ void __launch_bounds__(256, 2) dcn_split_window_kernel(const ConvArgs
   }
   wait_vmcnt<0>();
   __syncthreads();
-  // ---- consumer mapping: lane (fr, q) samples tile pixel (row 2*wave + fr/8, col 8p + fr%8), channels 4q..4q+3 of the chunk
+  // ---- consumer mapping: lane (fr, q) samples channels 4q..4q+3 of the chunk for tile pixel (row 2*wave + fr/8, col 8p +
+  // fr%8) [TP = 2] or (row wave, col fr) [TP = 1]
   const int fr = lane & 15, q = lane >> 4;
-  const int prow = 2 * wave + (fr >> 3), pcol = fr & 7;
+  const int prow = TP == 2 ? 2 * wave + (fr >> 3) : wave, pcol = TP == 2 ? (fr & 7) : fr;
   const unsigned q4 = (unsigned)q << 4;
 
   // sampling of tap t in two halves, so that the MFMAs of the previous tap can be issued between them: `gather` starts the
@@ -859,7 +864,7 @@ __global__ void __launch_bounds__(256, 2) dcn_split_window_kernel(const ConvArgs
     unsigned far = 0;
 #pragma unroll
     for (int p = 0; p < TP; ++p) {
-      const int px = prow * 16 + 8 * p + pcol;
+      const int px = prow * 16 + (TP == 2 ? 8 * p : 0) + pcol;
       r.w[p] = *(const f32x4*)(geow + (t * BP + px) * 16);
       code[p] = *(const unsigned*)(geoc + (t * BP + px) * 4);
       far |= code[p] >> 31;
@@ -874,7 +879,7 @@ __global__ void __launch_bounds__(256, 2) dcn_split_window_kernel(const ConvArgs
       r.v[p][2] = *(const f32x4*)(c2p); r.v[p][3] = *(const f32x4*)(c2p + 64);
       if (any_far) {                                          // rare: the lanes concerned re-derive the sample from the offsets
         const bool out = code[p] >> 31;
-        const int py = ty0 + prow, pxx = tx0 + 8 * p + pcol, tr = t / 3, ts = t - 3 * (t / 3);
+        const int py = ty0 + prow, pxx = tx0 + (TP == 2 ? 8 * p : 0) + pcol, tr = t / 3, ts = t - 3 * (t / 3);
         const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
         const float h_im = (float)(py - 1 + tr) + omrow[2 * t], w_im = (float)(pxx - 1 + ts) + omrow[2 * t + 1];
         const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
@@ -973,7 +978,7 @@ __global__ void __launch_bounds__(256, 2) dcn_split_window_kernel(const ConvArgs
 
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
-    const int m = (b * a.H + ty0 + prow) * a.W + tx0 + 8 * p + pcol;
+    const int m = (b * a.H + ty0 + prow) * a.W + tx0 + (TP == 2 ? 8 * p : 0) + pcol;
     epilogue_tiles<float, TC>(a, m, n0, q, acc[p]);
   }
 }
@@ -1285,8 +1290,17 @@ static int launch_conv_f32_t(const ConvArgs& a, bool deform, hipStream_t s) {
       // 64 couts per workgroup (128 would spill under two workgroups per CU); wider layers sample the window once per cout tile
       const int nbx = a.B * (a.H / 8) * (a.W / 16);
       dim3 grid(8 * ((nbx + 7) / 8) * (a.Cout_pad / 64));
-      if (SP && !(ctdet_tuning_flags() & CTDET_TUNE_DCN_WINDOW_V1))
-        hipLaunchKernelGGL(dcn_split_window_kernel, grid, dim3(256), 0, s, a);
+      if (SP && !(ctdet_tuning_flags() & CTDET_TUNE_DCN_WINDOW_V1)) {
+        // the sampling (conflict-laden LDS gathers, blend, split) is this kernel's larger half and is repeated for every cout
+        // tile: the 128- and 256-cout layers use 128-cout tiles -- eight 16-pixel waves, one workgroup per CU, the same
+        // eight waves per CU with half the gathers per MFMA (CTDET_TUNE_DCN_SPLIT_4W: 64-cout tiles everywhere)
+        if (a.Cout_pad % 128 == 0 && !(ctdet_tuning_flags() & CTDET_TUNE_DCN_SPLIT_4W)) {
+          dim3 grid128(8 * ((nbx + 7) / 8) * (a.Cout_pad / 128));
+          hipLaunchKernelGGL((dcn_split_window_kernel<1, 128>), grid128, dim3(512), 0, s, a);
+        } else {
+          hipLaunchKernelGGL((dcn_split_window_kernel<2, 64>), grid, dim3(256), 0, s, a);
+        }
+      }
       else
         hipLaunchKernelGGL((dcn_f32_window_kernel<64, SP>), grid, dim3(256), 0, s, a);
       CTDET_LAUNCH_CHECK();
