@@ -99,7 +99,8 @@ static int fill_args(const ctdet_conv_desc* d, ConvArgs& a) {
   a.M = d->B * d->Ho * d->Wo;
   a.act = d->act; a.clamp_lo = d->clamp_lo; a.clamp_hi = d->clamp_hi; a.korder = d->korder; a.in_dil = idl;
   CTDET_CHECK(d->korder == 0 || (d->korder == 1 && d->Cin % 32 == 0 && d->compute_dtype == CTDET_DT_F16) ||
-                  (d->korder == 2 && d->Cin % 16 == 0 && d->compute_dtype == CTDET_DT_F16X3 && d->R == 3 && d->S == 3),
+                  (d->korder == 2 && d->Cin % 16 == 0 && d->compute_dtype == CTDET_DT_F16X3 && d->R == 3 && d->S == 3) ||
+                  (d->korder == 3 && d->Cin % 32 == 0 && d->compute_dtype == CTDET_DT_F16X3 && d->R == 3 && d->S == 3),
               "conv: korder=%d invalid for Cin=%d", d->korder, d->Cin);
   CTDET_CHECK((long)d->B * d->Ho * d->Wo < (1L << 31), "conv: too many output pixels");
   return 0;

@@ -1199,6 +1199,7 @@ __global__ void __launch_bounds__(256) conv_direct_f32_kernel(const ConvArgs a) 
 // ------------------------------------------------------------------------------------------
 int launch_halo_split(const ConvArgs& a, hipStream_t s);   // conv_igemm.hip
 int launch_halo_pair(const ConvArgs& a, hipStream_t s);    // conv_igemm.hip
+int launch_halo_pair2(const ConvArgs& a, hipStream_t s);   // conv_igemm.hip
 
 static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
 
@@ -1255,9 +1256,9 @@ template <bool SP>
 static int launch_conv_f32_t(const ConvArgs& a, bool deform, hipStream_t s) {
   CTDET_CHECK((long)a.B * a.H * a.W * a.in_stride < (1L << 31), "conv: input too large for 32-bit element offsets");
   CTDET_CHECK(a.in_dil >= 1 && (!deform || a.in_dil == 1), "conv: bad in_dil %d", a.in_dil);
-  CTDET_CHECK((a.Kpad >= a.K || (SP && a.korder == 2)) && a.Cout_pad >= a.Cout,
+  CTDET_CHECK((a.Kpad >= a.K || (SP && a.korder >= 2)) && a.Cout_pad >= a.Cout,
               "conv(f32): packed weights [%d][%d] too small for Cout=%d K=%d", a.Cout_pad, a.Kpad, a.Cout, a.K);
-  CTDET_CHECK(a.korder == 0 || (SP && a.korder == 2), "conv(f32 / f16x3): korder %d", a.korder);
+  CTDET_CHECK(a.korder == 0 || (SP && (a.korder == 2 || a.korder == 3)), "conv(f32 / f16x3): korder %d", a.korder);
   const int bc = pick_bc(a.Cout);
   const bool vec = f32_vector_ok(a, bc) && (!deform || (a.Cin % 16 == 0 && a.nsrc <= 1));
   if (vec && !deform && (a.Cin == 4 || a.Cin == 8 || a.Cin == 16) && a.in_dil == 1 && a.nsrc <= 1 && a.R == a.S && a.dil == 1 &&
@@ -1274,9 +1275,9 @@ static int launch_conv_f32_t(const ConvArgs& a, bool deform, hipStream_t s) {
       return launch_f32_win<3, 16, 2, 2, 4, SP>(a, s);
   }
   if constexpr (SP) {
-    if (a.korder == 2) {                  // pair-packed weights: only the halo pair kernel reads them
+    if (a.korder >= 2) {                  // pair-packed weights: only the halo pair kernels read them
       CTDET_CHECK(!deform && f32_vector_ok(a, bc), "conv(f16x3, pair weights): unaligned operands or deformable conv");
-      return launch_halo_pair(a, s);
+      return a.korder == 3 ? launch_halo_pair2(a, s) : launch_halo_pair(a, s);
     }
     if (vec && !deform) {                 // 3x3 / s1 / p1: the halo-resident kernel of conv_igemm.hip on f32 activations
       const int rc = launch_halo_split(a, s);

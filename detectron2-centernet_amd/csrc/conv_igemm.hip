@@ -823,6 +823,271 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_pair_kernel(const ConvArg
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// korder 3: the pair kernel above spends a tenth tap of zeros on every 16-channel chunk (nine taps = four pairs and a half).
+// Here tap 8 of a chunk is paired with tap 8 of the NEXT chunk: two chunks = nine steps instead of ten (-10 % MFMAs and
+// operand reads).  Both windows of a chunk pair sit in the two halo buffers at once (A = even chunk in buffer 0, B = odd
+// chunk in buffer 1); weights: ops.PackedConv._pack_pairs, nine 128-byte {X, Y} steps per chunk pair.  Cin % 32 == 0.
+// ------------------------------------------------------------------------------------------
+template <int BC, int WP, int WC_>
+__global__ void __launch_bounds__(256, 2) conv3x3_halo_pair2_kernel(const ConvArgs a) {
+  constexpr int TH = 8, TW = 32, BP = TH * TW;
+  constexpr int TP = BP / WP / 16;      // 16-pixel tiles per wave
+  constexpr int TC = BC / WC_ / 16;
+  constexpr int ROWS_W = TH / WP;       // tile rows per wave
+  constexpr int BCL = BC < 64 ? 64 : BC;
+  constexpr int W_LD = BCL / 64;        // DMA rounds per image (X or Y) and stage
+  constexpr int HMAIN = 10 * 32 * 64, HSIDE = 4096, HBUF = HMAIN + HSIDE;
+  constexpr int WIMG = BCL * 64, WST = 2 * WIMG, NST = 3;
+  static_assert(WP * WC_ == 4 && TP == 2 * ROWS_W, "wave layout");
+  static_assert(2 * HBUF + NST * WST <= 81920, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) char smem[2 * HBUF + NST * WST];
+  char* const ring = smem + 2 * HBUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave / WC_, wc = wave % WC_;
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  int m_tile, n_tile;
+  if (!tile_of_block(a.B * tiles_y * tiles_x, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int tx0 = (m_tile % tiles_x) * TW;
+  const int ty0 = ((m_tile / tiles_x) % tiles_y) * TH;
+  const int b = m_tile / (tiles_x * tiles_y);
+  const int n0 = n_tile * BC;
+  const float* zero = (const float*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+  const float* ximg = (const float*)a.x + (long)b * a.H * a.W * a.in_stride;
+
+  // ---- halo loader (as conv3x3_halo_kernel): 5 main pieces + 1 side piece per thread and chunk ----
+  const int hslot = tid & 3, hpx = (tid >> 2) & 31, hr0 = tid >> 7;
+  const int y0 = ty0 - 1 + hr0;
+  const float* hp0 = ximg + ((long)y0 * a.W + tx0 + hpx) * a.in_stride + (hslot ^ swz(hpx)) * 4;
+  const long row2 = 2L * a.W * a.in_stride;
+  unsigned hmask = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) hmask |= (y0 + 2 * i >= 0 && y0 + 2 * i < a.H) ? (1u << i) : 0u;
+  const float* hps;
+  {
+    const int side = (tid >> 2) & 1, hr = tid >> 3;   // [hr 0..9][side][slot], tid < 80
+    const int y = ty0 - 1 + hr, x = side ? tx0 + TW : tx0 - 1;
+    const bool ok = tid < 80 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    hps = ximg + ((long)(ok ? y : 0) * a.W + (ok ? x : 0)) * a.in_stride + hslot * 4;
+    hmask |= ok ? 32u : 0u;
+  }
+  const int lrow = tid >> 2;
+  const int gw = hslot ^ swz(lrow);
+  const float* wptr[W_LD];             // packed row (X image of step 0) of the cout this thread stages, + its k group
+#pragma unroll
+  for (int j = 0; j < W_LD; ++j) {
+    const int L = lrow + 64 * j;
+    const int Lw = L % (16 * TC), wv = L / (16 * TC);
+    const int tt = Lw >> 4, r = Lw & 15;
+    const int cl = wv * 16 * TC + cout_of<TC>(tt, r >> 2, r & 3);
+    wptr[j] = (const float*)a.w + (long)(n0 + (L < BC ? cl : 0)) * a.Kpad + gw * 4;
+  }
+  auto issue_halo = [&](int chunk, int hb) {
+    char* dst = smem + hb * HBUF + wave * 1024;
+    const long coff = (long)chunk * 16;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dma16((hmask & (1u << i)) ? hp0 + i * row2 + coff : zero, dst + i * 4096);
+    dma16((hmask & 32u) ? hps + coff : zero, smem + hb * HBUF + HMAIN + wave * 1024);
+  };
+  // K step kt = chunk * 5 + pair: 32 floats of every packed row = X (16) then Y (16)
+  auto issue_w = [&](int kt, int st) {
+#pragma unroll
+    for (int j = 0; j < W_LD; ++j) {
+      dma16(wptr[j] + (long)kt * 32, ring + st * WST + wave * 1024 + j * 4096);
+      dma16(wptr[j] + (long)kt * 32 + 16, ring + st * WST + WIMG + wave * 1024 + j * 4096);
+    }
+  };
+  // the thread's own six pieces of halo buffer hb: 4 f32 -> {hi[4], lo[4]} f16, in place
+  auto convert = [&](int hb) {
+    char* base = smem + hb * HBUF + wave * 1024 + lane * 16;
+    f32x4 v[6];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] = *(const f32x4*)(base + i * 4096);
+    v[5] = *(const f32x4*)(base + HMAIN);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const f16x4 hi = __builtin_convertvector(v[i], f16x4);
+      f32x4 r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = v[i][j] - (float)hi[j];
+      const f16x4 lo = __builtin_convertvector(r, f16x4);
+      *(f16x8*)(base + (i < 5 ? i * 4096 : HMAIN)) = __builtin_shufflevector(hi, lo, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+
+  // ---- fragment addressing (as conv3x3_halo_kernel) ----
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int row0 = wp * ROWS_W;
+  int abase[2][3];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+      const int X = 16 * e + l15 + s2 - 1;
+      if (X < 0) abase[e][s2] = HMAIN + kg * 16 + row0 * 128;
+      else if (X > 31) abase[e][s2] = HMAIN + 64 + kg * 16 + row0 * 128;
+      else abase[e][s2] = X * 64 + ((kg ^ swz(X)) << 4) + row0 * 2048;
+    }
+  const int estride0 = (l15 == 0) ? 128 : 2048;    // row stride of this lane for (e=0, s=0)
+  const int estride1 = (l15 == 15) ? 128 : 2048;   // ... for (e=1, s=2)
+  const int fr_off = l15 * 64 + ((kg ^ swz(l15)) << 4);
+  const char* fragB = ring + (wc * 16 * TC) * 64 + fr_off;
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  typedef unsigned long long u64;
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  // window offset of this lane's fragment of pixel tile p for tap T
+  auto tap_off = [&](int p, int T) {
+    const int R_ = T / 3, S_ = T % 3;
+    const int e = p & 1, lr = p >> 1;
+    if (e == 0 && S_ == 0) return abase[0][0] + (lr + R_) * estride0;
+    if (e == 1 && S_ == 2) return abase[1][2] + (lr + R_) * estride1;
+    return abase[e][S_] + (lr + R_) * 2048;
+  };
+  // operands of a K step: X / Y weight fragments (two register sets) and H / L pixel fragments
+  static_assert(TP == 4, "two pixel-tile pairs per wave");
+  typedef __attribute__((address_space(3))) const volatile u64 lds_u64;
+  f16x8 xf[2][TC], yf[2][TC];
+  u64x2 hq[TP], lq[TP];
+  // weight fragment j of ring stage st into register set PAR: j = 2 * c + (0: X, 1: Y)
+  auto load_w1 = [&](auto parc, int st, int j) {
+    constexpr int PAR = decltype(parc)::value;
+    const int c = j >> 1;
+    if (j & 1) yf[PAR][c] = *(const f16x8*)(fragB + st * WST + WIMG + c * 1024);
+    else xf[PAR][c] = *(const f16x8*)(fragB + st * WST + c * 1024);
+  };
+  // step S of a chunk pair (A in halo buffer 0, B in buffer 1) multiplies two (buffer, tap) operands: S = 0..3 taps (2S, 2S+1)
+  // of A, S = 4 tap 8 of A and tap 8 of B, S = 5..8 taps (2(S-5), 2(S-5)+1) of B.  Piece q of the pixel fragments of tile p
+  // for step S: q = 0, 1 the hi halves of the two operands (H), q = 2, 3 the lo halves (L).  Separate 8-byte reads
+  // (volatile: not merged into one 16-byte read whose halves then have to be moved apart, with a wait for the data in the
+  // middle of the MFMA stream)
+  auto load_px1 = [&](int p, auto sc, int q) {
+    constexpr int S = decltype(sc)::value;
+    constexpr int B0 = S <= 4 ? 0 : 1, B1 = S < 4 ? 0 : 1;
+    constexpr int T0 = S < 4 ? 2 * S : (S == 4 ? 8 : 2 * (S - 5)), T1 = S < 4 ? 2 * S + 1 : (S == 4 ? 8 : 2 * (S - 5) + 1);
+    const char* src = smem + ((q & 1) ? B1 : B0) * HBUF + tap_off(p, (q & 1) ? T1 : T0) + (q >> 1) * 8;
+    if (q >> 1) lq[p][q & 1] = *(lds_u64*)src;
+    else hq[p][q & 1] = *(lds_u64*)src;
+  };
+  // MFMA i (0 .. 6 * TC) of the tile pair (p, p + 1): three groups of 2 * TC -- kinds[g] = 0: X.H, 1: Y.H, 2: X.L -- each
+  // over (tile u, cout tile c); consecutive MFMAs write different accumulators, the three that accumulate into one tile are
+  // 2 * TC instructions apart
+  auto mfma1 = [&](auto parc, int p, int i, int k0, int k1, int k2) {
+    constexpr int PAR = decltype(parc)::value;
+    const int g = i / (2 * TC), w = i % (2 * TC), u = w / TC, c = w % TC;
+    const int kind = g == 0 ? k0 : (g == 1 ? k1 : k2);
+    const f16x8 wfrag = kind == 1 ? yf[PAR][c] : xf[PAR][c];
+    const f16x8 pfrag = __builtin_bit_cast(f16x8, kind == 2 ? lq[p + u] : hq[p + u]);
+    acc[p + u][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfrag, pfrag, acc[p + u][c], 0, 0, 0);
+  };
+
+  const int npair = a.Cin / 32, nk = npair * 9;
+  using I0 = std::integral_constant<int, 0>;
+  issue_halo(0, 0);
+  issue_halo(1, 1);
+  issue_w(0, 0);
+  issue_w(1, 1);
+  issue_w(2, 2);
+  wait_vmcnt<6 * W_LD>();               // both windows of pair 0 (older than the weight stages)
+  convert(0);
+  convert(1);
+  wait_vmcnt<4 * W_LD>();               // weights(0)
+  wait_lgkm0();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 2 * TC; ++j) load_w1(std::integral_constant<int, 1>{}, 0, j);     // set 1: step 0 moves it to set 0
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_px1(p, I0{}, q);
+
+  // K step kt = 9 * pair + S (ring stage S % 3, weight fragments in register set S & 1): the slot plan of
+  // conv3x3_halo_pair_kernel.  Window traffic: B of this pair goes out in step 0 (buffer 1 was last read for step 8 of the
+  // previous pair), is split at the end of step 2 and first read -- for step 4 -- during step 3; A of the next pair goes out in
+  // step 5 (buffer 0 was last read for step 4), is split at the end of step 7 and first read during step 8.
+  auto kstep = [&](int kt, int pair, auto sc) {
+    constexpr int S = decltype(sc)::value, PAR = S & 1, ST = S % 3, NST = (S + 1) % 3;
+    using NextS = std::integral_constant<int, (S + 1) % 9>;
+    using Par = std::integral_constant<int, PAR>;
+    using NextPar = std::integral_constant<int, PAR ^ 1>;
+    const bool last = pair + 1 == npair;
+    // weights(kt + 1) have landed once only what was queued behind them is still in flight: weights(kt + 2) and, in the
+    // step after a window prefetch, its 6 pieces
+    if (last && S >= 7) wait_vmcnt<0>();
+    else if ((S == 1 && pair > 0) || (S == 6 && !last)) wait_vmcnt<2 * W_LD + 6>();
+    else wait_vmcnt<2 * W_LD>();
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (S == 0) {      // nine steps per pair: the fragments step 8 (or the prologue) fetched sit in set 1
+#pragma unroll
+      for (int c = 0; c < TC; ++c) { xf[0][c] = xf[1][c]; yf[0][c] = yf[1][c]; }
+    }
+    constexpr int SLOTS = 2 * TC;
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      load_w1(NextPar{}, NST, sl);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 3 * sl; i < 3 * sl + 3; ++i) mfma1(Par{}, 0, i, 0, 1, 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (S == 0 && pair > 0) issue_halo(2 * pair + 1, 1);
+    if (S == 5 && !last) issue_halo(2 * pair + 2, 0);
+    if (kt + 3 < nk) issue_w(kt + 3, ST);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      if (sl < TC) {                 // 8 reads for tiles 0, 1 over the first TC slots
+#pragma unroll
+        for (int r = sl * (8 / TC); r < (sl + 1) * (8 / TC); ++r) load_px1(r >> 2, NextS{}, r & 3);
+      } else {                       // the 4 L reads of tiles 2, 3 over the other TC slots (X.L of this pair ran first)
+#pragma unroll
+        for (int r = (sl - TC) * 4 / TC; r < (sl - TC + 1) * 4 / TC; ++r) load_px1(2 + (r >> 1), NextS{}, 2 + (r & 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 3 * sl; i < 3 * sl + 3; ++i) mfma1(Par{}, 2, i, 2, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) load_px1(2 + (r >> 1), NextS{}, r & 1);
+    if (S == 2 && pair > 0) convert(1);
+    if (S == 7 && !last) convert(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int pair = 0; pair < npair; ++pair) {
+    const int kt = pair * 9;
+    kstep(kt + 0, pair, std::integral_constant<int, 0>{});
+    kstep(kt + 1, pair, std::integral_constant<int, 1>{});
+    kstep(kt + 2, pair, std::integral_constant<int, 2>{});
+    kstep(kt + 3, pair, std::integral_constant<int, 3>{});
+    kstep(kt + 4, pair, std::integral_constant<int, 4>{});
+    kstep(kt + 5, pair, std::integral_constant<int, 5>{});
+    kstep(kt + 6, pair, std::integral_constant<int, 6>{});
+    kstep(kt + 7, pair, std::integral_constant<int, 7>{});
+    kstep(kt + 8, pair, std::integral_constant<int, 8>{});
+  }
+
+  const int q = lane >> 4;
+  const int cb = n0 + wc * 16 * TC;
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int y = ty0 + row0 + (p >> 1), x = tx0 + 16 * (p & 1) + l15;
+    const int m = (b * a.H + y) * a.W + x;
+    epilogue_tiles<float, TC>(a, m, cb, q, acc[p]);
+  }
+}
+
 template <int BC, int WP, int WC_>
 static int launch_halo_pair_t(const ConvArgs& a, hipStream_t s) {
   const int nbx = a.B * (a.H / 8) * (a.W / 32), nby = a.Cout_pad / BC;
@@ -830,6 +1095,26 @@ static int launch_halo_pair_t(const ConvArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((conv3x3_halo_pair_kernel<BC, WP, WC_>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
+}
+
+template <int BC, int WP, int WC_>
+static int launch_halo_pair2_t(const ConvArgs& a, hipStream_t s) {
+  const int nbx = a.B * (a.H / 8) * (a.W / 32), nby = a.Cout_pad / BC;
+  dim3 grid(8 * ((nbx + 7) / 8) * nby);
+  hipLaunchKernelGGL((conv3x3_halo_pair2_kernel<BC, WP, WC_>), grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+// korder 3 (cross-chunk pair-packed split weights, Kpad = Cin / 32 * 288)
+int launch_halo_pair2(const ConvArgs& a, hipStream_t s) {
+  CTDET_CHECK(a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.in_dil == 1 && a.nsrc <= 1 &&
+                  a.Cin % 32 == 0 && a.Kpad == a.Cin / 32 * 288 && a.H % 8 == 0 && a.W % 32 == 0 && a.Ho == a.H && a.Wo == a.W &&
+                  a.in_stride % 4 == 0 && (((size_t)a.x | (size_t)a.w) & 15) == 0,
+              "conv(f16x3, cross-chunk pair weights): needs 3x3/s1/p1, Cin %% 32 == 0 and a map divisible by 8x32 (Cin=%d, %dx%d, Kpad=%d)",
+              a.Cin, a.H, a.W, a.Kpad);
+  if (pick_bc(a.Cout) <= 32) return launch_halo_pair2_t<32, 4, 1>(a, s);
+  return launch_halo_pair2_t<64, 4, 1>(a, s);
 }
 
 // korder 2 (pair-packed split weights, Kpad = Cin / 16 * 160): only this kernel reads them

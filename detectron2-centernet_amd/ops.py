@@ -359,22 +359,35 @@ class PackedConv:
         self.scale = self._pad_vec(scale, 1.0, dev)
         self.bias = self._pad_vec(bias, 0.0, dev)
 
-    w_pair = None      # F16X3, 3x3 / s1 / p1: the tap-pair image of the halo-resident kernel (ctdet_conv_desc.korder 2),
+    pair_korder = 2
+    w_pair = None      # F16X3, 3x3 / s1 / p1: the tap-pair image of the halo-resident kernels (ctdet_conv_desc.korder 2 / 3),
     _wp_scaled = None  # built on the first conv2d() that can use it (a DCNv2 weight never does)
 
     def _pack_pairs(self, wp):
-        """wp: the scaled tap-major f32 image [Cout_pad, 9*Cin] -> pair image viewed as f32 [Cout_pad', Cin/16*160]: per row and
-        16-channel chunk five 128-byte steps {X, Y}; X = for q in 0..3 {w_hi[tap 2s][4q..4q+3], w_hi[tap 2s+1][4q..4q+3]},
-        Y likewise from w_lo; tap 9 is zero.  Rows are padded to a multiple of 32 (the narrowest tile of the kernel)."""
+        """wp: the scaled tap-major f32 image [Cout_pad, 9*Cin] -> pair image viewed as f32, rows padded to a multiple of 32 (the
+        narrowest tile of the kernel).  A 128-byte step {X, Y} multiplies two (tap, 16-channel chunk) operands a, b:
+        X = for q in 0..3 {w_hi[a][4q..4q+3], w_hi[b][4q..4q+3]}, Y likewise from w_lo.
+        Cin % 32 == 0 (korder 3, [rows, Cin/32*288]): per chunk PAIR (A, B) nine steps -- taps (2s, 2s+1) of A, s = 0..3; tap 8
+        of A with tap 8 of B; taps (2s, 2s+1) of B.  Otherwise (korder 2, [rows, Cin/16*160]): per chunk five steps, taps
+        (2s, 2s+1), the tenth tap zero.  Returns (image, korder)."""
         rows = round_up(self.Cout_pad, 32)
         nch = self.Cin // 16
         w = torch.zeros(rows, 10, self.Cin, dtype=torch.float32, device=wp.device)
         w[:wp.shape[0], :9] = wp.reshape(wp.shape[0], 9, self.Cin)
         hi = w.to(torch.float16)
         lo = (w - hi.float()).to(torch.float16)
+        if nch % 2 == 0:
+            hl = torch.stack([hi, lo], 0).reshape(2, rows, 10, nch // 2, 2, 4, 4)   # [X/Y, row, tap, chunk pair, A/B, q, j]
+            steps = ([((2 * s, 0), (2 * s + 1, 0)) for s in range(4)] + [((8, 0), (8, 1))]
+                     + [((2 * s, 1), (2 * s + 1, 1)) for s in range(4)])
+            tap = torch.tensor([[a[0], b[0]] for a, b in steps], device=wp.device)    # [9, 2]
+            ab = torch.tensor([[a[1], b[1]] for a, b in steps], device=wp.device)
+            g = hl[:, :, tap, :, ab]                # [9, 2, X/Y, row, chunk pair, q, j] (advanced indices first)
+            img = g.permute(3, 4, 0, 2, 5, 1, 6).contiguous()                       # [row, chunk pair, step, X/Y, q, operand, j]
+            return img.reshape(rows, nch // 2 * 576).view(torch.float32), 3
         hl = torch.stack([hi, lo], 0).reshape(2, rows, 5, 2, nch, 4, 4)     # [X/Y, row, pair, tap of pair, chunk, q, j]
         img = hl.permute(1, 4, 2, 0, 5, 3, 6).contiguous()                  # [row, chunk, pair, X/Y, q, tap of pair, j]
-        return img.reshape(rows, nch * 320).view(torch.float32)
+        return img.reshape(rows, nch * 320).view(torch.float32), 2
 
     def pair_ok(self, x):
         """may the halo pair kernel take this input? (mirrors launch_halo_pair in csrc/conv_igemm.hip)"""
@@ -382,7 +395,7 @@ class PackedConv:
               and x.shape[2] % 32 == 0 and _nhwc_stride(x) % 4 == 0 and x.data_ptr() % 16 == 0
               and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_HALO))
         if ok and self.w_pair is None:
-            self.w_pair, self._wp_scaled = self._pack_pairs(self._wp_scaled), None
+            (self.w_pair, self.pair_korder), self._wp_scaled = self._pack_pairs(self._wp_scaled), None
         return ok
 
     def _pad_vec(self, v, fill, dev):
@@ -424,7 +437,7 @@ class PackedConv:
         d.korder = self.korder
         d.in_dil = self.in_dil
         if allow_pair and self.pair_ok(x):
-            d.korder, d.Kpad, d.Cout_pad = 2, self.w_pair.shape[1], self.w_pair.shape[0]
+            d.korder, d.Kpad, d.Cout_pad = self.pair_korder, self.w_pair.shape[1], self.w_pair.shape[0]
         return d
 
 
@@ -447,7 +460,7 @@ def conv2d(x, p, out=None, act=ACT_NONE, residual=None, out_dtype=None, clamp=(0
         assert residual.dtype == out.dtype and residual.shape[:3] == out.shape[:3]
     d = p.desc(x, out, act, residual, clamp, allow_pair=True)
     prof = _Prof(p, d.B * d.Ho * d.Wo, False, d.out_dtype, x.shape)
-    w = p.w_pair if d.korder == 2 else p.w
+    w = p.w_pair if d.korder >= 2 else p.w
     for _ in range(prof.reps()):
         rc = _lib.lib().ctdet_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w), _ptr(p.scale), _ptr(p.bias), _ptr(residual),
                                          _ptr(out), _stream())

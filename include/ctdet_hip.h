@@ -52,6 +52,9 @@ typedef struct ctdet_conv_desc {
                            "pair" packing for the halo-resident kernel -- per cout row, per 16-channel chunk, five tap pairs
                            (taps 2s, 2s+1; the tenth tap is zero), each 128 bytes: X = for q = 0..3 {w_hi[tap 2s][4q..4q+3],
                            w_hi[tap 2s+1][4q..4q+3]} f16, then Y = the same of w_lo; Kpad = Cin / 16 * 160 (4-byte units) */
+                        /* 3 (as 2, Cin % 32 == 0): "cross-chunk pair" packing -- per cout row, per PAIR of 16-channel chunks
+                           (A, B) nine 128-byte {X, Y} steps: steps 0..3 taps (2s, 2s+1) of A, step 4 tap 8 of A with tap 8
+                           of B, steps 5..8 taps (2(s-5), 2(s-5)+1) of B; no zero tap; Kpad = Cin / 32 * 288 */
   int32_t in_dil;       /* 0/1 = none.  >1: the input is read as if zero-stuffed by this factor (input-gradient of a
                            strided conv expressed as a conv over dY); Ho/Wo may then exceed the formula by < in_dil */
 } ctdet_conv_desc;

@@ -76,6 +76,28 @@ def test_conv_f32_random_shapes(ops, dev, comp):
             f"case {it}: B{B} {H}x{W} {Cin}->{Cout} k{k} s{stride} d{dil} res={use_res}: max err {err}"
 
 
+@pytest.mark.parametrize("Cin,Cout", [(16, 64), (32, 27), (48, 80), (64, 64), (64, 256), (96, 32), (128, 128), (256, 16)])
+def test_f16x3_halo_pair_kernels(ops, dev, Cin, Cout):
+    """3x3 / s1 / p1 on tile-divisible maps in the f16x3 mode: the tap-pair kernels.  An even number of 16-channel chunks takes the
+    cross-chunk packing (korder 3: tap 8 of a chunk pairs with tap 8 of the next, nine steps per two chunks), an odd one the
+    per-chunk packing with a zero tenth tap (korder 2); both 32- and 64-cout tiles, one to sixteen chunks, image borders
+    inside and across workgroup tiles, residual + ReLU epilogue"""
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    for (B, H, W) in ((1, 8, 32), (2, 16, 64), (3, 24, 32)):
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+        scale, bias = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+        res = torch.randn(B, Cout, H, W, generator=g)
+        ref = (F.conv2d(x, w, None, 1, 1) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1) + res).relu()
+        pc = ops.PackedConv(w.to(dev), scale.to(dev), bias.to(dev), stride=1, pad=1, compute=ops.F16X3)
+        res_d = torch.zeros(B, H, W, pc.Cout_eff)
+        res_d[..., :Cout] = nhwc(res)
+        y = ops.conv2d(nhwc(x).to(dev), pc, act=ops.ACT_RELU, residual=res_d.to(dev))
+        assert pc.w_pair is not None and pc.pair_korder == (3 if (Cin // 16) % 2 == 0 else 2)
+        err = (nchw(y[..., :Cout].cpu()) - ref).abs().max().item()
+        assert err < TOL * max(1.0, ref.abs().max().item()), f"B{B} {H}x{W} {Cin}->{Cout}: max err {err}"
+
+
 def test_conv_f32_slices_and_cat(ops, dev, comp):
     """channel-slice input / output views and Root's multi-source 1x1 (dla.py:86-94) in f32"""
     g = torch.Generator().manual_seed(5)
