@@ -126,6 +126,7 @@ class HeadDesc(C.Structure):
 
 TUNE_NO_HALO, TUNE_NO_WIN, TUNE_DCN_MIXED, TUNE_NO_WGRAD_WINDOW, TUNE_NO_COL2IM_WINDOW, TUNE_NO_F32_DCN_WINDOW, TUNE_DCN_WINDOW_V1, TUNE_NO_SMALL_GRID_TILES = 1, 2, 4, 8, 16, 32, 64, 128
 TUNE_DCN_SPLIT_4W = 256
+TUNE_NO_HALO_TAP2 = 512
 
 
 class tuning:

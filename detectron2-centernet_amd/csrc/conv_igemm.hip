@@ -1088,6 +1088,242 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_pair2_kernel(const ConvAr
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// f16 form of the kernel above (the per-tap cadence of conv3x3_halo_kernel -- a barrier, the DMA issue, the
+// operand reads and an s_waitcnt in front of every 16..32 MFMAs): two taps per K step and barrier (nine steps per pair of
+// 32-channel chunks, tap 8 of a chunk with tap 8 of the next), the next step's operand reads pinned between this step's
+// MFMAs, weight fragments double-buffered in registers.  Same LDS images; weights are the chunk-major rows (korder 1)
+// the per-tap kernel reads.  Cin % 64 == 0.
+// ------------------------------------------------------------------------------------------
+template <int BC, int WP, int WC_, typename TOut>
+__global__ void __launch_bounds__(256, 2) conv3x3_halo_tap2_kernel(const ConvArgs a) {
+  constexpr int TH = 8, TW = 32, BP = TH * TW;
+  constexpr int TP = BP / WP / 16;      // 16-pixel tiles per wave
+  constexpr int TC = BC / WC_ / 16;
+  constexpr int ROWS_W = TH / WP;       // tile rows per wave
+  constexpr int BCL = BC < 64 ? 64 : BC;
+  constexpr int W_LD = BCL / 64;        // DMA rounds per image (X or Y) and stage
+  constexpr int HMAIN = 10 * 32 * 64, HSIDE = 4096, HBUF = HMAIN + HSIDE;
+  constexpr int WIMG = BCL * 64, WST = 2 * WIMG, NST = 3;
+  static_assert(WP * WC_ == 4 && TP == 2 * ROWS_W, "wave layout");
+  static_assert(2 * HBUF + NST * WST <= 81920, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) char smem[2 * HBUF + NST * WST];
+  char* const ring = smem + 2 * HBUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave / WC_, wc = wave % WC_;
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  int m_tile, n_tile;
+  if (!tile_of_block(a.B * tiles_y * tiles_x, a.Cout_pad / BC, m_tile, n_tile)) return;
+  const int tx0 = (m_tile % tiles_x) * TW;
+  const int ty0 = ((m_tile / tiles_x) % tiles_y) * TH;
+  const int b = m_tile / (tiles_x * tiles_y);
+  const int n0 = n_tile * BC;
+  const f16* zero = (const f16*)g_zero_page;
+  asm volatile("" : "+v"(zero));
+  const f16* ximg = (const f16*)a.x + (long)b * a.H * a.W * a.in_stride;
+
+  // ---- halo loader (as conv3x3_halo_kernel): 5 main pieces + 1 side piece per thread and chunk ----
+  const int hslot = tid & 3, hpx = (tid >> 2) & 31, hr0 = tid >> 7;
+  const int y0 = ty0 - 1 + hr0;
+  const f16* hp0 = ximg + ((long)y0 * a.W + tx0 + hpx) * a.in_stride + (hslot ^ swz(hpx)) * 8;
+  const long row2 = 2L * a.W * a.in_stride;
+  unsigned hmask = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) hmask |= (y0 + 2 * i >= 0 && y0 + 2 * i < a.H) ? (1u << i) : 0u;
+  const f16* hps;
+  {
+    const int side = (tid >> 2) & 1, hr = tid >> 3;   // [hr 0..9][side][slot], tid < 80
+    const int y = ty0 - 1 + hr, x = side ? tx0 + TW : tx0 - 1;
+    const bool ok = tid < 80 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    hps = ximg + ((long)(ok ? y : 0) * a.W + (ok ? x : 0)) * a.in_stride + hslot * 8;
+    hmask |= ok ? 32u : 0u;
+  }
+  const int lrow = tid >> 2;
+  const int gw = hslot ^ swz(lrow);
+  const f16* wptr[W_LD];               // chunk-major packed row of the cout this thread stages, + its k group
+#pragma unroll
+  for (int j = 0; j < W_LD; ++j) {
+    const int L = lrow + 64 * j;
+    const int Lw = L % (16 * TC), wv = L / (16 * TC);
+    const int tt = Lw >> 4, r = Lw & 15;
+    const int cl = wv * 16 * TC + cout_of<TC>(tt, r >> 2, r & 3);
+    wptr[j] = (const f16*)a.w + (long)(n0 + (L < BC ? cl : 0)) * a.Kpad + gw * 8;
+  }
+  auto issue_halo = [&](int chunk, int hb) {
+    char* dst = smem + hb * HBUF + wave * 1024;
+    const long coff = (long)chunk * 32;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dma16((hmask & (1u << i)) ? hp0 + i * row2 + coff : zero, dst + i * 4096);
+    dma16((hmask & 32u) ? hps + coff : zero, smem + hb * HBUF + HMAIN + wave * 1024);
+  };
+  // K step kt = 9 * pair + S: the 64-byte pieces (chunk, tap) of its two operands from the chunk-major rows (korder 1: piece
+  // index chunk * 9 + tap) -- X = (A, 2S) / (A, 8) / (B, 2(S-5)), Y = (A, 2S+1) / (B, 8) / (B, 2(S-5)+1)
+  auto issue_w = [&](int kt, int st) {
+    const int pair = kt / 9, S = kt - 9 * pair;
+    const int kx = 18 * pair + (S < 4 ? 2 * S : (S == 4 ? 8 : 9 + 2 * (S - 5)));
+    const int ky = S == 4 ? 18 * pair + 17 : kx + 1;
+#pragma unroll
+    for (int j = 0; j < W_LD; ++j) {
+      dma16(wptr[j] + (long)kx * 32, ring + st * WST + wave * 1024 + j * 4096);
+      dma16(wptr[j] + (long)ky * 32, ring + st * WST + WIMG + wave * 1024 + j * 4096);
+    }
+  };
+
+  // ---- fragment addressing (as conv3x3_halo_kernel) ----
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int row0 = wp * ROWS_W;
+  int abase[2][3];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+      const int X = 16 * e + l15 + s2 - 1;
+      if (X < 0) abase[e][s2] = HMAIN + kg * 16 + row0 * 128;
+      else if (X > 31) abase[e][s2] = HMAIN + 64 + kg * 16 + row0 * 128;
+      else abase[e][s2] = X * 64 + ((kg ^ swz(X)) << 4) + row0 * 2048;
+    }
+  const int estride0 = (l15 == 0) ? 128 : 2048;    // row stride of this lane for (e=0, s=0)
+  const int estride1 = (l15 == 15) ? 128 : 2048;   // ... for (e=1, s=2)
+  const int fr_off = l15 * 64 + ((kg ^ swz(l15)) << 4);
+  const char* fragB = ring + (wc * 16 * TC) * 64 + fr_off;
+
+  f32x4 acc[TP][TC];
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // window offset of this lane's fragment of pixel tile p for tap T
+  auto tap_off = [&](int p, int T) {
+    const int R_ = T / 3, S_ = T % 3;
+    const int e = p & 1, lr = p >> 1;
+    if (e == 0 && S_ == 0) return abase[0][0] + (lr + R_) * estride0;
+    if (e == 1 && S_ == 2) return abase[1][2] + (lr + R_) * estride1;
+    return abase[e][S_] + (lr + R_) * 2048;
+  };
+  // operands of a K step: X / Y weight fragments (two register sets) and the pixel fragments of its two (buffer, tap) operands
+  static_assert(TP == 4, "two pixel-tile pairs per wave");
+  f16x8 xf[2][TC], yf[2][TC], pf[TP][2];
+  // weight fragment j of ring stage st into register set PAR: j = 2 * c + (0: X, 1: Y)
+  auto load_w1 = [&](auto parc, int st, int j) {
+    constexpr int PAR = decltype(parc)::value;
+    const int c = j >> 1;
+    if (j & 1) yf[PAR][c] = *(const f16x8*)(fragB + st * WST + WIMG + c * 1024);
+    else xf[PAR][c] = *(const f16x8*)(fragB + st * WST + c * 1024);
+  };
+  // step S of a chunk pair (A in halo buffer 0, B in buffer 1): operand q = 0 is (A, 2S) / (A, 8) / (B, 2(S-5)), q = 1 is
+  // (A, 2S+1) / (B, 8) / (B, 2(S-5)+1) for S = 0..3 / 4 / 5..8; the fragment of tile p: 8 channels of 16 pixels
+  auto load_px1 = [&](int p, auto sc, int q) {
+    constexpr int S = decltype(sc)::value;
+    constexpr int B0 = S <= 4 ? 0 : 1, B1 = S < 4 ? 0 : 1;
+    constexpr int T0 = S < 4 ? 2 * S : (S == 4 ? 8 : 2 * (S - 5)), T1 = S < 4 ? 2 * S + 1 : (S == 4 ? 8 : 2 * (S - 5) + 1);
+    pf[p][q] = *(const f16x8*)(smem + (q ? B1 : B0) * HBUF + tap_off(p, q ? T1 : T0));
+  };
+  // MFMA i (0 .. 4 * TC) of the tile pair (p, p + 1): two groups of 2 * TC -- kind 0: X . operand 0, kind 1: Y . operand 1 --
+  // each over (tile u, cout tile c)
+  auto mfma1 = [&](auto parc, int p, int i, int k0, int k1) {
+    constexpr int PAR = decltype(parc)::value;
+    const int g = i / (2 * TC), w = i % (2 * TC), u = w / TC, c = w % TC;
+    const int kind = g == 0 ? k0 : k1;
+    acc[p + u][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kind ? yf[PAR][c] : xf[PAR][c], pf[p + u][kind], acc[p + u][c], 0, 0, 0);
+  };
+
+  const int npair = a.Cin / 64, nk = npair * 9;      // a chunk = 32 f16 channels
+  using I0 = std::integral_constant<int, 0>;
+  issue_halo(0, 0);
+  issue_halo(1, 1);
+  issue_w(0, 0);
+  issue_w(1, 1);
+  issue_w(2, 2);
+  wait_vmcnt<4 * W_LD>();               // weights(0), and both windows of pair 0 in front of them
+  wait_lgkm0();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 2 * TC; ++j) load_w1(std::integral_constant<int, 1>{}, 0, j);     // set 1: step 0 moves it to set 0
+#pragma unroll
+  for (int p = 0; p < TP; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) load_px1(p, I0{}, q);
+
+  // K step kt = 9 * pair + S (ring stage S % 3, weight fragments in register set S & 1), the slot plan of
+  // conv3x3_halo_pair_kernel with two MFMAs per slot.  Window traffic: B of this pair goes out in step 0 (buffer 1 was last
+  // read for step 8 of the previous pair) and is first read -- for step 4 -- during step 3; A of the next pair goes out in
+  // step 5 (buffer 0 was last read for step 4) and is first read during step 8.
+  auto kstep = [&](int kt, int pair, auto sc) {
+    constexpr int S = decltype(sc)::value, PAR = S & 1, ST = S % 3, NST = (S + 1) % 3;
+    using NextS = std::integral_constant<int, (S + 1) % 9>;
+    using Par = std::integral_constant<int, PAR>;
+    using NextPar = std::integral_constant<int, PAR ^ 1>;
+    const bool last = pair + 1 == npair;
+    // weights(kt + 1) have landed once only what was queued behind them is still in flight: weights(kt + 2) and, in the
+    // step after a window prefetch, its 6 pieces
+    if (last && S >= 7) wait_vmcnt<0>();
+    else if ((S == 1 && pair > 0) || (S == 6 && !last)) wait_vmcnt<2 * W_LD + 6>();
+    else wait_vmcnt<2 * W_LD>();
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (S == 0) {      // nine steps per pair: the fragments step 8 (or the prologue) fetched sit in set 1
+#pragma unroll
+      for (int c = 0; c < TC; ++c) { xf[0][c] = xf[1][c]; yf[0][c] = yf[1][c]; }
+    }
+    constexpr int SLOTS = 2 * TC;        // 4 * TC MFMAs per tile pair in slots of two
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      load_w1(NextPar{}, NST, sl);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 2 * sl; i < 2 * sl + 2; ++i) mfma1(Par{}, 0, i, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (S == 0 && pair > 0) issue_halo(2 * pair + 1, 1);
+    if (S == 5 && !last) issue_halo(2 * pair + 2, 0);
+    if (kt + 3 < nk) issue_w(kt + 3, ST);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      if (sl < TC) {                 // the 4 fragments of tiles 0, 1 over the first TC slots
+#pragma unroll
+        for (int r = sl * 4 / TC; r < (sl + 1) * 4 / TC; ++r) load_px1(r >> 1, NextS{}, r & 1);
+      } else {                       // operand 1 of tiles 2, 3 over the other TC slots (Y . operand 1 of this pair ran first)
+#pragma unroll
+        for (int r = (sl - TC) * 2 / TC; r < (sl - TC + 1) * 2 / TC; ++r) load_px1(2 + r, NextS{}, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 2 * sl; i < 2 * sl + 2; ++i) mfma1(Par{}, 2, i, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    load_px1(2, NextS{}, 0);
+    load_px1(3, NextS{}, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int pair = 0; pair < npair; ++pair) {
+    const int kt = pair * 9;
+    kstep(kt + 0, pair, std::integral_constant<int, 0>{});
+    kstep(kt + 1, pair, std::integral_constant<int, 1>{});
+    kstep(kt + 2, pair, std::integral_constant<int, 2>{});
+    kstep(kt + 3, pair, std::integral_constant<int, 3>{});
+    kstep(kt + 4, pair, std::integral_constant<int, 4>{});
+    kstep(kt + 5, pair, std::integral_constant<int, 5>{});
+    kstep(kt + 6, pair, std::integral_constant<int, 6>{});
+    kstep(kt + 7, pair, std::integral_constant<int, 7>{});
+    kstep(kt + 8, pair, std::integral_constant<int, 8>{});
+  }
+
+  const int q = lane >> 4;
+  const int cb = n0 + wc * 16 * TC;
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int y = ty0 + row0 + (p >> 1), x = tx0 + 16 * (p & 1) + l15;
+    const int m = (b * a.H + y) * a.W + x;
+    epilogue_tiles<TOut, TC>(a, m, cb, q, acc[p]);
+  }
+}
+
 template <int BC, int WP, int WC_>
 static int launch_halo_pair_t(const ConvArgs& a, hipStream_t s) {
   const int nbx = a.B * (a.H / 8) * (a.W / 32), nby = a.Cout_pad / BC;
@@ -1102,6 +1338,15 @@ static int launch_halo_pair2_t(const ConvArgs& a, hipStream_t s) {
   const int nbx = a.B * (a.H / 8) * (a.W / 32), nby = a.Cout_pad / BC;
   dim3 grid(8 * ((nbx + 7) / 8) * nby);
   hipLaunchKernelGGL((conv3x3_halo_pair2_kernel<BC, WP, WC_>), grid, dim3(256), 0, s, a);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int BC, int WP, int WC_, typename TOut>
+static int launch_halo_tap2(const ConvArgs& a, hipStream_t s) {
+  const int nbx = a.B * (a.H / 8) * (a.W / 32), nby = a.Cout_pad / BC;
+  dim3 grid(8 * ((nbx + 7) / 8) * nby);
+  hipLaunchKernelGGL((conv3x3_halo_tap2_kernel<BC, WP, WC_, TOut>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
@@ -2492,6 +2737,10 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
     if (nk == 5 && bc == 16) return launch_smallc<1, 5, TOut>(a, s);
     if (nk == 5 && bc == 32) return launch_smallc<2, 5, TOut>(a, s);
     if (nk == 13 && bc == 32) return launch_smallc<2, 13, TOut>(a, s);
+  }
+  if (halo_ok(a) && a.Cin % 64 == 0 && a.Kpad == 9 * a.Cin && !(ctdet_tuning_flags() & CTDET_TUNE_NO_HALO_TAP2)) {
+    if (bc == 32) return launch_halo_tap2<32, 4, 1, TOut>(a, s);
+    if (bc == 64 || bc == 128) return launch_halo_tap2<64, 4, 1, TOut>(a, s);
   }
   if (halo_ok(a)) {
     switch (bc) {
