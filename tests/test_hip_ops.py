@@ -482,6 +482,31 @@ def _rand_heat(B, C, H, W, seed, lo=1e-4, hi=1 - 1e-4):
     return torch.clamp(torch.sigmoid(logits), lo, hi)
 
 
+@pytest.mark.parametrize("case", [(1, 8, 32, 64, 64), (2, 16, 64, 128, 27), (3, 24, 32, 64, 80), (2, 8, 64, 256, 256), (1, 16, 32, 192, 128)])
+def test_f16_halo_two_tap_kernel(ops, dev, case):
+    """3x3 / s1 / p1, Cin % 64 == 0 on tile-divisible maps in the f16 mode: conv3x3_halo_tap2_kernel (two taps per K step, tap 8 of a
+    32-channel chunk paired with tap 8 of the next) against torch on f16-representable operands (products exact, f32 sums: 1e-5)
+    and against the per-tap kernel it replaces (same f32 values up to the summation order; f16 outputs within one ulp)"""
+    from detectron2_centernet_amd import _lib
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = h16(torch.randn(B, Cin, H, W, generator=g))
+    w = h16(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    bias = torch.randn(Cout, generator=g)
+    ref = (F.conv2d(x, w, None, 1, 1) + bias.view(1, -1, 1, 1)).relu()
+    pc = ops.PackedConv(w.to(dev), None, bias.to(dev), stride=1, pad=1, compute=ops.F16)
+    xd = nhwc(x).half().to(dev)
+    outs = {}
+    for name, flag in (("tap2", 0), ("per_tap", _lib.TUNE_NO_HALO_TAP2)):
+        with _lib.tuning(flag):
+            outs[name] = [ops.conv2d(xd, pc, act=ops.ACT_RELU, out_dtype=od)[..., :Cout].float().cpu().permute(0, 3, 1, 2)
+                          for od in (torch.float32, torch.float16)]
+    scale = max(1.0, ref.abs().max().item())
+    assert (outs["tap2"][0] - ref).abs().max().item() < 1e-5 * scale
+    assert (outs["tap2"][0] - outs["per_tap"][0]).abs().max().item() < 1e-5 * scale
+    assert (outs["tap2"][1] - outs["per_tap"][1]).abs().max().item() <= 2.0 ** -9 * scale
+
+
 @pytest.mark.parametrize("shape", [(1, 80, 128, 128), (3, 80, 32, 48), (2, 4, 16, 16), (2, 8, 128, 128)])
 def test_decode_matches_oracle(ops, dev, shape):
     B, C, H, W = shape

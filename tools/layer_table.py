@@ -1,7 +1,7 @@
 """Dev tool: one line per conv-shaped launch of the bench workload's eval forward (instrumented eager pass, every
 launch repeated ops.PROFILE_REP times between one HIP event pair): time, TFLOP/s, algorithmic GB/s and the fraction of
 max(MFMA time, HBM time) at 2.5 PFLOP/s (f16; f16x3: a third of it; f32: 157.3 TFLOP/s) / 8 TB/s.
-usage: python3 tools/layer_table.py [batch] [f16|f32|f16x3]"""
+usage: python3 tools/layer_table.py [batch] [f16|f32|f16x3] [ctdet tuning flags]"""
 import os
 import sys
 
@@ -14,6 +14,9 @@ from detectron2_centernet_amd.modeling.meta_arch.centernet import _EvalEngine  #
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 PREC = sys.argv[2] if len(sys.argv) > 2 else "f16"
+if len(sys.argv) > 3:
+    from detectron2_centernet_amd import _lib  # noqa: E402
+    _lib.lib().ctdet_set_tuning_flags(int(sys.argv[3]))
 PEAK = {"f16": 2.5e15, "f32": 157.3e12, "f16x3": 2.5e15 / 3}[PREC]
 dev = torch.device("cuda:0")
 model, cfg = bench.build_model(PREC, dev)
