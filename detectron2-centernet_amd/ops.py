@@ -33,7 +33,7 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
                 and p.Cin % 16 == 0 and p.Kpad == p.K and H and H % 8 == 0 and W % 32 == 0 and bc in (32, 64, 128)
                 and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_HALO)):
             bc = min(bc, 64)
-            return f"conv3x3_halo_pair_kernel<256x{max(bc, 32)},f16x3>"
+            return f"conv3x3_halo_pair{'2' if (p.Cin // 16) % 2 == 0 else ''}_kernel<256x{max(bc, 32)},f16x3>"
         p32 = _F32View(p)
         return _kernel_name(p32, M, deform, out_dt, x_shape, nsrc).replace("_f32_", "_f16x3_", 1)
     if p.compute != F16:
@@ -393,8 +393,10 @@ class PackedConv:
 
     def pair_ok(self, x):
         """may the halo pair kernel take this input? (mirrors launch_halo_pair in csrc/conv_igemm.hip)"""
+        # (a 16-channel input on a 64-divisible map is the LDS-window kernel's: level0 of DLA-34, 492 vs 825 us per 64 images)
         ok = ((self.w_pair is not None or self._wp_scaled is not None) and self.in_dil == 1 and x.shape[1] % 8 == 0
               and x.shape[2] % 32 == 0 and _nhwc_stride(x) % 4 == 0 and x.data_ptr() % 16 == 0
+              and (self.Cin > 16 or x.shape[2] % 64 != 0 or _nhwc_stride(x) != self.Cin)
               and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_HALO))
         if ok and self.w_pair is None:
             (self.w_pair, self.pair_korder), self._wp_scaled = self._pack_pairs(self._wp_scaled), None

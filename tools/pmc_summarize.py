@@ -53,6 +53,9 @@ def bench_name(mangled):
     m = re.search(r"dcn_window_kernelILi(\d+)ELi\d+ELb[01]E(DF16_|f)", mangled)
     if m:
         return f"dcn_window_kernel<128x{m.group(1)},{'f16' if m.group(2) == 'DF16_' else 'f32'}>"
+    m = re.search(r"conv3x3_halo_pair2_kernel(?:ILi|<)(\d+)", mangled)
+    if m:
+        return f"conv3x3_halo_pair2_kernel<256x{m.group(1)},f16x3>"
     m = re.search(r"conv3x3_halo_pair_kernel(?:ILi|<)(\d+)", mangled)
     if m:
         return f"conv3x3_halo_pair_kernel<256x{m.group(1)},f16x3>"
