@@ -149,6 +149,82 @@ def resnet_features(backbone, x, ctx, want="res4"):
     raise KeyError(want)
 
 
+# ---------------------------------------------------------------------------------------------- VoVNet configs
+def _frozen_seq(seq, x):
+    """a Sequential of (conv, FrozenBatchNorm2d, ReLU) triples (vovnet.py:120-163) as autograd nodes"""
+    mods = list(seq)
+    for i in range(0, len(mods), 3):
+        conv, norm = mods[i], mods[i + 1]
+        if any(p.requires_grad for p in norm.parameters()):
+            raise NotImplementedError("VoVNet training is built for MODEL.VOVNET.NORM = FrozenBN (the configs' value)")
+        scale, bias = hipnn.fold_bn(norm)
+        x = FrozenConvFn.apply(x, conv.weight, scale, bias, None, conv.stride[0], conv.padding[0], True)
+    return x
+
+
+class _ParamOfTorchOp(torch.autograd.Function):
+    """a parameter consumed by a torch op inside the HIP graph: gradients travel through the graph multiplied by the loss
+    scale (ops_train.GRAD_SCALE; the HIP nodes take it out of their parameter gradients, and divide by the world size, with
+    PARAM_GRAD_MULT) -- this identity does the same for the gradient torch's autograd hands to the parameter"""
+
+    @staticmethod
+    def forward(ctx, p):
+        return p.view_as(p)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import ops_train
+        return g * ops_train.PARAM_GRAD_MULT
+
+
+def _ese(m, x, identity):
+    """eSEModule (vovnet.py:200-213) in training: x * hsigmoid(fc(avgpool(x))) (+ identity of the later blocks of a stage).
+    B x C numbers through a C x C matrix: device-side torch ops with their own autograd (the eval path has fused kernels)"""
+    Cc = m.fc.weight.shape[0]
+    # (multiply + reduce instead of F.linear: no BLAS call, hence no BLAS workspace, inside a HIP-graph capture of the step)
+    pooled = x.float().mean(dim=(1, 2))
+    s = (pooled[:, None, :] * _ParamOfTorchOp.apply(m.fc.weight).view(1, Cc, Cc)).sum(dim=2) + _ParamOfTorchOp.apply(m.fc.bias)
+    s = torch.nn.functional.relu6(s + 3.0) / 6.0
+    y = x * s.to(x.dtype)[:, None, None, :]
+    return y + identity if identity is not None else y
+
+
+def vovnet_osa(m, x):
+    """_OSA_module.forward (vovnet.py:250-273)"""
+    outs = [x]
+    for layer in m.layers:
+        x = _frozen_seq(layer, x)
+        outs.append(x)
+    xt = _frozen_seq(m.concat, torch.cat(outs, dim=3))
+    return _ese(m.ese, xt, outs[0] if m.identity else None)
+
+
+def vovnet_features(backbone, x, ctx, want="stage4"):
+    """stem + stages up to `want` (vovnet.py:397-407).  Frozen parts (MODEL.BACKBONE.FREEZE_AT, vovnet.py:384-395) run on the
+    inference kernels without a tape, the others as autograd nodes; the stage pooling MaxPool2d(3, 2, ceil_mode=True) of a
+    trainable stage is torch's (its backward is needed; the eval path has its own kernel)."""
+    from ..modeling.backbone.vovnet import _run_seq
+    frozen = lambda mod: not any(p.requires_grad for p in mod.parameters())
+    if not frozen(backbone.stem):
+        raise NotImplementedError("training an unfrozen VoVNet stem (FREEZE_AT < 1) is not part of the CenterNet configs")
+    with torch.no_grad():
+        x = _run_seq(backbone.stem, x, ctx, cin_pad=x.shape[3])
+    for name in backbone.stage_names:
+        stage = getattr(backbone, name)
+        if frozen(stage) and not x.requires_grad:
+            with torch.no_grad():
+                x = stage.hip_forward(x, ctx)
+        else:
+            for m in stage.children():
+                if isinstance(m, torch.nn.MaxPool2d):
+                    x = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, ceil_mode=True).permute(0, 2, 3, 1).contiguous()
+                else:
+                    x = vovnet_osa(m, x)
+        if name == want:
+            return x
+    raise KeyError(want)
+
+
 def deconv_layers(model, y):
     """(ConvTranspose2d 4x4 s2 p1, BatchNorm2d, ReLU) x 2 in training mode (centernet.py:268-293)"""
     mods = list(model.deconv_layers)
@@ -184,6 +260,8 @@ def centernet_train_forward(model, batched_inputs):
 def train_forward_tensors(model, x_nhwc, targets):
     if model.backbone_type == "resnet":
         y = deconv_layers(model, resnet_features(model.backbone, x_nhwc, model._ctx))
+    elif model.backbone_type == "vovnet":
+        y = deconv_layers(model, vovnet_features(model.backbone, x_nhwc, model._ctx))
     elif model.backbone_type != "dla34":
         raise NotImplementedError(f"training of the '{model.backbone_type}' backbone is not built (inference only)")
     else:

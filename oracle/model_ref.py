@@ -259,9 +259,10 @@ def vovnet_features(sd, p, x, body="V-19-slim-eSE"):
     return outs
 
 
-def centernet_vovnet_forward(sd, images_nchw, body="V-19-slim-eSE"):
-    """centernet.py:140-154 for backbone_type == 'vovnet': stage4 -> deconv_layers -> heads"""
-    y = deconv_layers(sd, "deconv_layers", vovnet_features(sd, "backbone", images_nchw, body)["stage4"])
+def centernet_vovnet_forward(sd, images_nchw, body="V-19-slim-eSE", training=False):
+    """centernet.py:140-154 for backbone_type == 'vovnet': stage4 -> deconv_layers -> heads.  The VoVNet's FrozenBatchNorm2d
+    layers are affine in both modes; `training` switches the deconv BatchNorms to batch statistics."""
+    y = deconv_layers(sd, "deconv_layers", vovnet_features(sd, "backbone", images_nchw, body)["stage4"], training)
     return centernet_heads(Net(sd), y)
 
 

@@ -188,3 +188,92 @@ def test_vovnet39_centernet_eval_matches_oracle(tmp_path, dev, precision):
     rb, rs, rc, ri = O.ctdet_decode(hm, wh, reg, down_ratio=4, K=100)
     boxes, scores, classes, inds = [t.cpu() for t in eng.dec]
     assert torch.equal(scores, rs) and torch.equal(classes, rc) and torch.equal(inds.long(), ri)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_vovnet19_slim_training_step_matches_oracle(tmp_path, dev, precision):
+    """the VoVNet configs' training path (`ctdet_vovnet2_19_slim_1x.yaml`): frozen stem + stage2 (FREEZE_AT 2) on the inference
+    kernels, stage3 / stage4 with FrozenBatchNorm as autograd nodes (3x3 and concat 1x1 convs on the HIP kernels, eSE attention
+    and the stage pooling through device-side torch ops), dense ConvTranspose2d 4x4 s2 + BatchNorm (batch statistics) + ReLU,
+    64-channel heads, the three losses -- against torch autograd through the oracle (its VoVNet code pinned to the reference's
+    module by G12).  f32: losses 1e-3, gradients cos >= 0.999; f16: rounding-level agreement."""
+    import sys
+    from detectron2_centernet_amd.config import get_cfg
+    from detectron2_centernet_amd.data.catalog import register_synthetic, synthetic_sample
+    from detectron2_centernet_amd.modeling import build_model
+    from detectron2_centernet_amd.structures import Boxes, Instances
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from weights import fill_state_dict
+
+    (tmp_path / "Base-CenterNet.yaml").write_text(BASE)
+    (tmp_path / "ctdet_vovnet2_19_slim_1x.yaml").write_text(VOV_YAML)
+    cfg = get_cfg()
+    cfg.merge_from_file(str(tmp_path / "ctdet_vovnet2_19_slim_1x.yaml"))
+    cfg.MODEL.CENTERNET.HIP_PRECISION = precision
+    register_synthetic("bulb_train", num_classes=80)
+    model = build_model(cfg)
+    sd0 = fill_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, seed=19)
+    model.load_state_dict({k: v.to(model.device) for k, v in sd0.items()})
+    model.train()
+    frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
+    assert any(n.startswith("backbone.stem") for n in frozen) and any(n.startswith("backbone.stage2") for n in frozen)
+    assert not any(n.startswith(("backbone.stage3", "backbone.stage4", "deconv_layers", "hm", "wh", "reg")) and "norm" not in n
+                   for n in frozen)
+    inputs = []
+    for i in range(2):
+        smp = synthetic_sample(i, size=128, num_classes=80, max_boxes=6)
+        inst = Instances((128, 128))
+        inst.gt_boxes, inst.gt_classes = Boxes(smp["boxes"]), smp["classes"]
+        inputs.append({"image": smp["image"], "instances": inst})
+    losses = model(inputs)
+    sum(losses.values()).backward()
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    sd = {k: (v.float().clone().requires_grad_(True) if k in trainable else v.float().clone()) for k, v in sd0.items()}
+    x_ref, _ = O.preprocess([d["image"] for d in inputs], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 16)
+    z = MR.centernet_vovnet_forward(sd, x_ref, training=True)
+    targets = [O.gen_heatmap(d["instances"].gt_boxes.tensor, d["instances"].gt_classes, 32, 32, 80) for d in inputs]
+    ref = MR.centernet_losses(z, targets, [1.0])
+    sum(ref.values()).backward()
+    ltol = 1e-3 if precision == "f32" else 1e-2
+    for k in ("hm_loss", "wh_loss", "off_loss"):
+        got, want = losses[k].item(), ref[k].item()
+        print(precision, k, got, want)
+        assert abs(got - want) <= ltol * max(1.0, abs(want)), (k, got, want)
+    worst, name_of, seen = 1.0, "", 0
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None, name
+            continue
+        gref = sd[name].grad
+        if name.startswith("backbone.stage5"):       # not on the path to the loss (stage4 feeds the deconv layers)
+            assert p.grad is None or p.grad.abs().max() == 0
+            continue
+        assert p.grad is not None and gref is not None, name
+        if gref.abs().max() == 0:
+            continue
+        seen += 1
+        cos = torch.nn.functional.cosine_similarity(p.grad.float().cpu().flatten(), gref.flatten(), dim=0).item()
+        ratio = (p.grad.float().cpu().norm() / gref.norm()).item()
+        if cos < worst:
+            worst, name_of = cos, name
+        assert (0.99 if precision == "f32" else 0.9) < ratio < (1.01 if precision == "f32" else 1.1), (name, ratio)
+    print(precision, "worst gradient cosine", worst, name_of, "over", seen, "tensors")
+    assert seen >= 20 and worst >= (0.999 if precision == "f32" else 0.98), (worst, name_of)
+    # the same model through the trainer (flat-buffer SGD, HIP-graph capture of the step): parameters of the torch-op nodes
+    # (eSE fc) and of the HIP nodes move, the frozen stem does not, losses stay finite over captured replays
+    from detectron2_centernet_amd.engine.bench_train import synthetic_batch
+    from detectron2_centernet_amd.engine.train_loop import SimpleTrainer
+    model.zero_grad(set_to_none=True)
+    cfg.SOLVER.IMS_PER_BATCH = 2
+    tr = SimpleTrainer(model, None, cfg)
+    fc0 = model.backbone.stage3.OSA3_1.ese.fc.weight.detach().clone()
+    w0 = getattr(model.backbone.stage4.OSA4_1.layers[0], "OSA4_1_0/conv").weight.detach().clone()
+    stem0 = getattr(model.backbone.stem, "stem_1/conv").weight.detach().clone()
+    batch = synthetic_batch(2, 128, 0, dev)
+    for _ in range(4):
+        vals = {k: float(v) for k, v in tr.run_step_tensors(*batch).items()}
+        assert all(v == v and abs(v) < 1e9 for v in vals.values()), vals
+    assert (model.backbone.stage3.OSA3_1.ese.fc.weight.detach() - fc0).abs().max() > 0
+    assert (getattr(model.backbone.stage4.OSA4_1.layers[0], "OSA4_1_0/conv").weight.detach() - w0).abs().max() > 0
+    assert torch.equal(getattr(model.backbone.stem, "stem_1/conv").weight.detach(), stem0)
+    print(precision, "trainer graph_state", tr.graph_state, vals)
