@@ -337,3 +337,48 @@ def test_coco_results_writer_gathers_on_main_rank(tmp_path):
     assert sorted((r["image_id"], r["category_id"]) for r in recs) == [(7, 100), (8, 101), (8, 101)]
     assert json.load(open(tmp_path / "res0.json")) == {"bbox": {"num_detections": 3}}
     assert json.load(open(tmp_path / "res1.json")) == {}
+
+
+@pytest.mark.parametrize("cin", [16, 32, 48, 64])
+def test_tap_pair_weight_images_reproduce_the_convolution(cin):
+    """host logic of the f16x3 3x3 kernels (include/ctdet_hip.h, ctdet_conv_desc.korder 2 / 3): `PackedConv._pack_pairs` lays a
+    cout row out as 128-byte steps {X, Y}; a step multiplies two (tap, 16-channel chunk) operands.  Emulated here exactly as the
+    kernel consumes it -- per step and channel group q: X.H + Y.H + X.L with H = {hi(a)[4q..], hi(b)[4q..]}, L = the lo halves --
+    the sum over the steps must be the 3x3 convolution to the accuracy of the split (1e-6), for an odd number of chunks
+    (korder 2: tap pairs within a chunk, a zero tenth tap) and an even one (korder 3: tap 8 pairs across two chunks)"""
+    import torch.nn.functional as F
+    from types import SimpleNamespace
+    from detectron2_centernet_amd import ops
+    g = torch.Generator().manual_seed(cin)
+    cout, H, W = 8, 5, 6
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    x = torch.randn(1, cin, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)[0]                         # [cout, H, W]
+    wp = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()                # tap-major rows, as PackedConv holds them
+    img, korder = ops.PackedConv._pack_pairs(SimpleNamespace(Cout_pad=cout, Cin=cin), wp)
+    nch = cin // 16
+    assert korder == (3 if nch % 2 == 0 else 2) and img.shape == (32, nch // 2 * 288 if korder == 3 else nch * 160)
+    h = img.view(torch.float16).double()                                          # [rows, steps * 64 halves]
+    if korder == 3:
+        steps = [(pair, [((2 * s, 0), (2 * s + 1, 0)) for s in range(4)] + [((8, 0), (8, 1))]
+                  + [((2 * s, 1), (2 * s + 1, 1)) for s in range(4)]) for pair in range(nch // 2)]
+        ops_of = [(t0, 2 * pair + c0, t1, 2 * pair + c1) for pair, ss in steps for (t0, c0), (t1, c1) in ss]
+    else:
+        ops_of = [(2 * s, c, 2 * s + 1 if s < 4 else None, c) for c in range(nch) for s in range(5)]
+    assert h.shape[1] == len(ops_of) * 64
+    xp = F.pad(x[0], (1, 1, 1, 1))                                                # [cin, H+2, W+2]
+    x_hi = xp.to(torch.float16)
+    x_lo = (xp - x_hi.float()).to(torch.float16)
+    out = torch.zeros(cout, H, W, dtype=torch.float64)
+    for si, (t0, c0, t1, c1) in enumerate(ops_of):
+        blk = h[:cout, si * 64:(si + 1) * 64].reshape(cout, 2, 4, 2, 4)           # [row, X/Y, q, operand, j]
+        for o, (t, c) in enumerate(((t0, c0), (t1, c1))):
+            if t is None:                                                         # the zero tenth tap
+                assert blk[:, :, :, o].abs().max() == 0
+                continue
+            r, s = divmod(t, 3)
+            hi = x_hi[16 * c:16 * c + 16, r:r + H, s:s + W].double().reshape(4, 4, H, W)   # [q, j, y, x]
+            lo = x_lo[16 * c:16 * c + 16, r:r + H, s:s + W].double().reshape(4, 4, H, W)
+            X, Y = blk[:, 0, :, o], blk[:, 1, :, o]                               # [row, q, j]: w_hi, w_lo
+            out += torch.einsum("rqj,qjyx->ryx", X, hi) + torch.einsum("rqj,qjyx->ryx", Y, hi) + torch.einsum("rqj,qjyx->ryx", X, lo)
+    assert (out - ref).abs().max().item() < 1e-6 * max(1.0, ref.abs().max().item())
