@@ -175,6 +175,22 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Encoding (gfx9): vmcnt 63 and expcnt 7 = "don't wait", lgkmcnt 0.
 __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
 
+// Global loads of the rare slow paths (a DCNv2 sample outside the LDS window), issued AND awaited inside one asm block.  A
+// plain C++ load there leaves "a VMEM load may be pending" in the compiler's waitcnt bookkeeping at the join with the fast
+// path, and the pass then puts s_waitcnt vmcnt(0) into the fast path's MFMA stream -- every tap -- which also waits for the
+// LDS-DMAs this file issues through asm (weights of the next kernel row, the next window): their latency, meant to be
+// hidden until the next barrier, is exposed right behind the issue.
+__device__ __forceinline__ void gload2_sync(const float* p, float& v0, float& v1) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  f32x2_ v;
+  asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  v0 = v[0]; v1 = v[1];
+}
+// the active lanes replace v by the 16 bytes at p (the others keep theirs: call it inside the divergent branch)
+__device__ __forceinline__ void gload4_sync_into(const float* p, f32x4& v) {
+  asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "+v"(v) : "v"(p) : "memory");
+}
+
 // One 16-byte-per-lane global->LDS DMA (global_load_lds_dwordx4: LDS address = M0 + lane*16).  Issued through inline
 // asm on purpose: the compiler's waitcnt pass treats every LDS read as possibly aliasing every outstanding
 // __builtin_amdgcn_global_load_lds and puts s_waitcnt vmcnt(0) in front of it, which serialises the multi-stage

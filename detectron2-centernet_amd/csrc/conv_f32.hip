@@ -809,8 +809,11 @@ __global__ void __launch_bounds__(512 / TP, 2) dcn_split_window_kernel(const Con
   auto issue_window = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < W_LD; ++i) {
-      if (i < W_LD - 1 || (wave * 64 + NT * i) * 16 < WINB)  // wave-uniform: the last round ends with the window
-        dma16(wofs[i] >= 0 ? ximg + wofs[i] + chunk * 16 : zero, win + (wave * 64 + NT * i) * 16);
+      if (i < W_LD - 1 || (wave * 64 + NT * i) * 16 < WINB) { // wave-uniform: the last round ends with the window
+        int o = wofs[i];
+        asm volatile("" : "+v"(o));     // the 64-bit address is formed here, from the 32-bit offset, not kept across the K loop
+        dma16(o >= 0 ? ximg + o + chunk * 16 : zero, win + (wave * 64 + NT * i) * 16);
+      }
     }
   };
   issue_window(0);
@@ -881,17 +884,19 @@ __global__ void __launch_bounds__(512 / TP, 2) dcn_split_window_kernel(const Con
         const bool out = code[p] >> 31;
         const int py = ty0 + prow, pxx = tx0 + (TP == 2 ? 8 * p : 0) + pcol, tr = t / 3, ts = t - 3 * (t / 3);
         const float* omrow = a.om + ((long)(b * a.H + py) * a.W + pxx) * a.om_stride;
-        const float h_im = (float)(py - 1 + tr) + omrow[2 * t], w_im = (float)(pxx - 1 + ts) + omrow[2 * t + 1];
+        float dh, dw;
+        gload2_sync(omrow + 2 * t, dh, dw);                  // (asm loads: see gload2_sync)
+        const float h_im = (float)(py - 1 + tr) + dh, w_im = (float)(pxx - 1 + ts) + dw;
         const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
         const bool r0 = out && h_low >= 0, r1 = out && h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
         const long o0 = ((long)h_low * a.W + w_low) * a.in_stride, o2 = o0 + (long)a.W * a.in_stride;
         const float* base = ximg + chunk * 16 + q * 4;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 g1 = (r0 && c0) ? *(const f32x4*)(base + o0) : z;
-        const f32x4 g2 = (r0 && c1) ? *(const f32x4*)(base + o0 + a.in_stride) : z;
-        const f32x4 g3 = (r1 && c0) ? *(const f32x4*)(base + o2) : z;
-        const f32x4 g4 = (r1 && c1) ? *(const f32x4*)(base + o2 + a.in_stride) : z;
-        if (out) { r.v[p][0] = g1; r.v[p][1] = g2; r.v[p][2] = g3; r.v[p][3] = g4; }
+        if (out) {                                            // corners outside the image read the zero page
+          gload4_sync_into((r0 && c0) ? base + o0 : zero, r.v[p][0]);
+          gload4_sync_into((r0 && c1) ? base + o0 + a.in_stride : zero, r.v[p][1]);
+          gload4_sync_into((r1 && c0) ? base + o2 : zero, r.v[p][2]);
+          gload4_sync_into((r1 && c1) ? base + o2 + a.in_stride : zero, r.v[p][3]);
+        }
       }
     }
   };
