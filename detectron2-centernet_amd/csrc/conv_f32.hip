@@ -634,12 +634,12 @@ __global__ void __launch_bounds__(256, 2) dcn_f32_window_kernel(const ConvArgs a
         const bool r0 = out && h_low >= 0, r1 = out && h_low + 1 <= a.H - 1, c0 = w_low >= 0, c1 = w_low + 1 <= a.W - 1;
         const long o0 = ((long)h_low * a.W + w_low) * a.in_stride, o2 = o0 + (long)a.W * a.in_stride;
         const float* base = ximg + chunk * 16 + q * 4;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 g1 = (r0 && c0) ? *(const f32x4*)(base + o0) : z;
-        const f32x4 g2 = (r0 && c1) ? *(const f32x4*)(base + o0 + a.in_stride) : z;
-        const f32x4 g3 = (r1 && c0) ? *(const f32x4*)(base + o2) : z;
-        const f32x4 g4 = (r1 && c1) ? *(const f32x4*)(base + o2 + a.in_stride) : z;
-        if (out) { v1 = g1; v2 = g2; v3 = g3; v4 = g4; }
+        if (out) {      // asm loads (gload4_sync_into): no VMEM state for the compiler to wait on in the fast path; corners
+          gload4_sync_into((r0 && c0) ? base + o0 : zero, v1);                    // outside the image read the zero page
+          gload4_sync_into((r0 && c1) ? base + o0 + a.in_stride : zero, v2);
+          gload4_sync_into((r1 && c0) ? base + o2 : zero, v3);
+          gload4_sync_into((r1 && c1) ? base + o2 + a.in_stride : zero, v4);
+        }
       }
       const float lh = g[p][0], lw = g[p][1], mk = g[p][2];
       const float hh = 1.f - lh, hw = 1.f - lw;
