@@ -2739,18 +2739,8 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
     if (nk == 13 && bc == 32) return launch_smallc<2, 13, TOut>(a, s);
   }
   if (halo_ok(a) && a.Cin % 64 == 0 && a.Kpad == 9 * a.Cin && !(ctdet_tuning_flags() & CTDET_TUNE_NO_HALO_TAP2)) {
-    // the two-tap kernel where the layer's tensors stay in the Infinity Cache between launches (training batches, the deep
-    // levels): there it is 8-20 % faster than the per-tap kernel.  Layers that stream from HBM (batch 64 at 128^2: 150 us in
-    // the network against 80 us back to back) gain nothing from the leaner K step, and 128-cout layers with a grid that fills
-    // the chip keep the per-tap kernel's 128-cout tiles, which read their input once.  A/B on one box, f16 bench step: every
-    // eligible layer on the two-tap kernel 7.72-7.75 ms, only the <= 64-cout ones 7.60-7.61, none 7.54-7.55.
-    const bool resident = (long)a.M * (a.Cin + a.Cout) * 2 <= (64L << 20);
-    if (resident) {
-      if (bc == 32) return launch_halo_tap2<32, 4, 1, TOut>(a, s);
-      if (bc == 64) return launch_halo_tap2<64, 4, 1, TOut>(a, s);
-      if (bc == 128 && (long)a.B * (a.H / 8) * (a.W / 32) * (a.Cout_pad / 128) < 512 && !(ctdet_tuning_flags() & CTDET_TUNE_NO_SMALL_GRID_TILES))
-        return launch_halo_tap2<64, 4, 1, TOut>(a, s);
-    }
+    if (bc == 32) return launch_halo_tap2<32, 4, 1, TOut>(a, s);
+    if (bc == 64 || bc == 128) return launch_halo_tap2<64, 4, 1, TOut>(a, s);
   }
   if (halo_ok(a)) {
     switch (bc) {

@@ -61,12 +61,11 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
     bp = 256 if (big or bc == 16) else 128
     if (p.R == 3 and p.S == 3 and p.stride == 1 and p.pad == 1 and p.dil == 1 and p.in_dil == 1 and nsrc <= 1
             and p.korder == 1 and H % 8 == 0 and W % 32 == 0 and bc in (32, 64, 128)):
+        if p.Cin % 64 == 0 and p.Kpad == 9 * p.Cin and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_HALO_TAP2):
+            return f"conv3x3_halo_tap2_kernel<256x{min(bc, 64)},{o}>"
         small = not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_SMALL_GRID_TILES)
         if bc == 128 and small and (M // 256) * (p.Cout_pad // 128) < 512:
             bc = 64                      # fewer workgroups than the chip holds: 64-cout tiles
-        if (bc <= 64 and p.Cin % 64 == 0 and p.Kpad == 9 * p.Cin and M * (p.Cin + p.Cout_eff) * 2 <= (64 << 20)
-                and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_HALO_TAP2)):
-            return f"conv3x3_halo_tap2_kernel<256x{bc},{o}>"
         return f"conv3x3_halo_kernel<256x{bc},{o}>"
     Wo = (W + 2 * p.pad - p.dil * (p.S - 1) - 1) // p.stride + 1 if W else 0
     if p.Cin in (8, 16) and p.korder == 0 and nsrc <= 1 and Wo and Wo % 64 == 0 and p.Cout_pad <= 32:
