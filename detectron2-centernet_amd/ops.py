@@ -30,7 +30,8 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
     if p.compute == F16X3:       # the f32 kernels' split instantiations: same selection, tagged
         H, W = (x_shape[1], x_shape[2]) if x_shape is not None else (0, 0)
         if (not deform and p.R == 3 and p.S == 3 and p.stride == 1 and p.pad == 1 and p.dil == 1 and p.in_dil == 1 and nsrc <= 1
-                and p.Cin % 16 == 0 and p.Kpad == p.K and H and H % 8 == 0 and W % 32 == 0 and bc in (32, 64, 128)
+                and p.Cin % 16 == 0 and p.Kpad == p.K and H and ((H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0 and (p.Cin // 16) % 2 == 0))
+                and bc in (32, 64, 128)
                 and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_HALO)):
             bc = min(bc, 64)
             return f"conv3x3_halo_pair{'2' if (p.Cin // 16) % 2 == 0 else ''}_kernel<256x{max(bc, 32)},f16x3>"
@@ -394,8 +395,10 @@ class PackedConv:
     def pair_ok(self, x):
         """may the halo pair kernel take this input? (mirrors launch_halo_pair in csrc/conv_igemm.hip)"""
         # (a 16-channel input on a 64-divisible map is the LDS-window kernel's: level0 of DLA-34, 492 vs 825 us per 64 images)
-        ok = ((self.w_pair is not None or self._wp_scaled is not None) and self.in_dil == 1 and x.shape[1] % 8 == 0
-              and x.shape[2] % 32 == 0 and _nhwc_stride(x) % 4 == 0 and x.data_ptr() % 16 == 0
+        tile32 = x.shape[1] % 8 == 0 and x.shape[2] % 32 == 0
+        tile16 = x.shape[1] % 16 == 0 and x.shape[2] % 16 == 0 and (self.Cin // 16) % 2 == 0     # (16x16 tiles: korder 3 only)
+        ok = ((self.w_pair is not None or self._wp_scaled is not None) and self.in_dil == 1 and (tile32 or tile16)
+              and _nhwc_stride(x) % 4 == 0 and x.data_ptr() % 16 == 0
               and (self.Cin > 16 or x.shape[2] % 64 != 0 or _nhwc_stride(x) != self.Cin)
               and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_HALO))
         if ok and self.w_pair is None:

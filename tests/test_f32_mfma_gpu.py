@@ -83,7 +83,7 @@ def test_f16x3_halo_pair_kernels(ops, dev, Cin, Cout):
     per-chunk packing with a zero tenth tap (korder 2); both 32- and 64-cout tiles, one to sixteen chunks, image borders
     inside and across workgroup tiles, residual + ReLU epilogue"""
     g = torch.Generator().manual_seed(Cin * 1000 + Cout)
-    for (B, H, W) in ((1, 8, 32), (2, 16, 64), (3, 24, 32)):
+    for (B, H, W) in ((1, 8, 32), (2, 16, 64), (3, 24, 32), (3, 16, 16), (2, 32, 48)):      # the last two: 16x16-pixel tiles
         x = torch.randn(B, Cin, H, W, generator=g)
         w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
         scale, bias = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
@@ -94,6 +94,8 @@ def test_f16x3_halo_pair_kernels(ops, dev, Cin, Cout):
         res_d[..., :Cout] = nhwc(res)
         y = ops.conv2d(nhwc(x).to(dev), pc, act=ops.ACT_RELU, residual=res_d.to(dev))
         if Cin == 16 and W % 64 == 0:       # a contiguous 16-channel input on a 64-divisible map is the LDS-window kernel's
+            assert pc.w_pair is None
+        elif W % 32 != 0 and (Cin // 16) % 2 != 0:      # 16x16 tiles exist for the cross-chunk packing only: uniform-K kernel
             assert pc.w_pair is None
         else:
             assert pc.w_pair is not None and pc.pair_korder == (3 if (Cin // 16) % 2 == 0 else 2)
