@@ -1099,9 +1099,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_pair2_kernel(const ConvAr
 // MFMAs, weight fragments double-buffered in registers.  Same LDS images; weights are the chunk-major rows (korder 1)
 // the per-tap kernel reads.  Cin % 64 == 0.
 // ------------------------------------------------------------------------------------------
-template <int BC, int WP, int WC_, typename TOut>
+template <int BC, int WP, int WC_, typename TOut, int TW = 32>
 __global__ void __launch_bounds__(256, 2) conv3x3_halo_tap2_kernel(const ConvArgs a) {
-  constexpr int TH = 8, TW = 32, BP = TH * TW;
+  constexpr int TH = 256 / TW, BP = TH * TW;     // TW = 32: 8 x 32-pixel tiles; TW = 16: 16 x 16 (see conv3x3_halo_pair2_kernel)
+  constexpr int EN = TW / 16, RS = TW * 64, RPR = 256 * 16 / RS;
   constexpr int TP = BP / WP / 16;      // 16-pixel tiles per wave
   constexpr int TC = BC / WC_ / 16;
   constexpr int ROWS_W = TH / WP;       // tile rows per wave
@@ -1109,7 +1110,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_tap2_kernel(const ConvArg
   constexpr int W_LD = BCL / 64;        // DMA rounds per image (X or Y) and stage
   constexpr int HMAIN = 10 * 32 * 64, HSIDE = 4096, HBUF = HMAIN + HSIDE;
   constexpr int WIMG = BCL * 64, WST = 2 * WIMG, NST = 3;
-  static_assert(WP * WC_ == 4 && TP == 2 * ROWS_W, "wave layout");
+  static_assert(WP * WC_ == 4 && TP == EN * ROWS_W && (TH + 2 + RPR - 1) / RPR == 5, "wave layout");
   static_assert(2 * HBUF + NST * WST <= 81920, "two workgroups per CU");
   __shared__ __attribute__((aligned(16))) char smem[2 * HBUF + NST * WST];
   char* const ring = smem + 2 * HBUF;
@@ -1129,18 +1130,18 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_tap2_kernel(const ConvArg
   const f16* ximg = (const f16*)a.x + (long)b * a.H * a.W * a.in_stride;
 
   // ---- halo loader (as conv3x3_halo_kernel): 5 main pieces + 1 side piece per thread and chunk ----
-  const int hslot = tid & 3, hpx = (tid >> 2) & 31, hr0 = tid >> 7;
+  const int hslot = tid & 3, hpx = (tid >> 2) & (TW - 1), hr0 = tid / (4 * TW);
   const int y0 = ty0 - 1 + hr0;
   const f16* hp0 = ximg + ((long)y0 * a.W + tx0 + hpx) * a.in_stride + (hslot ^ swz(hpx)) * 8;
-  const long row2 = 2L * a.W * a.in_stride;
+  const long row2 = (long)RPR * a.W * a.in_stride;
   unsigned hmask = 0;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) hmask |= (y0 + 2 * i >= 0 && y0 + 2 * i < a.H) ? (1u << i) : 0u;
+  for (int i = 0; i < 5; ++i) hmask |= (hr0 + RPR * i < TH + 2 && y0 + RPR * i >= 0 && y0 + RPR * i < a.H) ? (1u << i) : 0u;
   const f16* hps;
   {
     const int side = (tid >> 2) & 1, hr = tid >> 3;   // [hr 0..9][side][slot], tid < 80
     const int y = ty0 - 1 + hr, x = side ? tx0 + TW : tx0 - 1;
-    const bool ok = tid < 80 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    const bool ok = tid < 8 * (TH + 2) && y >= 0 && y < a.H && x >= 0 && x < a.W;
     hps = ximg + ((long)(ok ? y : 0) * a.W + (ok ? x : 0)) * a.in_stride + hslot * 8;
     hmask |= ok ? 32u : 0u;
   }
@@ -1178,18 +1179,18 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_tap2_kernel(const ConvArg
   // ---- fragment addressing (as conv3x3_halo_kernel) ----
   const int l15 = lane & 15, kg = lane >> 4;
   const int row0 = wp * ROWS_W;
-  int abase[2][3];
+  int abase[EN][3];
 #pragma unroll
-  for (int e = 0; e < 2; ++e)
+  for (int e = 0; e < EN; ++e)
 #pragma unroll
     for (int s2 = 0; s2 < 3; ++s2) {
       const int X = 16 * e + l15 + s2 - 1;
       if (X < 0) abase[e][s2] = HMAIN + kg * 16 + row0 * 128;
-      else if (X > 31) abase[e][s2] = HMAIN + 64 + kg * 16 + row0 * 128;
-      else abase[e][s2] = X * 64 + ((kg ^ swz(X)) << 4) + row0 * 2048;
+      else if (X > TW - 1) abase[e][s2] = HMAIN + 64 + kg * 16 + row0 * 128;
+      else abase[e][s2] = X * 64 + ((kg ^ swz(X)) << 4) + row0 * RS;
     }
-  const int estride0 = (l15 == 0) ? 128 : 2048;    // row stride of this lane for (e=0, s=0)
-  const int estride1 = (l15 == 15) ? 128 : 2048;   // ... for (e=1, s=2)
+  const int estride0 = (l15 == 0) ? 128 : RS;      // row stride of this lane for (e = 0, s = 0)
+  const int estride1 = (l15 == 15) ? 128 : RS;     // ... for (e = EN - 1, s = 2)
   const int fr_off = l15 * 64 + ((kg ^ swz(l15)) << 4);
   const char* fragB = ring + (wc * 16 * TC) * 64 + fr_off;
 
@@ -1202,10 +1203,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_tap2_kernel(const ConvArg
   // window offset of this lane's fragment of pixel tile p for tap T
   auto tap_off = [&](int p, int T) {
     const int R_ = T / 3, S_ = T % 3;
-    const int e = p & 1, lr = p >> 1;
+    const int e = p % EN, lr = p / EN;
     if (e == 0 && S_ == 0) return abase[0][0] + (lr + R_) * estride0;
-    if (e == 1 && S_ == 2) return abase[1][2] + (lr + R_) * estride1;
-    return abase[e][S_] + (lr + R_) * 2048;
+    if (e == EN - 1 && S_ == 2) return abase[EN - 1][2] + (lr + R_) * estride1;
+    return abase[e][S_] + (lr + R_) * RS;
   };
   // operands of a K step: X / Y weight fragments (two register sets) and the pixel fragments of its two (buffer, tap) operands
   static_assert(TP == 4, "two pixel-tile pairs per wave");
@@ -1322,7 +1323,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_tap2_kernel(const ConvArg
   const int cb = n0 + wc * 16 * TC;
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
-    const int y = ty0 + row0 + (p >> 1), x = tx0 + 16 * (p & 1) + l15;
+    const int y = ty0 + row0 + p / EN, x = tx0 + 16 * (p % EN) + l15;
     const int m = (b * a.H + y) * a.W + x;
     epilogue_tiles<TOut, TC>(a, m, cb, q, acc[p]);
   }
@@ -1346,11 +1347,11 @@ static int launch_halo_pair2_t(const ConvArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <int BC, int WP, int WC_, typename TOut>
+template <int BC, int WP, int WC_, typename TOut, int TW = 32>
 static int launch_halo_tap2(const ConvArgs& a, hipStream_t s) {
-  const int nbx = a.B * (a.H / 8) * (a.W / 32), nby = a.Cout_pad / BC;
+  const int nbx = a.B * (a.H / (256 / TW)) * (a.W / TW), nby = a.Cout_pad / BC;
   dim3 grid(8 * ((nbx + 7) / 8) * nby);
-  hipLaunchKernelGGL((conv3x3_halo_tap2_kernel<BC, WP, WC_, TOut>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv3x3_halo_tap2_kernel<BC, WP, WC_, TOut, TW>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
@@ -1613,6 +1614,12 @@ int launch_head_fused(const HeadArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(head_fused_kernel, grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
+}
+
+static bool halo16_ok(const ConvArgs& a) {
+  return a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.in_dil == 1 && a.nsrc <= 1 &&
+         a.korder == 1 && a.Cin % 32 == 0 && a.Kpad == a.K && a.H % 16 == 0 && a.W % 16 == 0 && a.W % 32 != 0 && a.Ho == a.H &&
+         a.Wo == a.W && !(ctdet_tuning_flags() & CTDET_TUNE_NO_HALO);
 }
 
 static bool halo_ok(const ConvArgs& a) {
@@ -2750,6 +2757,11 @@ static int launch_conv_f16_t(const ConvArgs& a, bool deform, hipStream_t s) {
   if (halo_ok(a) && a.Cin % 64 == 0 && a.Kpad == 9 * a.Cin && !(ctdet_tuning_flags() & CTDET_TUNE_NO_HALO_TAP2)) {
     if (bc == 32) return launch_halo_tap2<32, 4, 1, TOut>(a, s);
     if (bc == 64 || bc == 128) return launch_halo_tap2<64, 4, 1, TOut>(a, s);
+  }
+  // 16 x 16-pixel tiles of the two-tap kernel: maps the 8 x 32 tile does not divide (the 512-channel level at 16 x 16)
+  if (halo16_ok(a) && a.Cin % 64 == 0 && a.Kpad == 9 * a.Cin && !(ctdet_tuning_flags() & CTDET_TUNE_NO_HALO_TAP2)) {
+    if (bc == 32) return launch_halo_tap2<32, 4, 1, TOut, 16>(a, s);
+    if (bc == 64 || bc == 128) return launch_halo_tap2<64, 4, 1, TOut, 16>(a, s);
   }
   if (halo_ok(a)) {
     switch (bc) {

@@ -60,6 +60,10 @@ def _kernel_name(p, M, deform, out_dt, x_shape=None, nsrc=1):
     H, W = (x_shape[1], x_shape[2]) if x_shape is not None else (0, 0)
     big = ((M + 255) // 256) * (p.Cout_pad // bc) >= 512
     bp = 256 if (big or bc == 16) else 128
+    if (p.R == 3 and p.S == 3 and p.stride == 1 and p.pad == 1 and p.dil == 1 and p.in_dil == 1 and nsrc <= 1 and p.korder == 1
+            and H and H % 16 == 0 and W % 16 == 0 and W % 32 != 0 and bc in (32, 64, 128) and p.Cin % 64 == 0 and p.Kpad == 9 * p.Cin
+            and not (_lib.lib().ctdet_get_tuning_flags() & (_lib.TUNE_NO_HALO_TAP2 | _lib.TUNE_NO_HALO))):
+        return f"conv3x3_halo_tap2_kernel<16x16x{min(bc, 64)},{o}>"
     if (p.R == 3 and p.S == 3 and p.stride == 1 and p.pad == 1 and p.dil == 1 and p.in_dil == 1 and nsrc <= 1
             and p.korder == 1 and H % 8 == 0 and W % 32 == 0 and bc in (32, 64, 128)):
         if p.Cin % 64 == 0 and p.Kpad == 9 * p.Cin and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_HALO_TAP2):
