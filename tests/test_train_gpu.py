@@ -459,8 +459,11 @@ def test_training_step_graph_replay_matches_eager(tmp_path, dev):
                      tr.iter)
     (he, de, me, lre, ite), (hg, dg, mg, lrg, itg) = res["eager"], res["graph"]
     assert ite == itg == 6 and lre == lrg
-    for a, b in zip(he, hg):
-        assert abs(a - b) <= 2e-3 * abs(a), (he, hg)
+    # the two trajectories separate exponentially (observed 0, 1e-4, 4e-4, 3e-4, 1e-3, 2e-3 relative over the six steps), so the
+    # bound doubles per step; a replay on stale parameters -- the bug this guards against -- leaves the loss where it was at
+    # capture time: 0.8 % off at the third step, 1.8 % at the fourth, 3 % at the sixth
+    for i, (a, b) in enumerate(zip(he, hg)):
+        assert abs(a - b) <= 1e-3 * 2 ** i * abs(a) * 0.5 + 5e-4 * abs(a), (i, he, hg)
     assert de > 0 and abs(de - dg) <= 0.05 * de, (de, dg)          # six optimiser steps of the same size
     assert abs(me.norm().item() - mg.norm().item()) <= 0.05 * me.norm().item()
     cos = torch.nn.functional.cosine_similarity(me, mg, dim=0).item()
