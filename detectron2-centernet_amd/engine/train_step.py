@@ -258,6 +258,7 @@ def centernet_train_forward(model, batched_inputs):
 
 
 def train_forward_tensors(model, x_nhwc, targets):
+    _COUNTERS.clear()        # counters collected by a forward that did not reach its flush (an exception, a partial walk) are dropped
     if model.backbone_type == "resnet":
         y = deconv_layers(model, resnet_features(model.backbone, x_nhwc, model._ctx))
     elif model.backbone_type == "vovnet":
