@@ -43,6 +43,8 @@ SIGNATURES = {
     "ctdet_pack_weights": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_pack_weights_batch": (_i32, [_vp, _i32, _i32, _vp]),
     "ctdet_split_weights": (_i32, [_vp, _vp, _i64, _vp]),
+    "ctdet_pack_weights_x3": (_i32, [_vp, _vp, _vp] + [_i32] * 10 + [_vp]),
+    "ctdet_pack_weights_x3_batch": (_i32, [_vp, _i32, _i32, _vp]),
     "ctdet_dwconvT_add": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_decode_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "ctdet_decode": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -61,7 +63,7 @@ SIGNATURES = {
     "ctdet_conv_wgrad": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _f32, _vp]),
     "ctdet_conv_wgrad_oihw": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_grad_scatter_oihw": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
-    "ctdet_depth_to_space2": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_depth_to_space2": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_maxpool2x2_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_dwconvT_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_dcn_cols": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -107,6 +109,12 @@ class PackDesc(C.Structure):
     """mirrors ctdet_pack_desc"""
     _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p)] + [(n, C.c_int32) for n in (
         "O", "I", "R", "S", "chans_pad", "rows_pad", "Kpad", "korder", "transposed", "blk0")]
+
+
+class Pack3Desc(C.Structure):
+    """mirrors ctdet_pack3_desc"""
+    _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("scale_out", C.c_void_p)] + [(n, C.c_int32) for n in (
+        "O", "I", "R", "S", "chans_pad", "rows_pad", "Kpad", "layout", "transposed", "scale_n", "blk0", "pad_")]
 
 
 class DlaBaseDesc(C.Structure):

@@ -45,7 +45,7 @@ int launch_sgd_runs(float*, const float*, float*, long, const long*, const int*,
                     hipStream_t);
 
 struct WgradArgs {
-  const f16* x; const f16* dy; float* dw;
+  const void* x; const void* dy; float* dw;
   int B, H, W, Cin, in_stride, Cout, Ho, Wo, dy_stride, R, S, stride, pad, dil, K, M, msplit;
   float scale;
   int lw, lh;
@@ -53,6 +53,8 @@ struct WgradArgs {
 };
 int launch_grad_scatter_oihw(const void* const*, void* const*, const int*, const int*, const int*, const int*, int, hipStream_t);
 int launch_pack_weights_batch(const void*, int, int, hipStream_t);
+int launch_pack_weights_x3(const float*, void*, float*, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+int launch_pack_weights_x3_batch(const void*, int, int, hipStream_t);
 int launch_split_weights(const float*, void*, long, hipStream_t);
 bool dcn_offset_fused_ok(const ConvArgs& a);
 size_t chan_reduce_workspace_bytes(int C);
@@ -62,6 +64,7 @@ int launch_bn_train_bwd(const f16*, int, const f16*, int, const f16*, int, const
                         int, int, f16*, int, f16*, int, float*, float*, float, void*, hipStream_t);
 int launch_conv_wgrad(const WgradArgs&, hipStream_t);
 int launch_conv_wgrad_f32(const WgradArgs&, hipStream_t);
+int launch_conv_wgrad_x3(const WgradArgs&, hipStream_t);
 int launch_bn_train_fwd_f32(const float*, int, const float*, int, float*, int, int, int, const float*, const float*, float,
                             float, float*, float*, float*, float*, float*, float*, void*, int, hipStream_t);
 int launch_bn_train_bwd_f32(const float*, int, const float*, int, const float*, int, const float*, const float*, const float*,
@@ -71,9 +74,9 @@ int launch_dwconvT_bwd_f32(const float*, int, const float*, int, const float*, f
                            hipStream_t);
 int launch_dcn_cols_f32(const float*, int, const float*, int, float*, int, int, int, int, int, hipStream_t);
 int launch_dcn_col2im_coord_f32(const float*, const float*, int, const float*, int, float*, float*, int, int, int, int, int, int,
-                                hipStream_t);
+                                int, int, hipStream_t);
 int launch_maxpool2x2_bwd(const f16*, int, const f16*, int, f16*, int, int, int, int, int, hipStream_t);
-int launch_depth_to_space2(const f16*, int, f16*, int, int, int, int, int, int, int, hipStream_t);
+int launch_depth_to_space2(const void*, int, void*, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_dwconvT_bwd(const f16*, int, const f16*, int, const float*, f16*, int, float*, int, int, int, int, int,
                        hipStream_t);
 int launch_dcn_cols(const f16*, int, const float*, int, f16*, int, int, int, int, int, hipStream_t);
@@ -127,7 +130,7 @@ extern "C" {
 const char* ctdet_last_error(void) { return g_err; }
 int32_t ctdet_set_tuning_flags(uint32_t flags) { g_tuning.store(flags, std::memory_order_relaxed); return 0; }
 uint32_t ctdet_get_tuning_flags(void) { return g_tuning.load(std::memory_order_relaxed); }
-int32_t ctdet_abi_version(void) { return 5; }
+int32_t ctdet_abi_version(void) { return 6; }
 int32_t ctdet_conv_cout_tile(int32_t cout) {
   if (cout <= 16) return 16;
   if (cout <= 32) return 32;
@@ -320,6 +323,19 @@ int32_t ctdet_pack_weights_batch(const ctdet_pack_desc* table_dev, int32_t n, in
   return launch_pack_weights_batch(table_dev, n, total_blocks, (hipStream_t)stream);
 }
 
+int32_t ctdet_pack_weights_x3(const float* w, void* packed, float* scale_out, int32_t O, int32_t I, int32_t R, int32_t S,
+                              int32_t chans_pad, int32_t rows_pad, int32_t Kpad, int32_t layout, int32_t transposed,
+                              int32_t scale_n, void* stream) {
+  return launch_pack_weights_x3(w, packed, scale_out, O, I, R, S, chans_pad, rows_pad, Kpad, layout, transposed, scale_n,
+                                (hipStream_t)stream);
+}
+
+int32_t ctdet_pack_weights_x3_batch(const ctdet_pack3_desc* table_dev, int32_t n, int32_t total_blocks, void* stream) {
+  CTDET_CHECK(n >= 0 && total_blocks >= 0 && (n == 0 || table_dev), "pack_weights_x3_batch: bad arguments");
+  static_assert(sizeof(ctdet_pack3_desc) == 72, "ctdet_pack3_desc layout");
+  return launch_pack_weights_x3_batch(table_dev, n, total_blocks, (hipStream_t)stream);
+}
+
 int32_t ctdet_dwconvT_add(const void* x, const float* w, const void* skip, void* y, int32_t dtype, int32_t B,
                           int32_t H, int32_t W, int32_t C, int32_t f, int32_t in_stride, int32_t skip_stride,
                           int32_t out_stride, void* stream) {
@@ -455,12 +471,14 @@ int32_t ctdet_conv_wgrad_oihw(const ctdet_conv_desc* d, const void* x, const voi
               "conv_wgrad_oihw: taps=%d cin_k=%d cin_real=%d do not factor K=%d", taps, cin_k, cin_real, d->R * d->S * d->Cin);
   WgradArgs a;
   a.perm_rs = taps; a.perm_cin = cin_k; a.cin_real = cin_real; a.cout_real = cout_real;
-  a.x = (const f16*)x; a.dy = (const f16*)dy; a.dw = dw;
+  a.x = x; a.dy = dy; a.dw = dw;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_stride = d->in_stride; a.Cout = d->Cout; a.Ho = d->Ho;
   a.Wo = d->Wo; a.dy_stride = d->out_stride; a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
   a.K = d->R * d->S * d->Cin; a.M = d->B * d->Ho * d->Wo; a.msplit = 1; a.scale = scale;
   if (a.M == 0) return 0;
   if (d->compute_dtype == CTDET_DT_F32) return launch_conv_wgrad_f32(a, (hipStream_t)stream);
+  if (d->compute_dtype == CTDET_DT_F16X3) return launch_conv_wgrad_x3(a, (hipStream_t)stream);
+  CTDET_CHECK(d->compute_dtype == CTDET_DT_F16, "conv_wgrad: bad compute dtype %d", d->compute_dtype);
   return launch_conv_wgrad(a, (hipStream_t)stream);
 }
 
@@ -471,9 +489,10 @@ int32_t ctdet_grad_scatter_oihw(const void* const* src, void* const* dst, const 
 }
 
 int32_t ctdet_depth_to_space2(const void* src, int32_t src_stride, void* dst, int32_t dst_stride, int32_t B, int32_t H,
-                              int32_t W, int32_t C, int32_t Hs, int32_t Ws, void* stream) {
+                              int32_t W, int32_t C, int32_t Hs, int32_t Ws, int32_t dtype, void* stream) {
   CTDET_CHECK(src && dst, "depth_to_space2: null pointer");
-  return launch_depth_to_space2((const f16*)src, src_stride, (f16*)dst, dst_stride, B, H, W, C, Hs, Ws, (hipStream_t)stream);
+  CTDET_CHECK(dtype == CTDET_DT_F16 || dtype == CTDET_DT_F32, "depth_to_space2: bad dtype %d", dtype);
+  return launch_depth_to_space2(src, src_stride, dst, dst_stride, B, H, W, C, Hs, Ws, dtype, (hipStream_t)stream);
 }
 
 int32_t ctdet_maxpool2x2_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, void* dx,
@@ -512,10 +531,9 @@ int32_t ctdet_dcn_col2im_coord(const void* dcol, const void* x, int32_t x_stride
   CTDET_CHECK(dcol && x && om && dx && dom, "dcn_col2im_coord: null pointer");
   CTDET_CHECK(dom_dtype == CTDET_DT_F32 || (dom_dtype == CTDET_DT_F16 && dtype == CTDET_DT_F16),
               "dcn_col2im_coord: dom dtype %d with data dtype %d", dom_dtype, dtype);
-  CTDET_CHECK(!dcol_chunked || dtype == CTDET_DT_F16, "dcn_col2im_coord: the chunked dcol layout is an f16 layout");
-  if (dtype == CTDET_DT_F32)
+  if (dtype == CTDET_DT_F32 || dtype == CTDET_DT_F16X3)
     return launch_dcn_col2im_coord_f32((const float*)dcol, (const float*)x, x_stride, om, om_stride, dx, (float*)dom, dom_stride,
-                                       B, H, W, Cin, mask_is_prob, (hipStream_t)stream);
+                                       B, H, W, Cin, mask_is_prob, dcol_chunked, dtype == CTDET_DT_F16X3, (hipStream_t)stream);
   return launch_dcn_col2im_coord((const f16*)dcol, (const f16*)x, x_stride, om, om_stride, dx, dom, dom_stride,
                                  dom_dtype == CTDET_DT_F16, B, H, W, Cin, mask_is_prob, dcol_chunked, (hipStream_t)stream);
 }

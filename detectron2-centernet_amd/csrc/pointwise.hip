@@ -441,6 +441,146 @@ int launch_pack_weights_batch(const void* table_dev, int n, int total_blocks, hi
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight packing for the f16x3 kernels (f32 tensors, products as hi*hi + lo*hi + hi*lo on the f16 matrix pipe), one
+// workgroup per packed row.  A row is first scaled by the power of two that brings its largest magnitude into [1024, 2048)
+// (exact; the lo halves of the row's significant weights then stay f16 normals whatever the layer's weight scale is), the
+// inverse goes to scale_out[row] -- the conv epilogue's per-cout multiplier.  Layouts (ctdet_pack3_desc.layout):
+//   0  split tap-major image [rows_pad][Kpad f32 units], k = tap*chans_pad + c, every group of 4 k = 16 bytes {hi[4], lo[4]} f16
+//      (what ctdet_split_weights makes of an f32 image): 1x1 / strided / 7x7 convs, DCNv2, the d(columns) operand
+//   3  tap-pair image of conv3x3_halo_pair2_kernel (chans_pad % 32 == 0): per chunk PAIR (A, B) of 16-channel chunks nine
+//      128-byte steps {X, Y}: X = for q in 0..3 {hi[a][4q..4q+3], hi[b][4q..4q+3]}, Y likewise from lo, with (a, b) =
+//      taps (2s, 2s+1) of A for s = 0..3, then tap 8 of A with tap 8 of B, then taps (2s, 2s+1) of B;  Kpad = chans_pad/32*288
+//   2  the same for an odd number of chunks (conv3x3_halo_pair_kernel): per chunk five steps, taps (2s, 2s+1), the tenth tap
+//      zero;  Kpad = chans_pad/16*160
+// transposed as in ctdet_pack_weights (0 forward, 1 input-gradient operand, 2 / 3 DCNv2's d(columns) operand).
+// ------------------------------------------------------------------------------------------------
+struct Pack3Desc {
+  const float* w; void* out; float* scale_out;
+  int O, I, R, S, chans_pad, rows_pad, Kpad, layout, transposed, scale_n, blk0;
+  int pad_;
+};
+
+__device__ __forceinline__ void pack3_row(const Pack3Desc& d, int row, float* red) {
+  const int tid = threadIdx.x;
+  const int rows = d.transposed >= 2 ? 9 * d.I : (d.transposed ? d.I : d.O);
+  const int K = d.R * d.S * d.chans_pad;
+  float amax = 0.f;
+  if (row < rows)
+    for (int k = tid; k < K; k += 256)
+      amax = fmaxf(amax, fabsf(pack_value(d.w, d.O, d.I, d.R, d.S, d.chans_pad, 0, d.transposed, row, k)));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  int ex = 0;
+  (void)frexpf(amax, &ex);                       // amax = f * 2^ex, f in [0.5, 1): floor(log2(amax)) = ex - 1
+  const float pw = amax > 0.f ? ldexpf(1.f, 11 - ex) : 1.f;
+  if (tid == 0 && row < d.scale_n) d.scale_out[row] = amax > 0.f ? ldexpf(1.f, ex - 11) : 1.f;
+  auto val = [&](int tap, int c) -> float {      // scaled weight of (row, tap, channel); taps >= R*S and padding are zero
+    if (row >= rows || tap >= d.R * d.S) return 0.f;
+    return pw * pack_value(d.w, d.O, d.I, d.R, d.S, d.chans_pad, 0, d.transposed, row, tap * d.chans_pad + c);
+  };
+  f16* const orow = (f16*)d.out + (long)row * d.Kpad * 2;
+  if (d.layout == 0) {
+    for (int g = tid; g < d.Kpad / 4; g += 256) {
+      f16x8 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 4 * g + j;
+        const float v = (k < K && row < rows) ? pw * pack_value(d.w, d.O, d.I, d.R, d.S, d.chans_pad, 0, d.transposed, row, k) : 0.f;
+        const f16 h = (f16)v;
+        o[j] = h; o[4 + j] = (f16)(v - (float)h);
+      }
+      *(f16x8*)(orow + 8 * g) = o;
+    }
+    return;
+  }
+  // pair layouts: one 16-byte piece = {operand a: 4 channels, operand b: 4 channels} of X (hi) or Y (lo)
+  const int npieces = d.Kpad / 4;
+  for (int pc = tid; pc < npieces; pc += 256) {
+    const int q = pc & 3, xy = (pc >> 2) & 1, st = pc >> 3;       // piece = ((step * 2 + xy) * 4 + q)
+    int ta, tb, ca, cb;                                            // (tap, first channel) of the two operands
+    if (d.layout == 3) {
+      const int cp = st / 9, s9 = st - cp * 9;
+      if (s9 < 4) { ta = 2 * s9; tb = ta + 1; ca = cb = 32 * cp; }
+      else if (s9 == 4) { ta = tb = 8; ca = 32 * cp; cb = ca + 16; }
+      else { ta = 2 * (s9 - 5); tb = ta + 1; ca = cb = 32 * cp + 16; }
+    } else {
+      const int ch = st / 5, s5 = st - ch * 5;
+      ta = 2 * s5; tb = ta + 1; ca = cb = 16 * ch;
+    }
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float va = val(ta, ca + 4 * q + j), vb = val(tb, cb + 4 * q + j);
+      const f16 ha = (f16)va, hb = (f16)vb;
+      o[j] = xy ? (f16)(va - (float)ha) : ha;
+      o[4 + j] = xy ? (f16)(vb - (float)hb) : hb;
+    }
+    *(f16x8*)(orow + 8 * pc) = o;
+  }
+}
+
+__global__ void __launch_bounds__(256) pack3_kernel(const Pack3Desc d) {
+  __shared__ float red[4];
+  pack3_row(d, blockIdx.x, red);
+}
+__global__ void __launch_bounds__(256) pack3_batch_kernel(const Pack3Desc* __restrict__ table, int n) {
+  __shared__ float red[4];
+  int lo = 0, hi = n - 1;                         // last descriptor with blk0 <= blockIdx.x (block-uniform)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const Pack3Desc d = table[lo];
+  const int row = (int)blockIdx.x - d.blk0;
+  if (row >= d.rows_pad) return;
+  pack3_row(d, row, red);
+}
+
+static int pack3_check(const Pack3Desc& d) {
+  CTDET_CHECK(d.w && d.out && d.scale_out, "pack_weights_x3: null pointer");
+  const int taps = d.R * d.S;
+  if (d.transposed >= 2) {
+    CTDET_CHECK(d.transposed <= 3 && d.R == 1 && d.S == 1 && d.layout == 0 && d.chans_pad >= d.O && d.rows_pad >= 9 * d.I &&
+                    (d.transposed == 2 || d.I % 32 == 0),
+                "pack_weights_x3: the DCNv2 d(columns) operand is a 1x1 contraction (R = S = 1 here) over a [O,I,3,3] weight, layout 0, rows_pad >= 9*I");
+  } else {
+    const int rows = d.transposed ? d.I : d.O, chans = d.transposed ? d.O : d.I;
+    CTDET_CHECK(d.chans_pad >= chans && d.rows_pad >= rows, "pack_weights_x3: padded sizes too small");
+  }
+  CTDET_CHECK(d.scale_n >= 0 && d.scale_n <= d.rows_pad, "pack_weights_x3: scale_n=%d beyond rows_pad=%d", d.scale_n, d.rows_pad);
+  if (d.layout == 0) CTDET_CHECK(d.Kpad % 4 == 0 && d.Kpad >= taps * d.chans_pad, "pack_weights_x3: Kpad=%d too small / not a multiple of 4", d.Kpad);
+  else if (d.layout == 3) CTDET_CHECK(taps == 9 && d.chans_pad % 32 == 0 && d.Kpad == d.chans_pad / 32 * 288, "pack_weights_x3: layout 3 needs a 3x3 kernel, channels %% 32 == 0, Kpad = channels/32*288");
+  else if (d.layout == 2) CTDET_CHECK(taps == 9 && d.chans_pad % 16 == 0 && d.Kpad == d.chans_pad / 16 * 160, "pack_weights_x3: layout 2 needs a 3x3 kernel, channels %% 16 == 0, Kpad = channels/16*160");
+  else CTDET_CHECK(false, "pack_weights_x3: bad layout %d", d.layout);
+  CTDET_CHECK((((size_t)d.out) & 15) == 0, "pack_weights_x3: output must be 16-byte aligned");
+  return 0;
+}
+
+int launch_pack_weights_x3(const float* w, void* out, float* scale_out, int O, int I, int R, int S, int chans_pad, int rows_pad,
+                           int Kpad, int layout, int transposed, int scale_n, hipStream_t s) {
+  Pack3Desc d = {};
+  d.w = w; d.out = out; d.scale_out = scale_out;
+  d.O = O; d.I = I; d.R = R; d.S = S; d.chans_pad = chans_pad; d.rows_pad = rows_pad; d.Kpad = Kpad; d.layout = layout;
+  d.transposed = transposed; d.scale_n = scale_n;
+  const int rc = pack3_check(d);
+  if (rc) return rc;
+  if (rows_pad == 0) return 0;
+  hipLaunchKernelGGL(pack3_kernel, dim3(rows_pad), dim3(256), 0, s, d);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_pack_weights_x3_batch(const void* table_dev, int n, int total_blocks, hipStream_t s) {
+  if (n == 0 || total_blocks == 0) return 0;
+  hipLaunchKernelGGL(pack3_batch_kernel, dim3(total_blocks), dim3(256), 0, s, (const Pack3Desc*)table_dev, n);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_pack_weights(const float* w, void* out, int O, int I, int R, int S, int chans_pad, int rows_pad, int Kpad,
                         int korder, int transposed, hipStream_t s) {
   if (transposed >= 2) {

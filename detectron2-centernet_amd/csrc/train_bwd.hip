@@ -1,4 +1,4 @@
-// Training-side kernels of the conv stack (NHWC, f16 activations, f32 statistics / weight gradients).
+// Training-side kernels of the conv stack (NHWC; f16 or f32 activations, f32 statistics / weight gradients).
 //   BatchNorm2d in training mode (batch statistics, momentum 0.1 running stats) forward and backward, fused with
 //   ReLU and the residual add of DLABasicBlock (detectron2/modeling/backbone/dla.py:59-73, 86-94; deform_conv.py:501-519)
 //   conv weight gradient on MFMA (reduction over pixels, operands read from LDS with ds_read_b64_tr_b16)
@@ -23,27 +23,36 @@ __device__ __forceinline__ float wsum(float v) {
 //   mode 1 (BN/act backward):   g = dz * (z > 0 if relu);  r0 = sum g,  r1 = sum g * xhat   (xhat = (y-mean)*invstd)
 // partial[blk][2][C] f32, reduced in fixed order by chan_finalize (f64) => deterministic.
 // ------------------------------------------------------------------------------------------------
+// element type of an activation tensor and its 16-byte vector: f16 (8 channels) or f32 (4 channels: the f32 and f16x3 modes)
+template <typename T> struct VecT;
+template <> struct VecT<f16> { typedef f16x8 type; static constexpr int N = 8; };
+template <> struct VecT<float> { typedef f32x4 type; static constexpr int N = 4; };
+
+template <typename T>
 struct ChanRedArgs {
-  const f16* y; int y_stride;      // mode 0: tensor; mode 1: pre-BN conv output (may be null => no xhat term)
-  const f16* dz; int dz_stride;    // mode 1
-  const f16* z; int z_stride;      // mode 1: post-activation output (relu mask), may be null
+  const T* y; int y_stride;      // mode 0: tensor; mode 1: pre-BN conv output (may be null => no xhat term)
+  const T* dz; int dz_stride;    // mode 1
+  const T* z; int z_stride;      // mode 1: post-activation output (relu mask), may be null
   const float* mean; const float* invstd;
   int M, C, mode, relu;
   float* partial;
 };
 
-__global__ void __launch_bounds__(256) chan_reduce_kernel(ChanRedArgs a) {
-  __shared__ float red[2][256][8];
-  const int CV = a.C >> 3;
-  const int rows_per_pass = 256 / CV;  // CV in {2,4,8,16,32,64}
+template <typename T>
+__global__ void __launch_bounds__(256) chan_reduce_kernel(ChanRedArgs<T> a) {
+  typedef typename VecT<T>::type V;
+  constexpr int N = VecT<T>::N;
+  __shared__ float red[2][256][N];
+  const int CV = a.C / N;
+  const int rows_per_pass = 256 / CV;  // CV <= 256
   const int cv = threadIdx.x % CV, rl = threadIdx.x / CV;
-  float s0[8], s1[8];
+  float s0[N], s1[N];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
-  float mu[8], is[8];
+  for (int e = 0; e < N; ++e) s0[e] = s1[e] = 0.f;
+  float mu[N], is[N];
   if (a.mode == 1 && a.y) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { mu[e] = a.mean[cv * 8 + e]; is[e] = a.invstd[cv * 8 + e]; }
+    for (int e = 0; e < N; ++e) { mu[e] = a.mean[cv * N + e]; is[e] = a.invstd[cv * N + e]; }
   }
   if (rl < rows_per_pass) {
     const long step = (long)gridDim.x * rows_per_pass;
@@ -52,28 +61,28 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(ChanRedArgs a) {
       // four rows in flight per thread: with one 16-byte load outstanding per thread the pass ran at ~2 TB/s (latency x
       // occupancy), the mid-sized maps at a quarter of that
       for (; m + 3 * step < a.M; m += 4 * step) {
-        f16x8 v[4];
+        V v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(const f16x8*)(a.y + (m + u * step) * a.y_stride + cv * 8);
+        for (int u = 0; u < 4; ++u) v[u] = *(const V*)(a.y + (m + u * step) * a.y_stride + cv * N);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e]; s0[e] += f; s1[e] += f * f; }
+          for (int e = 0; e < N; ++e) { const float f = (float)v[u][e]; s0[e] += f; s1[e] += f * f; }
       }
     } else {
       for (; m + step < a.M; m += 2 * step) {      // two rows of the (up to) three tensors in flight
-        f16x8 g[2], zz[2], yy[2];
+        V g[2], zz[2], yy[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          g[u] = *(const f16x8*)(a.dz + (m + u * step) * a.dz_stride + cv * 8);
+          g[u] = *(const V*)(a.dz + (m + u * step) * a.dz_stride + cv * N);
           zz[u] = g[u]; yy[u] = g[u];
-          if (a.relu) zz[u] = *(const f16x8*)(a.z + (m + u * step) * a.z_stride + cv * 8);
-          if (a.y) yy[u] = *(const f16x8*)(a.y + (m + u * step) * a.y_stride + cv * 8);
+          if (a.relu) zz[u] = *(const V*)(a.z + (m + u * step) * a.z_stride + cv * N);
+          if (a.y) yy[u] = *(const V*)(a.y + (m + u * step) * a.y_stride + cv * N);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
+          for (int e = 0; e < N; ++e) {
             const float gf = (a.relu && !((float)zz[u][e] > 0.f)) ? 0.f : (float)g[u][e];
             s0[e] += gf;
             if (a.y) s1[e] += gf * (((float)yy[u][e] - mu[e]) * is[e]);
@@ -82,16 +91,16 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(ChanRedArgs a) {
     }
     for (; m < a.M; m += step) {
       if (a.mode == 0) {
-        const f16x8 v = *(const f16x8*)(a.y + m * a.y_stride + cv * 8);
+        const V v = *(const V*)(a.y + m * a.y_stride + cv * N);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s0[e] += f; s1[e] += f * f; }
+        for (int e = 0; e < N; ++e) { const float f = (float)v[e]; s0[e] += f; s1[e] += f * f; }
       } else {
-        const f16x8 g = *(const f16x8*)(a.dz + m * a.dz_stride + cv * 8);
-        f16x8 zz = g, yy = g;
-        if (a.relu) zz = *(const f16x8*)(a.z + m * a.z_stride + cv * 8);
-        if (a.y) yy = *(const f16x8*)(a.y + m * a.y_stride + cv * 8);
+        const V g = *(const V*)(a.dz + m * a.dz_stride + cv * N);
+        V zz = g, yy = g;
+        if (a.relu) zz = *(const V*)(a.z + m * a.z_stride + cv * N);
+        if (a.y) yy = *(const V*)(a.y + m * a.y_stride + cv * N);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < N; ++e) {
           const float gf = (a.relu && !((float)zz[e] > 0.f)) ? 0.f : (float)g[e];
           s0[e] += gf;
           if (a.y) s1[e] += gf * (((float)yy[e] - mu[e]) * is[e]);
@@ -100,7 +109,7 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(ChanRedArgs a) {
     }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s0[e]; red[1][threadIdx.x][e] = s1[e]; }
+  for (int e = 0; e < N; ++e) { red[0][threadIdx.x][e] = s0[e]; red[1][threadIdx.x][e] = s1[e]; }
   __syncthreads();
   // tree over the row lanes of a channel vector (fixed order => deterministic): with few channels (C = 8 ... 32: 256 ... 64
   // row lanes) one thread summing them all was most of the kernel's time on the small maps
@@ -108,7 +117,7 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(ChanRedArgs a) {
     const int half = (n + 1) >> 1;
     if (rl + half < n) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < N; ++e) {
         red[0][threadIdx.x][e] += red[0][threadIdx.x + half * CV][e];
         red[1][threadIdx.x][e] += red[1][threadIdx.x + half * CV][e];
       }
@@ -118,9 +127,9 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(ChanRedArgs a) {
   }
   if (rl == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      a.partial[((long)blockIdx.x * 2 + 0) * a.C + cv * 8 + e] = red[0][cv][e];
-      a.partial[((long)blockIdx.x * 2 + 1) * a.C + cv * 8 + e] = red[1][cv][e];
+    for (int e = 0; e < N; ++e) {
+      a.partial[((long)blockIdx.x * 2 + 0) * a.C + cv * N + e] = red[0][cv][e];
+      a.partial[((long)blockIdx.x * 2 + 1) * a.C + cv * N + e] = red[1][cv][e];
     }
   }
 }
@@ -173,120 +182,183 @@ __global__ void __launch_bounds__(256) chan_finalize_kernel(const float* __restr
   }
 }
 
-// z = act(y * scale + shift + res)   (BN apply, f16 in/out)
-__global__ void __launch_bounds__(256) affine_act_kernel(const f16* __restrict__ y, int y_stride,
+// z = act(y * scale + shift + res)   (BN apply)
+template <typename T>
+__global__ void __launch_bounds__(256) affine_act_kernel(const T* __restrict__ y, int y_stride,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         const f16* __restrict__ res, int res_stride, f16* __restrict__ z,
+                                                         const T* __restrict__ res, int res_stride, T* __restrict__ z,
                                                          int z_stride, long M, int C, int relu) {
-  const int CV = C >> 3;
+  typedef typename VecT<T>::type V;
+  constexpr int N = VecT<T>::N;
+  const int CV = C / N;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= M * CV) return;
   const int cv = (int)(idx % CV);
   const long m = idx / CV;
-  const f16x8 v = *(const f16x8*)(y + m * y_stride + cv * 8);
-  f16x8 r = v;
-  if (res) r = *(const f16x8*)(res + m * res_stride + cv * 8);
-  f16x8 o;
+  const V v = *(const V*)(y + m * y_stride + cv * N);
+  V r = v;
+  if (res) r = *(const V*)(res + m * res_stride + cv * N);
+  V o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float f = (float)v[e] * scale[cv * 8 + e] + shift[cv * 8 + e];
+  for (int e = 0; e < N; ++e) {
+    float f = (float)v[e] * scale[cv * N + e] + shift[cv * N + e];
     if (res) f += (float)r[e];
     if (relu) f = fmaxf(f, 0.f);
-    o[e] = (f16)f;
+    o[e] = (T)f;
   }
-  *(f16x8*)(z + m * z_stride + cv * 8) = o;
+  *(V*)(z + m * z_stride + cv * N) = o;
+}
+
+// the same for channel-vector counts that are powers of two: a thread owns one channel group, keeps its coefficients in
+// registers and walks AA_ROWS pixels, four rows in flight
+constexpr int AA_ROWS = 8;
+template <typename T>
+__global__ void __launch_bounds__(256) affine_act_rows_kernel(const T* __restrict__ y, int y_stride,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const T* __restrict__ res, int res_stride, T* __restrict__ z,
+                                                              int z_stride, long M, int cv_shift, int relu) {
+  typedef typename VecT<T>::type V;
+  constexpr int N = VecT<T>::N;
+  const int CV = 1 << cv_shift;
+  const int cv = threadIdx.x & (CV - 1), lane_px = threadIdx.x >> cv_shift;
+  const int ppb = 256 >> cv_shift;
+  const long m0 = (long)blockIdx.x * ppb * AA_ROWS + lane_px;
+  float sc[N], sh[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { sc[e] = scale[cv * N + e]; sh[e] = shift[cv * N + e]; }
+  auto finish = [&](long m, const V& v, const V& r) {
+    V o;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      float f = (float)v[e] * sc[e] + sh[e];      // same expression as the generic kernel
+      if (res) f += (float)r[e];
+      if (relu) f = fmaxf(f, 0.f);
+      o[e] = (T)f;
+    }
+    *(V*)(z + m * z_stride + cv * N) = o;
+  };
+  if (m0 + (long)(AA_ROWS - 1) * ppb < M) {
+#pragma unroll
+    for (int r0 = 0; r0 < AA_ROWS; r0 += 4) {
+      V v[4], r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long m = m0 + (long)(r0 + u) * ppb;
+        v[u] = *(const V*)(y + m * y_stride + cv * N);
+        r[u] = v[u];
+        if (res) r[u] = *(const V*)(res + m * res_stride + cv * N);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) finish(m0 + (long)(r0 + u) * ppb, v[u], r[u]);
+    }
+    return;
+  }
+  for (int r = 0; r < AA_ROWS; ++r) {
+    const long m = m0 + (long)r * ppb;
+    if (m >= M) break;
+    const V v = *(const V*)(y + m * y_stride + cv * N);
+    V rr = v;
+    if (res) rr = *(const V*)(res + m * res_stride + cv * N);
+    finish(m, v, rr);
+  }
 }
 
 // BN backward apply: g = dz*(z>0); dy = scale*(g - s0/M - xhat*s1/M); optional dres = g.
 // With y == null (bias+act layers): dy = g.
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const f16* __restrict__ dz, int dz_stride,
-                                                           const f16* __restrict__ z, int z_stride,
-                                                           const f16* __restrict__ y, int y_stride,
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dz, int dz_stride,
+                                                           const T* __restrict__ z, int z_stride,
+                                                           const T* __restrict__ y, int y_stride,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ scale, const float* __restrict__ s0,
-                                                           const float* __restrict__ s1, f16* __restrict__ dy, int dy_stride,
-                                                           f16* __restrict__ dres, int dres_stride, long M, int C, int relu) {
-  const int CV = C >> 3;
+                                                           const float* __restrict__ s1, T* __restrict__ dy, int dy_stride,
+                                                           T* __restrict__ dres, int dres_stride, long M, int C, int relu) {
+  typedef typename VecT<T>::type V;
+  constexpr int N = VecT<T>::N;
+  const int CV = C / N;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= M * CV) return;
   const int cv = (int)(idx % CV);
   const long m = idx / CV;
-  const f16x8 g = *(const f16x8*)(dz + m * dz_stride + cv * 8);
-  f16x8 zz = g, yy = g;
-  if (relu) zz = *(const f16x8*)(z + m * z_stride + cv * 8);
-  if (y) yy = *(const f16x8*)(y + m * y_stride + cv * 8);
+  const V g = *(const V*)(dz + m * dz_stride + cv * N);
+  V zz = g, yy = g;
+  if (relu) zz = *(const V*)(z + m * z_stride + cv * N);
+  if (y) yy = *(const V*)(y + m * y_stride + cv * N);
   const float invM = 1.f / (float)M;
-  f16x8 o, gr;
+  V o, gr;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = cv * 8 + e;
+  for (int e = 0; e < N; ++e) {
+    const int c = cv * N + e;
     const float gf = (relu && !((float)zz[e] > 0.f)) ? 0.f : (float)g[e];
-    gr[e] = (f16)gf;
+    gr[e] = (T)gf;
     if (y) {
       const float xh = ((float)yy[e] - mean[c]) * invstd[c];
-      o[e] = (f16)(scale[c] * (gf - s0[c] * invM - xh * s1[c] * invM));
+      o[e] = (T)(scale[c] * (gf - s0[c] * invM - xh * s1[c] * invM));
     } else {
-      o[e] = (f16)gf;
+      o[e] = (T)gf;
     }
   }
-  *(f16x8*)(dy + m * dy_stride + cv * 8) = o;
-  if (dres) *(f16x8*)(dres + m * dres_stride + cv * 8) = gr;
+  *(V*)(dy + m * dy_stride + cv * N) = o;
+  if (dres) *(V*)(dres + m * dres_stride + cv * N) = gr;
 }
 
-// the same for channel-vector counts that are powers of two (every BatchNorm of DLA-34): a thread owns one 8-channel group,
-// keeps its 40 per-channel coefficients in registers and walks BN_ROWS pixels -- 3 loads + 1-2 stores per 16 output bytes
+// the same for channel-vector counts that are powers of two (every BatchNorm of DLA-34): a thread owns one channel group,
+// keeps its per-channel coefficients in registers and walks BN_ROWS pixels -- 3 loads + 1-2 stores per 16 output bytes
 // instead of 13 loads (10 of them the coefficients, re-fetched per pixel)
 constexpr int BN_ROWS = 8;
-__global__ void __launch_bounds__(256) bn_bwd_apply_rows_kernel(const f16* __restrict__ dz, int dz_stride,
-                                                                const f16* __restrict__ z, int z_stride,
-                                                                const f16* __restrict__ y, int y_stride,
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_apply_rows_kernel(const T* __restrict__ dz, int dz_stride,
+                                                                const T* __restrict__ z, int z_stride,
+                                                                const T* __restrict__ y, int y_stride,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ scale, const float* __restrict__ s0,
-                                                                const float* __restrict__ s1, f16* __restrict__ dy, int dy_stride,
-                                                                f16* __restrict__ dres, int dres_stride, long M, int cv_shift,
+                                                                const float* __restrict__ s1, T* __restrict__ dy, int dy_stride,
+                                                                T* __restrict__ dres, int dres_stride, long M, int cv_shift,
                                                                 int relu) {
+  typedef typename VecT<T>::type V;
+  constexpr int N = VecT<T>::N;
   const int CV = 1 << cv_shift;
   const int cv = threadIdx.x & (CV - 1), lane_px = threadIdx.x >> cv_shift;
   const int ppb = 256 >> cv_shift;                      // pixels a workgroup covers per step
   const long m0 = (long)blockIdx.x * ppb * BN_ROWS + lane_px;
   const float invM = 1.f / (float)M;
-  float mu[8], is[8], sc[8], a0[8], a1[8];
+  float mu[N], is[N], sc[N], a0[N], a1[N];
   if (y) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = cv * 8 + e;
+    for (int e = 0; e < N; ++e) {
+      const int c = cv * N + e;
       mu[e] = mean[c]; is[e] = invstd[c]; sc[e] = scale[c]; a0[e] = s0[c] * invM; a1[e] = s1[c] * invM;
     }
   }
-  auto finish = [&](long m, const f16x8& g, const f16x8& zz, const f16x8& yy) {
-    f16x8 o, gr;
+  auto finish = [&](long m, const V& g, const V& zz, const V& yy) {
+    V o, gr;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < N; ++e) {
       const float gf = (relu && !((float)zz[e] > 0.f)) ? 0.f : (float)g[e];
-      gr[e] = (f16)gf;
+      gr[e] = (T)gf;
       if (y) {
         const float xh = ((float)yy[e] - mu[e]) * is[e];
-        o[e] = (f16)(sc[e] * (gf - a0[e] - xh * a1[e]));     // same expression as the generic kernel
+        o[e] = (T)(sc[e] * (gf - a0[e] - xh * a1[e]));     // same expression as the generic kernel
       } else {
-        o[e] = (f16)gf;
+        o[e] = (T)gf;
       }
     }
-    *(f16x8*)(dy + m * dy_stride + cv * 8) = o;
-    if (dres) *(f16x8*)(dres + m * dres_stride + cv * 8) = gr;
+    *(V*)(dy + m * dy_stride + cv * N) = o;
+    if (dres) *(V*)(dres + m * dres_stride + cv * N) = gr;
   };
   if (m0 + (long)(BN_ROWS - 1) * ppb < M) {
     // whole range in bounds: four rows of the three tensors in flight before the first use (a loop with a bounds `break`
     // keeps one row's loads outstanding per thread and runs at latency x occupancy)
 #pragma unroll
     for (int r0 = 0; r0 < BN_ROWS; r0 += 4) {
-      f16x8 g[4], zz[4], yy[4];
+      V g[4], zz[4], yy[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long m = m0 + (long)(r0 + u) * ppb;
-        g[u] = *(const f16x8*)(dz + m * dz_stride + cv * 8);
+        g[u] = *(const V*)(dz + m * dz_stride + cv * N);
         zz[u] = g[u]; yy[u] = g[u];
-        if (relu) zz[u] = *(const f16x8*)(z + m * z_stride + cv * 8);
-        if (y) yy[u] = *(const f16x8*)(y + m * y_stride + cv * 8);
+        if (relu) zz[u] = *(const V*)(z + m * z_stride + cv * N);
+        if (y) yy[u] = *(const V*)(y + m * y_stride + cv * N);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) finish(m0 + (long)(r0 + u) * ppb, g[u], zz[u], yy[u]);
@@ -296,10 +368,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_rows_kernel(const f16* __res
   for (int r = 0; r < BN_ROWS; ++r) {
     const long m = m0 + (long)r * ppb;
     if (m >= M) break;
-    const f16x8 g = *(const f16x8*)(dz + m * dz_stride + cv * 8);
-    f16x8 zz = g, yy = g;
-    if (relu) zz = *(const f16x8*)(z + m * z_stride + cv * 8);
-    if (y) yy = *(const f16x8*)(y + m * y_stride + cv * 8);
+    const V g = *(const V*)(dz + m * dz_stride + cv * N);
+    V zz = g, yy = g;
+    if (relu) zz = *(const V*)(z + m * z_stride + cv * N);
+    if (y) yy = *(const V*)(y + m * y_stride + cv * N);
     finish(m, g, zz, yy);
   }
 }
@@ -312,7 +384,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_rows_kernel(const f16* __res
 // Results are added to the f32 dW with atomics (split over pixel ranges across workgroups).
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
-  const f16* x; const f16* dy; float* dw;
+  const void* x; const void* dy; float* dw;   // x, dy: f16 (f16 mode) or f32 (f16x3 mode: split into hi + lo f16 halves on the way to LDS)
   int B, H, W, Cin, in_stride, Cout, Ho, Wo, dy_stride, R, S, stride, pad, dil, K, M, msplit;
   float scale;   // multiplier applied to every partial sum before it is added to dw
   int lw, lh;    // log2(Wo), log2(Ho) when both are powers of two, else -1
@@ -339,15 +411,77 @@ __device__ __forceinline__ f16x4 lds_tr_read(const f16* p) {
   return __builtin_bit_cast(f16x4, v);
 }
 
+// ---- operand pieces of the weight-gradient kernels ---------------------------------------------------------------
+// A piece = 8 consecutive channels of one pixel as it comes from global memory: one f16x8 (f16 mode) or two f32x4 (the
+// f16x3 mode, X3 = true: f32 tensors).  On the way to LDS an f32 piece is split into hi = f16(v) and lo = f16(v - hi) and
+// stored into two tiles of the same shape (the lo tile `lo_off` elements behind the hi tile); the MFMAs then run
+// dY_hi . X_hi + dY_lo . X_hi + dY_hi . X_lo with f32 accumulation (conv_common.h: the f16x3 arithmetic of the forward
+// kernels; the dropped lo . lo term is 2^-22 of the product).
+template <bool X3> struct Piece;
+template <> struct Piece<false> { f16x8 v; };
+template <> struct Piece<true> { f32x4 a, b; };
+
+template <bool X3>
+__device__ __forceinline__ Piece<X3> piece_load(const char* p) {
+  Piece<X3> r;
+  if constexpr (X3) { r.a = *(const f32x4*)p; r.b = *(const f32x4*)(p + 16); }
+  else r.v = *(const f16x8*)p;
+  return r;
+}
+
+template <bool X3>
+__device__ __forceinline__ void piece_store(f16* dst, int lo_off, const Piece<X3>& r, bool ok) {
+  const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (X3) {
+    f16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hi[j] = (f16)r.a[j]; lo[j] = (f16)(r.a[j] - (float)hi[j]);
+      hi[4 + j] = (f16)r.b[j]; lo[4 + j] = (f16)(r.b[j] - (float)hi[4 + j]);
+    }
+    *(f16x8*)dst = ok ? hi : z8;
+    *(f16x8*)(dst + lo_off) = ok ? lo : z8;
+  } else {
+    *(f16x8*)dst = ok ? r.v : z8;
+  }
+}
+
+// a transposed 16 x 32 MFMA operand (8 pixels per lane of one channel) from a row-major [pixel][channel] LDS tile
+template <bool X3> struct Frag { f16x8 h; f16x8 l; };
+template <bool X3>
+__device__ __forceinline__ Frag<X3> frag_read(const f16* base, int pitch, int lo_off) {
+  Frag<X3> f;
+  {
+    const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * pitch);
+    f.h = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+  if constexpr (X3) {
+    const f16x4 lo = lds_tr_read(base + lo_off), hi = lds_tr_read(base + lo_off + 4 * pitch);
+    f.l = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+  return f;
+}
+template <bool X3>
+__device__ __forceinline__ f32x4 mma_frag(const Frag<X3>& y, const Frag<X3>& x, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(y.h, x.h, acc, 0, 0, 0);
+  if constexpr (X3) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(y.l, x.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(y.h, x.l, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 #define WG_BN 64
 #define WG_BK 128
 #define WG_BM 64            // pixels per K-loop step (two MFMA K slabs of 32)
 #define WG_LDA (WG_BK + 8)  // row padding (elements) to spread banks
 #define WG_LDY (WG_BN + 8)
-template <bool PERM>
+template <bool PERM, bool X3>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) f16 sA[WG_BM * WG_LDA];
-  __shared__ __attribute__((aligned(16))) f16 sY[WG_BM * WG_LDY];
+  constexpr int NT = X3 ? 2 : 1, ES = X3 ? 4 : 2;          // LDS tiles per operand (hi, lo); bytes per element in memory
+  constexpr int LOA = WG_BM * WG_LDA, LOY = WG_BM * WG_LDY;
+  __shared__ __attribute__((aligned(16))) f16 sA[NT * LOA];
+  __shared__ __attribute__((aligned(16))) f16 sY[NT * LOY];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid; the gx*gy workgroups of one pixel range get ids 8 apart = the same XCD / L2 (see conv_wgrad_win_kernel)
   const int gx = (a.K + WG_BK - 1) / WG_BK, gy = (a.Cout + WG_BN - 1) / WG_BN, nxy = gx * gy;
@@ -366,7 +500,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // loaders: A tile 64 rows x 128 k = 1024 16-byte groups (4 per thread); dY tile 64 x 64 = 512 groups (2 per thread)
+  // loaders: A tile 64 rows x 128 k = 1024 8-channel pieces (4 per thread); dY tile 64 x 64 = 512 pieces (2 per thread)
   const int a_row = tid >> 4, a_kg = tid & 15;      // rows a_row + 16 i ; k-group a_kg (8 channels)
   const int y_row = tid >> 3, y_ng = tid & 7;       // rows y_row + 32 i
   const int kk = k0 + a_kg * 8;
@@ -375,13 +509,16 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
   const int c0 = kk - tap * a.Cin;
   const int tr = tap / a.S, ts = tap - tr * a.S;
   const bool n_ok = n0 + y_ng * 8 < a.Cout;
+  const char* const xb = (const char*)a.x;
+  const char* const yb = (const char*)a.dy;
 
   const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
-  f16x8 av[4], yv[2];
-  const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  // the 64-pixel slab `mb` of both operands into registers (unconditional loads from clamped addresses + select, so the
-  // loads of the next slab stay in flight behind the MFMAs of the current one)
+  Piece<X3> av[4], yv[2];
+  unsigned okbits = 0;
+  // the 64-pixel slab `mb` of both operands into registers (unconditional loads from clamped addresses, zeroed when they
+  // go to LDS, so the loads of the next slab stay in flight behind the MFMAs of the current one)
   auto fetch = [&](int mb) {
+    okbits = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = mb + a_row + 16 * i;
@@ -399,47 +536,39 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
       }
       const int hi = ho * a.stride - a.pad + tr * a.dil, wi = wo * a.stride - a.pad + ts * a.dil;
       const bool ok = m < m_end && k_ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-      const f16x8 v = *(const f16x8*)(ok ? a.x + ((long)(b * a.H + hi) * a.W + wi) * a.in_stride + c0 : a.x);
-      av[i] = ok ? v : z8;
+      av[i] = piece_load<X3>(ok ? xb + (((long)(b * a.H + hi) * a.W + wi) * a.in_stride + c0) * ES : xb);
+      okbits |= ok ? 1u << i : 0u;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = mb + y_row + 32 * i;
       const bool ok = m < m_end && n_ok;
-      const f16x8 v = *(const f16x8*)(ok ? a.dy + (long)m * a.dy_stride + n0 + y_ng * 8 : a.dy);
-      yv[i] = ok ? v : z8;
+      yv[i] = piece_load<X3>(ok ? yb + ((long)m * a.dy_stride + n0 + y_ng * 8) * ES : yb);
+      okbits |= ok ? 16u << i : 0u;
     }
   };
   if (m_begin < m_end) fetch(m_begin);
   for (int mb = m_begin; mb < m_end; mb += WG_BM) {
     __syncthreads();  // previous iteration's fragment reads are done
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(f16x8*)(sA + (a_row + 16 * i) * WG_LDA + a_kg * 8) = av[i];
+    for (int i = 0; i < 4; ++i) piece_store<X3>(sA + (a_row + 16 * i) * WG_LDA + a_kg * 8, LOA, av[i], (okbits >> i) & 1u);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *(f16x8*)(sY + (y_row + 32 * i) * WG_LDY + y_ng * 8) = yv[i];
+    for (int i = 0; i < 2; ++i) piece_store<X3>(sY + (y_row + 32 * i) * WG_LDY + y_ng * 8, LOY, yv[i], (okbits >> (4 + i)) & 1u);
     __syncthreads();
     if (mb + WG_BM < m_end) fetch(mb + WG_BM);
     // fragments: lane group grp covers pixels 8*grp .. 8*grp+7 of a 32-pixel K slab (two 4-row blocks); lane 4q+p
     // addresses row q, columns 4p..4p+3 of a 4x16 block and receives column li of its 4 rows
 #pragma unroll
     for (int h = 0; h < WG_BM / 32; ++h) {
-      f16x8 fy[2], fa[4];
+      Frag<X3> fy[2], fa[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const f16* base = sY + (32 * h + 8 * grp + q) * WG_LDY + wn * 32 + i * 16 + 4 * p;
-        const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * WG_LDY);
-        fy[i] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
+      for (int i = 0; i < 2; ++i) fy[i] = frag_read<X3>(sY + (32 * h + 8 * grp + q) * WG_LDY + wn * 32 + i * 16 + 4 * p, WG_LDY, LOY);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f16* base = sA + (32 * h + 8 * grp + q) * WG_LDA + wk * 64 + j * 16 + 4 * p;
-        const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * WG_LDA);
-        fa[j] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
+      for (int j = 0; j < 4; ++j) fa[j] = frag_read<X3>(sA + (32 * h + 8 * grp + q) * WG_LDA + wk * 64 + j * 16 + 4 * p, WG_LDA, LOA);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[i], fa[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mma_frag<X3>(fy[i], fa[j], acc[i][j]);
     }
   }
   // D[row = cout][col = k]: lane holds rows 4*(lane>>4)+reg, col lane&15
@@ -463,10 +592,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 // ------------------------------------------------------------------------------------------------
 // MaxPool2d(2,2) backward: the gradient goes to the first maximum in (dy,dx) scan order (PyTorch's argmax rule)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) maxpool2x2_bwd_kernel(const f16* __restrict__ x, int x_stride,
-                                                             const f16* __restrict__ dz, int dz_stride,
-                                                             f16* __restrict__ dx, int dx_stride, int B, int H, int W, int C) {
-  const int Ho = H / 2, Wo = W / 2, CV = C >> 3;
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool2x2_bwd_kernel(const T* __restrict__ x, int x_stride,
+                                                             const T* __restrict__ dz, int dz_stride,
+                                                             T* __restrict__ dx, int dx_stride, int B, int H, int W, int C) {
+  typedef typename VecT<T>::type V;
+  constexpr int N = VecT<T>::N;
+  const int Ho = H / 2, Wo = W / 2, CV = C / N;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)B * Ho * Wo * CV) return;
   const int cv = (int)(idx % CV);
@@ -476,23 +608,23 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_kernel(const f16* __restri
   const int b = (int)(t / Ho);
   const long p00 = (long)(b * H + 2 * ho) * W + 2 * wo;
   const long offs[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
-  f16x8 v[4];
+  V v[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = *(const f16x8*)(x + offs[i] * x_stride + cv * 8);
-  const f16x8 g = *(const f16x8*)(dz + ((long)(b * Ho + ho) * Wo + wo) * dz_stride + cv * 8);
-  f16x8 o[4];
+  for (int i = 0; i < 4; ++i) v[i] = *(const V*)(x + offs[i] * x_stride + cv * N);
+  const V g = *(const V*)(dz + ((long)(b * Ho + ho) * Wo + wo) * dz_stride + cv * N);
+  V o[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
+  for (int e = 0; e < N; ++e) {
     int best = 0;
     float bv = (float)v[0][e];
 #pragma unroll
     for (int i = 1; i < 4; ++i)
       if ((float)v[i][e] > bv) { bv = (float)v[i][e]; best = i; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i][e] = i == best ? g[e] : (f16)0.f;
+    for (int i = 0; i < 4; ++i) o[i][e] = i == best ? g[e] : (T)0.f;
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) *(f16x8*)(dx + offs[i] * dx_stride + cv * 8) = o[i];
+  for (int i = 0; i < 4; ++i) *(V*)(dx + offs[i] * dx_stride + cv * N) = o[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -504,18 +636,21 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_kernel(const f16* __restri
 // taps (ky1 + {0,f}, kx1 + {0,f}), so a thread (fixed 8-channel group) keeps its 4 x 8 partial sums in registers while it
 // walks the phase's pixels; partials are combined across the workgroup through LDS with plain stores (LDS float atomics
 // measured ~170 cycles per wave-instruction here) and leave as 4*C global atomics per workgroup.
-__global__ void __launch_bounds__(256) dwconvT_dw_kernel(const f16* __restrict__ x, int x_stride, const f16* __restrict__ dz,
+template <typename T>
+__global__ void __launch_bounds__(256) dwconvT_dw_kernel(const T* __restrict__ x, int x_stride, const T* __restrict__ dz,
                                                          int dz_stride, float* __restrict__ dw, int B, int H, int W, int C,
                                                          int f) {
+  typedef typename VecT<T>::type V;
+  constexpr int N = VecT<T>::N;
   extern __shared__ float part[];  // [S][4][C]
-  const int CV = C >> 3, S = 256 / CV, k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f;
+  const int CV = C / N, S = 256 / CV, k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f;
   const int cv = threadIdx.x % CV, sub = threadIdx.x / CV;
   const int ky1 = blockIdx.y / f, kx1 = blockIdx.y % f;
-  float acc[4][8];
+  float acc[4][N];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    for (int e = 0; e < N; ++e) acc[t][e] = 0.f;
   const long npos = (long)B * (H + 1) * (W + 1);
   if (sub < S) {
     for (long pos = (long)blockIdx.x * S + sub; pos < npos; pos += (long)gridDim.x * S) {
@@ -524,7 +659,7 @@ __global__ void __launch_bounds__(256) dwconvT_dw_kernel(const f16* __restrict__
       const int iy1 = (int)(t2 % (H + 1)), b = (int)(t2 / (H + 1));
       const int oy = iy1 * f + ky1 - p, ox = ix1 * f + kx1 - p;
       if (oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
-      const f16x8 g = *(const f16x8*)(dz + ((long)(b * Ho + oy) * Wo + ox) * dz_stride + cv * 8);
+      const V g = *(const V*)(dz + ((long)(b * Ho + oy) * Wo + ox) * dz_stride + cv * N);
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy) {
         const int iy = iy1 - dy;
@@ -533,16 +668,16 @@ __global__ void __launch_bounds__(256) dwconvT_dw_kernel(const f16* __restrict__
         for (int dxx = 0; dxx < 2; ++dxx) {
           const int ix = ix1 - dxx;
           if (ix < 0 || ix >= W) continue;
-          const f16x8 xv = *(const f16x8*)(x + ((long)(b * H + iy) * W + ix) * x_stride + cv * 8);
+          const V xv = *(const V*)(x + ((long)(b * H + iy) * W + ix) * x_stride + cv * N);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[dy * 2 + dxx][e] += (float)xv[e] * (float)g[e];
+          for (int e = 0; e < N; ++e) acc[dy * 2 + dxx][e] += (float)xv[e] * (float)g[e];
         }
       }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) part[(sub * 4 + t) * C + cv * 8 + e] = acc[t][e];
+      for (int e = 0; e < N; ++e) part[(sub * 4 + t) * C + cv * N + e] = acc[t][e];
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 4 * C; i += 256) {
@@ -555,9 +690,12 @@ __global__ void __launch_bounds__(256) dwconvT_dw_kernel(const f16* __restrict__
 }
 
 // dx: gather the k x k output window of every input pixel
-__global__ void __launch_bounds__(256) dwconvT_dx_kernel(const f16* __restrict__ dz, int dz_stride, const float* __restrict__ w,
-                                                         f16* __restrict__ dx, int dx_stride, int B, int H, int W, int C, int f) {
-  const int CV = C >> 3, k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f;
+template <typename T>
+__global__ void __launch_bounds__(256) dwconvT_dx_kernel(const T* __restrict__ dz, int dz_stride, const float* __restrict__ w,
+                                                         T* __restrict__ dx, int dx_stride, int B, int H, int W, int C, int f) {
+  typedef typename VecT<T>::type V;
+  constexpr int N = VecT<T>::N;
+  const int CV = C / N, k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f;
   const long nin = (long)B * H * W * CV;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nin; idx += (long)gridDim.x * 256) {
     const int cv = (int)(idx % CV);
@@ -565,25 +703,25 @@ __global__ void __launch_bounds__(256) dwconvT_dx_kernel(const f16* __restrict__
     const int ix = (int)(pix % W);
     const long t = pix / W;
     const int iy = (int)(t % H), b = (int)(t / H);
-    float acc[8];
+    float acc[N];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int e = 0; e < N; ++e) acc[e] = 0.f;
     for (int ky = 0; ky < k; ++ky) {
       const int oy = iy * f - p + ky;
       if (oy < 0 || oy >= Ho) continue;
       for (int kx = 0; kx < k; ++kx) {
         const int ox = ix * f - p + kx;
         if (ox < 0 || ox >= Wo) continue;
-        const f16x8 g = *(const f16x8*)(dz + ((long)(b * Ho + oy) * Wo + ox) * dz_stride + cv * 8);
-        const float* wt = w + (long)(ky * k + kx) * C + cv * 8;
+        const V g = *(const V*)(dz + ((long)(b * Ho + oy) * Wo + ox) * dz_stride + cv * N);
+        const float* wt = w + (long)(ky * k + kx) * C + cv * N;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += (float)g[e] * wt[e];
+        for (int e = 0; e < N; ++e) acc[e] += (float)g[e] * wt[e];
       }
     }
-    f16x8 o;
+    V o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (f16)acc[e];
-    *(f16x8*)(dx + pix * dx_stride + cv * 8) = o;
+    for (int e = 0; e < N; ++e) o[e] = (T)acc[e];
+    *(V*)(dx + pix * dx_stride + cv * N) = o;
   }
 }
 
@@ -733,19 +871,37 @@ struct ColGeo {        // staged per (pixel, tap): 32 bytes
   float pad;
 };
 
+// 8 consecutive channels as floats (global or LDS)
+template <typename T>
+__device__ __forceinline__ void load8f(const T* p, float (&o)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    const f16x8 v = *(const f16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+  } else {
+    const f32x4 v0 = *(const f32x4*)p, v1 = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = v0[e]; o[4 + e] = v1[e]; }
+  }
+}
+
 // NT = taps per workgroup: 9, or 3 with gridDim.y = 3 (one kernel row each) when the map has fewer tiles than the chip has
 // CUs -- every tap's scatter and its d(offset) / d(mask) entries are independent of the other taps'.
-template <int NT>
-__global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __restrict__ dcol, const f16* __restrict__ x,
+// T = f16 (dcol, x f16: the f16 mode) or float (f32 dcol / x: the f16x3 training mode; the x window then takes 60 KB, 157 KB
+// in all -- one workgroup per CU either way -- and the fixed-point quantum is 2^-20 of the tile's largest dcol magnitude).
+template <int NT, typename T>
+__global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const T* __restrict__ dcol, const T* __restrict__ x,
                                                                 int x_stride, const float* __restrict__ om, int om_stride,
                                                                 float* __restrict__ dx, void* __restrict__ dom, int dom_stride,
                                                                 int dom_f16, int B, int H, int W, int Cin, int mask_is_prob,
                                                                 int chunked) {
   constexpr int TH = 8, TW = 16, MG = 4, WR = TH + 2 + 2 * MG, WC = TW + 2 + 2 * MG, NPX = WR * WC;  // 18 x 26 = 468
+  constexpr bool F32 = sizeof(T) == 4;
+  constexpr int FXB = F32 ? 20 : 19;      // fixed-point bits: 9 * 128 contributions * 2^20 < 2^31
   // d(input) window, int32 fixed point, laid out [e = channel % 8][window pixel][q = channel / 8]: the 64 lanes (16
   // pixels x 4 groups) of one ds_add then touch 64 consecutive words
   __shared__ __attribute__((aligned(16))) int dxw[NPX * 32];        // 59,904 B
-  __shared__ __attribute__((aligned(16))) f16 xw[NPX * 32];         // 29,952 B
+  __shared__ __attribute__((aligned(16))) T xw[NPX * 32];           // 29,952 B (f16) / 59,904 B (f32)
   __shared__ __attribute__((aligned(16))) ColGeo geo[9 * TH * TW];  // 36,864 B
   __shared__ float wmax[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -753,7 +909,7 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
   const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = ((blockIdx.x / tiles_x) % tiles_y) * TH;
   const int b = blockIdx.x / (tiles_x * tiles_y);
   const int wy0 = ty0 - 1 - MG, wx0 = tx0 - 1 - MG;
-  const f16* ximg = x + (long)b * H * W * x_stride;
+  const T* ximg = x + (long)b * H * W * x_stride;
   float* dximg = dx + (long)b * H * W * Cin;
   const int t0 = blockIdx.y * NT;   // first tap of this workgroup
 
@@ -791,29 +947,36 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
   const int nch = Cin / 32;
   for (int chunk = 0; chunk < nch; ++chunk) {
     // ---- this lane's dcol vectors of the chunk, and the tile's largest magnitude (fixed-point scale) ----
-    f16x8 dv[NT];
-    // chunked dcol ([Cin/32][tap][32] per pixel): the nine 64-byte pieces of this chunk are one contiguous 576-byte run
-    const f16* dcp = dcol + m * (9L * Cin) + (chunked ? chunk * 288 : chunk * 32) + q * 8;
+    float dv[NT][8];
+    // chunked dcol ([Cin/32][tap][32] per pixel): the nine 32-channel pieces of this chunk are one contiguous run
+    const T* dcp = dcol + m * (9L * Cin) + (chunked ? chunk * 288 : chunk * 32) + q * 8;
     const int tstep = chunked ? 32 : Cin;
     float amax = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (t0 + t >= 9) { dv[t] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0}; continue; }
-      dv[t] = *(const f16x8*)(dcp + (t0 + t) * tstep);
+      if (t0 + t >= 9) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)dv[t][e]));
+        for (int e = 0; e < 8; ++e) dv[t][e] = 0.f;
+        continue;
+      }
+      load8f<T>(dcp + (t0 + t) * tstep, dv[t]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(dv[t][e]));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
     __syncthreads();   // geometry staged (first chunk) / previous chunk's flush finished, wmax free
     if (lane == 0) wmax[wave] = amax;
-    // ---- stage the x window (f16) and clear the dx window ----
-    for (int i = tid; i < NPX * 4; i += 512) {
-      const int pw = i >> 2, sl = i & 3;
+    // ---- stage the x window and clear the dx window ----
+    constexpr int PV = F32 ? 4 : 8, PPX = 32 / PV;    // channels per 16-byte piece, pieces per window pixel
+    for (int i = tid; i < NPX * PPX; i += 512) {
+      const int pw = i / PPX, sl = i % PPX;
       const int y = wy0 + pw / WC, xx = wx0 + pw % WC;
-      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (y >= 0 && y < H && xx >= 0 && xx < W) v = *(const f16x8*)(ximg + ((long)y * W + xx) * x_stride + chunk * 32 + sl * 8);
-      *(f16x8*)(xw + pw * 32 + sl * 8) = v;
+      typename VecT<T>::type v;
+#pragma unroll
+      for (int e = 0; e < PV; ++e) v[e] = (T)0.f;
+      if (y >= 0 && y < H && xx >= 0 && xx < W) v = *(const typename VecT<T>::type*)(ximg + ((long)y * W + xx) * x_stride + chunk * 32 + sl * PV);
+      *(typename VecT<T>::type*)(xw + pw * 32 + sl * PV) = v;
     }
     for (int i = tid; i < NPX * 8; i += 512) *(int4*)(dxw + i * 4) = make_int4(0, 0, 0, 0);
     __syncthreads();
@@ -821,43 +984,67 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
 #pragma unroll
     for (int i = 0; i < 8; ++i) tmax = fmaxf(tmax, wmax[i]);
     int ex = 0;
-    (void)frexpf(tmax, &ex);                       // tmax = f * 2^ex, f in [0.5, 1)  =>  tmax * 2^(19-ex) < 2^19
-    const float fscale = ldexpf(1.f, 19 - ex), finv = ldexpf(1.f, ex - 19);
+    (void)frexpf(tmax, &ex);                       // tmax = f * 2^ex, f in [0.5, 1)  =>  tmax * 2^(FXB-ex) < 2^FXB
+    const float fscale = ldexpf(1.f, FXB - ex), finv = ldexpf(1.f, ex - FXB);
     // ---- per tap: dots for d(offset)/d(mask), scatter of d(input) ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (t0 + t >= 9) continue;
       const ColGeo g = geo[t * (TH * TW) + pl];
       if (!(g.off & 0x40000000u)) continue;            // sample outside the image: no contribution
-      const f16x8 d = dv[t];
       const bool inwin = !(g.off & 0x80000000u);
       const int base = (int)(g.off & 0x3FFFFFFFu);
       const int pix0 = (base << 2) >> 2;               // image pixel of corner 0 when the sample leaves the window
-      f16x8 v[4];
-      const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (inwin) {
-        // the window is zero-filled outside the image, so invalid corners read zeros
-        const f16* c0 = xw + base * 32 + q * 8;
-        v[0] = *(const f16x8*)c0; v[1] = *(const f16x8*)(c0 + 32);
-        v[2] = *(const f16x8*)(c0 + WC * 32); v[3] = *(const f16x8*)(c0 + WC * 32 + 32);
-      } else {
-        const f16* c0 = ximg + (long)pix0 * x_stride + chunk * 32 + q * 8;
-        v[0] = (g.valid & 1u) ? *(const f16x8*)c0 : z8;
-        v[1] = (g.valid & 2u) ? *(const f16x8*)(c0 + x_stride) : z8;
-        v[2] = (g.valid & 4u) ? *(const f16x8*)(c0 + (long)W * x_stride) : z8;
-        v[3] = (g.valid & 8u) ? *(const f16x8*)(c0 + (long)(W + 1) * x_stride) : z8;
-      }
       float sq[4];
+      if constexpr (F32) {
+        float v[4][8];
+        if (inwin) {
+          // the window is zero-filled outside the image, so invalid corners read zeros
+          const T* c0 = xw + base * 32 + q * 8;
+          load8f<T>(c0, v[0]); load8f<T>(c0 + 32, v[1]); load8f<T>(c0 + WC * 32, v[2]); load8f<T>(c0 + WC * 32 + 32, v[3]);
+        } else {
+          const T* c0 = ximg + (long)pix0 * x_stride + chunk * 32 + q * 8;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float a = 0.f;
+          for (int c = 0; c < 4; ++c) {
+            if (g.valid & (1u << c)) load8f<T>(c0 + ((long)(c >> 1) * W + (c & 1)) * x_stride, v[c]);
+            else {
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          typedef f16 f16x2 __attribute__((ext_vector_type(2)));
-          const f16x2 dd = {d[e], d[e + 1]}, vv = {v[c][e], v[c][e + 1]};
-          a = __builtin_amdgcn_fdot2(dd, vv, a, false);
+              for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+            }
+          }
         }
-        sq[c] = a;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float a2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a2 = fmaf(dv[t][e], v[c][e], a2);
+          sq[c] = a2;
+        }
+      } else {
+        f16x8 v[4];
+        const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (inwin) {
+          const f16* c0 = (const f16*)xw + base * 32 + q * 8;
+          v[0] = *(const f16x8*)c0; v[1] = *(const f16x8*)(c0 + 32);
+          v[2] = *(const f16x8*)(c0 + WC * 32); v[3] = *(const f16x8*)(c0 + WC * 32 + 32);
+        } else {
+          const f16* c0 = (const f16*)ximg + (long)pix0 * x_stride + chunk * 32 + q * 8;
+          v[0] = (g.valid & 1u) ? *(const f16x8*)c0 : z8;
+          v[1] = (g.valid & 2u) ? *(const f16x8*)(c0 + x_stride) : z8;
+          v[2] = (g.valid & 4u) ? *(const f16x8*)(c0 + (long)W * x_stride) : z8;
+          v[3] = (g.valid & 8u) ? *(const f16x8*)(c0 + (long)(W + 1) * x_stride) : z8;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float a2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+            const f16x2 dd = {(f16)dv[t][e], (f16)dv[t][e + 1]}, vv = {v[c][e], v[c][e + 1]};
+            a2 = __builtin_amdgcn_fdot2(dd, vv, a2, false);
+          }
+          sq[c] = a2;
+        }
       }
       const float w0 = g.hh * g.hw, w1 = g.hh * g.lw, w2 = g.lh * g.hw, w3 = g.lh * g.lw;
       s_val[t] += w0 * sq[0] + w1 * sq[1] + w2 * sq[2] + w3 * sq[3];
@@ -873,7 +1060,7 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
           int* ap = a0 + ((c >> 1) * WC + (c & 1)) * 4;
           const float ws = wq[c] * fscale;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) atomicAdd(ap + e * (NPX * 4), (int)rintf(ws * (float)d[e]));
+          for (int e = 0; e < 8; ++e) atomicAdd(ap + e * (NPX * 4), (int)rintf(ws * dv[t][e]));
         }
       } else {
 #pragma unroll
@@ -881,7 +1068,7 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const f16* __res
           if (!(g.valid & (1u << c))) continue;
           float* ap = dximg + (long)(pix0 + (c >> 1) * W + (c & 1)) * Cin + chunk * 32 + q * 8;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) atomicAdd(ap + e, wq[c] * (float)d[e]);
+          for (int e = 0; e < 8; ++e) atomicAdd(ap + e, wq[c] * dv[t][e]);
         }
       }
     }
@@ -918,60 +1105,107 @@ static inline unsigned nblk256(long n) { return (unsigned)((n + 255) / 256); }
 // 1024 block partials of (sum0, sum1) per channel + the two finalized sums the BN backward apply pass reads
 size_t chan_reduce_workspace_bytes(int C) { return (size_t)(1024 * 2 + 2) * C * sizeof(float); }
 
-static int chan_blocks(int M, int C) {
-  const int rows = 256 / (C / 8);
+static int chan_blocks(int M, int C, int N) {
+  const int rows = 256 / (C / N);
   long nb = ((long)M + rows * 8 - 1) / (rows * 8);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
 
-int launch_bn_train_fwd(const f16* y, int y_stride, const f16* res, int res_stride, f16* z, int z_stride, int M, int C,
-                        const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                        float* running_var, float* mean, float* invstd, float* scale, float* shift, void* workspace,
-                        int relu, hipStream_t s) {
-  CTDET_CHECK(C % 8 == 0 && C / 8 <= 256, "bn: unsupported channel count %d", C);
-  ChanRedArgs a = {};
+template <typename T>
+static int launch_bn_train_fwd_t(const T* y, int y_stride, const T* res, int res_stride, T* z, int z_stride, int M, int C,
+                                 const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                 float* running_var, float* mean, float* invstd, float* scale, float* shift, void* workspace,
+                                 int relu, hipStream_t s) {
+  constexpr int N = VecT<T>::N;
+  CTDET_CHECK(C % N == 0 && C / N <= 256, "bn: unsupported channel count %d", C);
+  CTDET_CHECK(y_stride % N == 0 && z_stride % N == 0 && (!res || res_stride % N == 0) && ((((size_t)y | (size_t)z | (size_t)res)) & 15) == 0,
+              "bn: tensors must be 16-byte aligned with pixel strides that are multiples of %d", N);
+  ChanRedArgs<T> a = {};
   a.y = y; a.y_stride = y_stride; a.M = M; a.C = C; a.mode = 0; a.partial = (float*)workspace;
-  const int nb = chan_blocks(M, C);
-  hipLaunchKernelGGL(chan_reduce_kernel, dim3(nb), dim3(256), 0, s, a);
+  const int nb = chan_blocks(M, C, N);
+  hipLaunchKernelGGL(chan_reduce_kernel<T>, dim3(nb), dim3(256), 0, s, a);
   hipLaunchKernelGGL(chan_finalize_kernel, dim3(C), dim3(256), 0, s, (const float*)workspace, nb, C, M, 0, eps,
                      momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
-  hipLaunchKernelGGL(affine_act_kernel, dim3(nblk256((long)M * (C / 8))), dim3(256), 0, s, y, y_stride, scale, shift, res,
-                     res_stride, z, z_stride, (long)M, C, relu);
+  const int CV = C / N;
+  if ((CV & (CV - 1)) == 0) {
+    int sh = 0;
+    while ((1 << sh) < CV) ++sh;
+    const long ppb = (256 >> sh) * AA_ROWS;
+    hipLaunchKernelGGL(affine_act_rows_kernel<T>, dim3((unsigned)(((long)M + ppb - 1) / ppb)), dim3(256), 0, s, y, y_stride,
+                       (const float*)scale, (const float*)shift, res, res_stride, z, z_stride, (long)M, sh, relu);
+  } else {
+    hipLaunchKernelGGL(affine_act_kernel<T>, dim3(nblk256((long)M * CV)), dim3(256), 0, s, y, y_stride, (const float*)scale,
+                       (const float*)shift, res, res_stride, z, z_stride, (long)M, C, relu);
+  }
   CTDET_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_bn_train_bwd(const f16* dz, int dz_stride, const f16* z, int z_stride, const f16* y, int y_stride,
-                        const float* mean, const float* invstd, const float* scale, int M, int C, int relu, f16* dy,
-                        int dy_stride, f16* dres, int dres_stride, float* dgamma, float* dbeta, float grad_mult,
-                        void* workspace, hipStream_t s) {
-  CTDET_CHECK(C % 8 == 0 && C / 8 <= 256, "bn_bwd: unsupported channel count %d", C);
-  ChanRedArgs a = {};
+template <typename T>
+static int launch_bn_train_bwd_t(const T* dz, int dz_stride, const T* z, int z_stride, const T* y, int y_stride,
+                                 const float* mean, const float* invstd, const float* scale, int M, int C, int relu, T* dy,
+                                 int dy_stride, T* dres, int dres_stride, float* dgamma, float* dbeta, float grad_mult,
+                                 void* workspace, hipStream_t s) {
+  constexpr int N = VecT<T>::N;
+  CTDET_CHECK(C % N == 0 && C / N <= 256, "bn_bwd: unsupported channel count %d", C);
+  CTDET_CHECK(dz_stride % N == 0 && dy_stride % N == 0 && (!z || z_stride % N == 0) && (!y || y_stride % N == 0) &&
+                  (!dres || dres_stride % N == 0) && ((((size_t)dz | (size_t)z | (size_t)y | (size_t)dy | (size_t)dres)) & 15) == 0,
+              "bn_bwd: tensors must be 16-byte aligned with pixel strides that are multiples of %d", N);
+  ChanRedArgs<T> a = {};
   a.y = y; a.y_stride = y_stride; a.dz = dz; a.dz_stride = dz_stride; a.z = z; a.z_stride = z_stride;
   a.mean = mean; a.invstd = invstd; a.M = M; a.C = C; a.mode = 1; a.relu = relu; a.partial = (float*)workspace;
-  const int nb = chan_blocks(M, C);
-  hipLaunchKernelGGL(chan_reduce_kernel, dim3(nb), dim3(256), 0, s, a);
+  const int nb = chan_blocks(M, C, N);
+  hipLaunchKernelGGL(chan_reduce_kernel<T>, dim3(nb), dim3(256), 0, s, a);
   float* sums = (float*)workspace + (size_t)1024 * 2 * C;   // [2][C]: sum g, sum g*xhat
   hipLaunchKernelGGL(chan_finalize_kernel, dim3(C), dim3(256), 0, s, (const float*)workspace, nb, C, M, 1,
                      grad_mult, 0.f, (const float*)nullptr, (const float*)nullptr, dbeta, dgamma, sums, sums + C,
                      (float*)nullptr, (float*)nullptr);
-  const int CV = C / 8;
+  const int CV = C / N;
   if ((CV & (CV - 1)) == 0 && CV <= 256) {
     int sh = 0;
     while ((1 << sh) < CV) ++sh;
     const long ppb = (256 >> sh) * BN_ROWS;
-    hipLaunchKernelGGL(bn_bwd_apply_rows_kernel, dim3((unsigned)(((long)M + ppb - 1) / ppb)), dim3(256), 0, s, dz, dz_stride, z,
+    hipLaunchKernelGGL(bn_bwd_apply_rows_kernel<T>, dim3((unsigned)(((long)M + ppb - 1) / ppb)), dim3(256), 0, s, dz, dz_stride, z,
                        z_stride, y, y_stride, mean, invstd, scale, (const float*)sums, (const float*)(sums + C), dy, dy_stride,
                        dres, dres_stride, (long)M, sh, relu);
   } else {
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk256((long)M * (C / 8))), dim3(256), 0, s, dz, dz_stride, z, z_stride, y,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(nblk256((long)M * CV)), dim3(256), 0, s, dz, dz_stride, z, z_stride, y,
                        y_stride, mean, invstd, scale, (const float*)sums, (const float*)(sums + C), dy, dy_stride, dres,
                        dres_stride, (long)M, C, relu);
   }
   CTDET_LAUNCH_CHECK();
   return 0;
+}
+
+int launch_bn_train_fwd(const f16* y, int y_stride, const f16* res, int res_stride, f16* z, int z_stride, int M, int C,
+                        const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                        float* running_var, float* mean, float* invstd, float* scale, float* shift, void* workspace,
+                        int relu, hipStream_t s) {
+  return launch_bn_train_fwd_t<f16>(y, y_stride, res, res_stride, z, z_stride, M, C, gamma, beta, eps, momentum, running_mean,
+                                    running_var, mean, invstd, scale, shift, workspace, relu, s);
+}
+int launch_bn_train_fwd_f32(const float* y, int y_stride, const float* res, int res_stride, float* z, int z_stride, int M, int C,
+                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, float* mean, float* invstd, float* scale, float* shift, void* workspace,
+                            int relu, hipStream_t s) {
+  return launch_bn_train_fwd_t<float>(y, y_stride, res, res_stride, z, z_stride, M, C, gamma, beta, eps, momentum, running_mean,
+                                      running_var, mean, invstd, scale, shift, workspace, relu, s);
+}
+int launch_bn_train_bwd(const f16* dz, int dz_stride, const f16* z, int z_stride, const f16* y, int y_stride,
+                        const float* mean, const float* invstd, const float* scale, int M, int C, int relu, f16* dy,
+                        int dy_stride, f16* dres, int dres_stride, float* dgamma, float* dbeta, float grad_mult,
+                        void* workspace, hipStream_t s) {
+  return launch_bn_train_bwd_t<f16>(dz, dz_stride, z, z_stride, y, y_stride, mean, invstd, scale, M, C, relu, dy, dy_stride, dres,
+                                    dres_stride, dgamma, dbeta, grad_mult, workspace, s);
+}
+int launch_bn_train_bwd_f32(const float* dz, int dz_stride, const float* z, int z_stride, const float* y, int y_stride,
+                            const float* mean, const float* invstd, const float* scale, int M, int C, int relu, float* dy,
+                            int dy_stride, float* dres, int dres_stride, float* dgamma, float* dbeta, float grad_mult,
+                            void* workspace, hipStream_t s) {
+  return launch_bn_train_bwd_t<float>(dz, dz_stride, z, z_stride, y, y_stride, mean, invstd, scale, M, C, relu, dy, dy_stride,
+                                      dres, dres_stride, dgamma, dbeta, grad_mult, workspace, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -987,11 +1221,16 @@ int launch_bn_train_bwd(const f16* dz, int dz_stride, const f16* z, int z_stride
 // 63 -> 44, 256->256 @32^2 58 -> 40, head 64->256 @128^2 179 -> 142, offset convs (Cout 27) 68/43/26 -> 37/27/20.
 // ------------------------------------------------------------------------------------------------
 #define WW_LD 40   // LDS row pitch in f16 elements (32 channels + 8 pad: 80 bytes, spreads the transposing reads over banks)
-__global__ void __launch_bounds__(256, 2) conv_wgrad_win_kernel(const WgradArgs a) {
+// X3: f32 operands split on the way to LDS (hi and lo tiles of both operands: 95 KB, one workgroup per CU -- which is how
+// the kernel is launched anyway), three MFMAs per product
+template <bool X3>
+__global__ void __launch_bounds__(256, X3 ? 1 : 2) conv_wgrad_win_kernel(const WgradArgs a) {
   constexpr int TH = 8, TW = 32, WC = TW + 2, NWIN = (TH + 2) * WC;   // 340 window pixels
-  __shared__ __attribute__((aligned(16))) f16 sm[(TH * TW + NWIN) * WW_LD];   // 47680 B; the first 36864 B hold the f32 sums at the end
+  constexpr int NT = X3 ? 2 : 1, ES = X3 ? 4 : 2;
+  constexpr int LOY = TH * TW * WW_LD, LOX = NWIN * WW_LD;
+  __shared__ __attribute__((aligned(16))) f16 sm[NT * (LOY + LOX)];   // 47680 B per tile set; the first 36864 B hold the f32 sums at the end
   f16* const sY = sm;
-  f16* const sX = sm + TH * TW * WW_LD;
+  f16* const sX = sm + NT * LOY;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid of gx*gy*split workgroups.  Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2):
   // the gx*gy workgroups that walk the SAME pixel range (all channel tiles of it) are given ids 8 apart, so that they share
@@ -1013,15 +1252,15 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_win_kernel(const WgradArgs 
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // Operand pieces of 16 bytes, piece = tid + 256*i: dY 256 pixels x 4 cout groups (i < 4), window 340 pixels x 4 cin groups
+  // Operand pieces of 8 channels, piece = tid + 256*i: dY 256 pixels x 4 cout groups (i < 4), window 340 pixels x 4 cin groups
   // (i < 6).  The channel group is tid & 3 for every piece; the pixel of a piece inside the tile / window does not depend on
   // the tile, so its offset and its border flags (first / last window row / column, past the window) are computed once.
   // Loads are unconditional from a selected 32-bit byte offset (0 when the pixel is outside the image) and the zeroing
   // happens when the registers go to LDS one tile later: nothing in the loop waits on a load it has just issued.
   const int g = tid & 3, pix = tid >> 2;
   const bool n_ok = n0 + g * 8 < a.Cout;
-  const unsigned y_first = (unsigned)((((pix >> 5) * a.W + (pix & 31)) * a.dy_stride + n0 + g * 8) * 2);
-  const unsigned y_step = (unsigned)(2 * a.W * a.dy_stride * 2);      // 64 pixels of the tile = two rows further down
+  const unsigned y_first = (unsigned)((((pix >> 5) * a.W + (pix & 31)) * a.dy_stride + n0 + g * 8) * ES);
+  const unsigned y_step = (unsigned)(2 * a.W * a.dy_stride * ES);      // 64 pixels of the tile = two rows further down
   int woff[6];
   unsigned wflags = 0;
 #pragma unroll
@@ -1032,10 +1271,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_win_kernel(const WgradArgs 
                        (wpx >= NWIN ? 16u : 0u);
     wflags |= f << (5 * i);
   }
-  const char* const xbase = (const char*)(a.x + c0 + g * 8);
+  const char* const xbase = (const char*)a.x + (size_t)(c0 + g * 8) * ES;
   const char* const ybase = (const char*)a.dy;
-  const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  f16x8 yv[4], xv[6];
+  Piece<X3> yv[4], xv[6];
   unsigned okbits = 0;
   auto fetch = [&](int tile) {
     const int txi = tile % tiles_x, tq = tile / tiles_x, tyi = tq % tiles_y, b = tq / tiles_y;
@@ -1043,18 +1281,18 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_win_kernel(const WgradArgs 
     const unsigned edge = (tyi == 0 ? 1u : 0u) | (tyi == tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) | (txi == tiles_x - 1 ? 8u : 0u);
     const unsigned bad = wflags & (edge * 0x02108421u | 0x21084210u);
     const int tile_pix = (b * a.H + ty0 - 1) * a.W + tx0 - 1;
-    const unsigned ytile = (unsigned)(((b * a.H + ty0) * a.W + tx0) * a.dy_stride * 2);
+    const unsigned ytile = (unsigned)(((b * a.H + ty0) * a.W + tx0) * a.dy_stride * ES);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const unsigned off = n_ok ? ytile + y_first + y_step * i : 0u;
-      yv[i] = *(const f16x8*)(ybase + off);
+      yv[i] = piece_load<X3>(ybase + off);
     }
     okbits = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const bool ok = ((bad >> (5 * i)) & 31u) == 0u;
-      const unsigned off = ok ? (unsigned)((tile_pix + woff[i]) * a.in_stride * 2) : 0u;
-      xv[i] = *(const f16x8*)(xbase + off);
+      const unsigned off = ok ? (unsigned)((tile_pix + woff[i]) * a.in_stride * ES) : 0u;
+      xv[i] = piece_load<X3>(xbase + off);
       okbits |= ok ? 1u << i : 0u;
     }
   };
@@ -1063,34 +1301,26 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_win_kernel(const WgradArgs 
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();   // the previous tile's fragment reads are done
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(f16x8*)(sY + (pix + 64 * i) * WW_LD + g * 8) = n_ok ? yv[i] : z8;
+    for (int i = 0; i < 4; ++i) piece_store<X3>(sY + (pix + 64 * i) * WW_LD + g * 8, LOY, yv[i], n_ok);
 #pragma unroll
     for (int i = 0; i < 6; ++i)
-      if (pix + 64 * i < NWIN) *(f16x8*)(sX + (pix + 64 * i) * WW_LD + g * 8) = (okbits >> i) & 1u ? xv[i] : z8;
+      if (pix + 64 * i < NWIN) piece_store<X3>(sX + (pix + 64 * i) * WW_LD + g * 8, LOX, xv[i], (okbits >> i) & 1u);
     __syncthreads();
     if (tile + 1 < t_end) fetch(tile + 1);
     // dY fragments of this wave's two tile rows (K slabs of 32 pixels), both cout tiles: kept for all nine taps
-    f16x8 fy[2][2];
+    Frag<X3> fy[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const f16* base = sY + ((2 * wave + h) * TW + 8 * grp + q) * WW_LD + i * 16 + 4 * p;
-        const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * WW_LD);
-        fy[h][i] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
+      for (int i = 0; i < 2; ++i) fy[h][i] = frag_read<X3>(sY + ((2 * wave + h) * TW + 8 * grp + q) * WW_LD + i * 16 + 4 * p, WW_LD, LOY);
     // window rows 2*wave .. 2*wave+3: row v serves tap row v of tile row 0 and tap row v-1 of tile row 1
 #pragma unroll
     for (int v = 0; v < 4; ++v)
 #pragma unroll
       for (int ts = 0; ts < 3; ++ts) {
-        f16x8 fx[2];
+        Frag<X3> fx[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const f16* base = sX + ((2 * wave + v) * WC + ts + 8 * grp + q) * WW_LD + j * 16 + 4 * p;
-          const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * WW_LD);
-          fx[j] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
+        for (int j = 0; j < 2; ++j) fx[j] = frag_read<X3>(sX + ((2 * wave + v) * WC + ts + 8 * grp + q) * WW_LD + j * 16 + 4 * p, WW_LD, LOX);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int tr = v - h;
@@ -1098,8 +1328,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_win_kernel(const WgradArgs 
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[tr * 3 + ts][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[h][i], fx[j], acc[tr * 3 + ts][i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[tr * 3 + ts][i][j] = mma_frag<X3>(fy[h][i], fx[j], acc[tr * 3 + ts][i][j]);
         }
       }
   }
@@ -1143,20 +1372,21 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_win_kernel(const WgradArgs 
 // owns two tile rows and loads each window row's operand once for both.  The odd tap of a 7-wide row pairs with a column
 // that does not exist; those eight D columns are dropped in the epilogue.  Epilogue as in conv_wgrad_win_kernel.
 // ------------------------------------------------------------------------------------------------
-template <int KS, int CIN>
+template <int KS, int CIN, bool X3>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_narrow_kernel(const WgradArgs a) {
   constexpr int TH = 8, TW = 32, PADK = KS / 2, WR = TH + KS - 1, WCOL = TW + KS - 1, NWIN = WR * WCOL;
-  constexpr int SUB = CIN / 8;                             // 16-byte pieces per pixel
+  constexpr int SUB = CIN / 8;                             // 8-channel pieces per pixel
   constexpr int NROUND = (NWIN * SUB + 255) / 256;
   constexpr int NP = CIN == 8 ? (KS + 1) / 2 : KS;         // column tiles per kernel row
   constexpr int NT = KS * NP;
   constexpr int LDY = 24;                                  // dY row pitch: 16 couts + 8 pad
   constexpr int Y_ELEMS = TH * TW * LDY, X_ELEMS = (NWIN + 8) * CIN;
-  constexpr int SM_BYTES = (X_ELEMS + Y_ELEMS) * 2 > NT * 1024 ? (X_ELEMS + Y_ELEMS) * 2 : NT * 1024;
+  constexpr int NS = X3 ? 2 : 1, ES = X3 ? 4 : 2;
+  constexpr int SM_BYTES = NS * (X_ELEMS + Y_ELEMS) * 2 > NT * 1024 ? NS * (X_ELEMS + Y_ELEMS) * 2 : NT * 1024;
   static_assert(NROUND <= 6, "border flags are 5 bits per round in one word");
   __shared__ __attribute__((aligned(16))) unsigned char smraw[SM_BYTES];
   f16* const sY = (f16*)smraw;
-  f16* const sX = sY + Y_ELEMS;
+  f16* const sX = sY + NS * Y_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = a.W / TW, tiles_y = a.H / TH, ntiles = a.B * tiles_y * tiles_x;
   const int per = (ntiles + gridDim.x - 1) / gridDim.x;
@@ -1166,11 +1396,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_narrow_kernel(const WgradAr
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // 16-byte pieces, piece = tid + 256*i: dY 256 pixels x 2 cout groups (i < 2); window NWIN pixels x SUB channel groups
+  // 8-channel pieces, piece = tid + 256*i: dY 256 pixels x 2 cout groups (i < 2); window NWIN pixels x SUB channel groups
   const int yg = tid & 1, ypix = tid >> 1;
   const bool n_ok = yg * 8 < a.Cout;
-  const unsigned y_first = (unsigned)((((ypix >> 5) * a.W + (ypix & 31)) * a.dy_stride + yg * 8) * 2);
-  const unsigned y_step = (unsigned)(4 * a.W * a.dy_stride * 2);     // 128 pixels of the tile = four rows further down
+  const unsigned y_first = (unsigned)((((ypix >> 5) * a.W + (ypix & 31)) * a.dy_stride + yg * 8) * ES);
+  const unsigned y_step = (unsigned)(4 * a.W * a.dy_stride * ES);     // 128 pixels of the tile = four rows further down
   const int sub = SUB == 2 ? tid & 1 : 0, wpix = SUB == 2 ? tid >> 1 : tid;
   constexpr int WSTEP = 256 / SUB;
   int woff[NROUND];
@@ -1185,10 +1415,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_narrow_kernel(const WgradAr
     rep |= 1u << (5 * i);
     beyond |= 16u << (5 * i);
   }
-  const char* const xbase = (const char*)(a.x + sub * 8);
+  const char* const xbase = (const char*)a.x + (size_t)(sub * 8) * ES;
   const char* const ybase = (const char*)a.dy;
-  const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  f16x8 yv[2], xv[NROUND];
+  Piece<X3> yv[2], xv[NROUND];
   unsigned okbits = 0;
   auto fetch = [&](int tile) {
     const int txi = tile % tiles_x, tq = tile / tiles_x, tyi = tq % tiles_y, b = tq / tiles_y;
@@ -1196,18 +1425,18 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_narrow_kernel(const WgradAr
     const unsigned edge = (tyi == 0 ? 1u : 0u) | (tyi == tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) | (txi == tiles_x - 1 ? 8u : 0u);
     const unsigned bad = wflags & (edge * rep | beyond);
     const int tile_pix = (b * a.H + ty0 - PADK) * a.W + tx0 - PADK;
-    const unsigned ytile = (unsigned)(((b * a.H + ty0) * a.W + tx0) * a.dy_stride * 2);
+    const unsigned ytile = (unsigned)(((b * a.H + ty0) * a.W + tx0) * a.dy_stride * ES);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const unsigned off = n_ok ? ytile + y_first + y_step * i : 0u;
-      yv[i] = *(const f16x8*)(ybase + off);
+      yv[i] = piece_load<X3>(ybase + off);
     }
     okbits = 0;
 #pragma unroll
     for (int i = 0; i < NROUND; ++i) {
       const bool ok = ((bad >> (5 * i)) & 31u) == 0u;
-      const unsigned off = ok ? (unsigned)((tile_pix + woff[i]) * a.in_stride * 2) : 0u;
-      xv[i] = *(const f16x8*)(xbase + off);
+      const unsigned off = ok ? (unsigned)((tile_pix + woff[i]) * a.in_stride * ES) : 0u;
+      xv[i] = piece_load<X3>(xbase + off);
       okbits |= ok ? 1u << i : 0u;
     }
   };
@@ -1216,33 +1445,27 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_narrow_kernel(const WgradAr
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();   // the previous tile's fragment reads are done
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *(f16x8*)(sY + (ypix + 128 * i) * LDY + yg * 8) = n_ok ? yv[i] : z8;
+    for (int i = 0; i < 2; ++i) piece_store<X3>(sY + (ypix + 128 * i) * LDY + yg * 8, Y_ELEMS, yv[i], n_ok);
 #pragma unroll
     for (int i = 0; i < NROUND; ++i)
-      if (wpix + WSTEP * i < NWIN) *(f16x8*)(sX + (wpix + WSTEP * i) * CIN + sub * 8) = (okbits >> i) & 1u ? xv[i] : z8;
+      if (wpix + WSTEP * i < NWIN) piece_store<X3>(sX + (wpix + WSTEP * i) * CIN + sub * 8, X_ELEMS, xv[i], (okbits >> i) & 1u);
     __syncthreads();
     if (tile + 1 < t_end) fetch(tile + 1);
-    f16x8 fy[2];
+    Frag<X3> fy[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const f16* base = sY + ((2 * wave + h) * TW + 8 * grp + q) * LDY + 4 * p;
-      const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * LDY);
-      fy[h] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
+    for (int h = 0; h < 2; ++h) fy[h] = frag_read<X3>(sY + ((2 * wave + h) * TW + 8 * grp + q) * LDY + 4 * p, LDY, Y_ELEMS);
     // window rows 2*wave .. 2*wave+KS: row v serves tap row v of the first tile row and v-1 of the second
 #pragma unroll
     for (int v = 0; v <= KS; ++v)
 #pragma unroll
       for (int pr = 0; pr < NP; ++pr) {
         const int s0 = CIN == 8 ? 2 * pr : pr;
-        const f16* base = sX + ((2 * wave + v) * WCOL + s0 + 8 * grp + q) * CIN + 4 * p;
-        const f16x4 lo = lds_tr_read(base), hi = lds_tr_read(base + 4 * CIN);
-        const f16x8 fx = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const Frag<X3> fx = frag_read<X3>(sX + ((2 * wave + v) * WCOL + s0 + 8 * grp + q) * CIN + 4 * p, CIN, X_ELEMS);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int tr = v - h;
           if (tr < 0 || tr >= KS) continue;
-          acc[tr * NP + pr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[h], fx, acc[tr * NP + pr], 0, 0, 0);
+          acc[tr * NP + pr] = mma_frag<X3>(fy[h], fx, acc[tr * NP + pr]);
         }
       }
   }
@@ -1322,18 +1545,21 @@ int launch_grad_scatter_oihw(const void* const* src, void* const* dst, const int
 
 static int device_cu_count() { return ctdet_device_cu_count(); }
 
-int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
+template <bool X3>
+static int launch_conv_wgrad_t(const WgradArgs& a0, hipStream_t s) {
   WgradArgs a = a0;
+  constexpr int ES = X3 ? 4 : 2;
   const bool window_ok = a.stride == 1 && a.dil == 1 && a.R == a.S && a.pad == a.R / 2 && a.H % 8 == 0 && a.W % 32 == 0 &&
                          a.Ho == a.H && a.Wo == a.W && a.in_stride % 8 == 0 && a.dy_stride % 8 == 0 &&
-                         (long)a.B * a.H * a.W * (a.in_stride > a.dy_stride ? a.in_stride : a.dy_stride) * 2 < (1L << 31) &&
+                         (long)a.B * a.H * a.W * (a.in_stride > a.dy_stride ? a.in_stride : a.dy_stride) * ES < (1L << 31) &&
                          !(ctdet_tuning_flags() & CTDET_TUNE_NO_WGRAD_WINDOW);
+  CTDET_CHECK((((size_t)a.x | (size_t)a.dy) & 15) == 0, "wgrad: x and dy must be 16-byte aligned");
   if (window_ok && a.Cout <= 16 && ((a.R == 7 && a.Cin == 8) || (a.R == 3 && a.Cin == 16))) {
     const int ntiles = a.B * (a.H / 8) * (a.W / 32);
     int blocks = device_cu_count();   // 1x / 2x / 4x CUs measured the same within noise; fewest atomics wins
     if (blocks > ntiles) blocks = ntiles;
-    if (a.R == 7) hipLaunchKernelGGL((conv_wgrad_narrow_kernel<7, 8>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_wgrad_narrow_kernel<3, 16>), dim3(blocks), dim3(256), 0, s, a);
+    if (a.R == 7) hipLaunchKernelGGL((conv_wgrad_narrow_kernel<7, 8, X3>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_narrow_kernel<3, 16, X3>), dim3(blocks), dim3(256), 0, s, a);
     CTDET_LAUNCH_CHECK();
     return 0;
   }
@@ -1347,7 +1573,7 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
     if (split < 1) split = 1;
     if (split > ntiles) split = ntiles;
     a.msplit = split;
-    hipLaunchKernelGGL(conv_wgrad_win_kernel, dim3(gx * gy * split), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(conv_wgrad_win_kernel<X3>, dim3(gx * gy * split), dim3(256), 0, s, a);
     CTDET_LAUNCH_CHECK();
     return 0;
   }
@@ -1366,11 +1592,13 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
     while ((1 << a.lw) < a.Wo) ++a.lw;
     while ((1 << a.lh) < a.Ho) ++a.lh;
   }
-  if (a.perm_rs) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(gx * gy * split), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(gx * gy * split), dim3(256), 0, s, a);
+  if (a.perm_rs) hipLaunchKernelGGL((conv_wgrad_kernel<true, X3>), dim3(gx * gy * split), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<false, X3>), dim3(gx * gy * split), dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
+int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) { return launch_conv_wgrad_t<false>(a, s); }
+int launch_conv_wgrad_x3(const WgradArgs& a, hipStream_t s) { return launch_conv_wgrad_t<true>(a, s); }
 
 // ------------------------------------------------------------------------------------------------
 // depth-to-space for the input gradient of a stride-2 3x3 convolution.  dx of such a conv splits into four output phases
@@ -1378,9 +1606,12 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t s) {
 // convolution over dY with 4*C output channels (16 tap-products per output quad instead of the 36 of the zero-stuffed
 // form) and this kernel interleaves them:  dst[b, y, x, c] = src[b, (y+1)/2, (x+1)/2, ((y&1)*2 + (x&1))*C + c].
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) depth_to_space2_kernel(const f16* __restrict__ src, int src_stride, f16* __restrict__ dst,
+template <typename T>
+__global__ void __launch_bounds__(256) depth_to_space2_kernel(const T* __restrict__ src, int src_stride, T* __restrict__ dst,
                                                               int dst_stride, int B, int H, int W, int C, int Hs, int Ws) {
-  const int CV = C >> 3;
+  typedef typename VecT<T>::type V;
+  constexpr int N = VecT<T>::N;
+  const int CV = C / N;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)B * H * W * CV) return;
   const int cv = (int)(idx % CV);
@@ -1390,48 +1621,78 @@ __global__ void __launch_bounds__(256) depth_to_space2_kernel(const f16* __restr
   const int b = (int)(t / H);
   const int phase = (y & 1) * 2 + (x & 1);
   const long sp = ((long)b * Hs + ((y + 1) >> 1)) * Ws + ((x + 1) >> 1);
-  *(f16x8*)(dst + ((long)(b * H + y) * W + x) * dst_stride + cv * 8) = *(const f16x8*)(src + sp * src_stride + phase * C + cv * 8);
+  *(V*)(dst + ((long)(b * H + y) * W + x) * dst_stride + cv * N) = *(const V*)(src + sp * src_stride + phase * C + cv * N);
 }
 
-int launch_depth_to_space2(const f16* src, int src_stride, f16* dst, int dst_stride, int B, int H, int W, int C, int Hs, int Ws,
-                           hipStream_t s) {
-  CTDET_CHECK(C % 8 == 0 && src_stride % 8 == 0 && dst_stride % 8 == 0 && src_stride >= 4 * C,
-              "depth_to_space2: C=%d / strides must be multiples of 8, src_stride >= 4*C", C);
+template <typename T>
+static int launch_depth_to_space2_t(const T* src, int src_stride, T* dst, int dst_stride, int B, int H, int W, int C, int Hs, int Ws,
+                                    hipStream_t s) {
+  constexpr int N = VecT<T>::N;
+  CTDET_CHECK(C % N == 0 && src_stride % N == 0 && dst_stride % N == 0 && src_stride >= 4 * C,
+              "depth_to_space2: C=%d / strides must be multiples of %d, src_stride >= 4*C", C, N);
   CTDET_CHECK(Hs >= (H + 1) / 2 + ((H & 1) ? 0 : 1) && Ws >= (W + 1) / 2 + ((W & 1) ? 0 : 1), "depth_to_space2: source map %dx%d too small for %dx%d", Hs, Ws, H, W);
-  const long total = (long)B * H * W * (C / 8);
+  const long total = (long)B * H * W * (C / N);
   if (total == 0) return 0;
-  hipLaunchKernelGGL(depth_to_space2_kernel, dim3(nblk256(total)), dim3(256), 0, s, src, src_stride, dst, dst_stride, B, H, W, C,
+  hipLaunchKernelGGL(depth_to_space2_kernel<T>, dim3(nblk256(total)), dim3(256), 0, s, src, src_stride, dst, dst_stride, B, H, W, C,
                      Hs, Ws);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
+int launch_depth_to_space2(const void* src, int src_stride, void* dst, int dst_stride, int B, int H, int W, int C, int Hs, int Ws,
+                           int dtype, hipStream_t s) {
+  if (dtype == CTDET_F32)
+    return launch_depth_to_space2_t<float>((const float*)src, src_stride, (float*)dst, dst_stride, B, H, W, C, Hs, Ws, s);
+  return launch_depth_to_space2_t<f16>((const f16*)src, src_stride, (f16*)dst, dst_stride, B, H, W, C, Hs, Ws, s);
+}
 
-int launch_maxpool2x2_bwd(const f16* x, int x_stride, const f16* dz, int dz_stride, f16* dx, int dx_stride, int B, int H,
-                          int W, int C, hipStream_t s) {
-  CTDET_CHECK(C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool_bwd: bad shape");
-  const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+template <typename T>
+static int launch_maxpool2x2_bwd_t(const T* x, int x_stride, const T* dz, int dz_stride, T* dx, int dx_stride, int B, int H,
+                                   int W, int C, hipStream_t s) {
+  constexpr int N = VecT<T>::N;
+  CTDET_CHECK(C % N == 0 && H % 2 == 0 && W % 2 == 0 && x_stride % N == 0 && dz_stride % N == 0 && dx_stride % N == 0,
+              "maxpool_bwd: bad shape");
+  const long total = (long)B * (H / 2) * (W / 2) * (C / N);
   if (total == 0) return 0;
-  hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(nblk256(total)), dim3(256), 0, s, x, x_stride, dz, dz_stride, dx, dx_stride, B,
+  hipLaunchKernelGGL(maxpool2x2_bwd_kernel<T>, dim3(nblk256(total)), dim3(256), 0, s, x, x_stride, dz, dz_stride, dx, dx_stride, B,
                      H, W, C);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
+int launch_maxpool2x2_bwd(const f16* x, int x_stride, const f16* dz, int dz_stride, f16* dx, int dx_stride, int B, int H,
+                          int W, int C, hipStream_t s) {
+  return launch_maxpool2x2_bwd_t<f16>(x, x_stride, dz, dz_stride, dx, dx_stride, B, H, W, C, s);
+}
+int launch_maxpool2x2_bwd_f32(const float* x, int x_stride, const float* dz, int dz_stride, float* dx, int dx_stride, int B,
+                              int H, int W, int C, hipStream_t s) {
+  return launch_maxpool2x2_bwd_t<float>(x, x_stride, dz, dz_stride, dx, dx_stride, B, H, W, C, s);
+}
 
-int launch_dwconvT_bwd(const f16* x, int x_stride, const f16* dz, int dz_stride, const float* w, f16* dx, int dx_stride,
-                       float* dw, int B, int H, int W, int C, int f, hipStream_t s) {
-  CTDET_CHECK(C % 8 == 0 && f % 2 == 0 && C / 8 <= 256, "dwconvT_bwd: bad shape C=%d f=%d", C, f);
-  const int S = 256 / (C / 8);
-  const size_t lds = (size_t)S * 4 * C * sizeof(float);   // 32 KB for every C
+template <typename T>
+static int launch_dwconvT_bwd_t(const T* x, int x_stride, const T* dz, int dz_stride, const float* w, T* dx, int dx_stride,
+                                float* dw, int B, int H, int W, int C, int f, hipStream_t s) {
+  constexpr int N = VecT<T>::N;
+  CTDET_CHECK(C % N == 0 && f % 2 == 0 && C / N <= 256 && x_stride % N == 0 && dz_stride % N == 0 && dx_stride % N == 0,
+              "dwconvT_bwd: bad shape C=%d f=%d", C, f);
+  const int S = 256 / (C / N);
+  const size_t lds = (size_t)S * 4 * C * sizeof(float);   // <= 32 KB for every C
   long nb = ((long)B * (H + 1) * (W + 1) + S * 16 - 1) / (S * 16);
   if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(dwconvT_dw_kernel, dim3((unsigned)nb, (unsigned)(f * f)), dim3(256), lds, s, x, x_stride, dz, dz_stride,
+  hipLaunchKernelGGL(dwconvT_dw_kernel<T>, dim3((unsigned)nb, (unsigned)(f * f)), dim3(256), lds, s, x, x_stride, dz, dz_stride,
                      dw, B, H, W, C, f);
-  long nbx = ((long)B * H * W * (C / 8) + 255) / 256;
+  long nbx = ((long)B * H * W * (C / N) + 255) / 256;
   if (nbx > 4096) nbx = 4096;
-  hipLaunchKernelGGL(dwconvT_dx_kernel, dim3((unsigned)nbx), dim3(256), 0, s, dz, dz_stride, w, dx, dx_stride, B, H, W, C, f);
+  hipLaunchKernelGGL(dwconvT_dx_kernel<T>, dim3((unsigned)nbx), dim3(256), 0, s, dz, dz_stride, w, dx, dx_stride, B, H, W, C, f);
   CTDET_LAUNCH_CHECK();
   return 0;
+}
+int launch_dwconvT_bwd(const f16* x, int x_stride, const f16* dz, int dz_stride, const float* w, f16* dx, int dx_stride,
+                       float* dw, int B, int H, int W, int C, int f, hipStream_t s) {
+  return launch_dwconvT_bwd_t<f16>(x, x_stride, dz, dz_stride, w, dx, dx_stride, dw, B, H, W, C, f, s);
+}
+int launch_dwconvT_bwd_f32(const float* x, int x_stride, const float* dz, int dz_stride, const float* w, float* dx,
+                           int dx_stride, float* dw, int B, int H, int W, int C, int f, hipStream_t s) {
+  return launch_dwconvT_bwd_t<float>(x, x_stride, dz, dz_stride, w, dx, dx_stride, dw, B, H, W, C, f, s);
 }
 
 int launch_dcn_cols_window(const f16* x, int x_stride, const float* om, int om_stride, f16* col, int B, int H, int W, int Cin,
@@ -1450,6 +1711,23 @@ int launch_dcn_cols(const f16* x, int x_stride, const float* om, int om_stride, 
   return 0;
 }
 
+template <typename T>
+static void launch_col2im_window(const T* dcol, const T* x, int x_stride, const float* om, int om_stride, float* dx, void* dom,
+                                 int dom_stride, int dom_f16, int B, int H, int W, int Cin, int mask_is_prob, int chunked,
+                                 hipStream_t s) {
+  const unsigned tiles = (unsigned)(B * (H / 8) * (W / 16));
+  const int ncu = ctdet_device_cu_count();    // one workgroup per CU at a time: with fewer tiles, split a tile's taps
+  if ((int)tiles * 3 <= ncu)
+    hipLaunchKernelGGL((dcn_col2im_window_kernel<3, T>), dim3(tiles, 3), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
+                       dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
+  else if ((int)tiles * 2 <= ncu)
+    hipLaunchKernelGGL((dcn_col2im_window_kernel<5, T>), dim3(tiles, 2), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
+                       dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
+  else
+    hipLaunchKernelGGL((dcn_col2im_window_kernel<9, T>), dim3(tiles), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
+                       dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
+}
+
 int launch_dcn_col2im_coord(const f16* dcol, const f16* x, int x_stride, const float* om, int om_stride, float* dx,
                             void* dom, int dom_stride, int dom_f16, int B, int H, int W, int Cin, int mask_is_prob, int chunked,
                             hipStream_t s) {
@@ -1459,17 +1737,7 @@ int launch_dcn_col2im_coord(const f16* dcol, const f16* x, int x_stride, const f
   const long nwork = (long)B * H * W * 9;
   if (nwork == 0) return 0;
   if (H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && x_stride % 8 == 0 && !(ctdet_tuning_flags() & CTDET_TUNE_NO_COL2IM_WINDOW)) {
-    const unsigned tiles = (unsigned)(B * (H / 8) * (W / 16));
-    const int ncu = ctdet_device_cu_count();    // one workgroup per CU at a time: with fewer tiles, split a tile's taps
-    if ((int)tiles * 3 <= ncu)
-      hipLaunchKernelGGL(dcn_col2im_window_kernel<3>, dim3(tiles, 3), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
-                         dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
-    else if ((int)tiles * 2 <= ncu)
-      hipLaunchKernelGGL(dcn_col2im_window_kernel<5>, dim3(tiles, 2), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
-                         dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
-    else
-      hipLaunchKernelGGL(dcn_col2im_window_kernel<9>, dim3(tiles), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
-                         dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
+    launch_col2im_window<f16>(dcol, x, x_stride, om, om_stride, dx, dom, dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked, s);
     CTDET_LAUNCH_CHECK();
     return 0;
   }
@@ -1482,92 +1750,11 @@ int launch_dcn_col2im_coord(const f16* dcol, const f16* x, int x_stride, const f
 }
 
 // ================================================================================================================
-// f32 training kernels: the reference's own precision end to end (f32 activations, gradients and statistics), used to
-// show that the ALGORITHM of the training step is exact (tests compare against the fp32 oracle at 1e-3 on the losses and
-// 0.999 cosine on every gradient group).  Plain, unvectorised kernels: one thread per element or per (row lane,
-// channel); the throughput path is the f16 one above.
+// f32-tensor training kernels.  BatchNorm, pooling and the depthwise up-convolution are the templates above instantiated
+// for float (16-byte vectors of 4 channels): they serve both modes that keep f32 tensors -- f32 (the reference's own
+// arithmetic: contractions as f32 FMA chains) and f16x3 (contractions as three f16 MFMA products, f32 accumulation).
+// What is specific to the f32 mode is below: the weight gradient as plain f32 FMAs and the DCNv2 scatter with f32 atomics.
 // ================================================================================================================
-struct ChanRedArgsF {
-  const float* y; int y_stride;
-  const float* dz; int dz_stride;
-  const float* z; int z_stride;
-  const float* mean; const float* invstd;
-  int M, C, mode, relu;
-  float* partial;
-};
-
-// same contract as chan_reduce_kernel (partial[blk][2][C]); thread = (row lane, channel)
-__global__ void __launch_bounds__(256) chan_reduce_f32_kernel(ChanRedArgsF a) {
-  __shared__ float red[2][256];
-  const int CT = a.C < 256 ? a.C : 256;
-  const int rpp = 256 / CT;
-  const int ct = threadIdx.x % CT, rl = threadIdx.x / CT;
-  for (int c0 = 0; c0 < a.C; c0 += CT) {
-    const int c = c0 + ct;
-    float s0 = 0.f, s1 = 0.f;
-    if (c < a.C && rl < rpp) {
-      const float mu = (a.mode == 1 && a.y) ? a.mean[c] : 0.f, is = (a.mode == 1 && a.y) ? a.invstd[c] : 0.f;
-      for (long m = (long)blockIdx.x * rpp + rl; m < a.M; m += (long)gridDim.x * rpp) {
-        if (a.mode == 0) {
-          const float f = a.y[m * a.y_stride + c];
-          s0 += f; s1 += f * f;
-        } else {
-          float g = a.dz[m * a.dz_stride + c];
-          if (a.relu && !(a.z[m * a.z_stride + c] > 0.f)) g = 0.f;
-          s0 += g;
-          if (a.y) s1 += g * ((a.y[m * a.y_stride + c] - mu) * is);
-        }
-      }
-    }
-    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
-    __syncthreads();
-    if (c < a.C && rl == 0) {
-      for (int r = 1; r < rpp; ++r) { s0 += red[0][threadIdx.x + r * CT]; s1 += red[1][threadIdx.x + r * CT]; }
-      a.partial[((long)blockIdx.x * 2 + 0) * a.C + c] = s0;
-      a.partial[((long)blockIdx.x * 2 + 1) * a.C + c] = s1;
-    }
-    __syncthreads();
-  }
-}
-
-__global__ void __launch_bounds__(256) affine_act_f32_kernel(const float* __restrict__ y, int y_stride,
-                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                             const float* __restrict__ res, int res_stride,
-                                                             float* __restrict__ z, int z_stride, long M, int C, int relu) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= M * C) return;
-  const int c = (int)(idx % C);
-  const long m = idx / C;
-  float f = y[m * y_stride + c] * scale[c] + shift[c];
-  if (res) f += res[m * res_stride + c];
-  if (relu) f = fmaxf(f, 0.f);
-  z[m * z_stride + c] = f;
-}
-
-__global__ void __launch_bounds__(256) bn_bwd_apply_f32_kernel(const float* __restrict__ dz, int dz_stride,
-                                                               const float* __restrict__ z, int z_stride,
-                                                               const float* __restrict__ y, int y_stride,
-                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                               const float* __restrict__ scale, const float* __restrict__ s0,
-                                                               const float* __restrict__ s1, float* __restrict__ dy,
-                                                               int dy_stride, float* __restrict__ dres, int dres_stride, long M,
-                                                               int C, int relu) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= M * C) return;
-  const int c = (int)(idx % C);
-  const long m = idx / C;
-  float g = dz[m * dz_stride + c];
-  if (relu && !(z[m * z_stride + c] > 0.f)) g = 0.f;
-  const float invM = 1.f / (float)M;
-  float o = g;
-  if (y) {
-    const float xh = (y[m * y_stride + c] - mean[c]) * invstd[c];
-    o = scale[c] * (g - s0[c] * invM - xh * s1[c] * invM);
-  }
-  dy[m * dy_stride + c] = o;
-  if (dres) dres[m * dres_stride + c] = g;
-}
-
 // dW[n][k] += scale * sum_m dY[m][n] * im2col(x)[m][k], k = tap*Cin + c.  Block = 16 couts x 16 k, 16 pixels per step
 // staged in LDS, pixel range split over blockIdx.z, f32 atomics at the end.
 struct WgradArgsF {
@@ -1611,102 +1798,37 @@ __global__ void __launch_bounds__(256) conv_wgrad_f32_kernel(const WgradArgsF a)
   if (n0 + tn < a.Cout && k_ok && acc != 0.f) wg_add(a, n0 + tn, kl, acc * a.scale);
 }
 
-__global__ void __launch_bounds__(256) maxpool2x2_bwd_f32_kernel(const float* __restrict__ x, int x_stride,
-                                                                 const float* __restrict__ dz, int dz_stride,
-                                                                 float* __restrict__ dx, int dx_stride, int B, int H, int W,
-                                                                 int C) {
-  const int Ho = H / 2, Wo = W / 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)B * Ho * Wo * C) return;
-  const int c = (int)(idx % C);
-  long t = idx / C;
-  const int wo = (int)(t % Wo); t /= Wo;
-  const int ho = (int)(t % Ho);
-  const int b = (int)(t / Ho);
-  const long p00 = (long)(b * H + 2 * ho) * W + 2 * wo;
-  const long offs[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
-  int best = 0;
-  float bv = x[offs[0] * x_stride + c];
-#pragma unroll
-  for (int i = 1; i < 4; ++i) { const float v = x[offs[i] * x_stride + c]; if (v > bv) { bv = v; best = i; } }
-  const float g = dz[((long)(b * Ho + ho) * Wo + wo) * dz_stride + c];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) dx[offs[i] * dx_stride + c] = i == best ? g : 0.f;
-}
-
-__global__ void __launch_bounds__(256) dwconvT_dx_f32_kernel(const float* __restrict__ dz, int dz_stride,
-                                                             const float* __restrict__ w, float* __restrict__ dx, int dx_stride,
-                                                             int B, int H, int W, int C, int f) {
-  const int k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)B * H * W * C) return;
-  const int c = (int)(idx % C);
-  const long pix = idx / C;
-  const int ix = (int)(pix % W);
-  const long t = pix / W;
-  const int iy = (int)(t % H), b = (int)(t / H);
-  float acc = 0.f;
-  for (int ky = 0; ky < k; ++ky) {
-    const int oy = iy * f - p + ky;
-    if (oy < 0 || oy >= Ho) continue;
-    for (int kx = 0; kx < k; ++kx) {
-      const int ox = ix * f - p + kx;
-      if (ox < 0 || ox >= Wo) continue;
-      acc += dz[((long)(b * Ho + oy) * Wo + ox) * dz_stride + c] * w[(long)(ky * k + kx) * C + c];
-    }
-  }
-  dx[pix * dx_stride + c] = acc;
-}
-
-// dw[ky][kx][c] = sum over (b, iy, ix) of x * dz[b, iy*f - p + ky, ix*f - p + kx]: block = (tap, 64-channel chunk), the
-// 4 pixel lanes of a channel reduced through LDS; every dw element written once (no atomics)
-__global__ void __launch_bounds__(256) dwconvT_dw_f32_kernel(const float* __restrict__ x, int x_stride,
-                                                             const float* __restrict__ dz, int dz_stride, float* __restrict__ dw,
-                                                             int B, int H, int W, int C, int f) {
-  __shared__ float red[256];
-  const int k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f;
-  const int tap = blockIdx.x, ky = tap / k, kx = tap - ky * k;
-  const int c = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-  float acc = 0.f;
-  if (c < C)
-    for (long pos = pl; pos < (long)B * H * W; pos += 4) {
-      const int ix = (int)(pos % W);
-      const long t = pos / W;
-      const int iy = (int)(t % H), b = (int)(t / H);
-      const int oy = iy * f - p + ky, ox = ix * f - p + kx;
-      if (oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
-      acc += x[pos * x_stride + c] * dz[((long)(b * Ho + oy) * Wo + ox) * dz_stride + c];
-    }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  if (pl == 0 && c < C) dw[(long)tap * C + c] += (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
-}
-
+// col[m][tap*Cin + c] = mask * bilinear(x), f32: thread = (pixel, tap, 4 channels), the four corners as float4s; the blend in
+// the reference's operation order (kernel.cu:666-699: v1 w1 + v2 w2 + v3 w3 + v4 w4, then * mask :854-861)
 __global__ void __launch_bounds__(256) dcn_cols_f32_kernel(const float* __restrict__ x, int x_stride,
                                                            const float* __restrict__ om, int om_stride, float* __restrict__ col,
                                                            int B, int H, int W, int Cin, int mask_is_prob) {
+  const int CV = Cin >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)B * H * W * 9 * Cin) return;
-  const int c = (int)(idx % Cin);
-  long t = idx / Cin;
+  if (idx >= (long)B * H * W * 9 * CV) return;
+  const int cv = (int)(idx % CV);
+  long t = idx / CV;
   const int tap = (int)(t % 9);
   const long m = t / 9;
   const int wo = (int)(m % W);
   const long t2 = m / W;
   const int ho = (int)(t2 % H), b = (int)(t2 / H);
   const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride, mask_is_prob);
-  float v[4];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 v[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = g.off[q] >= 0 ? x[g.off[q] + c] : 0.f;
-  const float val = g.w[0] * v[0] + g.w[1] * v[1] + g.w[2] * v[2] + g.w[3] * v[3];
-  col[m * (9L * Cin) + (long)tap * Cin + c] = val * g.mask;
+  for (int q = 0; q < 4; ++q) v[q] = g.off[q] >= 0 ? *(const f32x4*)(x + g.off[q] + cv * 4) : z4;
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (g.w[0] * v[0][e] + g.w[1] * v[1][e] + g.w[2] * v[2][e] + g.w[3] * v[3][e]) * g.mask;
+  *(f32x4*)(col + m * (9L * Cin) + (long)tap * Cin + cv * 4) = o;
 }
 
 // the generic coordinate / col2im kernel above for f32 columns and inputs (same wave-per-(pixel, tap) structure)
 __global__ void __launch_bounds__(256) dcn_col2im_coord_f32_kernel(const float* __restrict__ dcol, const float* __restrict__ x,
                                                                    int x_stride, const float* __restrict__ om, int om_stride,
                                                                    float* __restrict__ dx, float* __restrict__ dom, int dom_stride, int B,
-                                                                   int H, int W, int Cin, int mask_is_prob) {
+                                                                   int H, int W, int Cin, int mask_is_prob, int chunked) {
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long nwork = (long)B * H * W * 9;
@@ -1719,9 +1841,10 @@ __global__ void __launch_bounds__(256) dcn_col2im_coord_f32_kernel(const float* 
     const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride, mask_is_prob);
     float val_dot = 0.f, dh = 0.f, dwv = 0.f;
     if (g.inside) {
-      const float* dcp = dcol + m * (9L * Cin) + (long)tap * Cin;
+      // dcol row of a pixel: [tap][Cin], or chunked [Cin/32][tap][32]
+      const float* dcp = dcol + m * (9L * Cin) + (chunked ? tap * 32 : tap * Cin);
       for (int c = lane; c < Cin; c += 64) {
-        const float d = dcp[c];
+        const float d = dcp[chunked ? (c >> 5) * 288 + (c & 31) : c];
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = g.off[q] >= 0 ? x[g.off[q] + c] : 0.f;
@@ -1745,50 +1868,6 @@ __global__ void __launch_bounds__(256) dcn_col2im_coord_f32_kernel(const float* 
   }
 }
 
-static int chan_blocks_f32(int M, int C) {
-  const int rpp = C < 256 ? 256 / C : 1;
-  long nb = ((long)M + rpp * 16 - 1) / (rpp * 16);
-  if (nb > 1024) nb = 1024;
-  if (nb < 1) nb = 1;
-  return (int)nb;
-}
-
-int launch_bn_train_fwd_f32(const float* y, int y_stride, const float* res, int res_stride, float* z, int z_stride, int M, int C,
-                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                            float* running_var, float* mean, float* invstd, float* scale, float* shift, void* workspace,
-                            int relu, hipStream_t s) {
-  ChanRedArgsF a = {};
-  a.y = y; a.y_stride = y_stride; a.M = M; a.C = C; a.mode = 0; a.partial = (float*)workspace;
-  const int nb = chan_blocks_f32(M, C);
-  hipLaunchKernelGGL(chan_reduce_f32_kernel, dim3(nb), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(chan_finalize_kernel, dim3(C), dim3(256), 0, s, (const float*)workspace, nb, C, M, 0, eps,
-                     momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
-  hipLaunchKernelGGL(affine_act_f32_kernel, dim3(nblk256((long)M * C)), dim3(256), 0, s, y, y_stride, scale, shift, res,
-                     res_stride, z, z_stride, (long)M, C, relu);
-  CTDET_LAUNCH_CHECK();
-  return 0;
-}
-
-int launch_bn_train_bwd_f32(const float* dz, int dz_stride, const float* z, int z_stride, const float* y, int y_stride,
-                            const float* mean, const float* invstd, const float* scale, int M, int C, int relu, float* dy,
-                            int dy_stride, float* dres, int dres_stride, float* dgamma, float* dbeta, float grad_mult,
-                            void* workspace, hipStream_t s) {
-  ChanRedArgsF a = {};
-  a.y = y; a.y_stride = y_stride; a.dz = dz; a.dz_stride = dz_stride; a.z = z; a.z_stride = z_stride;
-  a.mean = mean; a.invstd = invstd; a.M = M; a.C = C; a.mode = 1; a.relu = relu; a.partial = (float*)workspace;
-  const int nb = chan_blocks_f32(M, C);
-  hipLaunchKernelGGL(chan_reduce_f32_kernel, dim3(nb), dim3(256), 0, s, a);
-  float* sums = (float*)workspace + (size_t)1024 * 2 * C;
-  hipLaunchKernelGGL(chan_finalize_kernel, dim3(C), dim3(256), 0, s, (const float*)workspace, nb, C, M, 1,
-                     grad_mult, 0.f, (const float*)nullptr, (const float*)nullptr, dbeta, dgamma, sums, sums + C,
-                     (float*)nullptr, (float*)nullptr);
-  hipLaunchKernelGGL(bn_bwd_apply_f32_kernel, dim3(nblk256((long)M * C)), dim3(256), 0, s, dz, dz_stride, z, z_stride, y,
-                     y_stride, mean, invstd, scale, (const float*)sums, (const float*)(sums + C), dy, dy_stride, dres,
-                     dres_stride, (long)M, C, relu);
-  CTDET_LAUNCH_CHECK();
-  return 0;
-}
-
 int launch_conv_wgrad_f32(const WgradArgs& h, hipStream_t s) {
   WgradArgsF a;
   a.x = (const float*)h.x; a.dy = (const float*)h.dy; a.dw = h.dw;
@@ -1808,33 +1887,11 @@ int launch_conv_wgrad_f32(const WgradArgs& h, hipStream_t s) {
   return 0;
 }
 
-int launch_maxpool2x2_bwd_f32(const float* x, int x_stride, const float* dz, int dz_stride, float* dx, int dx_stride, int B,
-                              int H, int W, int C, hipStream_t s) {
-  CTDET_CHECK(H % 2 == 0 && W % 2 == 0, "maxpool_bwd: bad shape");
-  const long total = (long)B * (H / 2) * (W / 2) * C;
-  if (total == 0) return 0;
-  hipLaunchKernelGGL(maxpool2x2_bwd_f32_kernel, dim3(nblk256(total)), dim3(256), 0, s, x, x_stride, dz, dz_stride, dx,
-                     dx_stride, B, H, W, C);
-  CTDET_LAUNCH_CHECK();
-  return 0;
-}
-
-int launch_dwconvT_bwd_f32(const float* x, int x_stride, const float* dz, int dz_stride, const float* w, float* dx,
-                           int dx_stride, float* dw, int B, int H, int W, int C, int f, hipStream_t s) {
-  CTDET_CHECK(f % 2 == 0, "dwconvT_bwd: bad factor %d", f);
-  if ((long)B * H * W * C == 0) return 0;
-  hipLaunchKernelGGL(dwconvT_dw_f32_kernel, dim3(4 * f * f, (C + 63) / 64), dim3(256), 0, s, x, x_stride, dz, dz_stride, dw, B,
-                     H, W, C, f);
-  hipLaunchKernelGGL(dwconvT_dx_f32_kernel, dim3(nblk256((long)B * H * W * C)), dim3(256), 0, s, dz, dz_stride, w, dx,
-                     dx_stride, B, H, W, C, f);
-  CTDET_LAUNCH_CHECK();
-  return 0;
-}
-
 int launch_dcn_cols_f32(const float* x, int x_stride, const float* om, int om_stride, float* col, int B, int H, int W, int Cin,
                         int mask_is_prob, hipStream_t s) {
-  CTDET_CHECK(om_stride >= 27, "dcn_cols: bad shape");
-  const long total = (long)B * H * W * 9 * Cin;
+  CTDET_CHECK(om_stride >= 27 && Cin % 4 == 0 && x_stride % 4 == 0 && ((((size_t)x | (size_t)col)) & 15) == 0,
+              "dcn_cols(f32): Cin=%d / x_stride=%d must be multiples of 4, tensors 16-byte aligned", Cin, x_stride);
+  const long total = (long)B * H * W * 9 * (Cin / 4);
   if (total == 0) return 0;
   hipLaunchKernelGGL(dcn_cols_f32_kernel, dim3(nblk256(total)), dim3(256), 0, s, x, x_stride, om, om_stride, col, B, H, W, Cin,
                      mask_is_prob);
@@ -1842,15 +1899,25 @@ int launch_dcn_cols_f32(const float* x, int x_stride, const float* om, int om_st
   return 0;
 }
 
+// window = 1 (the f16x3 training mode): the LDS-window scatter with fixed-point accumulation where the shape allows;
+// window = 0 (the f32 mode): the generic kernel, plain f32 atomics
 int launch_dcn_col2im_coord_f32(const float* dcol, const float* x, int x_stride, const float* om, int om_stride, float* dx,
-                                float* dom, int dom_stride, int B, int H, int W, int Cin, int mask_is_prob, hipStream_t s) {
+                                float* dom, int dom_stride, int B, int H, int W, int Cin, int mask_is_prob, int chunked, int window,
+                                hipStream_t s) {
   CTDET_CHECK(dom_stride >= 27 && dom_stride <= 64, "dcn_col2im: dom_stride=%d", dom_stride);
   const long nwork = (long)B * H * W * 9;
   if (nwork == 0) return 0;
+  if (window && H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && x_stride % 4 == 0 && ((((size_t)x | (size_t)dcol)) & 15) == 0 &&
+      !(ctdet_tuning_flags() & CTDET_TUNE_NO_COL2IM_WINDOW)) {
+    launch_col2im_window<float>(dcol, x, x_stride, om, om_stride, dx, (void*)dom, dom_stride, 0, B, H, W, Cin, mask_is_prob, chunked, s);
+    CTDET_LAUNCH_CHECK();
+    return 0;
+  }
+  CTDET_CHECK(!chunked || Cin % 32 == 0, "dcn_col2im: the chunked dcol layout needs Cin %% 32 == 0 (Cin=%d)", Cin);
   long nb = (nwork + 3) / 4;
   if (nb > 256 * 32) nb = 256 * 32;
   hipLaunchKernelGGL(dcn_col2im_coord_f32_kernel, dim3((unsigned)nb), dim3(256), 0, s, dcol, x, x_stride, om, om_stride, dx,
-                     dom, dom_stride, B, H, W, Cin, mask_is_prob);
+                     dom, dom_stride, B, H, W, Cin, mask_is_prob, chunked);
   CTDET_LAUNCH_CHECK();
   return 0;
 }

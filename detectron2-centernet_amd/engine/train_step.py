@@ -3,8 +3,9 @@ graph of dla.py and DeformConvV2 of deform_conv.py:498-519, all modules in train
 
 The module tree is walked functionally; every node is an autograd Function from ops_train (HIP kernels forward and
 backward).  Root's torch.cat is materialised here (a device copy) -- the concat-free multi-source kernel is
-inference-only for now.  The mode follows MODEL.CENTERNET.HIP_PRECISION: f16 (throughput) or f32 (the reference's
-precision: every activation, gradient and statistic in f32).
+inference-only for now.  The mode follows MODEL.CENTERNET.HIP_PRECISION: f16 (throughput), f32 (the reference's
+precision: every activation, gradient and statistic in f32, contractions as f32 FMA chains) or f16x3 (the same f32 tensors,
+every contraction as three f16 products per term on the f16 matrix pipe: the parity-grade mode at matrix-pipe speed).
 """
 import torch
 
@@ -258,6 +259,9 @@ def centernet_train_forward(model, batched_inputs):
 
 
 def train_forward_tensors(model, x_nhwc, targets):
+    from .. import ops_train
+    # how the autograd nodes contract f32 tensors (each node remembers it for its backward pass)
+    ops_train.F32_COMPUTE = ops.F16X3 if model._ctx.compute == ops.F16X3 else ops.F32
     _COUNTERS.clear()        # counters collected by a forward that did not reach its flush (an exception, a partial walk) are dropped
     if model.backbone_type == "resnet":
         y = deconv_layers(model, resnet_features(model.backbone, x_nhwc, model._ctx))

@@ -107,7 +107,7 @@ class _Prof:
             if p is not None:   # algorithmic bytes: input once + output once (+ offsets/masks for the deformable conv)
                 isz = 2 if p.compute == F16 else 4
                 in_px = M * (p.stride * p.stride if not deform else 1)
-                self.bytes = in_px * p.Cin_real * isz + M * p.Cout * osz + (M * 27 * 4 if deform else 0) + p.w.numel() * isz
+                self.bytes = in_px * p.Cin_real * isz + M * p.Cout * osz + (M * 27 * 4 if deform else 0) + p.Cout_pad * p.Kpad * isz
                 self.info = f"M={M} {p.Cin_real}->{p.Cout} k{p.R} s{p.stride}" + (" dcn" if deform else "") + (f" cat{nsrc}" if nsrc > 1 else "")
             else:
                 self.bytes, self.info = 0.0, f"M={M}"
@@ -192,10 +192,11 @@ def round_up(a, b):
 
 
 class PackPlan:
-    """The f16 operands of every conv weight a training step packs (forward and input-gradient forms), kept in persistent
-    buffers and refreshed by ONE kernel after the optimizer update (`run()`, called by solver.FlatSGD.step) instead of one
-    pack launch per layer, direction and step.  An entry is valid while the weight's version counter still has the value
-    `run()` (or the recording pack) saw; a stale or unknown weight is packed on the spot as before and (re)recorded."""
+    """The packed operands of every conv weight a training step packs (forward and input-gradient forms; f16 images and the
+    split f16x3 images with their row scales), kept in persistent buffers and refreshed by ONE kernel per kind after the
+    optimizer update (`run()`, called by solver.FlatSGD.step) instead of one pack launch per layer, direction and step.  An entry
+    is valid while the weight's version counter still has the value `run()` (or the recording pack) saw; a stale or unknown
+    weight is packed on the spot as before and (re)recorded."""
 
     def __init__(self, flat_param):
         """flat_param: the optimizer's parameter buffer -- only weights that live inside it are planned (their address is
@@ -206,9 +207,9 @@ class PackPlan:
         its buffer (`repack`), a table that the entry set outgrew is retired, not dropped."""
         self.lo = flat_param.data_ptr()
         self.hi = self.lo + flat_param.numel() * flat_param.element_size()
-        self.entries = {}        # key -> [weight, packed, args, version]
-        self.table = None        # device descriptor table, rebuilt when the set of entries changes
-        self.blocks = 0
+        self.entries = {}        # key -> [weight, packed, args, version, scale buffer (f16x3 entries) or None]
+        self.table = {0: None, 1: None}     # device descriptor tables (f16 / f16x3), rebuilt when the set of entries changes
+        self.blocks = {0: 0, 1: 0}
         self._retired = []       # earlier tables: a captured graph may still launch the pack kernel on them
 
     def covers(self, weight):
@@ -217,43 +218,60 @@ class PackPlan:
     def lookup(self, key, weight):
         e = self.entries.get(key)
         if e is not None and e[3] == weight._version:
-            return e[1]
+            return e[1] if e[4] is None else (e[1], e[4])
         return None
 
     def stale_buffer(self, key):
-        """the packed buffer of a known entry whose weight has changed since it was packed (None: unknown key)"""
+        """the packed buffer (f16x3: the (buffer, scale) pair) of a known entry whose weight has changed since it was packed
+        (None: unknown key)"""
         e = self.entries.get(key)
-        return e[1] if e is not None else None
+        if e is None:
+            return None
+        return e[1] if e[4] is None else (e[1], e[4])
 
-    def record(self, key, weight, packed, args):
+    def record(self, key, weight, packed, args, scale=None):
         e = self.entries.get(key)
         if e is not None:                      # re-packed in place: same buffer, same table
             assert e[1].data_ptr() == packed.data_ptr()
             e[0], e[3] = weight, weight._version
             return
-        self.entries[key] = [weight, packed, args, weight._version]
-        if self.table is not None:
-            self._retired.append(self.table)
-        self.table = None
+        self.entries[key] = [weight, packed, args, weight._version, scale]
+        kind = 0 if scale is None else 1
+        if self.table[kind] is not None:
+            self._retired.append(self.table[kind])
+        self.table[kind] = None
 
-    def run(self):
-        if not self.entries:
-            return
-        es = list(self.entries.values())
-        if self.table is None:
+    def _build(self, kind, es):
+        if kind == 0:
             arr = (_lib.PackDesc * len(es))()
             blk = 0
-            for d, (w, wp, a, _) in zip(arr, es):
+            for d, (w, wp, a, _, _) in zip(arr, es):
                 d.w, d.packed = w.data_ptr(), wp.data_ptr()
                 d.O, d.I, d.R, d.S, d.chans_pad, d.rows_pad, d.Kpad, d.korder, d.transposed = a
                 d.blk0 = blk
                 blk += (d.rows_pad * d.Kpad + 255) // 256
-            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            self.table, self.blocks = raw.to(es[0][1].device), blk
-        _lib.check(_lib.lib().ctdet_pack_weights_batch(_ptr(self.table), len(es), self.blocks, _stream()),
-                   "ctdet_pack_weights_batch")
-        for e in es:
-            e[3] = e[0]._version
+        else:
+            arr = (_lib.Pack3Desc * len(es))()
+            blk = 0
+            for d, (w, wp, a, _, sc) in zip(arr, es):
+                d.w, d.packed, d.scale_out = w.data_ptr(), wp.data_ptr(), sc.data_ptr()
+                d.O, d.I, d.R, d.S, d.chans_pad, d.rows_pad, d.Kpad, d.layout, d.transposed, d.scale_n = a
+                d.blk0 = blk
+                blk += d.rows_pad
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table[kind], self.blocks[kind] = raw.to(es[0][1].device), blk
+
+    def run(self):
+        for kind in (0, 1):
+            es = [e for e in self.entries.values() if (e[4] is None) == (kind == 0)]
+            if not es:
+                continue
+            if self.table[kind] is None:
+                self._build(kind, es)
+            fn = _lib.lib().ctdet_pack_weights_batch if kind == 0 else _lib.lib().ctdet_pack_weights_x3_batch
+            _lib.check(fn(_ptr(self.table[kind]), len(es), self.blocks[kind], _stream()), "ctdet_pack_weights_batch")
+            for e in es:
+                e[3] = e[0]._version
 
 
 PACK_PLAN = None    # set by solver.FlatSGD on a GPU; None: every PackedConv packs for itself
@@ -271,18 +289,19 @@ class PackedConv:
     def __init__(self, weight, scale=None, bias=None, stride=1, pad=0, dil=1, compute=F16, cin_pad=None,
                  tap_major=False, transposed=False, cout_align=None):
         """transposed: pack the input-gradient operand of `weight` (rows = its input channels, taps flipped) -- the
-        conv that maps dY to dX; f16 only.  cout_align: pad the packed rows to a multiple of this (the DCNv2 window kernel
+        conv that maps dY to dX; f16 / f16x3.  cout_align: pad the packed rows to a multiple of this (the DCNv2 window kernel
         works on 64-cout tiles whatever Cout is)."""
         _require_cuda(weight)
         # transposed = "dcn_cols" / "dcn_cols_chunked": the operand of DCNv2's d(columns) contraction for a [O, I, 3, 3] weight,
         # a 1x1 conv from dY's O channels to 9*I column channels (ctdet_pack_weights transposed = 2 / 3)
         dcn_mode = {"dcn_cols": 2, "dcn_cols_chunked": 3}[transposed] if isinstance(transposed, str) else 0
         if dcn_mode:
-            assert compute == F16 and scale is None and bias is None and weight.dtype == torch.float32 and weight.is_contiguous()
+            assert compute in (F16, F16X3) and scale is None and bias is None and weight.dtype == torch.float32 and weight.is_contiguous()
             assert tuple(weight.shape[2:]) == (3, 3) and not tap_major
             Cin, Cout, R, S = weight.shape[0], 9 * weight.shape[1], 1, 1
         elif transposed:
-            assert compute == F16 and scale is None and bias is None
+            assert compute in (F16, F16X3) and scale is None and bias is None
+            assert compute == F16 or (weight.dtype == torch.float32 and weight.is_contiguous())
             Cin, Cout, R, S = weight.shape
         else:
             Cout, Cin, R, S = weight.shape
@@ -320,6 +339,18 @@ class PackedConv:
                     plan.record(args + (weight.data_ptr(),), weight, wp, args)
             self.w = wp
             self.scale = self._pad_vec(scale, 1.0, dev)
+            self.bias = self._pad_vec(bias, 0.0, dev)
+            return
+        if compute == F16X3 and weight.dtype == torch.float32 and weight.is_contiguous():
+            # the split operands come from ctdet_pack_weights_x3, one launch per layout, built when a kernel first asks for
+            # one (`w` / `scale`: the tap-major split image; `w_pair` / `scale_pair`: the tap-pair image of the 3x3 halo kernels)
+            tile = max(_lib.lib().ctdet_conv_cout_tile(self.Cout_eff), cout_align or 1)
+            self.Kpad = round_up(K, 16)
+            self.Cout_pad = round_up(self.Cout_eff, tile)
+            self._x3_src = (weight.detach(), dcn_mode if dcn_mode else int(bool(transposed)))
+            self._x3 = {}
+            self._user_scale = self._pad_vec(scale, 1.0, dev)
+            self._pair_capable = (R, S, stride, pad, dil) == (3, 3, 1, 1, 1) and self.Cin % 16 == 0 and not dcn_mode
             self.bias = self._pad_vec(bias, 0.0, dev)
             return
         if transposed:
@@ -368,7 +399,58 @@ class PackedConv:
 
     pair_korder = 2
     w_pair = None      # F16X3, 3x3 / s1 / p1: the tap-pair image of the halo-resident kernels (ctdet_conv_desc.korder 2 / 3),
+    scale_pair = None  # its epilogue scale (the kernel-packed path; the torch path shares `scale`)
     _wp_scaled = None  # built on the first conv2d() that can use it (a DCNv2 weight never does)
+    _x3_src = None     # (f32 OIHW parameter, transposed mode) when the f16x3 operands come from ctdet_pack_weights_x3
+    _pair_capable = False
+    _w = _scale = None
+
+    @property
+    def w(self):
+        return self._w if self._x3_src is None else self._x3_operand(0)[0]
+
+    @w.setter
+    def w(self, v):
+        self._w = v
+
+    @property
+    def scale(self):
+        return self._scale if self._x3_src is None else self._x3_operand(0)[1]
+
+    @scale.setter
+    def scale(self, v):
+        self._scale = v
+
+    def _x3_operand(self, layout):
+        """(packed image viewed as f32 [rows_pad, Kpad], epilogue scale) of one layout of ctdet_pack_weights_x3; planned
+        (persistent buffers refreshed in one launch after the optimizer step) when the weight lives in the optimizer's buffer"""
+        e = self._x3.get(layout)
+        if e is not None:
+            return e
+        weight, tmode = self._x3_src
+        nch = self.Cin // 16
+        if layout == 0:
+            rows_pad, Kpad = self.Cout_pad, self.Kpad
+        else:
+            rows_pad, Kpad = round_up(self.Cout_pad, 32), (nch // 2 * 288 if layout == 3 else nch * 160)
+        O, I = weight.shape[0], weight.shape[1]
+        R, S = (1, 1) if tmode >= 2 else (weight.shape[2], weight.shape[3])
+        args = (O, I, R, S, self.Cin, rows_pad, Kpad, layout, tmode, self.Cout_eff)
+        key = ("x3",) + args + (weight.data_ptr(),)
+        plan = PACK_PLAN if (PACK_PLAN is not None and PACK_PLAN.covers(weight)) else None
+        bufs = plan.lookup(key, weight) if plan is not None else None
+        if bufs is None:
+            bufs = plan.stale_buffer(key) if plan is not None else None
+            if bufs is None:
+                bufs = (torch.empty(rows_pad, Kpad, dtype=torch.float32, device=weight.device),
+                        torch.empty(self.Cout_eff, dtype=torch.float32, device=weight.device))
+            rc = _lib.lib().ctdet_pack_weights_x3(_ptr(weight), _ptr(bufs[0]), _ptr(bufs[1]), *args, _stream())
+            _lib.check(rc, "ctdet_pack_weights_x3")
+            if plan is not None:
+                plan.record(key, weight, bufs[0], args, scale=bufs[1])
+        sc = bufs[1] if self._user_scale is None else bufs[1] * self._user_scale
+        e = self._x3[layout] = (bufs[0], sc)
+        return e
 
     def _pack_pairs(self, wp):
         """wp: the scaled tap-major f32 image [Cout_pad, 9*Cin] -> pair image viewed as f32, rows padded to a multiple of 32 (the
@@ -401,12 +483,16 @@ class PackedConv:
         # (a 16-channel input on a 64-divisible map is the LDS-window kernel's: level0 of DLA-34, 492 vs 825 us per 64 images)
         tile32 = x.shape[1] % 8 == 0 and x.shape[2] % 32 == 0
         tile16 = x.shape[1] % 16 == 0 and x.shape[2] % 16 == 0 and (self.Cin // 16) % 2 == 0     # (16x16 tiles: korder 3 only)
-        ok = ((self.w_pair is not None or self._wp_scaled is not None) and self.in_dil == 1 and (tile32 or tile16)
+        ok = ((self.w_pair is not None or self._wp_scaled is not None or self._pair_capable) and self.in_dil == 1 and (tile32 or tile16)
               and _nhwc_stride(x) % 4 == 0 and x.data_ptr() % 16 == 0
               and (self.Cin > 16 or x.shape[2] % 64 != 0 or _nhwc_stride(x) != self.Cin)
               and not (_lib.lib().ctdet_get_tuning_flags() & _lib.TUNE_NO_HALO))
         if ok and self.w_pair is None:
-            (self.w_pair, self.pair_korder), self._wp_scaled = self._pack_pairs(self._wp_scaled), None
+            if self._x3_src is not None:
+                self.pair_korder = 3 if (self.Cin // 16) % 2 == 0 else 2
+                self.w_pair, self.scale_pair = self._x3_operand(self.pair_korder)
+            else:
+                (self.w_pair, self.pair_korder), self._wp_scaled = self._pack_pairs(self._wp_scaled), None
         return ok
 
     def _pad_vec(self, v, fill, dev):
@@ -471,9 +557,12 @@ def conv2d(x, p, out=None, act=ACT_NONE, residual=None, out_dtype=None, clamp=(0
         assert residual.dtype == out.dtype and residual.shape[:3] == out.shape[:3]
     d = p.desc(x, out, act, residual, clamp, allow_pair=True)
     prof = _Prof(p, d.B * d.Ho * d.Wo, False, d.out_dtype, x.shape)
-    w = p.w_pair if d.korder >= 2 else p.w
+    if d.korder >= 2:
+        w, sc = p.w_pair, (p.scale_pair if p.scale_pair is not None else p.scale)
+    else:
+        w, sc = p.w, p.scale
     for _ in range(prof.reps()):
-        rc = _lib.lib().ctdet_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w), _ptr(p.scale), _ptr(p.bias), _ptr(residual),
+        rc = _lib.lib().ctdet_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w), _ptr(sc), _ptr(p.bias), _ptr(residual),
                                          _ptr(out), _stream())
     _lib.check(rc, "ctdet_conv2d_fwd")
     prof.done()

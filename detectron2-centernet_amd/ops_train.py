@@ -1,11 +1,16 @@
 """Training-side op wrappers (C ABI) and the torch.autograd.Function glue of the CenterNet training path.
 
 Autograd is used as the tape only: every forward and backward body below is one or a few HIP kernel launches.
-Two modes, chosen by the dtype of the activations that enter: f16 NHWC activations / activation gradients with f32
-parameters and parameter gradients (the throughput mode: mixed precision with f32 accumulation everywhere), or f32
-throughout (the reference's own precision: the mode in which the whole step is compared with the fp32 oracle).  A static loss scale keeps
-small heatmap gradients inside the f16 range: it is applied in the loss backward and removed again on every
-parameter gradient, so `param.grad` and the returned loss values are unscaled.
+Three modes.  f16 NHWC activations / activation gradients with f32 parameters and parameter gradients (the throughput mode:
+mixed precision with f32 accumulation everywhere) is chosen by f16 activations entering.  f32 activations enter the other
+two, told apart by `F32_COMPUTE` (set per forward pass from the model's MODEL.CENTERNET.HIP_PRECISION, remembered by every
+autograd node for its backward): F32 -- the reference's own arithmetic, contractions as f32 FMA chains on the f32 matrix
+pipe / plain f32 kernels: the mode in which the whole step is compared with the fp32 oracle -- or F16X3 (round 4): the same
+f32 tensors, statistics and gradients, every contraction of the step (forward, input gradient, weight gradient, DCNv2's
+column GEMMs) as hi*hi + lo*hi + hi*lo on the f16 matrix pipe with f32 accumulation: f32-grade results at several times
+the f32 rate.  A static loss scale keeps small heatmap gradients inside the f16 range (f16 tensors in the first mode, the hi /
+lo halves of the split in the third): it is applied in the loss backward and removed again on every parameter gradient, so
+`param.grad` and the returned loss values are unscaled.
 """
 import ctypes as C
 
@@ -15,9 +20,15 @@ import torch
 
 from . import _lib, ops
 from ._lib import ConvDesc
-from .ops import ACT_NONE, ACT_RELU, F16, F32, _nhwc_stride, _ptr, _require_cuda, _stream, dt_of
+from .ops import ACT_NONE, ACT_RELU, F16, F16X3, F32, _nhwc_stride, _ptr, _require_cuda, _stream, dt_of
 
 GRAD_SCALE = 1024.0
+F32_COMPUTE = F32     # how contractions over f32 tensors run: F32 or F16X3 (engine/train_step.py sets it per forward pass)
+
+
+def comp_of(x):
+    """compute mode of the node that takes activation x"""
+    return F16 if x.dtype == torch.float16 else F32_COMPUTE
 # parameter gradients are multiplied by PARAM_GRAD_MULT = 1 / (GRAD_SCALE * world_size): removes the loss scale and
 # pre-divides by the data-parallel world size so a SUM all-reduce yields the mean (what DDP does)
 PARAM_GRAD_MULT = 1.0 / GRAD_SCALE
@@ -109,8 +120,9 @@ def bn_train_bwd(dz, z, y, mean, invstd, scale, relu=True, want_dres=False, grad
     return dy, dres, dgamma, dbeta
 
 
-def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1, scale=None, into=None):
-    """scale * dW, f32 [Cout, R*S*Cin] (tap-major) for y = conv(x, W); x, dy f16 NHWC.  scale defaults to PARAM_GRAD_MULT.
+def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1, scale=None, into=None, comp=None):
+    """scale * dW, f32 [Cout, R*S*Cin] (tap-major) for y = conv(x, W); x, dy NHWC, both f16 or both f32 (comp F32: plain f32
+    FMAs; F16X3: split products on the f16 matrix pipe).  scale defaults to PARAM_GRAD_MULT.
     into=(grad, taps, cin_k): accumulate into `grad`, the parameter's own OIHW gradient [Cout_real, Cin_real, kh, kw] (its
     slice of the optimizer's flat buffer), with k = tap*cin_k + c -- nothing is returned"""
     B, H, W, Cin = x.shape
@@ -120,7 +132,7 @@ def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1, scale=None, into=None):
     d.B, d.H, d.W, d.Cin, d.in_stride = B, H, W, Cin, _nhwc_stride(x)
     d.Cout, d.Ho, d.Wo, d.out_stride = Cout, Ho, Wo, _nhwc_stride(dy)
     d.R, d.S, d.stride, d.pad, d.dil = R, S, stride, pad, dil
-    d.compute_dtype = dt_of(x)
+    d.compute_dtype = dt_of(x) if comp is None or x.dtype == torch.float16 else comp
     assert dy.dtype == x.dtype
     sc = float(PARAM_GRAD_MULT if scale is None else scale)
     with ops.prof_region(f"conv_wgrad<{R}x{S}>", flops=2.0 * B * Ho * Wo * Cout * R * S * Cin, nbytes=0.0):
@@ -223,7 +235,7 @@ def flush_param_grads(ptr_lo=None, ptr_hi=None):
     _lib.check(rc, "ctdet_grad_scatter_oihw")
 
 
-def wgrad_to_param(p, x, dy, Cout_k, R, S, stride, pad, taps, cin_k, scale=None, make_x=None, keep=()):
+def wgrad_to_param(p, x, dy, Cout_k, R, S, stride, pad, taps, cin_k, scale=None, make_x=None, keep=(), comp=None):
     """The weight gradient of parameter p (OIHW [Cout, Cin, kh, kw], kh*kw = taps; k = tap*cin_k + c in the kernel's order)
     accumulated into p's slice of the optimizer's flat gradient buffer instead of being handed to autograd (whose
     AccumulateGrad would launch one strided add per parameter): tap-major partial sums in the step's zeroed arena as always
@@ -238,7 +250,7 @@ def wgrad_to_param(p, x, dy, Cout_k, R, S, stride, pad, taps, cin_k, scale=None,
 
     def work():
         xin = make_x() if make_x is not None else x
-        return conv_wgrad(xin, dy, Cout_k, R, S, stride, pad), xin
+        return conv_wgrad(xin, dy, Cout_k, R, S, stride, pad, comp=comp), xin
     dw, xin = SIDE.run(work, x, dy, *keep)
     if make_x is not None:
         SIDE.keep.append((xin,))
@@ -292,21 +304,22 @@ def dcn_weight_matrix(weight, Cw=None, chunked=False):
     return wmat
 
 
-def dcn_dcol(dyp, weight, chunked):
+def dcn_dcol(dyp, weight, chunked, comp=None):
     """d(columns) [B, H, W, 9*Cin] = dY . W of a DCNv2 layer (deform_conv_cuda.cu:1003-1009), rows tap-major or chunk-major.
-    f16: the operand is packed straight from the [Cout, Cin, 3, 3] parameter (a planned pack: no permuted copy per step);
+    f16 / f16x3: the operand is packed straight from the [Cout, Cin, 3, 3] parameter (a planned pack: no permuted copy per step);
     f32: the permuted weight matrix through the generic input-gradient path."""
     Cout, Cin = weight.shape[:2]
-    if dyp.dtype == torch.float32:
-        return conv_dgrad(dyp, dcn_weight_matrix(weight, dyp.shape[3], chunked), 1, 0, dyp.shape[1:3])
-    p = ops.PackedConv(weight.detach(), None, None, stride=1, pad=0, compute=F16, cin_pad=dyp.shape[3],
+    comp = comp_of(dyp) if comp is None else comp
+    if comp == F32:
+        return conv_dgrad(dyp, dcn_weight_matrix(weight, dyp.shape[3], chunked), 1, 0, dyp.shape[1:3], comp=F32)
+    p = ops.PackedConv(weight.detach(), None, None, stride=1, pad=0, compute=comp, cin_pad=dyp.shape[3],
                        transposed="dcn_cols_chunked" if chunked else "dcn_cols")
-    dcol = torch.empty(dyp.shape[0], dyp.shape[1], dyp.shape[2], p.Cout_eff, dtype=torch.float16, device=dyp.device)
+    dcol = torch.empty(dyp.shape[0], dyp.shape[1], dyp.shape[2], p.Cout_eff, dtype=dyp.dtype, device=dyp.device)
     ops.conv2d(dyp, p, out=dcol)
     return dcol
 
 
-def dcn_col2im_coord(dcol, x, om, mask_is_prob=False, dom_channels=None, dcol_chunked=False):
+def dcn_col2im_coord(dcol, x, om, mask_is_prob=False, dom_channels=None, dcol_chunked=False, comp=None):
     """dx (f32, atomically accumulated) and dom = d(offsets, mask logits).  dom_channels=None: f32, the shape of om;
     dom_channels=C (f16 data): an f16 [B, H, W, C] tensor whose channels 27.. are zero -- directly the dY of the offset conv's
     backward, without a cast or a channel pad in between"""
@@ -319,7 +332,8 @@ def dcn_col2im_coord(dcol, x, om, mask_is_prob=False, dom_channels=None, dcol_ch
     with ops.prof_region("dcn_col2im", flops=0.0, nbytes=float(B * H * W * Cin * (18 + 2 + 4) + B * H * W * 27 * 8)):
         rc = _lib.lib().ctdet_dcn_col2im_coord(_ptr(dcol), _ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(dx),
                                                _ptr(dom), dom.shape[3], dt_of(dom), B, H, W, Cin, int(mask_is_prob),
-                                               int(dcol_chunked), dt_of(x), _stream())
+                                               int(dcol_chunked), dt_of(x) if comp is None or x.dtype == torch.float16 else comp,
+                                               _stream())
     _lib.check(rc, "ctdet_dcn_col2im_coord")
     return dx, dom
 
@@ -350,7 +364,7 @@ def _phase_tap_index(device):
     return t
 
 
-def _conv_dgrad_s2_phases(dy, weight, in_hw):
+def _conv_dgrad_s2_phases(dy, weight, in_hw, comp=F16):
     """input gradient of a 3x3 / stride 2 / pad 1 conv without zero-stuffing: one 2x2 conv over dy to the four output phases
     (4*Cin channels), then ctdet_depth_to_space2"""
     Cout, Cin, _, _ = weight.shape
@@ -363,35 +377,39 @@ def _conv_dgrad_s2_phases(dy, weight, in_hw):
     w10 = torch.nn.functional.pad(w9, (0, 1, 0, Cp - Cin))                         # zero tap, channel padding -> [Cd, Cp, 10]
     wd = w10.index_select(2, _phase_tap_index(dy.device)).view(Cd, Cp, 4, 2, 2)     # [co, ci, phase, a, b]
     wd = wd.permute(2, 1, 0, 3, 4).reshape(4 * Cp, Cd, 2, 2).contiguous()
-    p = ops.PackedConv(wd, None, None, stride=1, pad=1, compute=F16)
+    p = ops.PackedConv(wd, None, None, stride=1, pad=1, compute=comp)
     ph = ops.conv2d(dy, p)                                                           # [B, Ho+1, Wo+1, 4*Cp]
-    dx = torch.empty(B, H, W, Cp, dtype=torch.float16, device=dy.device)
+    dx = torch.empty(B, H, W, Cp, dtype=dy.dtype, device=dy.device)
     rc = _lib.lib().ctdet_depth_to_space2(_ptr(ph), _nhwc_stride(ph), _ptr(dx), _nhwc_stride(dx), B, H, W, Cp, ph.shape[1],
-                                          ph.shape[2], _stream())
+                                          ph.shape[2], dt_of(dx), _stream())
     _lib.check(rc, "ctdet_depth_to_space2")
     return dx if Cp == Cin else dx[..., :Cin]
 
 
-def conv_dgrad(dy, weight, stride, pad, in_hw, cin_pad=None):
+def conv_dgrad(dy, weight, stride, pad, in_hw, cin_pad=None, comp=None):
     """dx of y = conv(x, weight): a conv over dy with the taps flipped and in/out channels swapped;
-    cin_pad (f16): dy carries that many channels (>= Cout, the extra ones zero) -- the operand gets zero columns for them;
-    f16: 3x3 / stride 2 / pad 1 goes through the four-phase form, other strides read dy as zero-stuffed (in_dil);
+    cin_pad (f16 / f16x3): dy carries that many channels (>= Cout, the extra ones zero) -- the operand gets zero columns for them;
+    f16 / f16x3: 3x3 / stride 2 / pad 1 goes through the four-phase form, other strides read dy as zero-stuffed (in_dil);
     f32: always the zero-stuffed form on the f32 MFMA kernel."""
     Cout, Cin, R, S = weight.shape
-    if dy.dtype == torch.float32:
+    comp = comp_of(dy) if comp is None else comp
+    if comp == F32:
         wt = weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()      # [Cin, Cout, R, S]: dX = conv(dY, wt)
         p = ops.PackedConv(wt, None, None, stride=1, pad=R - 1 - pad, compute=F32)
         p.in_dil = stride
         dx = torch.empty(dy.shape[0], in_hw[0], in_hw[1], p.Cout_eff, dtype=torch.float32, device=dy.device)
         ops.conv2d(dy, p, out=dx)
         return dx if p.Cout_eff == Cin else dx[..., :Cin]
-    if stride == 2 and R == 3 and S == 3 and pad == 1 and dy.shape[3] % 8 == 0:
-        return _conv_dgrad_s2_phases(dy, weight, in_hw)     # pads the operand to dy's channel count itself
-    p = ops.PackedConv(weight.detach(), None, None, stride=1, pad=R - 1 - pad, compute=F16, tap_major=stride > 1,
+    if stride == 2 and R == 3 and S == 3 and pad == 1 and dy.shape[3] % (8 if comp == F16 else 16) == 0:
+        return _conv_dgrad_s2_phases(dy, weight, in_hw, comp)     # pads the operand to dy's channel count itself
+    wsrc = weight.detach()
+    if comp == F16X3 and not (wsrc.dtype == torch.float32 and wsrc.is_contiguous()):
+        wsrc = wsrc.float().contiguous()
+    p = ops.PackedConv(wsrc, None, None, stride=1, pad=R - 1 - pad, compute=comp, tap_major=stride > 1,
                        transposed=True, cin_pad=cin_pad)
     p.in_dil = stride
     B = dy.shape[0]
-    dx = torch.empty(B, in_hw[0], in_hw[1], p.Cout_eff, dtype=torch.float16, device=dy.device)
+    dx = torch.empty(B, in_hw[0], in_hw[1], p.Cout_eff, dtype=dy.dtype, device=dy.device)
     ops.conv2d(dy, p, out=dx)
     return dx if p.Cout_eff == Cin else dx[..., :Cin]
 
@@ -410,8 +428,9 @@ class ConvFn(torch.autograd.Function):
         world-size protocol), 1.0 for stand-alone use behind the reference's module interface"""
         ctx.pgm = param_grad_mult
         f32 = x.dtype == torch.float32
+        comp = ctx.comp = comp_of(x)
         p = _fwd_pack(weight, stride, pad, cin_pad=x.shape[3] if x.shape[3] != weight.shape[1] else None, bias=bias,
-                      compute=F32 if f32 else F16)
+                      compute=comp)
         y = ops.conv2d(x, p, act=ACT_RELU if relu else ACT_NONE,
                        out_dtype=torch.float32 if (out_f32 or f32) else torch.float16)
         ctx.cfg = (stride, pad, relu, weight.shape[0], bias is not None)
@@ -424,35 +443,36 @@ class ConvFn(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         stride, pad, relu, Cout, has_bias = ctx.cfg
         Cout, Cin, R, S = weight.shape
+        comp = ctx.comp
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
-        dy = _pad_c(dy.contiguous())          # channel count -> multiple of 8 (padded channels carry zeros)
+        dy = _pad_c(dy.contiguous(), comp)    # channel count -> multiple of 8 / 4 (padded channels carry zeros)
         Cw = dy.shape[3]
         direct = ctx.pgm is None                  # the training step's protocol: gradients go straight into the flat buffer
         wparam, bparam = ctx.params
         dbias = None
         if relu or has_bias:
             sb = grad_slot(bparam) if (direct and has_bias) else None
-            dy, _, _, db = bn_train_bwd(dy, _pad_c(y) if relu else None, None, None, None, None, relu=relu, grad_mult=ctx.pgm,
+            dy, _, _, db = bn_train_bwd(dy, _pad_c(y, comp) if relu else None, None, None, None, None, relu=relu, grad_mult=ctx.pgm,
                                         into=(None, sb) if sb is not None and sb.numel() == Cw else None)
             dbias = db[:Cout] if has_bias else None
             if sb is not None and sb.numel() == Cw:
                 grad_done(bparam)
                 dbias = None
-        if direct and wgrad_to_param(wparam, x, dy, Cw, R, S, stride, pad, R * S, x.shape[3]):
+        if direct and wgrad_to_param(wparam, x, dy, Cw, R, S, stride, pad, R * S, x.shape[3], comp=comp):
             dwt = None
         else:
-            dw = conv_wgrad(x, dy, Cw, R, S, stride, pad, scale=ctx.pgm)[:Cout]
+            dw = conv_wgrad(x, dy, Cw, R, S, stride, pad, scale=ctx.pgm, comp=comp)[:Cout]
             dwt = _wgrad_to_oihw(dw, Cout, Cin, x.shape[3], R, S)
         dx = None
         if ctx.needs_input_grad[0]:
-            if x.shape[3] != Cin or x.dtype == torch.float32:
+            if x.shape[3] != Cin or comp == F32:
                 wpad = weight if Cw == Cout else torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
                 if x.shape[3] != Cin:         # input channels were padded (the 3 -> 8 channel image): so is dX
                     wpad = torch.nn.functional.pad(wpad.detach(), (0, 0, 0, 0, 0, x.shape[3] - Cin))
-                dx = conv_dgrad(dy, wpad, stride, pad, x.shape[1:3])
+                dx = conv_dgrad(dy, wpad, stride, pad, x.shape[1:3], comp=comp)
             else:                             # padded dY channels meet zero operand columns: no padded copy of the weight
-                dx = conv_dgrad(dy, weight, stride, pad, x.shape[1:3], cin_pad=Cw)
+                dx = conv_dgrad(dy, weight, stride, pad, x.shape[1:3], cin_pad=Cw, comp=comp)
         return dx, dwt, dbias, None, None, None, None, None
 
 
@@ -464,8 +484,8 @@ class FrozenConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, scale, bias, res, stride, pad, relu):
-        f32 = x.dtype == torch.float32
-        p = ops.PackedConv(weight.detach(), scale, bias, stride=stride, pad=pad, compute=F32 if f32 else F16,
+        comp = ctx.comp = comp_of(x)
+        p = ops.PackedConv(weight.detach(), scale, bias, stride=stride, pad=pad, compute=comp,
                            cin_pad=x.shape[3] if x.shape[3] != weight.shape[1] else None)
         z = ops.conv2d(x, p, act=ACT_RELU if relu else ACT_NONE, residual=res)
         ctx.cfg = (stride, pad, relu, res is not None)
@@ -477,22 +497,23 @@ class FrozenConvFn(torch.autograd.Function):
         x, weight, scale, z = ctx.saved_tensors
         stride, pad, relu, has_res = ctx.cfg
         Cout, Cin, R, S = weight.shape
-        dz = _pad_c(dz.contiguous().to(x.dtype))
+        comp = ctx.comp
+        dz = _pad_c(dz.contiguous().to(x.dtype), comp)
         g = dz
         if relu:
-            g, _, _, _ = bn_train_bwd(dz, _pad_c(z), None, None, None, None, relu=True)
+            g, _, _, _ = bn_train_bwd(dz, _pad_c(z, comp), None, None, None, None, relu=True)
         dres = (g if g.shape[3] == Cout else g[..., :Cout]) if has_res else None
         sc = scale if g.shape[3] == Cout else torch.nn.functional.pad(scale, (0, g.shape[3] - Cout))
         dconv = g * sc.to(g.dtype)
         Cw = dconv.shape[3]
         dwt = None
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(x, dconv, Cw, R, S, stride, pad)[:Cout]
+            dw = conv_wgrad(x, dconv, Cw, R, S, stride, pad, comp=comp)[:Cout]
             dwt = _wgrad_to_oihw(dw, Cout, Cin, x.shape[3], R, S)
         dx = None
         if ctx.needs_input_grad[0]:
             wpad = weight if Cw == Cout else torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
-            dx = conv_dgrad(dconv, wpad, stride, pad, x.shape[1:3])
+            dx = conv_dgrad(dconv, wpad, stride, pad, x.shape[1:3], comp=comp)
         return dx, dwt, None, None, dres, None, None, None
 
 
@@ -505,8 +526,8 @@ class ConvTransposeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, stride, pad):
-        f32 = x.dtype == torch.float32
-        y = ops.conv_transpose2d(x, weight.detach(), None, None, stride, pad, F32 if f32 else F16)
+        comp = ctx.comp = comp_of(x)
+        y = ops.conv_transpose2d(x, weight.detach(), None, None, stride, pad, comp)
         ctx.cfg = (stride, pad)
         ctx.save_for_backward(x, weight)
         return y if y.shape[3] == weight.shape[1] else y[..., :weight.shape[1]]
@@ -516,21 +537,22 @@ class ConvTransposeFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         stride, pad = ctx.cfg
         Cin, Cout, k, _ = weight.shape
-        dy = _pad_c(dy.contiguous().to(x.dtype))
+        comp = ctx.comp
+        dy = _pad_c(dy.contiguous().to(x.dtype), comp)
         Cw = dy.shape[3]
         wpad = weight.detach() if Cw == Cout else torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, Cw - Cout))
-        f32 = x.dtype == torch.float32
-        p = ops.PackedConv(wpad, None, None, stride=stride, pad=pad, compute=F32 if f32 else F16)   # rows = Cin, channels = Cw
+        p = ops.PackedConv(wpad, None, None, stride=stride, pad=pad, compute=comp)   # rows = Cin, channels = Cw
         dx = ops.conv2d(dy, p)
         dx = dx if dx.shape[3] == Cin else dx[..., :Cin]
-        dw = conv_wgrad(dy, _pad_c(x), _pad_c(x).shape[3], k, k, stride, pad)[:Cin]         # [Cin, k*k*Cw]
+        xp = _pad_c(x, comp)
+        dw = conv_wgrad(dy, xp, xp.shape[3], k, k, stride, pad, comp=comp)[:Cin]         # [Cin, k*k*Cw]
         dwt = dw.view(Cin, k, k, Cw)[..., :Cout].permute(0, 3, 1, 2)
         return dx, dwt, None, None
 
 
-def _pad_c(t):
-    """channel count up to a multiple of 8 (the f16 kernels vectorise 8 channels) / 4 (f32)"""
-    q = 8 if t is not None and t.dtype == torch.float16 else 4
+def _pad_c(t, comp=None):
+    """channel count up to a multiple of 8 (the f16 and f16x3 kernels work on 8-channel pieces) / 4 (f32)"""
+    q = 8 if t is not None and (t.dtype == torch.float16 or comp == F16X3) else 4
     if t is None or t.shape[3] % q == 0:
         return t
     return torch.nn.functional.pad(t, (0, q - t.shape[3] % q))
@@ -616,8 +638,8 @@ class DCNFn(torch.autograd.Function):
     def forward(ctx, x, om, weight, bias, mask_is_prob=False, param_grad_mult=None):
         ctx.pgm = param_grad_mult
         f32 = x.dtype == torch.float32
-        p = ops.PackedConv(weight.detach(), None, bias, stride=1, pad=1, compute=F32 if f32 else F16,
-                           cout_align=None if f32 else 64)
+        comp = ctx.comp = comp_of(x)
+        p = ops.PackedConv(weight.detach(), None, bias, stride=1, pad=1, compute=comp, cout_align=None if f32 else 64)
         y = ops.dcnv2(x, om, p, mask_is_prob=mask_is_prob)
         ctx.mask_is_prob = mask_is_prob
         ctx.has_bias = bias is not None
@@ -633,14 +655,15 @@ class DCNFn(torch.autograd.Function):
             dy = dy.to(x.dtype)
         if dy.shape[3] != Cout:
             dy = dy[..., :Cout].contiguous()
-        dyp = _pad_c(dy)
+        comp = ctx.comp
+        dyp = _pad_c(dy, comp)
         col = dcn_cols(x, om, ctx.mask_is_prob)
-        chunked = x.dtype == torch.float16 and Cin % 32 == 0
+        chunked = comp != F32 and Cin % 32 == 0
         _, _, _, dbias = bn_train_bwd(dyp, None, None, None, None, None, relu=False, grad_mult=ctx.pgm)
-        dw = conv_wgrad(col, dyp, dyp.shape[3], 1, 1, 1, 0, scale=ctx.pgm)[:Cout]         # [Cout, 9*Cin]
+        dw = conv_wgrad(col, dyp, dyp.shape[3], 1, 1, 1, 0, scale=ctx.pgm, comp=comp)[:Cout]         # [Cout, 9*Cin]
         dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
-        dcol = dcn_dcol(dyp, weight, chunked)                              # [M, 9*Cin]
-        dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om, ctx.mask_is_prob, dcol_chunked=chunked)
+        dcol = dcn_dcol(dyp, weight, chunked, comp)                        # [M, 9*Cin]
+        dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om, ctx.mask_is_prob, dcol_chunked=chunked, comp=comp)
         return dx32.to(x.dtype), dom, dwt, dbias[:Cout] if ctx.has_bias else None, None, None
 
 
@@ -653,7 +676,7 @@ class DeformConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_off, b_off, weight, bias):
         f32 = x.dtype == torch.float32
-        comp = F32 if f32 else F16
+        comp = ctx.comp = comp_of(x)
         p_off = _fwd_pack(w_off, 1, 1, bias=b_off, compute=comp)
         p = ops.PackedConv(weight.detach(), None, bias, stride=1, pad=1, compute=comp, cout_align=None if f32 else 64)
         if not f32 and x.shape[3] % 32 == 0 and ops.dcnv2_offset_supported(x, p_off, p):
@@ -674,43 +697,44 @@ class DeformConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
-        dyp = _pad_c(dy if dy.shape[3] == Cout else dy[..., :Cout].contiguous())
+        comp = ctx.comp
+        dyp = _pad_c(dy if dy.shape[3] == Cout else dy[..., :Cout].contiguous(), comp)
         # ---- main conv: dW, d(columns) -> scatter (d input, f32) + d(offset / mask logits)
-        chunked = x.dtype == torch.float16 and Cin % 32 == 0
+        chunked = comp != F32 and Cin % 32 == 0
         p_woff, p_boff, p_w, p_b = ctx.params
         sb = grad_slot(p_b) if p_b is not None else None
         if sb is not None and sb.numel() != dyp.shape[3]:
             sb = None
         _, _, _, dbias = bn_train_bwd(dyp, None, None, None, None, None, relu=False, into=(None, sb))
         # k = tap*Cin + c of the columns, which are sampled on the weight-gradient stream as well
-        if wgrad_to_param(p_w, None, dyp, dyp.shape[3], 1, 1, 1, 0, 9, Cin, make_x=lambda: dcn_cols(x, om), keep=(x, om)):
+        if wgrad_to_param(p_w, None, dyp, dyp.shape[3], 1, 1, 1, 0, 9, Cin, make_x=lambda: dcn_cols(x, om), keep=(x, om), comp=comp):
             dwt = None
         else:
             col = dcn_cols(x, om)
-            dw = conv_wgrad(col, dyp, dyp.shape[3], 1, 1, 1, 0)[:Cout]
+            dw = conv_wgrad(col, dyp, dyp.shape[3], 1, 1, 1, 0, comp=comp)[:Cout]
             dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
         if sb is not None:
             grad_done(p_b)
-        dcol = dcn_dcol(dyp, weight, chunked)
-        # dom comes back in the data type and channel padding the offset conv's backward kernels take (f16: 32 channels)
+        dcol = dcn_dcol(dyp, weight, chunked, comp)
+        # dom comes back in the data type and channel padding the offset conv's backward kernels take (f16 / f16x3: 32 channels)
         n_om = w_off.shape[0]
         f32 = x.dtype == torch.float32
-        dx32, dom_p = dcn_col2im_coord(dcol.contiguous(), x, om, dom_channels=(n_om + 3) // 4 * 4 if f32 else (n_om + 7) // 8 * 8,
-                                       dcol_chunked=chunked)
+        dx32, dom_p = dcn_col2im_coord(dcol.contiguous(), x, om, dom_channels=(n_om + 3) // 4 * 4 if comp == F32 else (n_om + 7) // 8 * 8,
+                                       dcol_chunked=chunked, comp=comp)
         # ---- offset / mask conv: bias and weight gradients from dom; its input gradient lands on top of dx32
         Cw = dom_p.shape[3]
         _, _, _, db_off = bn_train_bwd(dom_p, None, None, None, None, None, relu=False)
-        if wgrad_to_param(p_woff, x, dom_p, Cw, 3, 3, 1, 1, 9, x.shape[3]):
+        if wgrad_to_param(p_woff, x, dom_p, Cw, 3, 3, 1, 1, 9, x.shape[3], comp=comp):
             dw_off_t = None
         else:
-            dw_off = conv_wgrad(x, dom_p, Cw, 3, 3, 1, 1)[:n_om]
+            dw_off = conv_wgrad(x, dom_p, Cw, 3, 3, 1, 1, comp=comp)[:n_om]
             dw_off_t = _wgrad_to_oihw(dw_off, n_om, Cin, x.shape[3], 3, 3)
-        if f32:
+        if comp == F32:
             wpad = torch.nn.functional.pad(w_off.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - n_om)) if Cw != n_om else w_off.detach()
             wt = wpad.flip(2, 3).permute(1, 0, 2, 3).contiguous()
             pt = ops.PackedConv(wt, None, None, stride=1, pad=1, compute=F32)
         else:   # the padded dY channels meet zero operand columns: packed from the parameter itself (a planned pack)
-            pt = ops.PackedConv(w_off.detach(), None, None, stride=1, pad=1, compute=F16, transposed=True, cin_pad=Cw)
+            pt = ops.PackedConv(w_off.detach(), None, None, stride=1, pad=1, compute=comp, transposed=True, cin_pad=Cw)
         dx = ops.conv2d(dom_p, pt, out=dx32 if pt.Cout_eff == Cin else None, residual=dx32 if pt.Cout_eff == Cin else None,
                         out_dtype=torch.float32)
         if pt.Cout_eff != Cin:

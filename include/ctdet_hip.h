@@ -196,6 +196,28 @@ typedef struct ctdet_pack_desc {
 } ctdet_pack_desc;
 int32_t ctdet_pack_weights_batch(const ctdet_pack_desc* table_dev, int32_t n, int32_t total_blocks, void* stream);
 
+/* Weight packing for CTDET_DT_F16X3 contractions in one launch per weight (round 4; replaces a chain of ~30 torch kernels per
+ * conv: permute, pad, row maximum, scale, split, pair interleave): the f32 OIHW parameter -> the split operand the kernels
+ * read.  Every packed row is scaled by the power of two that brings its largest magnitude into [1024, 2048) -- the lo halves
+ * then stay f16 normals -- and the inverse is written to scale_out[row] for row < scale_n (1.0 for rows of padding): pass
+ * it as the `scale` of ctdet_conv2d_fwd / ctdet_dcnv2_fwd (multiply it into a folded BatchNorm scale if there is one).
+ * layout 0: tap-major split image, rows of Kpad f32 units (Kpad % 4 == 0, >= R*S*chans_pad), each group of 4 k = {hi[4],
+ *           lo[4]} f16 -- ctdet_conv_desc.korder 0: 1x1 / strided / 7x7 convs, DCNv2, the d(columns) operand;
+ * layout 3: tap-pair image of the 3x3 halo kernel, korder 3 (chans_pad % 32 == 0, Kpad = chans_pad/32*288, rows_pad % 32 == 0);
+ * layout 2: the same for an odd number of 16-channel chunks, korder 2 (Kpad = chans_pad/16*160).
+ * transposed: as in ctdet_pack_weights (1: the input-gradient operand, rows = input channels, taps flipped; 2 / 3: DCNv2's
+ * d(columns) operand -- give R = S = 1 for those, the weight itself is [O, I, 3, 3]). */
+int32_t ctdet_pack_weights_x3(const float* w, void* packed, float* scale_out, int32_t O, int32_t I, int32_t R, int32_t S,
+                              int32_t chans_pad, int32_t rows_pad, int32_t Kpad, int32_t layout, int32_t transposed,
+                              int32_t scale_n, void* stream);
+/* n such packs in one launch from a DEVICE table; one 256-thread block per packed row: blk0 = sum of rows_pad of the
+ * descriptors before it, total_blocks = the sum over all. */
+typedef struct ctdet_pack3_desc {
+  const float* w; void* packed; float* scale_out;
+  int32_t O, I, R, S, chans_pad, rows_pad, Kpad, layout, transposed, scale_n, blk0, pad_;
+} ctdet_pack3_desc;
+int32_t ctdet_pack_weights_x3_batch(const ctdet_pack3_desc* table_dev, int32_t n, int32_t total_blocks, void* stream);
+
 /* y = ConvTranspose2d(C, C, 2f, stride=f, padding=f/2, groups=C, bias=False)(x) + skip  (dla.py:162-177).
  * w is f32 [2f][2f][C] (the ConvTranspose2d weight [C,1,2f,2f] with the channel dim moved last); skip may be NULL. */
 int32_t ctdet_dwconvT_add(const void* x, const float* w, const void* skip, void* y, int32_t dtype, int32_t B,
@@ -310,7 +332,7 @@ int32_t ctdet_grad_scatter_oihw(const void* const* src, void* const* dst, const 
  * dst[b,y,x,c] = src[b,(y+1)/2,(x+1)/2,((y&1)*2+(x&1))*C + c]; src is the [B,Hs,Ws,>=4C] result of the 2x2 "phase" conv
  * over dY (ops_train.conv_dgrad), dst the [B,H,W,C] gradient (C % 8 == 0). */
 int32_t ctdet_depth_to_space2(const void* src, int32_t src_stride, void* dst, int32_t dst_stride, int32_t B, int32_t H,
-                              int32_t W, int32_t C, int32_t Hs, int32_t Ws, void* stream);
+                              int32_t W, int32_t C, int32_t Hs, int32_t Ws, int32_t dtype, void* stream);
 int32_t ctdet_maxpool2x2_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, void* dx,
                              int32_t dx_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 /* depthwise ConvTranspose2d backward: dx f16, dw f32 [2f][2f][C] (+=, zeroed by the caller); w as in the forward */
