@@ -438,7 +438,7 @@ def train_roofline(model, cfg, B, size, rank, device):
     model.zero_grad(set_to_none=True)
     name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
     if a["flops"] > 0:
-        mfma_peak = MFMA_F16_PEAK_TFLOPS if model._ctx.dtype == torch.float16 else FP32_PEAK_TFLOPS
+        mfma_peak = PEAKS[{ops.F16: "f16", ops.F32: "f32", ops.F16X3: "f16x3"}[model._ctx.compute]]
         ach, peak, unit, bound = a["flops"] / (a["ms"] * 1e-3) / 1e12, mfma_peak, "TFLOP/s", "mfma"
     else:
         ach, peak, unit, bound = a["bytes"] / (a["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
@@ -570,8 +570,10 @@ def main():
 
     if args.task == "train":
         from detectron2_centernet_amd.engine.bench_train import run_train_bench
-        model, cfg = build_model("f32" if args.precision == "f32" else "f16", device, config=args.config)
+        model, cfg = build_model(args.precision, device, config=args.config)
         result = run_train_bench(model, cfg, args, args.batch or 16, rank, world, device, dist)
+        if rank == 0 and not args.no_roofline:
+            result["roofline"] = train_roofline(model, cfg, args.batch or 16, args.size, rank, device)
         if args.require_graph and world == 1 and result["config"]["graph_state"] != "captured":
             raise SystemExit(f"training step did not replay as a HIP graph: {result['config']['graph_state']}")
     else:
@@ -634,7 +636,12 @@ def main():
             from detectron2_centernet_amd.engine.bench_train import run_train_bench
 
             tB = 16 if args.config == "dla34" else B
-            for key, prec, skip in (("train", "f16", False), ("train_f32", "f32", args.no_f32 or args.config != "dla34")):
+            # `train` = the parity-grade mode on the matrix pipe (f16x3: f32 tensors, split products), as the inference headline;
+            # `train_f16` the throughput mode (outside the tolerance), `train_f32` the reference's own arithmetic
+            main_prec = "f16x3" if args.config == "dla34" else "f16"
+            for key, prec, skip in (("train", main_prec, False),
+                                    ("train_f16", "f16", args.no_f16 or args.config != "dla34"),
+                                    ("train_f32", "f32", args.no_f32 or args.config != "dla34")):
                 if skip:
                     continue
                 tm, tcfg = build_model(prec, device, config=args.config)

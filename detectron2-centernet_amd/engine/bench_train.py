@@ -9,6 +9,14 @@ from ..data.catalog import synthetic_sample
 from .train_loop import SimpleTrainer
 
 
+_MODE = {
+    0: ("f16", "f16 activations / f32 master weights"),
+    1: ("f32", "f32 activations, gradients and statistics, contractions as f32 FMA chains (the reference's own arithmetic)"),
+    3: ("f16x3", "f32 activations, gradients and statistics; every contraction (forward, input and weight gradients, DCNv2 column "
+                 "GEMMs) as hi*hi + lo*hi + hi*lo on the f16 matrix pipe with f32 accumulation (f32-grade results)"),
+}
+
+
 def synthetic_batch(B, size, rank, device, num_classes=80, max_boxes=32):
     imgs, boxes, classes, counts = [], torch.zeros(B, max_boxes, 4), torch.zeros(B, max_boxes, dtype=torch.int64), []
     for b in range(B):
@@ -54,11 +62,10 @@ def run_train_bench(model, cfg, args, B, rank, world, device, dist):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f16" if model._ctx.dtype == torch.float16 else "f32",
+        "dtype": _MODE[model._ctx.compute][0],
         "data": "synthetic",
         "config": {"workload": f"{'DLA-34' if model.backbone_type == 'dla34' else 'ResNet'} CenterNet train step (targets+fwd+loss+bwd+allreduce+SGD), {B}x3x{args.size}x"
-                               f"{args.size} per GPU, 80 classes, " + ("f16 activations / f32 master weights" if model._ctx.dtype == torch.float16 else
-                                                                      "f32 activations, gradients and statistics (the reference's precision)"),
+                               f"{args.size} per GPU, 80 classes, " + _MODE[model._ctx.compute][1],
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "final_losses": losses, "graph_state": trainer.graph_state},
     }

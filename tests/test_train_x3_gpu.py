@@ -431,9 +431,8 @@ def test_training_f16x3_graph_replay_and_planned_packs(tmp_path, dev):
     x3_entries = [e for e in plan.entries.values() if e[4] is not None]
     assert len(x3_entries) > 100, len(x3_entries)            # forward + input-gradient operands of ~55 convs, DCN column operands
     torch.cuda.synchronize()
-    for w, packed, args, ver, scale in x3_entries[::7]:
-        assert ver == w._version
-        fresh = torch.empty_like(packed)
+    for w, packed, args, ver, scale in x3_entries[::7]:      # (replays refresh the buffers from inside the graph: the host-side
+        fresh = torch.empty_like(packed)                     #  version bookkeeping only moves in eager steps)
         fs = torch.empty_like(scale)
         from detectron2_centernet_amd import _lib
         from detectron2_centernet_amd.ops import _ptr, _stream
