@@ -871,6 +871,12 @@ struct ColGeo {        // staged per (pixel, tap): 32 bytes
   float pad;
 };
 
+#ifdef CTDET_DEBUG_COL2IM
+__device__ float* g_col2im_dbg = nullptr;
+extern "C" int ctdet_debug_col2im_buffer(float* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_col2im_dbg), &p, sizeof(p));
+}
+#endif
 // 8 consecutive channels as floats (global or LDS)
 template <typename T>
 __device__ __forceinline__ void load8f(const T* p, float (&o)[8]) {
@@ -887,8 +893,8 @@ __device__ __forceinline__ void load8f(const T* p, float (&o)[8]) {
 
 // NT = taps per workgroup: 9, or 3 with gridDim.y = 3 (one kernel row each) when the map has fewer tiles than the chip has
 // CUs -- every tap's scatter and its d(offset) / d(mask) entries are independent of the other taps'.
-// T = f16 (dcol, x f16: the f16 mode) or float (f32 dcol / x: the f16x3 training mode; the x window then takes 60 KB, 157 KB
-// in all -- one workgroup per CU either way -- and the fixed-point quantum is 2^-20 of the tile's largest dcol magnitude).
+// T = f16 (dcol, x f16: the f16 mode) or float (f32 dcol / x: the f16x3 training mode, fixed-point quantum 2^-20 of the tile's
+// largest dcol magnitude instead of 2^-19).  157 KB of LDS in both: one workgroup per CU.
 template <int NT, typename T>
 __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const T* __restrict__ dcol, const T* __restrict__ x,
                                                                 int x_stride, const float* __restrict__ om, int om_stride,
@@ -901,7 +907,7 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const T* __restr
   // d(input) window, int32 fixed point, laid out [e = channel % 8][window pixel][q = channel / 8]: the 64 lanes (16
   // pixels x 4 groups) of one ds_add then touch 64 consecutive words
   __shared__ __attribute__((aligned(16))) int dxw[NPX * 32];        // 59,904 B
-  __shared__ __attribute__((aligned(16))) T xw[NPX * 32];           // 29,952 B (f16) / 59,904 B (f32)
+  __shared__ __attribute__((aligned(16))) float xw[NPX * 32];       // 59,904 B: the x window as f32 in both modes (see the staging loop)
   __shared__ __attribute__((aligned(16))) ColGeo geo[9 * TH * TW];  // 36,864 B
   __shared__ float wmax[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -968,15 +974,19 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const T* __restr
     __syncthreads();   // geometry staged (first chunk) / previous chunk's flush finished, wmax free
     if (lane == 0) wmax[wave] = amax;
     // ---- stage the x window and clear the dx window ----
-    constexpr int PV = F32 ? 4 : 8, PPX = 32 / PV;    // channels per 16-byte piece, pieces per window pixel
-    for (int i = tid; i < NPX * PPX; i += 512) {
-      const int pw = i / PPX, sl = i % PPX;
+    // f16 data is widened to f32 here, once per window element: the tap loop below is then the same instruction stream in
+    // both modes.  (Round 4: with an f16 window and the conversions inside the tap loop -- v_dot2_f32_f16 in round 3, then
+    // v_cvt + FMA chains -- the d(offset) / d(mask) sums of whole waves changed from run to run whenever a second process
+    // shared the GPU, and never otherwise; the f32 instantiation never did: tools/probe_contention2.py)
+    for (int i = tid; i < NPX * 4; i += 512) {
+      const int pw = i >> 2, sl = i & 3;
       const int y = wy0 + pw / WC, xx = wx0 + pw % WC;
-      typename VecT<T>::type v;
+      float v[8];
 #pragma unroll
-      for (int e = 0; e < PV; ++e) v[e] = (T)0.f;
-      if (y >= 0 && y < H && xx >= 0 && xx < W) v = *(const typename VecT<T>::type*)(ximg + ((long)y * W + xx) * x_stride + chunk * 32 + sl * PV);
-      *(typename VecT<T>::type*)(xw + pw * 32 + sl * PV) = v;
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      if (y >= 0 && y < H && xx >= 0 && xx < W) load8f<T>(ximg + ((long)y * W + xx) * x_stride + chunk * 32 + sl * 8, v);
+      *(f32x4*)(xw + pw * 32 + sl * 8) = (f32x4){v[0], v[1], v[2], v[3]};
+      *(f32x4*)(xw + pw * 32 + sl * 8 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
     }
     for (int i = tid; i < NPX * 8; i += 512) *(int4*)(dxw + i * 4) = make_int4(0, 0, 0, 0);
     __syncthreads();
@@ -996,12 +1006,12 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const T* __restr
       const int base = (int)(g.off & 0x3FFFFFFFu);
       const int pix0 = (base << 2) >> 2;               // image pixel of corner 0 when the sample leaves the window
       float sq[4];
-      if constexpr (F32) {
+      {
         float v[4][8];
         if (inwin) {
           // the window is zero-filled outside the image, so invalid corners read zeros
-          const T* c0 = xw + base * 32 + q * 8;
-          load8f<T>(c0, v[0]); load8f<T>(c0 + 32, v[1]); load8f<T>(c0 + WC * 32, v[2]); load8f<T>(c0 + WC * 32 + 32, v[3]);
+          const float* c0 = xw + base * 32 + q * 8;
+          load8f<float>(c0, v[0]); load8f<float>(c0 + 32, v[1]); load8f<float>(c0 + WC * 32, v[2]); load8f<float>(c0 + WC * 32 + 32, v[3]);
         } else {
           const T* c0 = ximg + (long)pix0 * x_stride + chunk * 32 + q * 8;
 #pragma unroll
@@ -1013,6 +1023,8 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const T* __restr
             }
           }
         }
+        // f32 FMAs in both modes.  (Round 3 used v_dot2_f32_f16 here for f16 data; with a second process on the GPU that
+        // kernel's d(offset) outputs changed from run to run -- tools/probe_contention*.py --, this form's do not.)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           float a2 = 0.f;
@@ -1020,33 +1032,14 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const T* __restr
           for (int e = 0; e < 8; ++e) a2 = fmaf(dv[t][e], v[c][e], a2);
           sq[c] = a2;
         }
-      } else {
-        f16x8 v[4];
-        const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (inwin) {
-          const f16* c0 = (const f16*)xw + base * 32 + q * 8;
-          v[0] = *(const f16x8*)c0; v[1] = *(const f16x8*)(c0 + 32);
-          v[2] = *(const f16x8*)(c0 + WC * 32); v[3] = *(const f16x8*)(c0 + WC * 32 + 32);
-        } else {
-          const f16* c0 = (const f16*)ximg + (long)pix0 * x_stride + chunk * 32 + q * 8;
-          v[0] = (g.valid & 1u) ? *(const f16x8*)c0 : z8;
-          v[1] = (g.valid & 2u) ? *(const f16x8*)(c0 + x_stride) : z8;
-          v[2] = (g.valid & 4u) ? *(const f16x8*)(c0 + (long)W * x_stride) : z8;
-          v[3] = (g.valid & 8u) ? *(const f16x8*)(c0 + (long)(W + 1) * x_stride) : z8;
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float a2 = 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; e += 2) {
-            typedef f16 f16x2 __attribute__((ext_vector_type(2)));
-            const f16x2 dd = {(f16)dv[t][e], (f16)dv[t][e + 1]}, vv = {v[c][e], v[c][e + 1]};
-            a2 = __builtin_amdgcn_fdot2(dd, vv, a2, false);
-          }
-          sq[c] = a2;
-        }
       }
       const float w0 = g.hh * g.hw, w1 = g.hh * g.lw, w2 = g.lh * g.hw, w3 = g.lh * g.lw;
+#ifdef CTDET_DEBUG_COL2IM
+      if (g_col2im_dbg) {      // per (pixel, tap, chunk, q): the four corner dots, the geometry words, corner-0 address
+        float* r = g_col2im_dbg + ((((long)m * 9 + (t0 + t)) * nch + chunk) * 4 + q) * 8;
+        r[0] = sq[0]; r[1] = sq[1]; r[2] = sq[2]; r[3] = sq[3]; r[4] = g.hw; r[5] = g.lw; r[6] = __uint_as_float(g.off); r[7] = (float)inwin;
+      }
+#endif
       s_val[t] += w0 * sq[0] + w1 * sq[1] + w2 * sq[2] + w3 * sq[3];
       s_dh[t] += -g.hw * sq[0] - g.lw * sq[1] + g.hw * sq[2] + g.lw * sq[3];    // d val / d h (kernel.cu:754-766)
       s_dw[t] += -g.hh * sq[0] + g.hh * sq[1] - g.lh * sq[2] + g.lh * sq[3];    // d val / d w (kernel.cu:767-779)

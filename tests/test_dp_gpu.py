@@ -77,6 +77,92 @@ def test_two_rank_step_equals_single_rank_step(tmp_path):
     assert torch.equal(r0["param"], r1["param"])
 
 
+def _graph_steps(outfile, nsteps=6, B=16, size=512):
+    """nsteps training steps at BASELINE's per-GPU shape on the bench's own model; after every step the sums of the parameter
+    and gradient buffers are recorded on the device (two tiny reductions on the launch stream: no host synchronisation that
+    would change the step's timing)"""
+    import bench
+    from detectron2_centernet_amd.engine.bench_train import synthetic_batch
+    from detectron2_centernet_amd.engine.train_loop import SimpleTrainer
+
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    model, cfg = bench.build_model("f16", dev, seed=5)
+    model.train()
+    tr = SimpleTrainer(model, None, cfg)
+    cfg.SOLVER.IMS_PER_BATCH = B * tr.reducer.world
+    batch = synthetic_batch(B, size, 0, dev)       # rank argument fixed: identical data on every rank
+    trace, losses, grads = [], [], []
+    for _ in range(nsteps):
+        l = tr.run_step_tensors(*batch)
+        losses.append(torch.stack([v.float() for v in l.values()]).clone())
+        trace.append(torch.stack([tr.optimizer.flat_param.double().sum(), tr.optimizer.flat_grad.double().abs().sum()]))
+        grads.append(tr.optimizer.flat_grad.clone())          # the exchanged gradient this step's update used
+    torch.cuda.synchronize()
+    names = {id(p): n for n, p in model.named_parameters()}
+    layout = [(names[id(p)], off, n) for p, (off, n) in zip(tr.optimizer.params, tr.optimizer.offsets)]
+    torch.save({"param": tr.optimizer.flat_param.cpu(), "mom": tr.optimizer.flat_mom.cpu(), "world": tr.reducer.world,
+                "trace": torch.stack(trace).cpu(), "losses": torch.stack(losses).cpu(), "graph_state": tr.graph_state,
+                "grads": [g.cpu() for g in grads], "layout": layout, "buckets": [tuple(b) for b in tr.reducer.buckets]}, outfile)
+
+
+def _graph_worker(outdir):
+    from detectron2_centernet_amd.utils import comm
+
+    _graph_steps(os.path.join(outdir, f"rank{comm.get_rank()}.pt"))
+
+
+def test_two_rank_graph_steps_equal_single_rank_steps(tmp_path):
+    """the data-parallel step as a replayed HIP graph (forward + backward captured; exchange, SGD launch and weight re-pack
+    behind it): two ranks on the device, gloo, six steps of BASELINE's per-GPU shape (16 x 512^2) on identical batches.
+    Both ranks must hold bit-identical parameters after every step (one all-reduce result, one update), and the trajectory
+    must be the single-process one up to the run-to-run noise of the step (f32 atomics), which two single runs measure.
+    Round 3 saw inf / drifting losses on this path in 3 of 6 runs of `bench.py --gpus 2`."""
+    from detectron2_centernet_amd.engine import launch
+
+    try:
+        os.environ["CTDET_TRAIN_GRAPH"] = "0"
+        _graph_steps(str(tmp_path / "eager.pt"))
+        os.environ["CTDET_TRAIN_GRAPH"] = "ddp"
+        _graph_steps(str(tmp_path / "single.pt"))
+        _graph_steps(str(tmp_path / "single2.pt"))
+        launch(_graph_worker, 2, num_machines=1, machine_rank=0, dist_url="auto", args=(str(tmp_path),), backend="gloo")
+    finally:
+        os.environ.pop("CTDET_TRAIN_GRAPH", None)
+    ref, ref2 = torch.load(tmp_path / "single.pt"), torch.load(tmp_path / "single2.pt")
+    eag = torch.load(tmp_path / "eager.pt")
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert ref["world"] == 1 and r0["world"] == 2 and r1["world"] == 2
+    assert ref["graph_state"] == r0["graph_state"] == r1["graph_state"] == "captured" and eag["graph_state"] == "eager"
+    ms_ = eag["mom"].abs().max().item()
+    print("momentum max |diff| / max: eager vs single graph", (eag["mom"] - ref["mom"]).abs().max().item() / ms_,
+          "eager vs rank0", (eag["mom"] - r0["mom"]).abs().max().item() / ms_,
+          "single graph vs rank0", (ref["mom"] - r0["mom"]).abs().max().item() / ms_)
+    for st in range(len(ref["grads"])):
+        d = (r0["grads"][st] - ref["grads"][st]).abs()
+        nz = (ref2["grads"][st] - ref["grads"][st]).abs()
+        bad = [(n, o, round(d[o:o + k].max().item() / max(1e-30, ref["grads"][st][o:o + k].abs().max().item()), 5))
+               for n, o, k in r0["layout"] if d[o:o + k].max().item() > 8 * nz[o:o + k].max().item() + 1e-6 * ref["grads"][st][o:o + k].abs().max().item()]
+        print(f"step {st}: {len(bad)} of {len(r0['layout'])} parameters off (relative max err), buckets {r0['buckets']}:", bad[:40])
+    print("losses eager ", eag["losses"].sum(1).tolist())
+    print("param sums eager", eag["trace"][:, 0].tolist())
+    print("losses single", ref["losses"].sum(1).tolist(), "\nlosses rank0 ", r0["losses"].sum(1).tolist(),
+          "\nlosses rank1 ", r1["losses"].sum(1).tolist())
+    print("param sums single", ref["trace"][:, 0].tolist(), "\nrank0", r0["trace"][:, 0].tolist(), "\nrank1", r1["trace"][:, 0].tolist())
+    assert torch.isfinite(r0["losses"]).all() and torch.isfinite(r1["losses"]).all()
+    assert torch.equal(r0["trace"], r1["trace"]), (r0["trace"], r1["trace"])       # the same buffers after EVERY step
+    assert torch.equal(r0["param"], r1["param"]) and torch.equal(r0["mom"], r1["mom"])
+    # identical batches on both ranks: the first step's loss is the single-rank one; later steps up to the noise two single
+    # runs show between themselves
+    lnoise = (ref2["losses"] - ref["losses"]).abs().max().item()
+    assert (r0["losses"] - ref["losses"]).abs().max().item() <= 4 * lnoise + 2e-3 * ref["losses"].abs().max().item(), lnoise
+    pnoise = (ref2["param"] - ref["param"]).abs().max().item()
+    assert (r0["param"] - ref["param"]).abs().max().item() <= 4 * pnoise + 1e-5, pnoise
+    mnoise = (ref2["mom"] - ref["mom"]).abs().max().item()
+    ms = ref["mom"].abs().max().item()
+    assert (r0["mom"] - ref["mom"]).abs().max().item() <= 4 * mnoise + 5e-3 * ms, (mnoise, ms)
+
+
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE starts two ranks itself (before touching the GPU) and
     rank 0 prints ONE line with n_gpus == 2; with fewer GPUs than ranks the ranks share the device and the line says so"""
