@@ -427,11 +427,18 @@ def train_roofline(model, cfg, B, size, rank, device):
     images, boxes, classes, counts = synthetic_batch(B, size, rank, device)
     ops.PROFILE.clear()
     ops.PROFILE_ON = True
+    # only rank 0 runs this step: a reducer of a data-parallel trainer that is still hooked to the parameters must not start
+    # collectives from it (the other ranks are not there to answer)
+    reducers = {id(r): r for r in (getattr(getattr(p, "_ctdet_grad_hook", None), "reducer", None) for p in model.parameters()) if r is not None}
+    for r in reducers.values():
+        r.enabled = False
     try:
         losses = model.train_batch_tensor(images, boxes, classes, counts)
         sum(losses.values()).backward()
     finally:
         ops.PROFILE_ON = False
+        for r in reducers.values():
+            r.enabled = True
     torch.cuda.synchronize()
     agg = _aggregate(ops.PROFILE, {})
     ops.PROFILE.clear()

@@ -59,6 +59,7 @@ class BucketedReducer:
             self._ready[b] += 1
             if self._ready[b] == self.buckets[b][2] and not self._launched[b]:
                 self._launch(b)
+        hook.reducer = self       # lets a caller that runs a backward pass outside the trainer switch the exchange off
         return hook
 
     def _launch(self, b):

@@ -27,16 +27,14 @@ class SimpleTrainer:
         self.iter = 0
         self.last_losses = None
         import os
-        # CTDET_TRAIN_GRAPH: "1" (default): a single-GPU step replays as one HIP graph; data-parallel steps stay eager with the
-        # bucketed all-reduce launched from autograd hooks (overlaps backward).  "ddp": data-parallel steps replay forward +
-        # backward as a graph, then the all-reduce and the SGD launch -- EXPERIMENTAL: in the two-ranks-on-one-GPU gloo rehearsal
-        # of `bench.py --gpus 2` this path corrupted the hm head in 3 of 6 runs (graph replay next to gloo's worker threads; not
-        # reproduced outside bench.py's flow, cause not found), the hooks path in 0 of 6, so it is not the default.  "0": eager.
+        # CTDET_TRAIN_GRAPH: "1" (default): the step replays as a HIP graph -- single GPU: targets, forward, losses, backward and
+        # the SGD launch in one graph; data parallel: forward + backward in the graph, then the bucketed all-reduce, the SGD launch
+        # and the batched weight re-pack behind it.  "hooks": data-parallel steps stay eager with the all-reduce of a bucket
+        # launched from autograd hooks as soon as its gradients are complete (overlaps backward; ~1,000 launches per step and
+        # rank).  "0": every step eager.  ("ddp", round 3's name of the data-parallel graph path, is accepted as "1".)
         mode = os.environ.get("CTDET_TRAIN_GRAPH", "1")
-        # (the VoVNet step -- HIP nodes mixed with torch's pooling / eSE ops -- runs eagerly: capturing it crashes
-        # hipGraphInstantiate on this ROCm, in capture_end; not root-caused)
-        self.use_hip_graph = mode != "0" and getattr(model, "backbone_type", "") != "vovnet"
-        self.graph_ddp = mode == "ddp"
+        self.use_hip_graph = mode != "0"
+        self.graph_ddp = mode not in ("0", "hooks")
         self._graphs = {}
 
     @staticmethod
@@ -67,11 +65,12 @@ class SimpleTrainer:
 
         From the third call with a given batch shape on, the step replays as ONE captured HIP graph: the eager step issues
         ~1,000 launches (23.9 ms against 20.5 replayed on an idle host; eight ranks' launch threads share one host).
-        Single GPU: targets, forward, losses, backward and the SGD launch are all in the graph.  Data parallel: eager, the
-        bucketed all-reduce launched from autograd hooks so that it overlaps backward.  CTDET_TRAIN_GRAPH=ddp replays forward
-        + backward as a graph there too and runs the all-reduce of the flat gradient buffer and the SGD launch after it
-        (experimental, see __init__).  The LR schedule and the per-parameter version counters stay on the host.
-        CTDET_TRAIN_GRAPH=0 keeps every step eager."""
+        Single GPU: targets, forward, losses, backward and the SGD launch are all in the graph.  Data parallel: forward +
+        backward replay as a graph, the all-reduce of the flat gradient buffer (three 32 MB buckets, back to back), the SGD
+        launch and the weight re-pack follow it (CTDET_TRAIN_GRAPH=hooks: eager, buckets launched from autograd hooks so that
+        they overlap backward).  Two ranks on one device == the single-process trajectory to 1e-7
+        (tests/test_dp_gpu.py::test_two_rank_graph_steps_equal_single_rank_steps).  The LR schedule and the per-parameter
+        version counters stay on the host.  CTDET_TRAIN_GRAPH=0 keeps every step eager."""
         multi = self.reducer.world > 1
         if not self.use_hip_graph or (multi and not self.graph_ddp):
             return self._finish_step(self.model.train_batch_tensor(images, boxes, classes, counts))
@@ -108,32 +107,48 @@ class SimpleTrainer:
         gc_on = gc.isenabled()
         gc.disable()
         self.reducer.enabled = False     # no collective may be launched from a hook while the stream is capturing
+        import warnings
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss_dict = self.model.train_batch_tensor(*inputs)
-                losses = sum(loss_dict.values())
-                self.optimizer.zero_grad()
-                losses.backward()
-                if with_step:
-                    self.optimizer.step()
-            g["graph"], g["inputs"] = graph, inputs
-            g["losses"] = {k: v.detach() for k, v in loss_dict.items()}
-            # the capture itself executed nothing: this call's step is the first replay
+            # An AccumulateGrad node that an older autograd graph keeps alive runs on the stream IT was created on (the default
+            # stream) and would fork the capture onto that stream: hipStreamEndCapture crashes on such a capture (round 3's
+            # VoVNet segfault; the step's own nodes write their gradients straight into the flat buffer and need no
+            # AccumulateGrad).  torch announces the situation with a warning: inside the capture it is an error, the capture is
+            # abandoned before the fork and the step stays eager (graph_state "failed", traceback logged).
+            with warnings.catch_warnings():
+                warnings.filterwarnings("error", message=".*AccumulateGrad node's stream does not match.*")
+                self._capture_body(graph, inputs, g, with_step)
         except RuntimeError as e:
-            # capture is an optimisation, but a failed one must be visible: the step falls back to eager launches, the state
-            # is reported by `graph_state` (bench.py prints it) and the traceback is logged once
-            import logging
-            import traceback
-            g["failed"] = repr(e)
-            g["traceback"] = traceback.format_exc()
-            logging.getLogger(__name__).warning("HIP-graph capture of the training step failed; running eagerly.\n%s",
-                                                g["traceback"])
-            torch.cuda.synchronize()
+            self._capture_failed(g, e)
+        except Warning as e:
+            self._capture_failed(g, RuntimeError(f"stale autograd graph alive during capture: {e}"))
         finally:
             self.reducer.enabled = True
             if gc_on:
                 gc.enable()
+
+    def _capture_failed(self, g, e):
+        # capture is an optimisation, but a failed one must be visible: the step falls back to eager launches, the state
+        # is reported by `graph_state` (bench.py prints it) and the traceback is logged once
+        import logging
+        import traceback
+        g["failed"] = repr(e)
+        g["traceback"] = traceback.format_exc()
+        logging.getLogger(__name__).warning("HIP-graph capture of the training step failed; running eagerly.\n%s",
+                                            g["traceback"])
+        torch.cuda.synchronize()
+
+    def _capture_body(self, graph, inputs, g, with_step):
+        with torch.cuda.graph(graph):
+            loss_dict = self.model.train_batch_tensor(*inputs)
+            losses = sum(loss_dict.values())
+            self.optimizer.zero_grad()
+            losses.backward()
+            if with_step:
+                self.optimizer.step()
+        g["graph"], g["inputs"] = graph, inputs
+        g["losses"] = {k: v.detach() for k, v in loss_dict.items()}
+        # the capture itself executed nothing: this call's step is the first replay
 
     @property
     def graph_state(self):

@@ -170,12 +170,15 @@ class _ParamOfTorchOp(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, p):
+        ctx.param = p
         return p.view_as(p)
 
     @staticmethod
     def backward(ctx, g):
         from .. import ops_train
-        return g * ops_train.PARAM_GRAD_MULT
+        g = g * ops_train.PARAM_GRAD_MULT
+        # into the parameter's slot of the flat gradient buffer when there is one: no AccumulateGrad node in the step
+        return None if ops_train.grad_into_slot(ctx.param, g) else g
 
 
 def _ese(m, x, identity):

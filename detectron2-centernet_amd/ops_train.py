@@ -167,6 +167,20 @@ def grad_done(p):
         h(p)
 
 
+def grad_into_slot(p, g):
+    """a finished (already scaled) gradient g of parameter p added straight to p's slice of the flat gradient buffer instead of
+    being returned to autograd; True if that was possible.  Besides saving AccumulateGrad's kernel this keeps AccumulateGrad
+    nodes out of the backward pass altogether: such a node runs on the stream that was current when IT was created, and a
+    node that an older autograd graph still keeps alive (a loss tensor the caller holds on to) drags the default stream into
+    a HIP-graph capture of the step -- hipStreamEndCapture then crashes (round 3's VoVNet capture: engine/train_loop.py)."""
+    slot = grad_slot(p)
+    if slot is None or slot.numel() != g.numel():
+        return False
+    slot.view(-1).add_(g.reshape(-1))
+    grad_done(p)
+    return True
+
+
 PENDING = []   # (slot, tap-major dw, taps, cin_k): finished weight gradients not yet added to their OIHW slots
 
 
@@ -459,6 +473,8 @@ class ConvFn(torch.autograd.Function):
             if sb is not None and sb.numel() == Cw:
                 grad_done(bparam)
                 dbias = None
+            elif direct and has_bias and grad_into_slot(bparam, dbias):
+                dbias = None
         if direct and wgrad_to_param(wparam, x, dy, Cw, R, S, stride, pad, R * S, x.shape[3], comp=comp):
             dwt = None
         else:
@@ -489,6 +505,7 @@ class FrozenConvFn(torch.autograd.Function):
                            cin_pad=x.shape[3] if x.shape[3] != weight.shape[1] else None)
         z = ops.conv2d(x, p, act=ACT_RELU if relu else ACT_NONE, residual=res)
         ctx.cfg = (stride, pad, relu, res is not None)
+        ctx.wparam = weight
         ctx.save_for_backward(x, weight, scale, z if relu else None)
         return z
 
@@ -507,7 +524,7 @@ class FrozenConvFn(torch.autograd.Function):
         dconv = g * sc.to(g.dtype)
         Cw = dconv.shape[3]
         dwt = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not wgrad_to_param(ctx.wparam, x, dconv, Cw, R, S, stride, pad, R * S, x.shape[3], comp=comp):
             dw = conv_wgrad(x, dconv, Cw, R, S, stride, pad, comp=comp)[:Cout]
             dwt = _wgrad_to_oihw(dw, Cout, Cin, x.shape[3], R, S)
         dx = None
@@ -529,6 +546,7 @@ class ConvTransposeFn(torch.autograd.Function):
         comp = ctx.comp = comp_of(x)
         y = ops.conv_transpose2d(x, weight.detach(), None, None, stride, pad, comp)
         ctx.cfg = (stride, pad)
+        ctx.wparam = weight
         ctx.save_for_backward(x, weight)
         return y if y.shape[3] == weight.shape[1] else y[..., :weight.shape[1]]
 
@@ -545,6 +563,9 @@ class ConvTransposeFn(torch.autograd.Function):
         dx = ops.conv2d(dy, p)
         dx = dx if dx.shape[3] == Cin else dx[..., :Cin]
         xp = _pad_c(x, comp)
+        # the parameter is [Cin, Cout, k, k]: "output channels" of this weight gradient = Cin, "input channels" = Cout
+        if wgrad_to_param(ctx.wparam, dy, xp, xp.shape[3], k, k, stride, pad, k * k, Cw, comp=comp):
+            return dx, None, None, None
         dw = conv_wgrad(dy, xp, xp.shape[3], k, k, stride, pad, comp=comp)[:Cin]         # [Cin, k*k*Cw]
         dwt = dw.view(Cin, k, k, Cw)[..., :Cout].permute(0, 3, 1, 2)
         return dx, dwt, None, None
@@ -741,7 +762,8 @@ class DeformConvFn(torch.autograd.Function):
             dx = dx[..., :Cin] + dx32
         # no gradient for a bias that is not there (autograd raises on a tensor returned for a None input) or that was written
         # straight into its slot
-        return dx.to(x.dtype), dw_off_t, db_off[:n_om], dwt, None if (sb is not None or p_b is None) else dbias[:Cout]
+        db_off_ret = None if grad_into_slot(p_boff, db_off[:n_om]) else db_off[:n_om]
+        return dx.to(x.dtype), dw_off_t, db_off_ret, dwt, None if (sb is not None or p_b is None) else dbias[:Cout]
 
 
 class FocalLossFn(torch.autograd.Function):

@@ -277,3 +277,8 @@ def test_vovnet19_slim_training_step_matches_oracle(tmp_path, dev, precision):
     assert (getattr(model.backbone.stage4.OSA4_1.layers[0], "OSA4_1_0/conv").weight.detach() - w0).abs().max() > 0
     assert torch.equal(getattr(model.backbone.stem, "stem_1/conv").weight.detach(), stem0)
     print(precision, "trainer graph_state", tr.graph_state, vals)
+    # round 3 ran this backbone's step eagerly: capturing it crashed hipStreamEndCapture.  Cause (round 4): the eager pass above
+    # is still alive (`losses`), and with it AccumulateGrad nodes created on the default stream; the eSE parameters' gradients
+    # went through them and forked the capture onto that stream.  Every parameter gradient of the step now goes straight into
+    # the optimizer's flat buffer, so no AccumulateGrad node runs inside the capture
+    assert tr.graph_state == "captured", tr._graphs
