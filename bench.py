@@ -475,26 +475,51 @@ def self_launch(args):
     import socket
     import subprocess
 
+    import tempfile
+    import time
+
     n = args.gpus
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     ndev = torch.cuda.device_count()       # does not initialise the GPU on this image
-    procs = []
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         if ndev < n:
             env.setdefault("CTDET_BENCH_BACKEND", "gloo")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+        out = tempfile.TemporaryFile()
+        logs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    # supervise every rank: the first one that fails takes the others down (a rank that died before the rendezvous would
+    # otherwise leave the rest in init_process_group / a barrier until the collective timeout), and the whole job has a deadline
+    deadline = time.time() + float(os.environ.get("CTDET_BENCH_TIMEOUT", "3000"))
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        failed = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if failed or time.time() > deadline:
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    try:
+                        rcs[i] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[i] = p.wait()
+            why = f"rank(s) {failed} failed" if failed else "deadline passed"
+            raise SystemExit(f"bench.py --gpus {n}: {why}; rank exit codes {rcs}")
+        time.sleep(0.2)
+    logs[0].seek(0)
+    out = logs[0].read().decode()
+    sys.stdout.write(out)
     sys.stdout.flush()
-    if any(rcs):
-        raise SystemExit(f"bench.py --gpus {n}: rank exit codes {rcs}")
-    line = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+    line = [ln for ln in out.splitlines() if ln.startswith("{")]
     if not line or json.loads(line[-1]).get("n_gpus") != n:
         raise SystemExit(f"bench.py --gpus {n}: fewer than {n} ranks joined")
 
@@ -566,7 +591,16 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-        world = dist.get_world_size()      # the ranks that actually joined
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but {dist.get_world_size()} ranks joined the group")
+        # one rank per GPU on the RCCL path: every rank reports the device it sits on (PCI bus id / uuid where torch exposes
+        # them, ordinal otherwise) and the set must have N members
+        props = torch.cuda.get_device_properties(device)
+        ident = f"{os.uname().nodename}:{getattr(props, 'uuid', None) or getattr(props, 'pci_bus_id', None) or dev_index}:{dev_index}"
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if backend == "nccl" and len(set(idents)) != world:
+            raise SystemExit(f"--gpus {args.gpus} over RCCL needs {world} distinct devices, the ranks sit on {idents}")
 
     if args.config == "r50":
         args.size = 800 if args.size == 512 else args.size

@@ -50,6 +50,37 @@ def run_train_bench(model, cfg, args, B, rank, world, device, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     losses = trainer.metrics()
+    comm_rec = allreduce_bandwidth(trainer, dist, device) if (dist is not None and world > 1) else None
+    return _record(model, args, B, world, elapsed, losses, trainer, comm_rec)
+
+
+def allreduce_bandwidth(trainer, dist, device, reps=10):
+    """the exchange of one step by itself: the bucketed all-reduce of the flat gradient buffer (78.7 MB for DLA-34), timed with
+    HIP events on the launch stream between two barriers, max over ranks.  bus bandwidth = 2 (N - 1) / N x bytes / time: what a
+    ring moves per link -- to be read against 153 GB/s per xGMI link (7 per GPU on a fully connected node)."""
+    red = trainer.reducer
+    nbytes = trainer.optimizer.flat_grad.numel() * 4
+    for _ in range(2):
+        red.reduce_all()
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        red.reduce_all()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    t = torch.tensor([ms], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item())
+    n = red.world
+    return {"bytes": nbytes, "buckets": len(red.buckets), "ms": ms, "algbw_GBs": nbytes / ms / 1e6,
+            "busbw_GBs": 2.0 * (n - 1) / n * nbytes / ms / 1e6, "backend": dist.get_backend(),
+            "note": "all buckets back to back, nothing overlapped; per-link peak 153 GB/s (xGMI)"}
+
+
+def _record(model, args, B, world, elapsed, losses, trainer, comm_rec):
     return {
         "metric": "images/sec at 512x512 (train bs=16/GPU)" if (B == 16 and args.size == 512) else
                   f"images/sec at {args.size}x{args.size} (train bs={B}/GPU)",
@@ -67,5 +98,5 @@ def run_train_bench(model, cfg, args, B, rank, world, device, dist):
         "config": {"workload": f"{'DLA-34' if model.backbone_type == 'dla34' else 'ResNet'} CenterNet train step (targets+fwd+loss+bwd+allreduce+SGD), {B}x3x{args.size}x"
                                f"{args.size} per GPU, 80 classes, " + _MODE[model._ctx.compute][1],
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "final_losses": losses, "graph_state": trainer.graph_state},
+                   "final_losses": losses, "graph_state": trainer.graph_state, "allreduce": comm_rec},
     }

@@ -43,7 +43,7 @@ def _worker(outdir):
 def test_two_rank_step_equals_single_rank_step(tmp_path):
     from detectron2_centernet_amd.engine import launch
 
-    os.environ["CTDET_TRAIN_GRAPH"] = "0"
+    os.environ["CTDET_TRAIN_GRAPH"] = "hooks"      # the eager path: buckets launched from autograd hooks
     try:
         _one_step(str(tmp_path / "single.pt"))
         _one_step(str(tmp_path / "single2.pt"))     # the run-to-run noise of the step itself (order of the f32 atomics)
@@ -77,7 +77,7 @@ def test_two_rank_step_equals_single_rank_step(tmp_path):
     assert torch.equal(r0["param"], r1["param"])
 
 
-def _graph_steps(outfile, nsteps=6, B=16, size=512):
+def _graph_steps(outfile, nsteps=6, B=16, size=512, device_index=0):
     """nsteps training steps at BASELINE's per-GPU shape on the bench's own model; after every step the sums of the parameter
     and gradient buffers are recorded on the device (two tiny reductions on the launch stream: no host synchronisation that
     would change the step's timing)"""
@@ -85,9 +85,9 @@ def _graph_steps(outfile, nsteps=6, B=16, size=512):
     from detectron2_centernet_amd.engine.bench_train import synthetic_batch
     from detectron2_centernet_amd.engine.train_loop import SimpleTrainer
 
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(0)
-    model, cfg = bench.build_model("f16", dev, seed=5)
+    dev = torch.device("cuda", device_index)
+    torch.cuda.set_device(device_index)
+    model, cfg = bench.build_model(os.environ.get("CTDET_TEST_DP_PRECISION", "f16"), dev, seed=5)
     model.train()
     tr = SimpleTrainer(model, None, cfg)
     cfg.SOLVER.IMS_PER_BATCH = B * tr.reducer.world
@@ -106,10 +106,10 @@ def _graph_steps(outfile, nsteps=6, B=16, size=512):
                 "grads": [g.cpu() for g in grads], "layout": layout, "buckets": [tuple(b) for b in tr.reducer.buckets]}, outfile)
 
 
-def _graph_worker(outdir):
+def _graph_worker(outdir, own_gpu=False):
     from detectron2_centernet_amd.utils import comm
 
-    _graph_steps(os.path.join(outdir, f"rank{comm.get_rank()}.pt"))
+    _graph_steps(os.path.join(outdir, f"rank{comm.get_rank()}.pt"), device_index=comm.get_local_rank() if own_gpu else 0)
 
 
 def test_two_rank_graph_steps_equal_single_rank_steps(tmp_path):
@@ -155,12 +155,86 @@ def test_two_rank_graph_steps_equal_single_rank_steps(tmp_path):
     # identical batches on both ranks: the first step's loss is the single-rank one; later steps up to the noise two single
     # runs show between themselves
     lnoise = (ref2["losses"] - ref["losses"]).abs().max().item()
-    assert (r0["losses"] - ref["losses"]).abs().max().item() <= 4 * lnoise + 2e-3 * ref["losses"].abs().max().item(), lnoise
+    assert (r0["losses"] - ref["losses"]).abs().max().item() <= 4 * lnoise + 1e-5 * ref["losses"].abs().max().item(), lnoise
     pnoise = (ref2["param"] - ref["param"]).abs().max().item()
-    assert (r0["param"] - ref["param"]).abs().max().item() <= 4 * pnoise + 1e-5, pnoise
+    assert (r0["param"] - ref["param"]).abs().max().item() <= 4 * pnoise + 1e-6, pnoise
     mnoise = (ref2["mom"] - ref["mom"]).abs().max().item()
     ms = ref["mom"].abs().max().item()
-    assert (r0["mom"] - ref["mom"]).abs().max().item() <= 4 * mnoise + 5e-3 * ms, (mnoise, ms)
+    assert (r0["mom"] - ref["mom"]).abs().max().item() <= 4 * mnoise + 1e-5 * ms, (mnoise, ms)
+    # and the eager single-process trajectory: replaying the step as a graph changes nothing
+    assert (eag["mom"] - ref["mom"]).abs().max().item() <= 4 * mnoise + 1e-5 * ms
+
+
+def _compare_with_single(tmp_path, what):
+    ref, ref2 = torch.load(tmp_path / "single.pt"), torch.load(tmp_path / "single2.pt")
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert r0["world"] == 2 and r1["world"] == 2 and r0["graph_state"] == r1["graph_state"] == "captured", what
+    assert torch.isfinite(r0["losses"]).all() and torch.equal(r0["trace"], r1["trace"]), what
+    assert torch.equal(r0["param"], r1["param"]) and torch.equal(r0["mom"], r1["mom"]), what
+    lnoise = (ref2["losses"] - ref["losses"]).abs().max().item()
+    assert (r0["losses"] - ref["losses"]).abs().max().item() <= 4 * lnoise + 1e-5 * ref["losses"].abs().max().item(), what
+    mnoise, ms = (ref2["mom"] - ref["mom"]).abs().max().item(), ref["mom"].abs().max().item()
+    assert (r0["mom"] - ref["mom"]).abs().max().item() <= 4 * mnoise + 1e-5 * ms, (what, mnoise, ms)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one rank per GPU over RCCL")
+@pytest.mark.parametrize("direct", [False, True])
+def test_two_gpus_rccl_graph_steps_equal_single_rank_steps(tmp_path, direct):
+    """the same check with the exchange that production uses: one rank per GPU, backend "nccl" (RCCL over xGMI) through
+    torch.distributed, and once more with CTDET_RCCL_DIRECT=1 (the C ABI's ctdet_comm_* / ctdet_allreduce_bucket entry points).
+    Skipped on one-GPU boxes; written in round 4 so that it runs the day two GPUs are visible."""
+    from detectron2_centernet_amd.engine import launch
+
+    os.environ["CTDET_TRAIN_GRAPH"] = "1"
+    if direct:
+        os.environ["CTDET_RCCL_DIRECT"] = "1"
+    try:
+        _graph_steps(str(tmp_path / "single.pt"))
+        _graph_steps(str(tmp_path / "single2.pt"))
+        launch(_graph_worker, 2, num_machines=1, machine_rank=0, dist_url="auto", args=(str(tmp_path), True), backend="nccl")
+    finally:
+        os.environ.pop("CTDET_TRAIN_GRAPH", None)
+        os.environ.pop("CTDET_RCCL_DIRECT", None)
+    _compare_with_single(tmp_path, f"RCCL, direct={direct}")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one rank per GPU over RCCL")
+def test_two_gpus_rccl_hooks_path(tmp_path):
+    """the eager data-parallel path (buckets launched from autograd hooks, overlapping backward) over RCCL on two GPUs"""
+    from detectron2_centernet_amd.engine import launch
+
+    os.environ["CTDET_TRAIN_GRAPH"] = "hooks"
+    try:
+        _graph_steps(str(tmp_path / "single.pt"))
+        _graph_steps(str(tmp_path / "single2.pt"))
+        launch(_graph_worker, 2, num_machines=1, machine_rank=0, dist_url="auto", args=(str(tmp_path), True), backend="nccl")
+    finally:
+        os.environ.pop("CTDET_TRAIN_GRAPH", None)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r0["graph_state"] = "captured"          # (_compare_with_single checks the graph path's state; this path is eager by design)
+    r1 = torch.load(tmp_path / "rank1.pt")
+    assert r1["graph_state"] == "eager"
+    r1["graph_state"] = "captured"
+    torch.save(r0, tmp_path / "rank0.pt")
+    torch.save(r1, tmp_path / "rank1.pt")
+    _compare_with_single(tmp_path, "RCCL, hooks")
+
+
+def test_two_rank_graph_steps_f16x3(tmp_path):
+    """the parity-grade training mode through the data-parallel graph path: two ranks on the device over gloo, six steps of
+    BASELINE's per-GPU shape, == the single-process trajectory"""
+    from detectron2_centernet_amd.engine import launch
+
+    os.environ["CTDET_TRAIN_GRAPH"] = "1"
+    os.environ["CTDET_TEST_DP_PRECISION"] = "f16x3"
+    try:
+        _graph_steps(str(tmp_path / "single.pt"))
+        _graph_steps(str(tmp_path / "single2.pt"))
+        launch(_graph_worker, 2, num_machines=1, machine_rank=0, dist_url="auto", args=(str(tmp_path),), backend="gloo")
+    finally:
+        os.environ.pop("CTDET_TRAIN_GRAPH", None)
+        os.environ.pop("CTDET_TEST_DP_PRECISION", None)
+    _compare_with_single(tmp_path, "gloo, f16x3")
 
 
 def test_bench_self_launches_its_ranks():

@@ -432,22 +432,23 @@ def test_full_training_step_matches_oracle(tmp_path, dev):
 
 
 def test_training_step_graph_replay_matches_eager(tmp_path, dev):
-    """the single-GPU trainer replays the whole step as one captured HIP graph from the third call on: losses and the
-    momentum buffer must follow the eager trajectory (f32 atomics make both slightly non-deterministic, and a random-init
-    batch-statistics network amplifies that, so the comparison is statistical), the LR schedule must keep advancing and
-    live parameters -- not capture-time copies -- must be used: the parameters move by the same amount"""
+    """the single-GPU trainer replays the whole step as one captured HIP graph from the third call on: losses, parameters and
+    the momentum buffer must follow the eager trajectory.  The bound is MEASURED: two eager runs give the step's own
+    run-to-run noise (order of the f32 atomics), the replayed run may deviate from the first eager run by four times that --
+    and the trajectory must move by far more than the bound, so that a replay on stale parameters (the bug this guards
+    against: the loss stays where it was at capture time, 0.8 % off at the third step, 3 % at the sixth) cannot hide in it."""
     from test_model_gpu import make_model
     from detectron2_centernet_amd.engine.bench_train import synthetic_batch
     from detectron2_centernet_amd.engine.train_loop import SimpleTrainer
 
     res = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "eager2", "graph"):
         model, cfg = make_model(tmp_path, "f16", seed=4)
-        cfg.SOLVER.IMS_PER_BATCH = 2
+        cfg.SOLVER.IMS_PER_BATCH = 4
         tr = SimpleTrainer(model, None, cfg)
         tr.use_hip_graph = mode == "graph"
         p0 = tr.optimizer.flat_param.clone()
-        batch = synthetic_batch(2, 128, 0, dev)
+        batch = synthetic_batch(4, 256, 0, dev)
         hist = []
         for i in range(6):
             l = tr.run_step_tensors(*batch)
@@ -455,19 +456,21 @@ def test_training_step_graph_replay_matches_eager(tmp_path, dev):
         if mode == "graph":
             g = next(iter(tr._graphs.values()))
             assert g["graph"] is not None, g.get("failed")
-        res[mode] = (hist, (tr.optimizer.flat_param - p0).norm().item(), tr.optimizer.flat_mom.clone(), tr.optimizer.lr,
-                     tr.iter)
-    (he, de, me, lre, ite), (hg, dg, mg, lrg, itg) = res["eager"], res["graph"]
+        res[mode] = (torch.tensor(hist, dtype=torch.float64), (tr.optimizer.flat_param - p0), tr.optimizer.flat_mom.clone(),
+                     tr.optimizer.lr, tr.iter)
+    (he, de, me, lre, ite), (he2, de2, me2, _, _), (hg, dg, mg, lrg, itg) = res["eager"], res["eager2"], res["graph"]
     assert ite == itg == 6 and lre == lrg
-    # the two trajectories separate exponentially (observed 0, 1e-4, 4e-4, 3e-4, 1e-3, 2e-3 relative over the six steps), so the
-    # bound doubles per step; a replay on stale parameters -- the bug this guards against -- leaves the loss where it was at
-    # capture time: 0.8 % off at the third step, 1.8 % at the fourth, 3 % at the sixth
-    for i, (a, b) in enumerate(zip(he, hg)):
-        assert abs(a - b) <= 1e-3 * 2 ** i * abs(a) * 0.5 + 5e-4 * abs(a), (i, he, hg)
-    assert de > 0 and abs(de - dg) <= 0.05 * de, (de, dg)          # six optimiser steps of the same size
-    assert abs(me.norm().item() - mg.norm().item()) <= 0.05 * me.norm().item()
-    cos = torch.nn.functional.cosine_similarity(me, mg, dim=0).item()
-    assert cos > 0.7, cos   # two eager runs of this chaotic toy problem differ by about as much (observed 0.85-0.97)
+    noise = ((he2 - he).abs() / he.abs()).max().item()
+    bound = 4 * noise + 1e-5
+    dev_g = ((hg - he).abs() / he.abs()).max().item()
+    move = abs(he[-1].item() - he[2].item()) / abs(he[2].item())
+    print(f"loss trajectories: run-to-run noise {noise:.2e}, graph vs eager {dev_g:.2e}, movement since the capture step {move:.2e}")
+    assert dev_g <= bound, (he.tolist(), hg.tolist(), noise)
+    assert move > 10 * bound, (move, bound)          # >= 10x margin between the bound and what stale parameters would show
+    mnoise, ms = (me2 - me).abs().max().item(), me.abs().max().item()
+    assert (mg - me).abs().max().item() <= 4 * mnoise + 1e-5 * ms, (mnoise, ms)
+    dnoise = (de2 - de).abs().max().item()
+    assert de.abs().max() > 0 and (dg - de).abs().max().item() <= 4 * dnoise + 1e-6 * de.abs().max().item()
 
 
 def test_trainer_on_ragged_list_batches(tmp_path, dev):
