@@ -829,8 +829,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_pair_kernel(const ConvArg
 // operand reads).  Both windows of a chunk pair sit in the two halo buffers at once (A = even chunk in buffer 0, B = odd
 // chunk in buffer 1); weights: ops.PackedConv._pack_pairs, nine 128-byte {X, Y} steps per chunk pair.  Cin % 32 == 0.
 // ------------------------------------------------------------------------------------------
+// BC = 128 (round 4, CTDET_TUNE_PAIR2_128): one workgroup per CU, a wave then has the whole 512-register file -- 128 accumulators
+// (AGPRs) next to both operand sets -- and every pixel fragment read feeds twice the MFMAs.
 template <int BC, int WP, int WC_, int TW = 32>
-__global__ void __launch_bounds__(256, 2) conv3x3_halo_pair2_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(256, BC > 64 ? 1 : 2) conv3x3_halo_pair2_kernel(const ConvArgs a) {
   // TW = 32: 8 x 32-pixel tiles; TW = 16: 16 x 16 (maps whose width is not a multiple of 32: the 16 x 16 level of DLA-34 at 512^2)
   constexpr int TH = 256 / TW, BP = TH * TW;
   constexpr int EN = TW / 16;           // 16-pixel tiles per tile row
@@ -844,7 +846,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_halo_pair2_kernel(const ConvAr
   constexpr int HMAIN = 10 * 32 * 64, HSIDE = 4096, HBUF = HMAIN + HSIDE;
   constexpr int WIMG = BCL * 64, WST = 2 * WIMG, NST = 3;
   static_assert(WP * WC_ == 4 && TP == EN * ROWS_W && (TH + 2 + RPR - 1) / RPR == 5, "wave layout");
-  static_assert(2 * HBUF + NST * WST <= 81920, "two workgroups per CU");
+  static_assert(BC > 64 || 2 * HBUF + NST * WST <= 81920, "two workgroups per CU");
   __shared__ __attribute__((aligned(16))) char smem[2 * HBUF + NST * WST];
   char* const ring = smem + 2 * HBUF;
 
@@ -1369,6 +1371,7 @@ int launch_halo_pair2(const ConvArgs& a, hipStream_t s) {
     return launch_halo_pair2_t<64, 4, 1, 16>(a, s);
   }
   if (pick_bc(a.Cout) <= 32) return launch_halo_pair2_t<32, 4, 1>(a, s);
+  if ((ctdet_tuning_flags() & CTDET_TUNE_PAIR2_128) && a.Cout_pad % 128 == 0) return launch_halo_pair2_t<128, 4, 1>(a, s);
   return launch_halo_pair2_t<64, 4, 1>(a, s);
 }
 
