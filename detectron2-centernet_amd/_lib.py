@@ -68,6 +68,7 @@ SIGNATURES = {
     "ctdet_dwconvT_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_dcn_cols": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_dcn_col2im_coord": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_dcn_col2im_fused": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_sgd_momentum": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _i32, _vp]),
     "ctdet_sgd_momentum_runs": (_i32, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _i32, _f32, _i32, _vp]),
     "ctdet_set_tuning_flags": (_i32, [C.c_uint32]),

@@ -75,6 +75,8 @@ int launch_dwconvT_bwd_f32(const float*, int, const float*, int, const float*, f
 int launch_dcn_cols_f32(const float*, int, const float*, int, float*, int, int, int, int, int, hipStream_t);
 int launch_dcn_col2im_coord_f32(const float*, const float*, int, const float*, int, float*, float*, int, int, int, int, int, int,
                                 int, int, hipStream_t);
+int launch_dcn_col2im_fused(const float*, int, int, const void*, const float*, const float*, int, const float*, int, float*, float*, int,
+                            int, int, int, int, int, hipStream_t);
 int launch_maxpool2x2_bwd(const f16*, int, const f16*, int, f16*, int, int, int, int, int, hipStream_t);
 int launch_depth_to_space2(const void*, int, void*, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_dwconvT_bwd(const f16*, int, const f16*, int, const float*, f16*, int, float*, int, int, int, int, int,
@@ -536,6 +538,14 @@ int32_t ctdet_dcn_col2im_coord(const void* dcol, const void* x, int32_t x_stride
                                        B, H, W, Cin, mask_is_prob, dcol_chunked, dtype == CTDET_DT_F16X3, (hipStream_t)stream);
   return launch_dcn_col2im_coord((const f16*)dcol, (const f16*)x, x_stride, om, om_stride, dx, dom, dom_stride,
                                  dom_dtype == CTDET_DT_F16, B, H, W, Cin, mask_is_prob, dcol_chunked, (hipStream_t)stream);
+}
+
+int32_t ctdet_dcn_col2im_fused(const float* dy, int32_t dy_stride, int32_t K, const void* w_packed, const float* w_scale,
+                               const float* x, int32_t x_stride, const float* om, int32_t om_stride, float* dx, float* dom,
+                               int32_t dom_stride, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t mask_is_prob, void* stream) {
+  CTDET_CHECK(dy && w_packed && w_scale && x && om && dx && dom, "dcn_col2im_fused: null pointer");
+  return launch_dcn_col2im_fused(dy, dy_stride, K, w_packed, w_scale, x, x_stride, om, om_stride, dx, dom, dom_stride, B, H, W, Cin,
+                                 mask_is_prob, (hipStream_t)stream);
 }
 
 int32_t ctdet_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, const float* lr_dev,

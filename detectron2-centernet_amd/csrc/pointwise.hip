@@ -453,6 +453,8 @@ int launch_pack_weights_batch(const void* table_dev, int n, int total_blocks, hi
 //      taps (2s, 2s+1) of A for s = 0..3, then tap 8 of A with tap 8 of B, then taps (2s, 2s+1) of B;  Kpad = chans_pad/32*288
 //   2  the same for an odd number of chunks (conv3x3_halo_pair_kernel): per chunk five steps, taps (2s, 2s+1), the tenth tap
 //      zero;  Kpad = chans_pad/16*160
+//   5  tap-major rows of Kpad f32 units (Kpad % 8 == 0), every group of 8 k = 32 bytes {hi[8], lo[8]}: operands that a kernel
+//      reads straight from memory as 16x16x32 MFMA fragments (the d(columns) GEMM inside dcn_col2im_window_kernel<FUSED>)
 // transposed as in ctdet_pack_weights (0 forward, 1 input-gradient operand, 2 / 3 DCNv2's d(columns) operand).
 // ------------------------------------------------------------------------------------------------
 struct Pack3Desc {
@@ -494,6 +496,21 @@ __device__ __forceinline__ void pack3_row(const Pack3Desc& d, int row, float* re
         o[j] = h; o[4 + j] = (f16)(v - (float)h);
       }
       *(f16x8*)(orow + 8 * g) = o;
+    }
+    return;
+  }
+  if (d.layout == 5) {      // groups of 8 k: {hi[8], lo[8]} (the A fragments of a 16x16x32 MFMA straight from memory)
+    for (int g = tid; g < d.Kpad / 8; g += 256) {
+      f16x8 oh, ol;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * g + j;
+        const float v = (k < K && row < rows) ? pw * pack_value(d.w, d.O, d.I, d.R, d.S, d.chans_pad, 0, d.transposed, row, k) : 0.f;
+        const f16 h = (f16)v;
+        oh[j] = h; ol[j] = (f16)(v - (float)h);
+      }
+      *(f16x8*)(orow + 16 * g) = oh;
+      *(f16x8*)(orow + 16 * g + 8) = ol;
     }
     return;
   }
@@ -544,9 +561,9 @@ static int pack3_check(const Pack3Desc& d) {
   CTDET_CHECK(d.w && d.out && d.scale_out, "pack_weights_x3: null pointer");
   const int taps = d.R * d.S;
   if (d.transposed >= 2) {
-    CTDET_CHECK(d.transposed <= 3 && d.R == 1 && d.S == 1 && d.layout == 0 && d.chans_pad >= d.O && d.rows_pad >= 9 * d.I &&
-                    (d.transposed == 2 || d.I % 32 == 0),
-                "pack_weights_x3: the DCNv2 d(columns) operand is a 1x1 contraction (R = S = 1 here) over a [O,I,3,3] weight, layout 0, rows_pad >= 9*I");
+    CTDET_CHECK(d.transposed <= 3 && d.R == 1 && d.S == 1 && (d.layout == 0 || d.layout == 5) && d.chans_pad >= d.O &&
+                    d.rows_pad >= 9 * d.I && (d.transposed == 2 || d.I % 32 == 0),
+                "pack_weights_x3: the DCNv2 d(columns) operand is a 1x1 contraction (R = S = 1 here) over a [O,I,3,3] weight, layout 0 or 5, rows_pad >= 9*I");
   } else {
     const int rows = d.transposed ? d.I : d.O, chans = d.transposed ? d.O : d.I;
     CTDET_CHECK(d.chans_pad >= chans && d.rows_pad >= rows, "pack_weights_x3: padded sizes too small");
@@ -555,6 +572,7 @@ static int pack3_check(const Pack3Desc& d) {
   if (d.layout == 0) CTDET_CHECK(d.Kpad % 4 == 0 && d.Kpad >= taps * d.chans_pad, "pack_weights_x3: Kpad=%d too small / not a multiple of 4", d.Kpad);
   else if (d.layout == 3) CTDET_CHECK(taps == 9 && d.chans_pad % 32 == 0 && d.Kpad == d.chans_pad / 32 * 288, "pack_weights_x3: layout 3 needs a 3x3 kernel, channels %% 32 == 0, Kpad = channels/32*288");
   else if (d.layout == 2) CTDET_CHECK(taps == 9 && d.chans_pad % 16 == 0 && d.Kpad == d.chans_pad / 16 * 160, "pack_weights_x3: layout 2 needs a 3x3 kernel, channels %% 16 == 0, Kpad = channels/16*160");
+  else if (d.layout == 5) CTDET_CHECK(d.Kpad % 8 == 0 && d.Kpad >= taps * d.chans_pad, "pack_weights_x3: layout 5 needs Kpad %% 8 == 0 and >= R*S*chans_pad");
   else CTDET_CHECK(false, "pack_weights_x3: bad layout %d", d.layout);
   CTDET_CHECK((((size_t)d.out) & 15) == 0, "pack_weights_x3: output must be 16-byte aligned");
   return 0;

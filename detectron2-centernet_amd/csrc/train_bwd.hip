@@ -8,6 +8,7 @@
 // Input-gradient of plain convs reuses the forward implicit-GEMM kernels with transposed/flipped weights.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -895,12 +896,24 @@ __device__ __forceinline__ void load8f(const T* p, float (&o)[8]) {
 // CUs -- every tap's scatter and its d(offset) / d(mask) entries are independent of the other taps'.
 // T = f16 (dcol, x f16: the f16 mode) or float (f32 dcol / x: the f16x3 training mode, fixed-point quantum 2^-20 of the tile's
 // largest dcol magnitude instead of 2^-19).  157 KB of LDS in both: one workgroup per CU.
-template <int NT, typename T>
+// FUSED (T = float, the f16x3 training mode): d(columns) = dY . W is not read from memory but computed here, per tile and
+// 32-channel chunk, on the matrix pipe: D[row = column (tap, channel)][col = pixel] = W^T (288 x Cout) . dY^T (Cout x 16 pixels
+// of the wave's tile row), f16x3 products (FusedDcol: the packed operand of ctdet_pack_weights_x3 layout 5, dY split in
+// registers).  The accumulator layout hands lane (pixel, g) channels 4g..4g+3 and 16+4g..16+4g+3 of every tap -- the lane's
+// eight channels of the scatter are those instead of 8g..8g+7 -- so the 302 MB (64 channels, batch 16; 604 MB in f32)
+// d(columns) tensor of a layer is never written or read, and the 1x1 GEMM launch that produced it is gone.
+struct FusedDcol {
+  const float* dy; int dy_stride; int K;     // dY [M][dy_stride] f32, K = its channels used (multiple of 32, zero padded)
+  const f16* wpk; const float* wscale;       // rows (Cin/32)*288 + tap*32 + c%32: K/8 groups of {hi[8], lo[8]}; per-row scale
+};
+
+template <int NT, typename T, bool FUSED = false>
 __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const T* __restrict__ dcol, const T* __restrict__ x,
                                                                 int x_stride, const float* __restrict__ om, int om_stride,
                                                                 float* __restrict__ dx, void* __restrict__ dom, int dom_stride,
                                                                 int dom_f16, int B, int H, int W, int Cin, int mask_is_prob,
-                                                                int chunked) {
+                                                                int chunked, const FusedDcol fz) {
+  static_assert(!FUSED || sizeof(T) == 4, "the fused d(columns) GEMM is the f16x3 mode's");
   constexpr int TH = 8, TW = 16, MG = 4, WR = TH + 2 + 2 * MG, WC = TW + 2 + 2 * MG, NPX = WR * WC;  // 18 x 26 = 468
   constexpr bool F32 = sizeof(T) == 4;
   constexpr int FXB = F32 ? 20 : 19;      // fixed-point bits: 9 * 128 contributions * 2^20 < 2^31
@@ -954,20 +967,75 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const T* __restr
   for (int chunk = 0; chunk < nch; ++chunk) {
     // ---- this lane's dcol vectors of the chunk, and the tile's largest magnitude (fixed-point scale) ----
     float dv[NT][8];
-    // chunked dcol ([Cin/32][tap][32] per pixel): the nine 32-channel pieces of this chunk are one contiguous run
-    const T* dcp = dcol + m * (9L * Cin) + (chunked ? chunk * 288 : chunk * 32) + q * 8;
-    const int tstep = chunked ? 32 : Cin;
     float amax = 0.f;
+    if constexpr (FUSED) {
+      f32x4 accd[2 * NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t0 + t >= 9) {
+      for (int j = 0; j < 2 * NT; ++j) accd[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* dyp = fz.dy + m * fz.dy_stride + q * 8;          // this lane's pixel, k group q of a 32-deep step
+      // W fragments come straight from memory (L2): groups of GJ tiles are fetched together, so that a group's 2 GJ loads are
+      // in flight at once instead of one tile's pair at a time in front of its three MFMAs
+      constexpr int GJ = 6;
+      const f16* const wrow = fz.wpk + ((long)chunk * 288 + fr) * fz.K * 2 + q * 16;
+      for (int ks = 0; ks < fz.K / 32; ++ks) {
+        const f32x4 y0 = *(const f32x4*)(dyp + ks * 32), y1 = *(const f32x4*)(dyp + ks * 32 + 4);
+        f16x8 bh, bl;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dv[t][e] = 0.f;
-        continue;
+        for (int e = 0; e < 4; ++e) {
+          bh[e] = (f16)y0[e]; bl[e] = (f16)(y0[e] - (float)bh[e]);
+          bh[4 + e] = (f16)y1[e]; bl[4 + e] = (f16)(y1[e] - (float)bh[4 + e]);
+        }
+#pragma unroll
+        for (int j0 = 0; j0 < 2 * NT; j0 += GJ) {
+          f16x8 ah[GJ], al[GJ];
+#pragma unroll
+          for (int u = 0; u < GJ; ++u) {
+            const int j = j0 + u;
+            if (j >= 2 * NT || t0 + (j >> 1) >= 9) continue;
+            const f16* wp = wrow + (long)((t0 + (j >> 1)) * 32 + (j & 1) * 16) * fz.K * 2 + ks * 64;
+            ah[u] = *(const f16x8*)wp; al[u] = *(const f16x8*)(wp + 8);
+          }
+#pragma unroll
+          for (int u = 0; u < GJ; ++u) {
+            const int j = j0 + u;
+            if (j >= 2 * NT || t0 + (j >> 1) >= 9) continue;
+            accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bh, accd[j], 0, 0, 0);
+            accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], bh, accd[j], 0, 0, 0);
+            accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bl, accd[j], 0, 0, 0);
+          }
+        }
       }
-      load8f<T>(dcp + (t0 + t) * tstep, dv[t]);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(dv[t][e]));
+      for (int j = 0; j < 2 * NT; ++j) {
+        if (t0 + (j >> 1) >= 9) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dv[j >> 1][(j & 1) * 4 + e] = 0.f;
+          continue;
+        }
+        // the lane's four rows of tile j: columns (tap, 16 * (j & 1) + 4 q + r); the pack scaled every row by a power of two
+        const f32x4 sc = *(const f32x4*)(fz.wscale + (long)chunk * 288 + (t0 + (j >> 1)) * 32 + (j & 1) * 16 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = accd[j][e] * sc[e];
+          dv[j >> 1][(j & 1) * 4 + e] = v;
+          amax = fmaxf(amax, fabsf(v));
+        }
+      }
+    } else {
+      // chunked dcol ([Cin/32][tap][32] per pixel): the nine 32-channel pieces of this chunk are one contiguous run
+      const T* dcp = dcol + m * (9L * Cin) + (chunked ? chunk * 288 : chunk * 32) + q * 8;
+      const int tstep = chunked ? 32 : Cin;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (t0 + t >= 9) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dv[t][e] = 0.f;
+          continue;
+        }
+        load8f<T>(dcp + (t0 + t) * tstep, dv[t]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(dv[t][e]));
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
@@ -1008,15 +1076,27 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const T* __restr
       float sq[4];
       {
         float v[4][8];
+        // the lane's eight channels of the chunk: 8q .. 8q+7, or (FUSED) 4q .. 4q+3 and 16+4q .. 16+4q+3
+        constexpr int C1 = FUSED ? 4 : 8, C2 = FUSED ? 16 : 4;     // offsets of the two 4-channel halves: q * C1 and q * C1 + C2
+        auto ld8 = [&](const auto* p, float (&o)[8]) {
+          typedef std::remove_cv_t<std::remove_reference_t<decltype(*p)>> PT;
+          if constexpr (FUSED) {
+            const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + C2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = a0[e]; o[4 + e] = a1[e]; }
+          } else {
+            load8f<PT>(p, o);
+          }
+        };
         if (inwin) {
           // the window is zero-filled outside the image, so invalid corners read zeros
-          const float* c0 = xw + base * 32 + q * 8;
-          load8f<float>(c0, v[0]); load8f<float>(c0 + 32, v[1]); load8f<float>(c0 + WC * 32, v[2]); load8f<float>(c0 + WC * 32 + 32, v[3]);
+          const float* c0 = xw + base * 32 + q * C1;
+          ld8(c0, v[0]); ld8(c0 + 32, v[1]); ld8(c0 + WC * 32, v[2]); ld8(c0 + WC * 32 + 32, v[3]);
         } else {
-          const T* c0 = ximg + (long)pix0 * x_stride + chunk * 32 + q * 8;
+          const T* c0 = ximg + (long)pix0 * x_stride + chunk * 32 + q * C1;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            if (g.valid & (1u << c)) load8f<T>(c0 + ((long)(c >> 1) * W + (c & 1)) * x_stride, v[c]);
+            if (g.valid & (1u << c)) ld8(c0 + ((long)(c >> 1) * W + (c & 1)) * x_stride, v[c]);
             else {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
@@ -1059,9 +1139,9 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const T* __restr
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           if (!(g.valid & (1u << c))) continue;
-          float* ap = dximg + (long)(pix0 + (c >> 1) * W + (c & 1)) * Cin + chunk * 32 + q * 8;
+          float* ap = dximg + (long)(pix0 + (c >> 1) * W + (c & 1)) * Cin + chunk * 32 + q * (FUSED ? 4 : 8);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) atomicAdd(ap + e, wq[c] * dv[t][e]);
+          for (int e = 0; e < 8; ++e) atomicAdd(ap + (FUSED ? (e & 3) + 16 * (e >> 2) : e), wq[c] * dv[t][e]);
         }
       }
     }
@@ -1070,7 +1150,9 @@ __global__ void __launch_bounds__(512) dcn_col2im_window_kernel(const T* __restr
     for (int i = tid; i < NPX * 32; i += 512) {
       const int pw = i >> 5, c = i & 31;
       const int y = wy0 + pw / WC, xx = wx0 + pw % WC;
-      const int vi = dxw[(c & 7) * (NPX * 4) + pw * 4 + (c >> 3)];
+      // [slot e of the owning lane][window pixel][lane group q]: channel c = 8q + e, or (FUSED) 4q + e % 4 + 16 (e / 4)
+      const int vi = FUSED ? dxw[((c & 3) + 4 * (c >> 4)) * (NPX * 4) + pw * 4 + ((c & 15) >> 2)]
+                           : dxw[(c & 7) * (NPX * 4) + pw * 4 + (c >> 3)];
       if (vi != 0 && y >= 0 && y < H && xx >= 0 && xx < W)
         atomicAdd(dximg + ((long)y * W + xx) * Cin + chunk * 32 + c, (float)vi * finv);
     }
@@ -1704,21 +1786,39 @@ int launch_dcn_cols(const f16* x, int x_stride, const float* om, int om_stride, 
   return 0;
 }
 
-template <typename T>
+template <typename T, bool FUSED = false>
 static void launch_col2im_window(const T* dcol, const T* x, int x_stride, const float* om, int om_stride, float* dx, void* dom,
                                  int dom_stride, int dom_f16, int B, int H, int W, int Cin, int mask_is_prob, int chunked,
-                                 hipStream_t s) {
+                                 hipStream_t s, const FusedDcol fz = FusedDcol()) {
   const unsigned tiles = (unsigned)(B * (H / 8) * (W / 16));
   const int ncu = ctdet_device_cu_count();    // one workgroup per CU at a time: with fewer tiles, split a tile's taps
   if ((int)tiles * 3 <= ncu)
-    hipLaunchKernelGGL((dcn_col2im_window_kernel<3, T>), dim3(tiles, 3), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
-                       dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
+    hipLaunchKernelGGL((dcn_col2im_window_kernel<3, T, FUSED>), dim3(tiles, 3), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
+                       dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked, fz);
   else if ((int)tiles * 2 <= ncu)
-    hipLaunchKernelGGL((dcn_col2im_window_kernel<5, T>), dim3(tiles, 2), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
-                       dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
+    hipLaunchKernelGGL((dcn_col2im_window_kernel<5, T, FUSED>), dim3(tiles, 2), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
+                       dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked, fz);
   else
-    hipLaunchKernelGGL((dcn_col2im_window_kernel<9, T>), dim3(tiles), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
-                       dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked);
+    hipLaunchKernelGGL((dcn_col2im_window_kernel<9, T, FUSED>), dim3(tiles), dim3(512), 0, s, dcol, x, x_stride, om, om_stride, dx, dom,
+                       dom_stride, dom_f16, B, H, W, Cin, mask_is_prob, chunked, fz);
+}
+
+// d(columns) GEMM + scatter in one kernel (f16x3 training mode): dy f32 [M][dy_stride] with K channels (multiple of 32; channels
+// beyond the layer's couts zero), wpk / wscale from ctdet_pack_weights_x3 (layout 5, transposed 3).  0 if launched, 1 if the
+// shape does not qualify (the caller then produces d(columns) and calls ctdet_dcn_col2im_coord).
+int launch_dcn_col2im_fused(const float* dy, int dy_stride, int K, const void* wpk, const float* wscale, const float* x, int x_stride,
+                            const float* om, int om_stride, float* dx, float* dom, int dom_stride, int B, int H, int W, int Cin,
+                            int mask_is_prob, hipStream_t s) {
+  CTDET_CHECK(dom_stride >= 27 && dom_stride <= 64, "dcn_col2im: dom_stride=%d", dom_stride);
+  if ((long)B * H * W == 0) return 0;
+  if (!(H % 8 == 0 && W % 16 == 0 && Cin % 32 == 0 && x_stride % 4 == 0 && K % 32 == 0 && K > 0 && dy_stride >= K && dy_stride % 4 == 0 &&
+        ((((size_t)x | (size_t)dy | (size_t)wpk | (size_t)wscale)) & 15) == 0) || (ctdet_tuning_flags() & CTDET_TUNE_NO_COL2IM_WINDOW))
+    return 1;
+  FusedDcol fz;
+  fz.dy = dy; fz.dy_stride = dy_stride; fz.K = K; fz.wpk = (const f16*)wpk; fz.wscale = wscale;
+  launch_col2im_window<float, true>(nullptr, x, x_stride, om, om_stride, dx, (void*)dom, dom_stride, 0, B, H, W, Cin, mask_is_prob, 1, s, fz);
+  CTDET_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_dcn_col2im_coord(const f16* dcol, const f16* x, int x_stride, const float* om, int om_stride, float* dx,

@@ -277,6 +277,26 @@ class PackPlan:
 PACK_PLAN = None    # set by solver.FlatSGD on a GPU; None: every PackedConv packs for itself
 
 
+def pack_x3(weight, args):
+    """(packed f32-viewed image [rows_pad, Kpad], row scale [scale_n]) of ctdet_pack_weights_x3 for the f32 contiguous parameter
+    `weight`; args = (O, I, R, S, chans_pad, rows_pad, Kpad, layout, transposed, scale_n).  Planned (persistent buffers, refreshed
+    by the batched pack after every optimizer step) when the weight lives in the optimizer's flat buffer."""
+    rows_pad, Kpad, scale_n = args[5], args[6], args[9]
+    key = ("x3",) + tuple(args) + (weight.data_ptr(),)
+    plan = PACK_PLAN if (PACK_PLAN is not None and PACK_PLAN.covers(weight)) else None
+    bufs = plan.lookup(key, weight) if plan is not None else None
+    if bufs is None:
+        bufs = plan.stale_buffer(key) if plan is not None else None
+        if bufs is None:
+            bufs = (torch.empty(rows_pad, Kpad, dtype=torch.float32, device=weight.device),
+                    torch.empty(scale_n, dtype=torch.float32, device=weight.device))
+        rc = _lib.lib().ctdet_pack_weights_x3(_ptr(weight), _ptr(bufs[0]), _ptr(bufs[1]), *args, _stream())
+        _lib.check(rc, "ctdet_pack_weights_x3")
+        if plan is not None:
+            plan.record(key, weight, bufs[0], tuple(args), scale=bufs[1])
+    return bufs
+
+
 class PackedConv:
     """Weights of one conv-shaped contraction, packed for the kernels, plus its folded epilogue.
 
@@ -435,19 +455,7 @@ class PackedConv:
             rows_pad, Kpad = round_up(self.Cout_pad, 32), (nch // 2 * 288 if layout == 3 else nch * 160)
         O, I = weight.shape[0], weight.shape[1]
         R, S = (1, 1) if tmode >= 2 else (weight.shape[2], weight.shape[3])
-        args = (O, I, R, S, self.Cin, rows_pad, Kpad, layout, tmode, self.Cout_eff)
-        key = ("x3",) + args + (weight.data_ptr(),)
-        plan = PACK_PLAN if (PACK_PLAN is not None and PACK_PLAN.covers(weight)) else None
-        bufs = plan.lookup(key, weight) if plan is not None else None
-        if bufs is None:
-            bufs = plan.stale_buffer(key) if plan is not None else None
-            if bufs is None:
-                bufs = (torch.empty(rows_pad, Kpad, dtype=torch.float32, device=weight.device),
-                        torch.empty(self.Cout_eff, dtype=torch.float32, device=weight.device))
-            rc = _lib.lib().ctdet_pack_weights_x3(_ptr(weight), _ptr(bufs[0]), _ptr(bufs[1]), *args, _stream())
-            _lib.check(rc, "ctdet_pack_weights_x3")
-            if plan is not None:
-                plan.record(key, weight, bufs[0], args, scale=bufs[1])
+        bufs = pack_x3(weight, (O, I, R, S, self.Cin, rows_pad, Kpad, layout, tmode, self.Cout_eff))
         sc = bufs[1] if self._user_scale is None else bufs[1] * self._user_scale
         e = self._x3[layout] = (bufs[0], sc)
         return e

@@ -23,6 +23,11 @@ from ._lib import ConvDesc
 from .ops import ACT_NONE, ACT_RELU, F16, F16X3, F32, _nhwc_stride, _ptr, _require_cuda, _stream, dt_of
 
 GRAD_SCALE = 1024.0
+# f16x3: DCNv2's d(columns) GEMM inside the scatter kernel (ctdet_dcn_col2im_fused).  Built, parity-green and OFF by default:
+# measured 7.4 ms per bs-16 step against 4.9 (scatter) + 2.1 (the sixteen 1x1 GEMM launches) for the two-step path -- the eight
+# waves of a workgroup each pull the same W fragments through L1 (no LDS left to share them: 157 KB are the scatter's), and
+# nothing overlaps the GEMM phase at one workgroup per CU.  CTDET_FUSED_DCOL=1 turns it on.
+FUSE_DCOL = os.environ.get("CTDET_FUSED_DCOL", "0") == "1"
 F32_COMPUTE = F32     # how contractions over f32 tensors run: F32 or F16X3 (engine/train_step.py sets it per forward pass)
 
 
@@ -349,6 +354,28 @@ def dcn_col2im_coord(dcol, x, om, mask_is_prob=False, dom_channels=None, dcol_ch
                                                int(dcol_chunked), dt_of(x) if comp is None or x.dtype == torch.float16 else comp,
                                                _stream())
     _lib.check(rc, "ctdet_dcn_col2im_coord")
+    return dx, dom
+
+
+def dcn_col2im_fused(dyp, weight, x, om, mask_is_prob=False, dom_channels=None):
+    """the f16x3 mode's DCNv2 backward through the sampler with the d(columns) GEMM inside the scatter kernel
+    (ctdet_dcn_col2im_fused): (dx f32, dom f32) or None when the shape does not qualify (the caller then materialises
+    d(columns)).  dyp f32 [B, H, W, K]: K % 32 == 0, channels beyond the layer's couts zero."""
+    B, H, W, Cin = x.shape
+    Cout, K = weight.shape[0], dyp.shape[3]
+    if (x.dtype != torch.float32 or dyp.dtype != torch.float32 or K % 32 or K < Cout or Cin % 32 or H % 8 or W % 16
+            or weight.dtype != torch.float32 or not weight.is_contiguous()):
+        return None
+    wpk, wscale = ops.pack_x3(weight.detach(), (Cout, Cin, 1, 1, K, 9 * Cin, K, 5, 3, 9 * Cin))
+    dx = torch.zeros(B, H, W, Cin, dtype=torch.float32, device=x.device)
+    dom = torch.empty(B, H, W, om.shape[3] if dom_channels is None else dom_channels, dtype=torch.float32, device=x.device)
+    with ops.prof_region("dcn_col2im_fused", flops=2.0 * B * H * W * K * 9 * Cin, nbytes=float(B * H * W * (Cin * 8 + K * 4 + 27 * 8))):
+        rc = _lib.lib().ctdet_dcn_col2im_fused(_ptr(dyp), _nhwc_stride(dyp), K, _ptr(wpk), _ptr(wscale), _ptr(x), _nhwc_stride(x),
+                                               _ptr(om), _nhwc_stride(om), _ptr(dx), _ptr(dom), dom.shape[3], B, H, W, Cin,
+                                               int(mask_is_prob), _stream())
+    if rc == 1:
+        return None
+    _lib.check(rc, "ctdet_dcn_col2im_fused")
     return dx, dom
 
 
@@ -683,8 +710,12 @@ class DCNFn(torch.autograd.Function):
         _, _, _, dbias = bn_train_bwd(dyp, None, None, None, None, None, relu=False, grad_mult=ctx.pgm)
         dw = conv_wgrad(col, dyp, dyp.shape[3], 1, 1, 1, 0, scale=ctx.pgm, comp=comp)[:Cout]         # [Cout, 9*Cin]
         dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
-        dcol = dcn_dcol(dyp, weight, chunked, comp)                        # [M, 9*Cin]
-        dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om, ctx.mask_is_prob, dcol_chunked=chunked, comp=comp)
+        fused = dcn_col2im_fused(dyp, weight, x, om, ctx.mask_is_prob) if (comp == F16X3 and FUSE_DCOL) else None
+        if fused is not None:
+            dx32, dom = fused
+        else:
+            dcol = dcn_dcol(dyp, weight, chunked, comp)                    # [M, 9*Cin]
+            dx32, dom = dcn_col2im_coord(dcol.contiguous(), x, om, ctx.mask_is_prob, dcol_chunked=chunked, comp=comp)
         return dx32.to(x.dtype), dom, dwt, dbias[:Cout] if ctx.has_bias else None, None, None
 
 
@@ -736,12 +767,16 @@ class DeformConvFn(torch.autograd.Function):
             dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
         if sb is not None:
             grad_done(p_b)
-        dcol = dcn_dcol(dyp, weight, chunked, comp)
         # dom comes back in the data type and channel padding the offset conv's backward kernels take (f16 / f16x3: 32 channels)
         n_om = w_off.shape[0]
         f32 = x.dtype == torch.float32
-        dx32, dom_p = dcn_col2im_coord(dcol.contiguous(), x, om, dom_channels=(n_om + 3) // 4 * 4 if comp == F32 else (n_om + 7) // 8 * 8,
-                                       dcol_chunked=chunked, comp=comp)
+        domc = (n_om + 3) // 4 * 4 if comp == F32 else (n_om + 7) // 8 * 8
+        fused = dcn_col2im_fused(dyp, weight, x, om, dom_channels=domc) if (comp == F16X3 and FUSE_DCOL) else None
+        if fused is not None:
+            dx32, dom_p = fused
+        else:
+            dcol = dcn_dcol(dyp, weight, chunked, comp)
+            dx32, dom_p = dcn_col2im_coord(dcol.contiguous(), x, om, dom_channels=domc, dcol_chunked=chunked, comp=comp)
         # ---- offset / mask conv: bias and weight gradients from dom; its input gradient lands on top of dx32
         Cw = dom_p.shape[3]
         _, _, _, db_off = bn_train_bwd(dom_p, None, None, None, None, None, relu=False)

@@ -204,7 +204,8 @@ int32_t ctdet_pack_weights_batch(const ctdet_pack_desc* table_dev, int32_t n, in
  * layout 0: tap-major split image, rows of Kpad f32 units (Kpad % 4 == 0, >= R*S*chans_pad), each group of 4 k = {hi[4],
  *           lo[4]} f16 -- ctdet_conv_desc.korder 0: 1x1 / strided / 7x7 convs, DCNv2, the d(columns) operand;
  * layout 3: tap-pair image of the 3x3 halo kernel, korder 3 (chans_pad % 32 == 0, Kpad = chans_pad/32*288, rows_pad % 32 == 0);
- * layout 2: the same for an odd number of 16-channel chunks, korder 2 (Kpad = chans_pad/16*160).
+ * layout 2: the same for an odd number of 16-channel chunks, korder 2 (Kpad = chans_pad/16*160);
+ * layout 5: tap-major rows, every group of 8 k = {hi[8], lo[8]} (Kpad % 8 == 0): the operand ctdet_dcn_col2im_fused reads.
  * transposed: as in ctdet_pack_weights (1: the input-gradient operand, rows = input channels, taps flipped; 2 / 3: DCNv2's
  * d(columns) operand -- give R = S = 1 for those, the weight itself is [O, I, 3, 3]). */
 int32_t ctdet_pack_weights_x3(const float* w, void* packed, float* scale_out, int32_t O, int32_t I, int32_t R, int32_t S,
@@ -353,6 +354,17 @@ int32_t ctdet_dcn_cols(const void* x, int32_t x_stride, const float* om, int32_t
 int32_t ctdet_dcn_col2im_coord(const void* dcol, const void* x, int32_t x_stride, const float* om, int32_t om_stride,
                                float* dx, void* dom, int32_t dom_stride, int32_t dom_dtype, int32_t B, int32_t H, int32_t W,
                                int32_t Cin, int32_t mask_is_prob, int32_t dcol_chunked, int32_t dtype, void* stream);
+
+/* The f16x3 training mode's form of the two steps above in one kernel: d(columns) = dY . W (deform_conv_cuda.cu:1003-1009) is
+ * computed per tile on the matrix pipe (f16x3 products) inside the scatter kernel instead of being written to and read from
+ * memory (9*Cin floats per pixel: 604 MB for a 64-channel 128x128 layer at batch 16).  dy f32 [M][dy_stride], its first K
+ * channels used (K % 32 == 0; channels beyond the layer's couts must be zero); w_packed / w_scale: ctdet_pack_weights_x3 of the
+ * [Cout, Cin, 3, 3] weight with layout 5, transposed 3, chans_pad = Kpad = K, rows_pad >= 9*Cin.  Other arguments as
+ * ctdet_dcn_col2im_coord (f32 x, f32 dom).  Returns 0 if launched, 1 if the shape does not qualify (map not divisible by 8x16,
+ * Cin % 32 != 0, ...): nothing was done and the caller takes the two-step path. */
+int32_t ctdet_dcn_col2im_fused(const float* dy, int32_t dy_stride, int32_t K, const void* w_packed, const float* w_scale,
+                               const float* x, int32_t x_stride, const float* om, int32_t om_stride, float* dx, float* dom,
+                               int32_t dom_stride, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t mask_is_prob, void* stream);
 
 /* ---- data-parallel exchange over RCCL / xGMI (one process per GPU) ---------------------------------------------
  * What DistributedDataParallel's reducer does over NCCL in the reference (detectron2/engine/defaults.py:279-285,

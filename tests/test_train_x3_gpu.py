@@ -304,6 +304,36 @@ def test_dcn_col2im_window_f32_vs_atomics(T, dev, x3, shape):
     assert torch.equal(dom_p[..., :27], dom_w[..., :27])
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 32, 64, 64), (12, 32, 32, 32, 256), (40, 32, 48, 64, 128), (1, 16, 16, 512, 256)])
+def test_dcn_col2im_fused_dcol_equals_two_step(T, dev, x3, shape):
+    """ctdet_dcn_col2im_fused (d(columns) = dY . W computed per tile on the matrix pipe inside the scatter kernel; tap split over
+    3 / 2 / 1 workgroups) against the two-step path (f16x3 1x1 GEMM writing d(columns), then the scatter kernel reading it):
+    same products, another summation order"""
+    ops, ot = T
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    dy = torch.randn(B, H, W, Cout, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * torch.rand(Cout, 1, 1, 1, generator=g) / (Cin * 9) ** 0.5).to(dev)
+    om = torch.randn(B, H, W, 28, generator=g)
+    om[..., :18] *= 2.0
+    om = om.to(dev)
+    fused = ot.dcn_col2im_fused(dy, w, x, om, dom_channels=32)       # (called directly: the training step's default is two-step)
+    assert fused is not None
+    dx_f, dom_f = fused
+    dcol = ot.dcn_dcol(dy, w, True, x3)
+    dx_t, dom_t = ot.dcn_col2im_coord(dcol, x, om, dom_channels=32, dcol_chunked=True, comp=x3)
+    close(dx_f.cpu(), dx_t.cpu(), 2e-5, "dx")
+    close(dom_f.cpu(), dom_t.cpu(), 2e-5, "dom")
+    assert dom_f[..., 27:].abs().max().item() == 0
+    # and against the exact f64 product for d(columns) feeding the generic f32 kernel
+    wm = w.double().reshape(Cout, Cin // 32, 32, 9).permute(0, 1, 3, 2).reshape(Cout, 9 * Cin)
+    dcol64 = (dy.double().reshape(-1, Cout) @ wm).float().reshape(B, H, W, 9 * Cin)
+    dx_r, dom_r = ot.dcn_col2im_coord(dcol64, x, om, dom_channels=32, dcol_chunked=True, comp=ops.F32)
+    close(dx_f.cpu(), dx_r.cpu(), 3e-5, "dx vs f64 columns")
+    close(dom_f.cpu(), dom_r.cpu(), 3e-5, "dom vs f64 columns")
+
+
 def test_deform_conv_node_x3(T, dev, x3):
     """DeformConvFn (offset conv + DCNv2 as one node) in the f16x3 mode against autograd through the oracle"""
     ops, ot = T
