@@ -1891,30 +1891,56 @@ __global__ void __launch_bounds__(256) conv_wgrad_f32_kernel(const WgradArgsF a)
   if (n0 + tn < a.Cout && k_ok && acc != 0.f) wg_add(a, n0 + tn, kl, acc * a.scale);
 }
 
-// col[m][tap*Cin + c] = mask * bilinear(x), f32: thread = (pixel, tap, 4 channels), the four corners as float4s; the blend in
-// the reference's operation order (kernel.cu:666-699: v1 w1 + v2 w2 + v3 w3 + v4 w4, then * mask :854-861)
+// col[m][tap*Cin + c] = mask * bilinear(x), f32.  A workgroup walks (pixel, tap) pairs, 256 / (Cin / 4) at a time: the sampling
+// geometry of a pair (floor, the four weights, the sigmoid of the mask logit) is computed ONCE, by one thread, and handed to the
+// Cin / 4 threads that each blend 4 channels of the four corners (float4 loads; consecutive threads = consecutive channels: every
+// corner is one contiguous run, every store of a pair one contiguous Cin * 4 bytes) -- round 4: the first f32 form had every
+// one of those threads re-derive the geometry (16 times for 64 channels).  The blend in the reference's operation order
+// (kernel.cu:666-699: v1 w1 + v2 w2 + v3 w3 + v4 w4, then * mask :854-861).
+struct ColsGeoS { float w[4]; int off[4]; float mask; };
+constexpr int COLS_PASSES = 8;
 __global__ void __launch_bounds__(256) dcn_cols_f32_kernel(const float* __restrict__ x, int x_stride,
                                                            const float* __restrict__ om, int om_stride, float* __restrict__ col,
                                                            int B, int H, int W, int Cin, int mask_is_prob) {
-  const int CV = Cin >> 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)B * H * W * 9 * CV) return;
-  const int cv = (int)(idx % CV);
-  long t = idx / CV;
-  const int tap = (int)(t % 9);
-  const long m = t / 9;
-  const int wo = (int)(m % W);
-  const long t2 = m / W;
-  const int ho = (int)(t2 % H), b = (int)(t2 / H);
-  const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride, mask_is_prob);
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 v[4];
+  __shared__ ColsGeoS geo[2][64];
+  const int CV = Cin >> 2;                       // <= 256
+  const int PP = 256 / CV;                       // pairs per pass (>= 1), <= 64 (Cin >= 16)
+  const long npairs = (long)B * H * W * 9;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  for (int pass = 0; pass < COLS_PASSES; ++pass) {
+    const long pair0 = ((long)blockIdx.x * COLS_PASSES + pass) * PP;
+    if (pair0 >= npairs) break;                  // block-uniform
+    ColsGeoS* gs = geo[pass & 1];
+    if (threadIdx.x < PP && pair0 + threadIdx.x < npairs) {
+      const long pr = pair0 + threadIdx.x;
+      const int tap = (int)(pr % 9);
+      const long m = pr / 9;
+      const int wo = (int)(m % W);
+      const long t2 = m / W;
+      const int ho = (int)(t2 % H), b = (int)(t2 / H);
+      const DcnGeom g = dcn_geom(om + m * om_stride, tap, b, ho, wo, H, W, x_stride, mask_is_prob);
+      ColsGeoS o;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = g.off[q] >= 0 ? *(const f32x4*)(x + g.off[q] + cv * 4) : z4;
-  f32x4 o;
+      for (int q = 0; q < 4; ++q) { o.w[q] = g.w[q]; o.off[q] = (int)g.off[q]; }
+      o.mask = g.mask;
+      gs[threadIdx.x] = o;
+    }
+    __syncthreads();                             // (two geometry buffers: the next pass writes the other one)
+    const long pr = pair0 + pl;
+    if (pl < PP && pr < npairs) {
+      const ColsGeoS g = gs[pl];
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 v[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (g.w[0] * v[0][e] + g.w[1] * v[1][e] + g.w[2] * v[2][e] + g.w[3] * v[3][e]) * g.mask;
-  *(f32x4*)(col + m * (9L * Cin) + (long)tap * Cin + cv * 4) = o;
+      for (int q = 0; q < 4; ++q) v[q] = g.off[q] >= 0 ? *(const f32x4*)(x + g.off[q] + cv * 4) : z4;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (g.w[0] * v[0][e] + g.w[1] * v[1][e] + g.w[2] * v[2][e] + g.w[3] * v[3][e]) * g.mask;
+      const int tap = (int)(pr % 9);
+      const long m = pr / 9;
+      *(f32x4*)(col + m * (9L * Cin) + (long)tap * Cin + cv * 4) = o;
+    }
+  }
 }
 
 // the generic coordinate / col2im kernel above for f32 columns and inputs (same wave-per-(pixel, tap) structure)
@@ -1982,12 +2008,15 @@ int launch_conv_wgrad_f32(const WgradArgs& h, hipStream_t s) {
 
 int launch_dcn_cols_f32(const float* x, int x_stride, const float* om, int om_stride, float* col, int B, int H, int W, int Cin,
                         int mask_is_prob, hipStream_t s) {
-  CTDET_CHECK(om_stride >= 27 && Cin % 4 == 0 && x_stride % 4 == 0 && ((((size_t)x | (size_t)col)) & 15) == 0,
-              "dcn_cols(f32): Cin=%d / x_stride=%d must be multiples of 4, tensors 16-byte aligned", Cin, x_stride);
-  const long total = (long)B * H * W * 9 * (Cin / 4);
-  if (total == 0) return 0;
-  hipLaunchKernelGGL(dcn_cols_f32_kernel, dim3(nblk256(total)), dim3(256), 0, s, x, x_stride, om, om_stride, col, B, H, W, Cin,
-                     mask_is_prob);
+  CTDET_CHECK(om_stride >= 27 && Cin % 4 == 0 && Cin >= 16 && Cin <= 1024 && x_stride % 4 == 0 && ((((size_t)x | (size_t)col)) & 15) == 0,
+              "dcn_cols(f32): Cin=%d (16..1024) / x_stride=%d must be multiples of 4, tensors 16-byte aligned", Cin, x_stride);
+  CTDET_CHECK((long)B * H * W * x_stride < (1L << 31), "dcn_cols(f32): input too large for 32-bit element offsets");
+  const long npairs = (long)B * H * W * 9;
+  if (npairs == 0) return 0;
+  const int PP = 256 / (Cin / 4);
+  const long per_block = (long)PP * COLS_PASSES;
+  hipLaunchKernelGGL(dcn_cols_f32_kernel, dim3((unsigned)((npairs + per_block - 1) / per_block)), dim3(256), 0, s, x, x_stride, om, om_stride,
+                     col, B, H, W, Cin, mask_is_prob);
   CTDET_LAUNCH_CHECK();
   return 0;
 }
