@@ -138,6 +138,11 @@ class _EvalEngine:
         hm, wh, reg = self.out
         # the head kernel's epilogue has just clamped hm to [1e-4, 1 - 1e-4]: the decode may skip the floor plateau
         self.dec = ops.decode(hm, wh, reg, m.topk_candidates, m.backbone.down_ratio, heat_floor=ops.SIGMOID_CLAMP_FLOOR)
+        # one flag per step, computed inside the captured part: are the size / offset maps finite?  They carry no clamp, so an
+        # activation that left the f16 range on its way through an f16x3 (or f16) layer -- hi = f16(x) is inf beyond 65504 --
+        # or any other blow-up of a diverged network ends up here as inf / NaN (the heat map would hide it: its epilogue
+        # clamps NaN to the floor).  _post() folds the flag into the per-image counts the host reads back anyway.
+        self.finite = torch.isfinite(wh).all() & torch.isfinite(reg).all()
 
     def _post(self):
         """threshold / rescale / clip / compact into FRESH output tensors: runs after the captured part, outside the graph, so
@@ -145,7 +150,8 @@ class _EvalEngine:
         m = self.model
         boxes, scores, classes, _ = self.dec
         max_det = min(m.max_detections_per_image, m.topk_candidates)
-        return ops.postprocess(boxes, scores, classes, max_det, m.score_threshold, self.img_params)
+        boxes, scores, classes, counts = ops.postprocess(boxes, scores, classes, max_det, m.score_threshold, self.img_params)
+        return boxes, scores, classes, torch.where(self.finite, counts, torch.full_like(counts, -1))
 
     def __call__(self, images=None):
         """one eval step on `images` ([B,3,H,W] device batch of the engine's shape and dtype, contiguous) or, when None, on
@@ -291,7 +297,7 @@ class CenterNet(nn.Module):
         while len(self._engines) >= MAX_ENGINES:
             old = self._engines.pop(next(iter(self._engines)))
             del old
-        eng = self._engines[key] = _EvalEngine(self, B, H, W, Hp, Wp, img_dtype, self.use_hip_graph)
+        eng = self._engines[key] = _EvalEngine(self, B, H, W, Hp, Wp, img_dtype, self.use_hip_graph and not ops.RANGE_CHECK)
         return eng
 
     # ------------------------------------------------------------------ network (NHWC, HIP kernels)
@@ -608,6 +614,9 @@ class _EvalHandle:
     def result(self):
         self.event.synchronize()  # the only host<->device synchronisation of the eval step
         counts = self.counts_host.tolist()
+        if counts and counts[0] < 0:
+            raise FloatingPointError("the network's size / offset maps are not finite: an activation left the range the "
+                                     "arithmetic mode can carry (f16x3 / f16: |x| must stay below 65504) or the weights hold inf / NaN")
         results = []
         for b, n in enumerate(counts):
             r = Instances(self.out_sizes[b])

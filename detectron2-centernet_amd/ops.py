@@ -146,6 +146,22 @@ class prof_region:
         return False
 
 
+# CTDET_RANGE_CHECK=1 (debug): after every f16x3 / f16 contraction the output's largest magnitude is read back and a value the
+# NEXT layer cannot carry raises.  f16x3 holds an activation as hi + lo with hi = f16(x): beyond 65504 hi is inf, the layer's
+# sums become inf / NaN -- and the ReLU of the epilogue (fmaxf) turns NaN into 0, so the network's outputs stay finite and
+# wrong.  The check costs a host synchronisation per layer, so the eval engines run eagerly (no graph) while it is on.
+RANGE_CHECK = os.environ.get("CTDET_RANGE_CHECK", "0") == "1"
+F16_MAX = 65504.0
+
+
+def _range_check(out, p, what):
+    if RANGE_CHECK and p.compute in (F16, F16X3):
+        amax = out.detach().float().abs().amax().item()
+        if not (amax <= F16_MAX):
+            raise FloatingPointError(f"{what}: output magnitude {amax:.4g} leaves the range the {'f16x3' if p.compute == F16X3 else 'f16'} "
+                                     f"mode can carry into the next layer (|x| <= {F16_MAX:.0f}; Cin={p.Cin_real}, Cout={p.Cout}, k={p.R})")
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -574,6 +590,7 @@ def conv2d(x, p, out=None, act=ACT_NONE, residual=None, out_dtype=None, clamp=(0
                                          _ptr(out), _stream())
     _lib.check(rc, "ctdet_conv2d_fwd")
     prof.done()
+    _range_check(out, p, "conv2d")
     return out
 
 
@@ -610,6 +627,7 @@ def conv1x1_cat(xs, p, out=None, act=ACT_NONE, residual=None, out_dtype=None):
                                               _ptr(p.bias), _ptr(residual), _ptr(out), _stream())
     _lib.check(rc, "ctdet_conv1x1_cat_fwd")
     prof.done()
+    _range_check(out, p, "conv1x1_cat")
     return out
 
 
@@ -640,6 +658,7 @@ def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_pro
                                         int(mask_is_prob), _ptr(p.w), _ptr(p.scale), _ptr(p.bias), _ptr(out), _stream())
     _lib.check(rc, "ctdet_dcnv2_fwd")
     prof.done()
+    _range_check(out, p, "dcnv2")
     return out
 
 

@@ -13,11 +13,12 @@ from oracle import ctdet_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def setup():
+@pytest.fixture(scope="module", params=["f16", "f16x3"])
+def setup(request):
+    """the whole network at BASELINE's size in the throughput mode and in the bench's headline mode (f16x3)"""
     import bench
     dev = torch.device("cuda:0")
-    model, cfg = bench.build_model("f16", dev, seed=3)
+    model, cfg = bench.build_model(request.param, dev, seed=3)
     model.eval()
     model.score_threshold = 0.0
     model.wh[2].bias.data.fill_(4.0)   # positive box sizes so that detections survive the empty-box filter
@@ -233,7 +234,7 @@ def test_resnet50_800x800_bs8_properties(dev):
 
 
 # ---- f16x3 (f32 tensors, split f16 products) at the BASELINE sizes: many rounds of workgroups per CU ----
-@pytest.mark.parametrize("case", [(64, 128, 128, 64, 64), (64, 64, 64, 128, 128), (64, 32, 32, 256, 256), (16, 128, 128, 64, 768),
+@pytest.mark.parametrize("case", [(64, 128, 128, 64, 64), (64, 64, 64, 128, 128), (64, 32, 32, 256, 256), (64, 128, 128, 64, 768),
                                   (64, 128, 128, 64, 27), (64, 16, 16, 512, 512)])
 def test_fullsize_conv3x3_f16x3_matches_torch_f32(case):
     """the tap-pair halo kernel (and, for the 16x16 map, the uniform-K kernel) in f16x3 mode against torch's fp32 conv:
@@ -256,15 +257,18 @@ def test_fullsize_conv3x3_f16x3_matches_torch_f32(case):
     assert worst <= 2e-5, worst
 
 
-def test_fullsize_dcn_f16x3_matches_oracle_on_sampled_images():
-    """f16x3 DCNv2 (LDS-window kernel, split operands) on a full 64 x 128 x 128 x 64 layer: deterministic, images 0 / 40 / 63
-    against the CPU oracle within 2e-5"""
+@pytest.mark.parametrize("shape", [(128, 64, 64), (64, 128, 128)])
+def test_fullsize_dcn_f16x3_matches_oracle_on_sampled_images(shape):
+    """f16x3 DCNv2 (LDS-window kernel, split operands) on full layers of the batch-64 step -- 64 x 128 x 128 x 64 -> 64 (the
+    <2,64> tile: four 32-pixel waves) and 64 x 64 x 64 x 128 -> 128 (the <1,128> tile: eight 16-pixel waves) --:
+    deterministic, images 0 / 40 / 63 against the CPU oracle within 2e-5"""
     from detectron2_centernet_amd import ops
     dev = torch.device("cuda:0")
+    C, H, W = shape
     g = torch.Generator().manual_seed(2)
-    x = torch.randn(64, 128, 128, 64, generator=g)
-    w = (torch.randn(64, 64, 3, 3, generator=g) / 24)
-    om = torch.randn(64, 128, 128, 28, generator=g)
+    x = torch.randn(64, H, W, C, generator=g)
+    w = (torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5)
+    om = torch.randn(64, H, W, 28, generator=g)
     om[..., :18] *= 1.5
     pw = ops.PackedConv(w.to(dev), None, None, stride=1, pad=1, compute=ops.F16X3)
     xd, omd = x.to(dev), om.to(dev)
@@ -306,29 +310,37 @@ def test_fullsize_fused_dcn_offset_matches_oracle_on_sampled_images():
         assert err <= 8e-3 * max(1.0, ref.abs().max().item()), (b, err)
 
 
-def test_fullsize_dla34_training_step_16x512(dev):
+@pytest.mark.parametrize("precision", ["f16", "f16x3"])
+def test_fullsize_dla34_training_step_16x512(dev, precision):
     """BASELINE configs[2] as a whole under -m gpu: DLA-34 CenterNet, 16 x 3 x 512 x 512, targets + forward + losses +
-    backward + SGD.  Finite losses, the step replays as a captured HIP graph, and the replayed trajectory follows the
-    eager one (f32 atomics make both slightly non-deterministic: losses within 2e-3, update norms within 5 %)."""
+    backward + SGD, in the throughput mode and in the parity-grade f16x3 mode.  Finite losses, the step replays as a captured
+    HIP graph, and the replayed trajectory is the eager one (at this size the step is reproducible to ~1e-7: the f32 atomics'
+    order only moves the last bits)."""
     import bench
     from detectron2_centernet_amd.engine.bench_train import synthetic_batch
     from detectron2_centernet_amd.engine.train_loop import SimpleTrainer
 
     res = {}
     for mode in ("eager", "graph"):
-        model, cfg = bench.build_model("f16", dev, seed=3)
+        model, cfg = bench.build_model(precision, dev, seed=3)
         cfg.SOLVER.IMS_PER_BATCH = 16
         tr = SimpleTrainer(model, None, cfg)
         tr.use_hip_graph = mode == "graph"
         p0 = tr.optimizer.flat_param.clone()
         batch = synthetic_batch(16, 512, 0, dev)
-        hist = [sum(float(v) for v in tr.run_step_tensors(*batch).values()) for _ in range(4)]
+        hist = [sum(float(v) for v in tr.run_step_tensors(*batch).values()) for _ in range(5)]
         assert all(math.isfinite(h) for h in hist), hist
         assert tr.graph_state == ("captured" if mode == "graph" else "eager"), tr.graph_state
-        res[mode] = (hist, (tr.optimizer.flat_param - p0).norm().item())
+        res[mode] = (hist, (tr.optimizer.flat_param - p0), tr.optimizer.flat_mom.clone())
         del tr, model
         torch.cuda.empty_cache()
-    (he, de), (hg, dg) = res["eager"], res["graph"]
+    (he, de, me), (hg, dg, mg) = res["eager"], res["graph"]
+    assert he[-1] != he[0]                                           # the trajectory moves
     for a, b in zip(he, hg):
-        assert abs(a - b) <= 2e-3 * abs(a), (he, hg)
-    assert de > 0 and abs(de - dg) <= 0.05 * de, (de, dg)
+        assert abs(a - b) <= 1e-5 * abs(a), (he, hg)
+    # f16 activations snap the f32 atomics' order noise back onto the f16 grid (runs are all but bit-identical); with f32
+    # activations it survives and the random-init network amplifies it from step to step: 4e-3 of the largest update after
+    # five steps, at losses still equal to 1e-5
+    tol = 1e-4 if precision == "f16" else 2e-2
+    assert de.abs().max() > 0 and (de - dg).abs().max().item() <= tol * de.abs().max().item()
+    assert (me - mg).abs().max().item() <= tol * me.abs().max().item()

@@ -528,3 +528,36 @@ def test_reference_dla34_state_dict_through_checkpointer(tmp_path, dev, precisio
         assert got.shape == ref.shape
         err = (got - ref).abs().max().item()
         assert ref.std().item() > 0.1 and err <= 1e-4 * max(1.0, ref.abs().max().item()), (i, err)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+def test_out_of_range_activations_raise(tmp_path, dev, precision):
+    """f16x3 carries an activation as hi + lo with hi = f16(x): beyond 65504 hi is inf (include/ctdet_hip.h states the
+    precondition).  A trained network does not get there, a diverged one does.  Two guards: (1) every eval step checks, inside
+    the captured graph, that the size / offset maps are finite and the step's result raises otherwise (inf / NaN weights, a
+    blow-up on a path without ReLU); (2) the debug switch ops.RANGE_CHECK (CTDET_RANGE_CHECK=1) reads every contraction's
+    largest output magnitude back and raises at the first layer whose output the next one cannot carry -- needed because the
+    ReLU of an epilogue (fmaxf) turns the NaN of an overflowed layer into 0 and the outputs stay finite.  Here the stem's
+    BatchNorm scale is blown up until the activations leave the f16 range."""
+    from detectron2_centernet_amd import ops
+    model, cfg = make_model(tmp_path, precision, seed=2)
+    imgs = images(2, 64, 96).to(dev)
+    assert len(model.infer_batch_tensor(imgs)) == 2          # a healthy network: fine
+    ops.RANGE_CHECK = True
+    try:
+        model._engines = {}
+        assert len(model.infer_batch_tensor(imgs)) == 2      # ... also with the per-layer check on
+        with torch.no_grad():
+            model.backbone.base.base_layer[1].weight.mul_(3e5)
+        model._engines = {}                                  # (weights changed behind the engine's back)
+        if precision == "f16x3":      # (the f16 mode's first three layers are one fused kernel, not the checked contractions)
+            with pytest.raises(FloatingPointError, match="leaves the range"):
+                model.infer_batch_tensor(imgs)
+    finally:
+        ops.RANGE_CHECK = False
+    # (1): a non-finite weight reaches the size map whatever the activations do
+    model2, _ = make_model(tmp_path, precision, seed=2)
+    with torch.no_grad():
+        model2.wh[2].weight[0, 0, 0, 0] = float("inf")
+    with pytest.raises(FloatingPointError, match="not finite"):
+        model2.infer_batch_tensor(imgs)

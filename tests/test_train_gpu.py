@@ -591,12 +591,15 @@ def test_rccl_c_abi_single_rank(dev):
 
 def test_inference_on_dataset_loop(tmp_path, dev):
     """evaluation/evaluator.py:101-180: batches from a fixed-length loader through the model in eval mode, per-image COCO
-    records collected and written, timing recorded, the model's mode restored"""
+    records collected and written, timing recorded, the model's mode restored.  The written records are the oracle's
+    detections of the same images (fp32 CPU forward + decode + postprocess) put through the reference's converter as G13
+    pins it (coco_evaluation.py:321-382: XYXY -> XYWH in f32, category ids through the dataset's mapping): same detections
+    per image (the f16x3 heat map is within 5e-6 of the oracle's, so only pairs closer than that may swap ranks)."""
     import json
-    from test_model_gpu import make_model
+    from test_model_gpu import cpu_state_dict, make_model
     from detectron2_centernet_amd.evaluation import COCOResultsWriter, inference_on_dataset
 
-    model, cfg = make_model(tmp_path, "f16", seed=8)
+    model, cfg = make_model(tmp_path, "f16x3", seed=8)
     model.score_threshold = 0.0
     model.wh[2].bias.data.fill_(3.0)
     model.train()
@@ -613,6 +616,31 @@ def test_inference_on_dataset_loop(tmp_path, dev):
     assert all(1000 <= r["category_id"] < 1080 and len(r["bbox"]) == 4 and r["bbox"][2] > 0 for r in recs)
     t = inference_on_dataset.last_timing
     assert t["iters"] == 2 and t["compute_s_per_iter"] > 0
+    # ---- the oracle's detections through the G13-pinned wire format
+    model.eval()
+    sd = cpu_state_dict(model)
+    total, matched = 0, 0
+    for batch in loader:
+        ores, _, _ = MR.centernet_inference(sd, [d["image"] for d in batch], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, thresh=0.0,
+                                            out_sizes=[(d["height"], d["width"]) for d in batch])
+        for d, (bb, ss, cc) in zip(batch, ores):
+            xywh = bb.float().clone()
+            xywh[:, 2] -= xywh[:, 0]
+            xywh[:, 3] -= xywh[:, 1]
+            want = [{"image_id": d["image_id"], "category_id": 1000 + int(c), "bbox": b, "score": float(sc)}
+                    for b, sc, c in zip(xywh.tolist(), ss.tolist(), cc.tolist())]
+            got = [r for r in recs if r["image_id"] == d["image_id"]]
+            assert len(got) == len(want) > 0, (d["image_id"], len(got), len(want))
+            total += len(want)
+            left = list(got)
+            for w in want:
+                hit = next((r for r in left if r["category_id"] == w["category_id"] and abs(r["score"] - w["score"]) <= 2e-5 and
+                            max(abs(a - b) for a, b in zip(r["bbox"], w["bbox"])) <= 2e-3), None)
+                if hit is not None:
+                    left.remove(hit)
+                    matched += 1
+    print(f"inference_on_dataset: {matched} of {total} written records are the oracle's")
+    assert matched >= 0.98 * total, (matched, total)
 
 
 def test_pack_plan_refreshes_weights_after_each_update(T, dev):
