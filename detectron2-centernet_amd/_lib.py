@@ -31,6 +31,8 @@ SIGNATURES = {
     "ctdet_conv1x1_cat_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctdet_dcnv2_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ctdet_dcnv2_offset_supported": (_i32, [C.POINTER(ConvDesc)]),
+    "ctdet_dcnv2_cols_supported": (_i32, [C.POINTER(ConvDesc), _vp, _vp]),
+    "ctdet_dcnv2_fwd_cols": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctdet_dcnv2_offset_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ctdet_preprocess": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp]),
     "ctdet_head_fused_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp]),

@@ -57,6 +57,7 @@ int launch_pack_weights_x3(const float*, void*, float*, int, int, int, int, int,
 int launch_pack_weights_x3_batch(const void*, int, int, hipStream_t);
 int launch_split_weights(const float*, void*, long, hipStream_t);
 bool dcn_offset_fused_ok(const ConvArgs& a);
+bool dcn_split_window_ok(const ConvArgs& a);
 size_t chan_reduce_workspace_bytes(int C);
 int launch_bn_train_fwd(const f16*, int, const f16*, int, f16*, int, int, int, const float*, const float*, float, float,
                         float*, float*, float*, float*, float*, float*, void*, int, hipStream_t);
@@ -212,6 +213,31 @@ int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* of
     return launch_conv_f32(a, true, d->compute_dtype == CTDET_DT_F16X3, (hipStream_t)stream);
   }
   CTDET_CHECK(false, "dcnv2: bad compute dtype %d", d->compute_dtype);
+}
+
+int32_t ctdet_dcnv2_cols_supported(const ctdet_conv_desc* d, const void* x, const void* y) {
+  ConvArgs a;
+  if (fill_args(d, a) || d->compute_dtype != CTDET_DT_F16X3 || d->out_dtype != CTDET_DT_F32) return 0;
+  a.x = x; a.y = const_cast<void*>(y);
+  return dcn_split_window_ok(a) ? 1 : 0;
+}
+
+int32_t ctdet_dcnv2_fwd_cols(const ctdet_conv_desc* d, const void* x, const float* offset_mask, int32_t om_stride,
+                             int32_t mask_is_prob, const void* w_packed, const float* scale, const float* bias, void* y,
+                             float* cols_out, void* stream) {
+  ConvArgs a;
+  int rc = fill_args(d, a);
+  if (rc) return rc;
+  if (a.M == 0) return 0;
+  CTDET_CHECK(x && w_packed && y && offset_mask && cols_out, "dcnv2_fwd_cols: null pointer");
+  CTDET_CHECK(om_stride >= 3 * d->R * d->S, "dcnv2: om_stride=%d < 3*R*S", om_stride);
+  CTDET_CHECK(d->compute_dtype == CTDET_DT_F16X3 && d->out_dtype == CTDET_DT_F32 && (((size_t)cols_out) & 15) == 0,
+              "dcnv2_fwd_cols: the f16x3 mode's entry point (f32 tensors), 16-byte aligned columns");
+  a.x = x; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = nullptr; a.y = y;
+  a.om = offset_mask; a.om_stride = om_stride; a.mask_is_prob = mask_is_prob;
+  CTDET_CHECK(dcn_split_window_ok(a), "dcnv2_fwd_cols: shape not served by the LDS-window kernel (ask ctdet_dcnv2_cols_supported first)");
+  a.cols_out = cols_out;
+  return launch_conv_f32(a, true, true, (hipStream_t)stream);
 }
 
 int32_t ctdet_dcnv2_offset_supported(const ctdet_conv_desc* d) {

@@ -64,6 +64,9 @@ struct ConvArgs {
   // DCNv2 with its offset / mask conv computed in the same kernel (ctdet_dcnv2_offset_fwd): that conv's packed f16 weights
   // (32 rows, chunk-major), its bias (32 f32), and optionally where to keep its f32 output for a backward pass
   const void* w_off; const float* b_off; float* om_out; int om_out_stride;
+  // DCNv2, f16x3 window kernel, training: the sampled columns (mask * bilinear(x), f32 [M][9*Cin], k = tap*Cin + c -- what
+  // modulated_deformable_im2col produces, kernel.cu:786-868) written as a by-product of the forward pass, or null
+  float* cols_out;
 };
 
 // argument block of the fused CenterNet head kernel (conv_igemm.hip): per head 3x3 conv Cin->256 + bias + ReLU, then

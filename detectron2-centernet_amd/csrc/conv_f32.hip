@@ -900,13 +900,21 @@ __global__ void __launch_bounds__(512 / TP, 2) dcn_split_window_kernel(const Con
       }
     }
   };
-  auto blend = [&](const Raw& r, f16x8 (&b1)[TP], f16x8 (&b2)[TP]) {
+  // training: the sampled value of (pixel, tap t, channels chunk*16 + 4q..) is also the backward pass's `columns` entry --
+  // stored from here (the cout tile 0 workgroup of the pixel tile) it costs a 16-byte store per blend and saves the separate
+  // sampling pass over the layer (ctdet_dcn_cols) in the backward
+  float* const colp = (a.cols_out && n0 == 0) ? a.cols_out + q * 4 : nullptr;
+  auto blend = [&](const Raw& r, f16x8 (&b1)[TP], f16x8 (&b2)[TP], int t, int chunk) {
 #pragma unroll
     for (int p = 0; p < TP; ++p) {
       f32x4 val;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         val[e] = r.w[p][0] * r.v[p][0][e] + r.w[p][1] * r.v[p][1][e] + r.w[p][2] * r.v[p][2][e] + r.w[p][3] * r.v[p][3][e];
+      if (colp) {
+        const long m = (long)(b * a.H + ty0 + prow) * a.W + tx0 + (TP == 2 ? 8 * p : 0) + pcol;
+        *(f32x4*)(colp + m * (9L * a.Cin) + t * a.Cin + chunk * 16) = val;
+      }
       split_b(val, b1[p], b2[p]);
     }
   };
@@ -925,7 +933,7 @@ __global__ void __launch_bounds__(512 / TP, 2) dcn_split_window_kernel(const Con
   {
     Raw r0;
     gather(0, 0, r0);
-    blend(r0, b1, b2);
+    blend(r0, b1, b2, 0, 0);
   }
   const int ns = nch * 3;
 
@@ -959,13 +967,13 @@ __global__ void __launch_bounds__(512 / TP, 2) dcn_split_window_kernel(const Con
     }
     __builtin_amdgcn_sched_barrier(0);                             // the operands above are consumed: b1 / b2 may be rewritten
     if (T < 8) {
-      blend(raw, b1, b2);
+      blend(raw, b1, b2, T + 1, chunk);
     } else if (chunk + 1 < nch) {
       wait_vmcnt<0>();                                             // next chunk's window, behind this tap's MFMAs
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       gather(0, chunk + 1, raw);
-      blend(raw, b1, b2);
+      blend(raw, b1, b2, 0, chunk + 1);
     }
   };
   for (int chunk = 0; chunk < nch; ++chunk) {
@@ -1337,6 +1345,14 @@ static int launch_conv_f32_t(const ConvArgs& a, bool deform, hipStream_t s) {
     hipLaunchKernelGGL((conv_direct_f32_kernel<false, SP>), grid, dim3(256), 0, s, a);
   CTDET_LAUNCH_CHECK();
   return 0;
+}
+
+// does launch_conv_f32(deform, split) take the LDS-window kernel that can also write the columns (ConvArgs::cols_out)?
+bool dcn_split_window_ok(const ConvArgs& a) {
+  const int bc = pick_bc(a.Cout);
+  return f32_vector_ok(a, bc) && a.Cin % 16 == 0 && a.nsrc <= 1 && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
+         a.H % 8 == 0 && a.W % 16 == 0 && a.H <= 4094 && a.W <= 4094 && a.Kpad == a.K && a.Cout_pad % 64 == 0 && a.korder == 0 &&
+         !(ctdet_tuning_flags() & (CTDET_TUNE_NO_F32_DCN_WINDOW | CTDET_TUNE_DCN_WINDOW_V1));
 }
 
 int launch_conv_f32(const ConvArgs& a, bool deform, bool split, hipStream_t s) {

@@ -634,9 +634,11 @@ def conv1x1_cat(xs, p, out=None, act=ACT_NONE, residual=None, out_dtype=None):
 HEADS_FUSED = os.environ.get("CTDET_NO_FUSED_HEADS", "0") != "1"
 
 
-def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_prob=False):
+def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_prob=False, want_cols=False):
     """Modulated deformable conv: offset_mask is the raw f32 NHWC output of conv_offset_mask (>= 27 ch);
-    with mask_is_prob the 9 mask channels already went through sigmoid."""
+    with mask_is_prob the 9 mask channels already went through sigmoid.
+    want_cols (f16x3, training): returns (y, cols) where cols f32 [B,H,W,9*Cin] are the sampled columns written by the same
+    kernel, or (y, None) when the layer is not served by the LDS-window kernel."""
     _require_cuda(x, offset_mask, out)
     assert dt_of(x) == p.act_dt and offset_mask.dtype == torch.float32
     if p.compute == F16 and p.Cout_pad % 64:
@@ -653,13 +655,20 @@ def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_pro
     p._wp_scaled = None          # a deformable conv's weights: no pair image will be needed
     d = p.desc(x, out, act, None)
     prof = _Prof(p, d.B * d.Ho * d.Wo, True, d.out_dtype, x.shape)
+    cols = None
+    if want_cols and p.compute == F16X3 and _lib.lib().ctdet_dcnv2_cols_supported(C.byref(d), _ptr(x), _ptr(out)):
+        cols = torch.empty(x.shape[0], x.shape[1], x.shape[2], 9 * p.Cin, dtype=torch.float32, device=x.device)
     for _ in range(prof.reps()):
-        rc = _lib.lib().ctdet_dcnv2_fwd(C.byref(d), _ptr(x), _ptr(offset_mask), _nhwc_stride(offset_mask),
-                                        int(mask_is_prob), _ptr(p.w), _ptr(p.scale), _ptr(p.bias), _ptr(out), _stream())
+        if cols is not None:
+            rc = _lib.lib().ctdet_dcnv2_fwd_cols(C.byref(d), _ptr(x), _ptr(offset_mask), _nhwc_stride(offset_mask), int(mask_is_prob),
+                                                 _ptr(p.w), _ptr(p.scale), _ptr(p.bias), _ptr(out), _ptr(cols), _stream())
+        else:
+            rc = _lib.lib().ctdet_dcnv2_fwd(C.byref(d), _ptr(x), _ptr(offset_mask), _nhwc_stride(offset_mask),
+                                            int(mask_is_prob), _ptr(p.w), _ptr(p.scale), _ptr(p.bias), _ptr(out), _stream())
     _lib.check(rc, "ctdet_dcnv2_fwd")
     prof.done()
     _range_check(out, p, "dcnv2")
-    return out
+    return (out, cols) if want_cols else out
 
 
 def dcnv2_offset_supported(x, p_off, p):

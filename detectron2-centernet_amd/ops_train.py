@@ -28,6 +28,7 @@ GRAD_SCALE = 1024.0
 # waves of a workgroup each pull the same W fragments through L1 (no LDS left to share them: 157 KB are the scatter's), and
 # nothing overlaps the GEMM phase at one workgroup per CU.  CTDET_FUSED_DCOL=1 turns it on.
 FUSE_DCOL = os.environ.get("CTDET_FUSED_DCOL", "0") == "1"
+KEEP_COLS = os.environ.get("CTDET_NO_KEEP_COLS", "0") != "1"   # f16x3: DCNv2's forward kernel also writes the sampled columns
 F32_COMPUTE = F32     # how contractions over f32 tensors run: F32 or F16X3 (engine/train_step.py sets it per forward pass)
 
 
@@ -734,11 +735,14 @@ class DeformConvFn(torch.autograd.Function):
         if not f32 and x.shape[3] % 32 == 0 and ops.dcnv2_offset_supported(x, p_off, p):
             # one kernel for both convs; the offsets / mask logits are kept for the backward pass
             om = torch.empty(x.shape[0], x.shape[1], x.shape[2], 28, dtype=torch.float32, device=x.device)
-            y = ops.dcnv2_offset(x, p_off, p, om_out=om)
+            y, cols = ops.dcnv2_offset(x, p_off, p, om_out=om), None
         else:
             om = ops.conv2d(x, p_off, out_dtype=torch.float32)
-            y = ops.dcnv2(x, om, p)
+            # f16x3: the forward kernel writes the sampled columns on the side (kept for the weight gradient: no second sampling
+            # pass over the layer in the backward; 9*Cin floats per pixel held between the two passes)
+            y, cols = ops.dcnv2(x, om, p, want_cols=True) if (comp == F16X3 and KEEP_COLS) else (ops.dcnv2(x, om, p), None)
         ctx.params = (w_off, b_off, weight, bias)
+        ctx.cols = cols
         ctx.save_for_backward(x, om, w_off, weight)
         return y
 
@@ -759,10 +763,12 @@ class DeformConvFn(torch.autograd.Function):
             sb = None
         _, _, _, dbias = bn_train_bwd(dyp, None, None, None, None, None, relu=False, into=(None, sb))
         # k = tap*Cin + c of the columns, which are sampled on the weight-gradient stream as well
-        if wgrad_to_param(p_w, None, dyp, dyp.shape[3], 1, 1, 1, 0, 9, Cin, make_x=lambda: dcn_cols(x, om), keep=(x, om), comp=comp):
+        kept, ctx.cols = ctx.cols, None
+        if wgrad_to_param(p_w, None, dyp, dyp.shape[3], 1, 1, 1, 0, 9, Cin, make_x=lambda: kept if kept is not None else dcn_cols(x, om),
+                          keep=(x, om), comp=comp):
             dwt = None
         else:
-            col = dcn_cols(x, om)
+            col = kept if kept is not None else dcn_cols(x, om)
             dw = conv_wgrad(col, dyp, dyp.shape[3], 1, 1, 1, 0, comp=comp)[:Cout]
             dwt = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
         if sb is not None:

@@ -99,6 +99,16 @@ int32_t ctdet_conv1x1_cat_fwd(const ctdet_conv_desc* d, const void* const* xs, c
 int32_t ctdet_dcnv2_fwd(const ctdet_conv_desc* d, const void* x, const float* offset_mask, int32_t om_stride,
                         int32_t mask_is_prob, const void* w_packed, const float* scale, const float* bias, void* y, void* stream);
 
+/* ctdet_dcnv2_fwd in the f16x3 mode that ALSO writes the sampled columns (modulated_deformable_im2col, kernel.cu:786-868:
+ * cols_out f32 [M][9*Cin], k = tap*Cin + c, value = mask * bilinear(x)) as a by-product of the forward pass -- training keeps
+ * them for the weight gradient (deform_conv_cuda.cu:1098-1106) instead of sampling the layer a second time in the backward.
+ * Only where the LDS-window kernel serves the layer: ctdet_dcnv2_cols_supported(d, x, y) -> 1 (3x3/s1/p1, map divisible by 8x16,
+ * Cin % 16 == 0, packed rows % 64 == 0, 16-byte aligned tensors); otherwise call ctdet_dcnv2_fwd and ctdet_dcn_cols. */
+int32_t ctdet_dcnv2_cols_supported(const ctdet_conv_desc* d, const void* x, const void* y);
+int32_t ctdet_dcnv2_fwd_cols(const ctdet_conv_desc* d, const void* x, const float* offset_mask, int32_t om_stride,
+                             int32_t mask_is_prob, const void* w_packed, const float* scale, const float* bias, void* y,
+                             float* cols_out, void* stream);
+
 /* DCNv2 together with the conv that produces its offsets and mask logits (the reference's DCN wrapper: conv_offset_mask 3x3 /
  * s1 / p1, Cin -> 27, then modulated_deform_conv on the same input; detectron2/layers/deform_conv.py and the wrapper the
  * CenterNet project uses) in ONE kernel: the offset conv is evaluated from the LDS window the sampling uses, its output never

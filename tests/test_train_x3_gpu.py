@@ -334,6 +334,36 @@ def test_dcn_col2im_fused_dcol_equals_two_step(T, dev, x3, shape):
     close(dom_f.cpu(), dom_r.cpu(), 3e-5, "dom vs f64 columns")
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 64, 1.5), (1, 16, 16, 128, 256, 5.0), (3, 8, 48, 32, 128, 0.0)])
+def test_dcn_forward_writes_the_columns(T, dev, x3, case):
+    """the f16x3 DCNv2 window kernel (64-, 128-cout tiles; two cout tiles for 256 couts: the first one writes) stores the sampled
+    columns as a by-product: bit-identical outputs with and without, columns == the stand-alone sampling kernel's (the same f32
+    blend) and == the oracle's bilinear sampling"""
+    ops, ot = T
+    B, H, W, Cin, Cout, off_std = case
+    g = torch.Generator().manual_seed(int(sum(case[:5])))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(dev)
+    om = torch.randn(B, 27, H, W, generator=g)
+    om[:, :18] *= off_std
+    om[:, 0, 0, 0], om[:, 1, 0, 0], om[:, 4, 3, 5], om[:, 5, 3, 5] = -0.0, -1.0, 4.0, -4.0
+    xd = nhwc(x).to(dev)
+    omd = torch.zeros(B, H, W, 28)
+    omd[..., :27] = nhwc(om)
+    omd = omd.to(dev)
+    p = ops.PackedConv(w, None, None, stride=1, pad=1, compute=ops.F16X3)
+    y0 = ops.dcnv2(xd, omd, p)
+    y1, cols = ops.dcnv2(xd, omd, p, want_cols=True)
+    assert cols is not None and torch.equal(y0, y1)
+    ref = ot.dcn_cols(xd, omd)
+    close(cols.cpu(), ref.cpu(), 1e-6, "columns vs the sampling kernel")
+    t, c = 4, 3
+    wsel = torch.zeros(1, Cin, 3, 3)
+    wsel[0, c, t // 3, t % 3] = 1.0
+    refo = O.dcnv2_forward(x, om[:, :18], torch.sigmoid(om[:, 18:]), wsel, None, 1, 1, 1)[:, 0]
+    close(cols[..., t * Cin + c].cpu(), refo, 1e-5, "columns vs the oracle")
+
+
 def test_deform_conv_node_x3(T, dev, x3):
     """DeformConvFn (offset conv + DCNv2 as one node) in the f16x3 mode against autograd through the oracle"""
     ops, ot = T
