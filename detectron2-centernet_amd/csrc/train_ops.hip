@@ -115,12 +115,24 @@ int launch_gaussian_radius(const int* hw, int n, double* out_r, int* out_i, hipS
   return 0;
 }
 
+// the target map is cleared by a KERNEL, not hipMemsetAsync: inside a captured training step the memset became a memset node,
+// and a replay launched on an idle stream ran it out of order with the splat kernel after it (two ranks sharing one GPU, the
+// data-parallel step whose SGD launch is eager: hm_loss 93.7 -> 127 ... inf within 12 steps, profiles/r04_graph_memset_node.txt)
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n) {
+  const long n4 = n >> 2, stride = (long)gridDim.x * 256;
+  float4* p4 = (float4*)p;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = 0.f;
+}
+
 int launch_gaussian_targets(const float* boxes, const int64_t* classes, const int* counts, int B, int Nmax, int H,
                             int W, int C, float* hm, float* wh, float* reg, int64_t* ind, uint8_t* reg_mask,
                             hipStream_t s) {
   if (B == 0) return 0;
-  hipError_t e = hipMemsetAsync(hm, 0, (size_t)B * H * W * C * sizeof(float), s);
-  CTDET_CHECK(e == hipSuccess, "gaussian_targets: memset failed: %s", hipGetErrorString(e));
+  CTDET_CHECK(((uintptr_t)hm & 15) == 0, "gaussian_targets: hm must be 16-byte aligned");
+  const long n = (long)B * H * W * C;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)std::min<long>((n / 4 + 255) / 256 + 1, 2048)), dim3(256), 0, s, hm, n);
+  CTDET_LAUNCH_CHECK();
   hipLaunchKernelGGL(gaussian_targets_kernel, dim3(128, B), dim3(256), 0, s, boxes, classes, counts, Nmax, H, W, C, hm,
                      wh, reg, ind, reg_mask);
   CTDET_LAUNCH_CHECK();

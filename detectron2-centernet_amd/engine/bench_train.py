@@ -49,9 +49,63 @@ def run_train_bench(model, cfg, args, B, rank, world, device, dist):
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    losses = trainer.metrics()
+    if hasattr(trainer, "_xlog_pre"):
+        import sys
+        torch.cuda.synchronize()
+        red = trainer.reducer
+        for it in range(2, trainer.iter):
+            pre = trainer._xlog_pre[it].cpu()
+            got = [torch.empty_like(pre) for _ in range(world)]
+            dist.all_gather(got, pre)
+            want = sum(got)
+            post = trainer._xlog_post[it].cpu()
+            line = []
+            for s, e, _ in red.buckets:
+                d = (post[s:e] - want[s:e]).abs()
+                bad = (d > 1e-6 * want[s:e].abs().max()).nonzero().flatten()
+                line.append(f"[{s}:{e}) max err {float(d.max()):.3g} of {float(want[s:e].abs().max()):.3g}, {bad.numel()} off"
+                            + (f" (first {int(bad[0]) + s}, last {int(bad[-1]) + s}; == own {bool(torch.equal(post[s:e], pre[s:e]))}"
+                               f" == other {bool(torch.equal(post[s:e], got[1 - rank][s:e]))})" if bad.numel() else ""))
+            print(f"[rank {rank}] step {it}: " + "; ".join(line), file=sys.stderr, flush=True)
+    if getattr(trainer, "_steplog", None) is not None:      # CTDET_TRAIN_CHECK=2
+        import sys
+        print(f"[rank {rank}] step log [hm, wh, off, max|feat|, max|logit|, max tgt, min tgt, grad ok, reduced ok, param ok]\n" +
+              "\n".join(f"  {i}: " + " ".join(f"{v:.6g}" for v in r) for i, r in enumerate(trainer.step_log().tolist())),
+              file=sys.stderr, flush=True)
+    try:
+        losses = trainer.metrics()
+    except FloatingPointError:
+        _diagnose(trainer, (images, boxes, classes, counts), rank)
+        raise
     comm_rec = allreduce_bandwidth(trainer, dist, device) if (dist is not None and world > 1) else None
     return _record(model, args, B, world, elapsed, losses, trainer, comm_rec)
+
+
+def _diagnose(trainer, batch, rank):
+    """a non-finite loss ends the bench: say where the non-finite values sit (stderr) before the exception goes up"""
+    import sys
+    torch.cuda.synchronize()
+    opt = trainer.optimizer
+    msg = [f"[rank {rank}] non-finite loss at iteration {trainer.iter}: "
+           f"params finite={bool(torch.isfinite(opt.flat_param).all())} grads finite={bool(torch.isfinite(opt.flat_grad).all())} "
+           f"momentum finite={bool(torch.isfinite(opt.flat_mom).all())}"]
+    for key, g in trainer._graphs.items():
+        if g.get("inputs") is not None:
+            same = [bool(torch.equal(a, b)) for a, b in zip(g["inputs"], batch)]
+            msg.append(f"  captured step's static inputs equal the batch (images, boxes, classes, counts): {same}")
+    bad = [n for n, b in trainer.model.named_buffers() if b.dtype.is_floating_point and not bool(torch.isfinite(b).all())]
+    msg.append(f"  non-finite buffers: {bad[:8]}")
+    names = {id(p): n for n, p in trainer.model.named_parameters()}
+    badp = [names.get(id(p), "?") for p in opt.params if not bool(torch.isfinite(p).all())]
+    msg.append(f"  non-finite parameters: {badp[:8]}")
+    if getattr(trainer, "_steplog", None) is not None:
+        msg.append("  step log [hm, wh, off, max|feat|, max|logit|, max tgt, min tgt, grad ok, reduced ok, param ok]:")
+        for i, r in enumerate(trainer.step_log().tolist()):
+            msg.append(f"    {i}: " + " ".join(f"{v:.6g}" for v in r))
+    with torch.no_grad():
+        t = trainer.model.train_batch_tensor(*batch)
+    msg.append(f"  an eager forward on the batch now gives {dict((k, float(v)) for k, v in t.items())}")
+    print("\n".join(msg), file=sys.stderr, flush=True)
 
 
 def allreduce_bandwidth(trainer, dist, device, reps=10):

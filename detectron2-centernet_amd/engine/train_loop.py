@@ -1,10 +1,12 @@
 """SimpleTrainer.run_step (detectron2/engine/train_loop.py:212-251) for the HIP training path."""
+import os
 import time
 
 import torch
 
 from .. import ops_train
 from ..solver import WarmupMultiStepLR, build_optimizer
+from . import graph_nodes, train_step
 from .reducer import BucketedReducer
 
 
@@ -72,6 +74,10 @@ class SimpleTrainer:
         (tests/test_dp_gpu.py::test_two_rank_graph_steps_equal_single_rank_steps).  The LR schedule and the per-parameter
         version counters stay on the host.  CTDET_TRAIN_GRAPH=0 keeps every step eager."""
         multi = self.reducer.world > 1
+        if multi and int(os.environ.get("CTDET_DBG_SYNC", "0")) & 64 and not hasattr(self, "_xlog_pre"):
+            n = self.optimizer.flat_grad.numel()
+            self._xlog_pre = torch.zeros(16, n, device=self.optimizer.flat_grad.device)
+            self._xlog_post = torch.zeros(16, n, device=self.optimizer.flat_grad.device)
         if not self.use_hip_graph or (multi and not self.graph_ddp):
             return self._finish_step(self.model.train_batch_tensor(images, boxes, classes, counts))
         key = tuple((tuple(t.shape), t.dtype) for t in (images, boxes, classes, counts))
@@ -89,15 +95,82 @@ class SimpleTrainer:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         g["graph"].replay()
+        dbg = int(os.environ.get("CTDET_DBG_SYNC", "0"))
+        if dbg & 1:
+            torch.cuda.synchronize()
+        if dbg & 16:
+            torch.isfinite(self.optimizer.flat_grad).all()
+        if train_step.STEP_CHECK == 1:
+            self._check_step("after the replayed forward + backward" + ("" if multi else " + SGD"), g["losses"])
+        elif train_step.STEP_CHECK == 2:
+            self._log_step(7, g["losses"])
+        if multi and dbg & 64:     # the exchange's operands and results of every step, in buffers allocated before step 0
+            self._xlog_pre[self.iter].copy_(self.optimizer.flat_grad)
         if multi:
             self.reducer.reduce_all()
+            if dbg & 64:
+                self._xlog_post[self.iter].copy_(self.optimizer.flat_grad)
+            if train_step.STEP_CHECK == 1:
+                self._check_step("after the all-reduce", g["losses"])
+            elif train_step.STEP_CHECK == 2:
+                self._log_step(8)
+            if dbg & 2:
+                torch.cuda.synchronize()
+            if dbg & 32:
+                torch.isfinite(self.optimizer.flat_grad).all()
             self.optimizer.step()
+            if dbg & 4:
+                torch.cuda.synchronize()
+            if dbg & 8:
+                torch.isfinite(self.optimizer.flat_param).all()
+        if train_step.STEP_CHECK == 2:
+            self._log_step(9)
         for p in self.optimizer.params:   # the captured SGD kernels wrote the parameters behind autograd's back
             torch.autograd.graph.increment_version(p)
         self.scheduler.step()
         self.iter += 1
         self.last_losses = g["losses"]
         return self.last_losses
+
+    def _log_step(self, col, losses=None):
+        """CTDET_TRAIN_CHECK=2: one row per step in a device tensor, written by stream-ordered launches only (no host sync, so
+        the timing of the step stays what it is): [hm, wh, off, max|features|, max|logits|, max target, min target,
+        gradients finite after backward, after the all-reduce, parameters finite after SGD]; `step_log()` reads it"""
+        if getattr(self, "_steplog", None) is None:
+            self._steplog = torch.full((4096, 10), -1.0, device=self.optimizer.flat_param.device)
+        row = self._steplog[self.iter % 4096]
+        if losses is not None:
+            row[0:3].copy_(torch.stack([losses[k].float().reshape(()) for k in ("hm_loss", "wh_loss", "off_loss")]))
+            st = train_step.STEP_STATS.get("forward")
+            if st is not None:
+                row[3:7].copy_(st)
+        src = self.optimizer.flat_param if col == 9 else self.optimizer.flat_grad
+        row[col:col + 1].copy_(torch.isfinite(src).all().float().reshape(1))
+
+    def step_log(self):
+        torch.cuda.synchronize()
+        return self._steplog[:self.iter].cpu()
+
+    def _check_step(self, where, losses):
+        """CTDET_TRAIN_CHECK=1 (debug; one host sync per check): the first step whose losses, forward statistics or flat
+        gradient / parameter buffers hold a non-finite value raises, naming the rank's step, the place and the parameters"""
+        torch.cuda.synchronize()
+        opt = self.optimizer
+        loss = {k: float(v) for k, v in losses.items()}
+        stats = train_step.STEP_STATS.get("forward")
+        stats = [float(v) for v in stats] if stats is not None else []
+        ok_g = bool(torch.isfinite(opt.flat_grad).all())
+        ok_p = bool(torch.isfinite(opt.flat_param).all())
+        fin = all(v == v and abs(v) != float("inf") for v in list(loss.values()) + stats)
+        if fin and ok_g and ok_p:
+            return
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        bad_g = [names.get(id(p), "?") for p in opt.params if p.grad is not None and not bool(torch.isfinite(p.grad).all())]
+        bad_p = [names.get(id(p), "?") for p in opt.params if not bool(torch.isfinite(p).all())]
+        raise FloatingPointError(
+            f"[rank {os.environ.get('RANK', '0')}] step {self.iter} {where}: losses {loss}; "
+            f"max|features|, max|logits|, max target, min target = {stats}; {len(bad_g)} non-finite gradients "
+            f"(first {bad_g[:6]}, last {bad_g[-3:]}); {len(bad_p)} non-finite parameters (first {bad_p[:6]})")
 
     def _capture(self, g, images, boxes, classes, counts, with_step=True):
         import gc
@@ -109,7 +182,7 @@ class SimpleTrainer:
         self.reducer.enabled = False     # no collective may be launched from a hook while the stream is capturing
         import warnings
         try:
-            graph = torch.cuda.CUDAGraph()
+            graph = torch.cuda.CUDAGraph(keep_graph=True)     # instantiated in _capture_body, after a look at its nodes
             # An AccumulateGrad node that an older autograd graph keeps alive runs on the stream IT was created on (the default
             # stream) and would fork the capture onto that stream: hipStreamEndCapture crashes on such a capture (round 3's
             # VoVNet segfault; the step's own nodes write their gradients straight into the flat buffer and need no
@@ -146,6 +219,17 @@ class SimpleTrainer:
             losses.backward()
             if with_step:
                 self.optimizer.step()
+        # The captured step must be kernels only.  A hipMemsetAsync / device-to-device hipMemcpyAsync issued inside it becomes a
+        # memset / memcpy node, and a replay launched on an idle stream ran such a node out of order with the kernel after it
+        # (the data-parallel step, whose SGD launch is eager: round 3's "CTDET_TRAIN_GRAPH=ddp gives inf hm_loss"; engine/
+        # graph_nodes.py).  Anything else found here is reported, loudly, once per capture.
+        g["nodes"] = graph_nodes.node_types(graph.raw_cuda_graph())
+        other = {k: v for k, v in g["nodes"].items() if k not in ("kernel", "empty")}
+        if other:
+            import logging
+            logging.getLogger(__name__).warning("the captured training step holds non-kernel nodes %s: replace the "
+                                                "hipMemsetAsync / contiguous copy_ behind them by kernels", other)
+        graph.instantiate()
         g["graph"], g["inputs"] = graph, inputs
         g["losses"] = {k: v.detach() for k, v in loss_dict.items()}
         # the capture itself executed nothing: this call's step is the first replay
@@ -170,6 +254,8 @@ class SimpleTrainer:
         self.scheduler.step()
         self.iter += 1
         self.last_losses = {k: v.detach() for k, v in loss_dict.items()}
+        if train_step.STEP_CHECK == 1:
+            self._check_step("after the eager step", self.last_losses)
         return self.last_losses
 
     def metrics(self):

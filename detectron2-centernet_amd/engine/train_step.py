@@ -7,6 +7,8 @@ inference-only for now.  The mode follows MODEL.CENTERNET.HIP_PRECISION: f16 (th
 precision: every activation, gradient and statistic in f32, contractions as f32 FMA chains) or f16x3 (the same f32 tensors,
 every contraction as three f16 products per term on the f16 matrix pipe: the parity-grade mode at matrix-pipe speed).
 """
+import os
+
 import torch
 
 from .. import ops
@@ -261,6 +263,10 @@ def centernet_train_forward(model, batched_inputs):
     return train_forward_tensors(model, images.nhwc, targets)
 
 
+STEP_CHECK = int(os.environ.get("CTDET_TRAIN_CHECK", "0"))    # 1: host check after every step; 2: device-side log, no syncs
+STEP_STATS = {}
+
+
 def train_forward_tensors(model, x_nhwc, targets):
     from .. import ops_train
     # how the autograd nodes contract f32 tensors (each node remembers it for its backward pass)
@@ -278,6 +284,12 @@ def train_forward_tensors(model, x_nhwc, targets):
     _flush_counters()
     C = model.num_classes
     hm = z["hm"] if z["hm"].shape[3] == C else z["hm"][..., :C].contiguous()
+    if STEP_CHECK:
+        # four scalars of this forward, computed on the device (inside a captured step too): max |features|, max |logits| and
+        # the range of the target map -- SimpleTrainer reads them after every step under CTDET_TRAIN_CHECK=1
+        with torch.no_grad():
+            t = targets["hm"]
+            STEP_STATS["forward"] = torch.stack([y.abs().amax(), hm.abs().amax(), t.amax(), t.amin()]).float()
     hm_loss = FocalLossFn.apply(hm, targets["hm"], model._alpha_tensor())
     wh_loss = RegL1Fn.apply(z["wh"], targets["reg_mask"], targets["ind"], targets["wh"])
     off_loss = RegL1Fn.apply(z["reg"], targets["reg_mask"], targets["ind"], targets["reg"])

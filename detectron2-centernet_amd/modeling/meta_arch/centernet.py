@@ -53,6 +53,9 @@ def ctdet_decode(heat, wh, reg=None, down_ratio=1, cat_spec_wh=False, K=100):
 
 
 MAX_ENGINES = 16   # captured eval graphs kept per model (least recently used goes first)
+# `_sigmoid`'s clamp (centernet.py:13-15).  ONE constant: the head epilogues clamp with it and the decode is promised its lower
+# end as the floor of the heat map (ops.decode(heat_floor=...)); two literals that drift apart would drop peaks silently
+SIGMOID_CLAMP = (ops.SIGMOID_CLAMP_FLOOR, 1.0 - ops.SIGMOID_CLAMP_FLOOR)
 
 
 def _engine_key(fused_base, B, H, W, Hp, Wp, img_dtype):
@@ -102,9 +105,18 @@ class _EvalEngine:
             gc_was_on = gc.isenabled()
             gc.disable()
             try:
-                g = torch.cuda.CUDAGraph()
+                g = torch.cuda.CUDAGraph(keep_graph=True)
                 with torch.cuda.graph(g):
                     self._run()
+                # kernels only, like the training step (engine/graph_nodes.py: a memset / memcpy node of a replay launched on
+                # an idle stream was seen to run out of order with the kernel after it)
+                from ...engine import graph_nodes
+                self.graph_nodes = graph_nodes.node_types(g.raw_cuda_graph())
+                other = {k: v for k, v in self.graph_nodes.items() if k not in ("kernel", "empty")}
+                if other:
+                    import logging
+                    logging.getLogger(__name__).warning("the captured eval step holds non-kernel nodes %s", other)
+                g.instantiate()
             finally:
                 if gc_was_on:
                     gc.enable()
@@ -320,7 +332,7 @@ class CenterNet(nn.Module):
                 ph = ops.PackedHeads([fc[0].weight for fc in fcs], [fc[0].bias for fc in fcs],
                                      [fc[2].weight for fc in fcs], [fc[2].bias for fc in fcs], acts)
                 hit = cache[("heads_fused", tuple(acts))] = (ver, ph)
-            outs = ops.heads_fused(y, hit[1], clamp=(1e-4, 1 - 1e-4))
+            outs = ops.heads_fused(y, hit[1], clamp=SIGMOID_CLAMP)
             return dict(zip(names, outs))
         if self.head_conv > 0:
             convs = [getattr(self, n)[0] for n in names]
@@ -336,12 +348,12 @@ class CenterNet(nn.Module):
                 c0 += self.head_conv
                 act = ACT_SIGMOID_CLAMP if (apply_sigmoid and n == "hm") else ACT_NONE
                 out[n] = hipnn.conv_module(hs, fc[2], None, act, ctx=ctx, out_dtype=torch.float32,
-                                           clamp=(1e-4, 1 - 1e-4))
+                                           clamp=SIGMOID_CLAMP)
         else:
             for n in names:
                 act = ACT_SIGMOID_CLAMP if (apply_sigmoid and n == "hm") else ACT_NONE
                 out[n] = hipnn.conv_module(y, getattr(self, n), None, act, ctx=ctx, out_dtype=torch.float32,
-                                           clamp=(1e-4, 1 - 1e-4))
+                                           clamp=SIGMOID_CLAMP)
         return out
 
     def _packed_cat(self, key, w, b, convs, pad):

@@ -525,9 +525,9 @@ class PackedConv:
         v = v.detach().to(torch.float32)
         if v.shape[0] == self.Cout_eff:
             return v.contiguous()
-        o = torch.full((self.Cout_eff,), fill, dtype=torch.float32, device=dev)
-        o[:self.Cout] = v
-        return o
+        # one pad KERNEL: a slice assignment is a device-to-device hipMemcpyAsync, which a captured training step would hold as a
+        # memcpy node (see SimpleTrainer._capture_body: the captured step is kernels only)
+        return torch.nn.functional.pad(v.contiguous(), (0, self.Cout_eff - v.shape[0]), value=float(fill))
 
     @property
     def act_dt(self):

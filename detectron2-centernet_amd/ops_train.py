@@ -93,7 +93,8 @@ def bn_train_fwd(y, gamma, beta, running_mean, running_var, eps, momentum, res=N
     dev = y.device
     z = torch.empty(B, H, W, Cc, dtype=y.dtype, device=dev)
     mean, invstd, scale, shift = (torch.empty(Cc, dtype=torch.float32, device=dev) for _ in range(4))
-    with ops.prof_region("bn_train_fwd", flops=0.0, nbytes=float(B * H * W * Cc * (6 if res is None else 8))):
+    # algorithmic bytes: y read twice (statistics, apply), z written, the residual read once
+    with ops.prof_region("bn_train_fwd", flops=0.0, nbytes=float(B * H * W * Cc * y.element_size() * (3 if res is None else 4))):
         rc = _lib.lib().ctdet_bn_train_fwd(_ptr(y), _nhwc_stride(y), _ptr(res), _nhwc_stride(res) if res is not None else 0,
                                            _ptr(z), _nhwc_stride(z), B * H * W, Cc, _ptr(gamma), _ptr(beta), float(eps),
                                            float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd),
@@ -116,7 +117,9 @@ def bn_train_bwd(dz, z, y, mean, invstd, scale, relu=True, want_dres=False, grad
         dgb = torch.empty(2, Cc, dtype=torch.float32, device=dev)   # written, not accumulated
         dgamma, dbeta = (dgb[0] if dgamma is None else dgamma), (dgb[1] if dbeta is None else dbeta)
     gm = PARAM_GRAD_MULT if grad_mult is None else grad_mult
-    with ops.prof_region("bn_train_bwd", flops=0.0, nbytes=float(B * H * W * Cc * 10)):
+    # algorithmic bytes: dz, z, y read twice (sums, apply) where present, dy (and dres) written
+    nt = 2 * (1 + (z is not None) + (y is not None)) + 1 + int(want_dres)
+    with ops.prof_region("bn_train_bwd", flops=0.0, nbytes=float(B * H * W * Cc * dz.element_size() * nt)):
         rc = _lib.lib().ctdet_bn_train_bwd(_ptr(dz), _nhwc_stride(dz), _ptr(z), _nhwc_stride(z) if z is not None else 0,
                                            _ptr(y), _nhwc_stride(y) if y is not None else 0, _ptr(mean), _ptr(invstd),
                                            _ptr(scale), B * H * W, Cc, int(relu), _ptr(dy), _nhwc_stride(dy), _ptr(dres),
@@ -304,7 +307,7 @@ def dwconvT_bwd(x, dz, weight, f, wk=None, raw=False):
 def dcn_cols(x, om, mask_is_prob=False):
     B, H, W, Cin = x.shape
     col = torch.empty(B, H, W, 9 * Cin, dtype=x.dtype, device=x.device)
-    with ops.prof_region("dcn_cols", flops=0.0, nbytes=float(B * H * W * Cin * (2 + 18) + B * H * W * 27 * 4)):
+    with ops.prof_region("dcn_cols", flops=0.0, nbytes=float(B * H * W * Cin * x.element_size() * 10 + B * H * W * 27 * 4)):
         rc = _lib.lib().ctdet_dcn_cols(_ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(col), B, H, W, Cin, int(mask_is_prob), dt_of(x), _stream())
     _lib.check(rc, "ctdet_dcn_cols")
     return col
@@ -349,7 +352,8 @@ def dcn_col2im_coord(dcol, x, om, mask_is_prob=False, dom_channels=None, dcol_ch
         dom = torch.empty(B, H, W, om.shape[3] if dom_channels is None else dom_channels, dtype=torch.float32, device=x.device)
     else:
         dom = torch.empty(B, H, W, dom_channels, dtype=torch.float16, device=x.device)
-    with ops.prof_region("dcn_col2im", flops=0.0, nbytes=float(B * H * W * Cin * (18 + 2 + 4) + B * H * W * 27 * 8)):
+    es = x.element_size()
+    with ops.prof_region("dcn_col2im", flops=0.0, nbytes=float(B * H * W * Cin * (9 * es + es + 4) + B * H * W * 27 * 8)):
         rc = _lib.lib().ctdet_dcn_col2im_coord(_ptr(dcol), _ptr(x), _nhwc_stride(x), _ptr(om), _nhwc_stride(om), _ptr(dx),
                                                _ptr(dom), dom.shape[3], dt_of(dom), B, H, W, Cin, int(mask_is_prob),
                                                int(dcol_chunked), dt_of(x) if comp is None or x.dtype == torch.float16 else comp,

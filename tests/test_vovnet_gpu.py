@@ -103,6 +103,7 @@ def test_vovnet19_slim_centernet_eval_matches_oracle(tmp_path, dev, precision):
     model.score_threshold = 0.0
     out = model([{"image": img[b]} for b in range(2)])
     eng = next(iter(model._engines.values()))
+    assert set(eng.graph_nodes) <= {"kernel", "empty"}, eng.graph_nodes      # engine/graph_nodes.py
     hm, wh, reg = [t.float().cpu().permute(0, 3, 1, 2) for t in eng.out]
     assert hm.shape == (2, 80, 24, 32)
     x, _ = O.preprocess([i for i in img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 16)
@@ -282,3 +283,5 @@ def test_vovnet19_slim_training_step_matches_oracle(tmp_path, dev, precision):
     # went through them and forked the capture onto that stream.  Every parameter gradient of the step now goes straight into
     # the optimizer's flat buffer, so no AccumulateGrad node runs inside the capture
     assert tr.graph_state == "captured", tr._graphs
+    for g in tr._graphs.values():        # kernels only: no memset / memcpy node (engine/graph_nodes.py)
+        assert set(g["nodes"]) <= {"kernel", "empty"}, g["nodes"]
