@@ -49,24 +49,6 @@ def run_train_bench(model, cfg, args, B, rank, world, device, dist):
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if hasattr(trainer, "_xlog_pre"):
-        import sys
-        torch.cuda.synchronize()
-        red = trainer.reducer
-        for it in range(2, trainer.iter):
-            pre = trainer._xlog_pre[it].cpu()
-            got = [torch.empty_like(pre) for _ in range(world)]
-            dist.all_gather(got, pre)
-            want = sum(got)
-            post = trainer._xlog_post[it].cpu()
-            line = []
-            for s, e, _ in red.buckets:
-                d = (post[s:e] - want[s:e]).abs()
-                bad = (d > 1e-6 * want[s:e].abs().max()).nonzero().flatten()
-                line.append(f"[{s}:{e}) max err {float(d.max()):.3g} of {float(want[s:e].abs().max()):.3g}, {bad.numel()} off"
-                            + (f" (first {int(bad[0]) + s}, last {int(bad[-1]) + s}; == own {bool(torch.equal(post[s:e], pre[s:e]))}"
-                               f" == other {bool(torch.equal(post[s:e], got[1 - rank][s:e]))})" if bad.numel() else ""))
-            print(f"[rank {rank}] step {it}: " + "; ".join(line), file=sys.stderr, flush=True)
     if getattr(trainer, "_steplog", None) is not None:      # CTDET_TRAIN_CHECK=2
         import sys
         print(f"[rank {rank}] step log [hm, wh, off, max|feat|, max|logit|, max tgt, min tgt, grad ok, reduced ok, param ok]\n" +

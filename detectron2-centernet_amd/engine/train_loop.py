@@ -74,10 +74,6 @@ class SimpleTrainer:
         (tests/test_dp_gpu.py::test_two_rank_graph_steps_equal_single_rank_steps).  The LR schedule and the per-parameter
         version counters stay on the host.  CTDET_TRAIN_GRAPH=0 keeps every step eager."""
         multi = self.reducer.world > 1
-        if multi and int(os.environ.get("CTDET_DBG_SYNC", "0")) & 64 and not hasattr(self, "_xlog_pre"):
-            n = self.optimizer.flat_grad.numel()
-            self._xlog_pre = torch.zeros(16, n, device=self.optimizer.flat_grad.device)
-            self._xlog_post = torch.zeros(16, n, device=self.optimizer.flat_grad.device)
         if not self.use_hip_graph or (multi and not self.graph_ddp):
             return self._finish_step(self.model.train_batch_tensor(images, boxes, classes, counts))
         key = tuple((tuple(t.shape), t.dtype) for t in (images, boxes, classes, counts))
@@ -95,34 +91,17 @@ class SimpleTrainer:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         g["graph"].replay()
-        dbg = int(os.environ.get("CTDET_DBG_SYNC", "0"))
-        if dbg & 1:
-            torch.cuda.synchronize()
-        if dbg & 16:
-            torch.isfinite(self.optimizer.flat_grad).all()
         if train_step.STEP_CHECK == 1:
             self._check_step("after the replayed forward + backward" + ("" if multi else " + SGD"), g["losses"])
         elif train_step.STEP_CHECK == 2:
             self._log_step(7, g["losses"])
-        if multi and dbg & 64:     # the exchange's operands and results of every step, in buffers allocated before step 0
-            self._xlog_pre[self.iter].copy_(self.optimizer.flat_grad)
         if multi:
             self.reducer.reduce_all()
-            if dbg & 64:
-                self._xlog_post[self.iter].copy_(self.optimizer.flat_grad)
             if train_step.STEP_CHECK == 1:
                 self._check_step("after the all-reduce", g["losses"])
             elif train_step.STEP_CHECK == 2:
                 self._log_step(8)
-            if dbg & 2:
-                torch.cuda.synchronize()
-            if dbg & 32:
-                torch.isfinite(self.optimizer.flat_grad).all()
             self.optimizer.step()
-            if dbg & 4:
-                torch.cuda.synchronize()
-            if dbg & 8:
-                torch.isfinite(self.optimizer.flat_param).all()
         if train_step.STEP_CHECK == 2:
             self._log_step(9)
         for p in self.optimizer.params:   # the captured SGD kernels wrote the parameters behind autograd's back

@@ -73,7 +73,7 @@ def to_nhwc(x_nchw, ctx, pad_to=None):
     if x.dtype != ctx.dtype:
         x = x.to(ctx.dtype)
     if pad_to is not None and x.shape[3] < pad_to:
-        x = torch.nn.functional.pad(x, (0, pad_to - x.shape[3]))
+        x = ops.kpad(x, (0, pad_to - x.shape[3]))
     return x.contiguous()
 
 

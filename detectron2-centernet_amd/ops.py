@@ -207,6 +207,26 @@ def round_up(a, b):
     return (a + b - 1) // b * b
 
 
+def flip_taps(w):
+    """w.flip(2, 3) of an OIHW weight; a 1x1 weight is returned as it is (torch's flip of size-1 dimensions is a plain copy, a
+    hipMemcpyAsync: see kpad)"""
+    return w if w.shape[2] * w.shape[3] == 1 else w.flip(2, 3)
+
+
+def kpad(t, pad, value=0.0):
+    """torch.nn.functional.pad(t, pad, value=value) for padding after the END of dimensions (pad = (0, n_last, 0, n_before_last,
+    ...)), made of kernels only.  F.pad is fill + narrow().copy_(), and a contiguous narrow (a 1-D vector, dimension 0 of a
+    weight) is copied by hipMemcpyAsync: a memcpy node in a captured step, which must hold kernels only (engine/graph_nodes.py)"""
+    for i in range(0, len(pad), 2):
+        assert pad[i] == 0, "kpad pads after the end of a dimension only"
+        n, dim = int(pad[i + 1]), t.dim() - 1 - i // 2
+        if n:
+            shape = list(t.shape)
+            shape[dim] = n
+            t = torch.cat([t, t.new_full(shape, value)], dim)
+    return t
+
+
 class PackPlan:
     """The packed operands of every conv weight a training step packs (forward and input-gradient forms; f16 images and the
     split f16x3 images with their row scales), kept in persistent buffers and refreshed by ONE kernel per kind after the
@@ -390,10 +410,10 @@ class PackedConv:
             self.bias = self._pad_vec(bias, 0.0, dev)
             return
         if transposed:
-            weight = weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()
+            weight = flip_taps(weight.detach()).permute(1, 0, 2, 3).contiguous()
         w = weight.detach().to(torch.float32).permute(0, 2, 3, 1)  # [Cout,R,S,Cin]
         if self.Cin != Cin:
-            w = torch.nn.functional.pad(w, (0, self.Cin - Cin))
+            w = kpad(w, (0, self.Cin - Cin))
         # k ordering (ctdet_conv_desc.korder): chunk-major keeps the R*S taps of one 32-channel chunk adjacent
         if self.korder == 1:
             w = w.reshape(Cout, R * S, self.Cin // 32, 32).permute(0, 2, 1, 3)
@@ -404,15 +424,15 @@ class PackedConv:
             tile = max(_lib.lib().ctdet_conv_cout_tile(self.Cout_eff), cout_align or 1)
             self.Kpad = round_up(K, 32)
             self.Cout_pad = round_up(self.Cout_eff, tile)
-            wp = torch.zeros(self.Cout_pad, self.Kpad, dtype=torch.float16, device=dev)
-            wp[:Cout, :K] = w.to(torch.float16)
+            wp = kpad(w.to(torch.float16), (0, self.Kpad - K, 0, self.Cout_pad - Cout))    # kernels only: see kpad
         else:
             # f32 MFMA path: the same [row = cout][k] image as the f16 operand, 16 k per LDS row
             tile = max(_lib.lib().ctdet_conv_cout_tile(self.Cout_eff), cout_align or 1)
             self.Kpad = round_up(K, 16)
             self.Cout_pad = round_up(self.Cout_eff, tile)
-            wp = torch.zeros(self.Cout_pad, self.Kpad, dtype=torch.float32, device=dev)
-            wp[:Cout, :K] = w
+            wp = kpad(w.to(torch.float32), (0, self.Kpad - K, 0, self.Cout_pad - Cout))
+            if wp.data_ptr() == weight.data_ptr():    # nothing to pad or reorder (1x1): the image is still a snapshot of the weight,
+                wp = torch.mul(wp, 1.0)               # made by a kernel (clone() of a contiguous tensor is a hipMemcpyAsync)
             if compute == F16X3:   # same image, every group of 4 k as {w_hi[4], w_lo[4]} f16
                 # rows are first scaled by a power of two (exact) so that their largest weight lies in [1024, 2048): the lo
                 # halves of a row's significant weights then stay f16 normals (2^-22 of the row maximum instead of the 3e-8
@@ -525,9 +545,7 @@ class PackedConv:
         v = v.detach().to(torch.float32)
         if v.shape[0] == self.Cout_eff:
             return v.contiguous()
-        # one pad KERNEL: a slice assignment is a device-to-device hipMemcpyAsync, which a captured training step would hold as a
-        # memcpy node (see SimpleTrainer._capture_body: the captured step is kernels only)
-        return torch.nn.functional.pad(v.contiguous(), (0, self.Cout_eff - v.shape[0]), value=float(fill))
+        return kpad(v.contiguous(), (0, self.Cout_eff - v.shape[0]), value=float(fill))   # not a slice assignment: see kpad
 
     @property
     def act_dt(self):

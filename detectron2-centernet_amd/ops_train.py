@@ -323,7 +323,7 @@ def dcn_weight_matrix(weight, Cw=None, chunked=False):
     else:
         wmat = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
     if Cw is not None and Cw != Cout:
-        wmat = torch.nn.functional.pad(wmat, (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
+        wmat = ops.kpad(wmat, (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
     return wmat
 
 
@@ -419,8 +419,8 @@ def _conv_dgrad_s2_phases(dy, weight, in_hw, comp=F16):
     Cp = (Cin + 7) // 8 * 8
     w9 = weight.detach().reshape(Cout, Cin, 9)
     if Cd != Cout:
-        w9 = torch.nn.functional.pad(w9, (0, 0, 0, 0, 0, Cd - Cout))
-    w10 = torch.nn.functional.pad(w9, (0, 1, 0, Cp - Cin))                         # zero tap, channel padding -> [Cd, Cp, 10]
+        w9 = ops.kpad(w9, (0, 0, 0, 0, 0, Cd - Cout))
+    w10 = ops.kpad(w9, (0, 1, 0, Cp - Cin))                         # zero tap, channel padding -> [Cd, Cp, 10]
     wd = w10.index_select(2, _phase_tap_index(dy.device)).view(Cd, Cp, 4, 2, 2)     # [co, ci, phase, a, b]
     wd = wd.permute(2, 1, 0, 3, 4).reshape(4 * Cp, Cd, 2, 2).contiguous()
     p = ops.PackedConv(wd, None, None, stride=1, pad=1, compute=comp)
@@ -440,7 +440,7 @@ def conv_dgrad(dy, weight, stride, pad, in_hw, cin_pad=None, comp=None):
     Cout, Cin, R, S = weight.shape
     comp = comp_of(dy) if comp is None else comp
     if comp == F32:
-        wt = weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()      # [Cin, Cout, R, S]: dX = conv(dY, wt)
+        wt = ops.flip_taps(weight.detach()).permute(1, 0, 2, 3).contiguous()      # [Cin, Cout, R, S]: dX = conv(dY, wt)
         p = ops.PackedConv(wt, None, None, stride=1, pad=R - 1 - pad, compute=F32)
         p.in_dil = stride
         dx = torch.empty(dy.shape[0], in_hw[0], in_hw[1], p.Cout_eff, dtype=torch.float32, device=dy.device)
@@ -515,9 +515,9 @@ class ConvFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if x.shape[3] != Cin or comp == F32:
-                wpad = weight if Cw == Cout else torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
+                wpad = weight if Cw == Cout else ops.kpad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
                 if x.shape[3] != Cin:         # input channels were padded (the 3 -> 8 channel image): so is dX
-                    wpad = torch.nn.functional.pad(wpad.detach(), (0, 0, 0, 0, 0, x.shape[3] - Cin))
+                    wpad = ops.kpad(wpad.detach(), (0, 0, 0, 0, 0, x.shape[3] - Cin))
                 dx = conv_dgrad(dy, wpad, stride, pad, x.shape[1:3], comp=comp)
             else:                             # padded dY channels meet zero operand columns: no padded copy of the weight
                 dx = conv_dgrad(dy, weight, stride, pad, x.shape[1:3], cin_pad=Cw, comp=comp)
@@ -552,7 +552,7 @@ class FrozenConvFn(torch.autograd.Function):
         if relu:
             g, _, _, _ = bn_train_bwd(dz, _pad_c(z, comp), None, None, None, None, relu=True)
         dres = (g if g.shape[3] == Cout else g[..., :Cout]) if has_res else None
-        sc = scale if g.shape[3] == Cout else torch.nn.functional.pad(scale, (0, g.shape[3] - Cout))
+        sc = scale if g.shape[3] == Cout else ops.kpad(scale, (0, g.shape[3] - Cout))
         dconv = g * sc.to(g.dtype)
         Cw = dconv.shape[3]
         dwt = None
@@ -561,7 +561,7 @@ class FrozenConvFn(torch.autograd.Function):
             dwt = _wgrad_to_oihw(dw, Cout, Cin, x.shape[3], R, S)
         dx = None
         if ctx.needs_input_grad[0]:
-            wpad = weight if Cw == Cout else torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
+            wpad = weight if Cw == Cout else ops.kpad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - Cout))
             dx = conv_dgrad(dconv, wpad, stride, pad, x.shape[1:3], comp=comp)
         return dx, dwt, None, None, dres, None, None, None
 
@@ -590,7 +590,7 @@ class ConvTransposeFn(torch.autograd.Function):
         comp = ctx.comp
         dy = _pad_c(dy.contiguous().to(x.dtype), comp)
         Cw = dy.shape[3]
-        wpad = weight.detach() if Cw == Cout else torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, Cw - Cout))
+        wpad = weight.detach() if Cw == Cout else ops.kpad(weight.detach(), (0, 0, 0, 0, 0, Cw - Cout))
         p = ops.PackedConv(wpad, None, None, stride=stride, pad=pad, compute=comp)   # rows = Cin, channels = Cw
         dx = ops.conv2d(dy, p)
         dx = dx if dx.shape[3] == Cin else dx[..., :Cin]
@@ -608,7 +608,7 @@ def _pad_c(t, comp=None):
     q = 8 if t is not None and (t.dtype == torch.float16 or comp == F16X3) else 4
     if t is None or t.shape[3] % q == 0:
         return t
-    return torch.nn.functional.pad(t, (0, q - t.shape[3] % q))
+    return ops.kpad(t, (0, q - t.shape[3] % q))
 
 
 class BNActFn(torch.autograd.Function):
@@ -796,8 +796,8 @@ class DeformConvFn(torch.autograd.Function):
             dw_off = conv_wgrad(x, dom_p, Cw, 3, 3, 1, 1, comp=comp)[:n_om]
             dw_off_t = _wgrad_to_oihw(dw_off, n_om, Cin, x.shape[3], 3, 3)
         if comp == F32:
-            wpad = torch.nn.functional.pad(w_off.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - n_om)) if Cw != n_om else w_off.detach()
-            wt = wpad.flip(2, 3).permute(1, 0, 2, 3).contiguous()
+            wpad = ops.kpad(w_off.detach(), (0, 0, 0, 0, 0, 0, 0, Cw - n_om)) if Cw != n_om else w_off.detach()
+            wt = ops.flip_taps(wpad).permute(1, 0, 2, 3).contiguous()
             pt = ops.PackedConv(wt, None, None, stride=1, pad=1, compute=F32)
         else:   # the padded dY channels meet zero operand columns: packed from the parameter itself (a planned pack)
             pt = ops.PackedConv(w_off.detach(), None, None, stride=1, pad=1, compute=comp, transposed=True, cin_pad=Cw)

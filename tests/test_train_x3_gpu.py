@@ -487,7 +487,7 @@ def test_training_f16x3_graph_replay_and_planned_packs(tmp_path, dev):
         hist.append({k: float(v) for k, v in l.items()})
         assert all(torch.isfinite(torch.tensor(list(hist[-1].values())))), hist
     assert tr.graph_state == "captured", tr._graphs
-    for g in tr._graphs.values():        # kernels only: no memset / memcpy node (engine/graph_nodes.py)
+    for g in (g for g in tr._graphs.values() if g["graph"] is not None):   # kernels only (engine/graph_nodes.py)
         assert set(g["nodes"]) <= {"kernel", "empty"}, g["nodes"]
     plan = ops.PACK_PLAN
     x3_entries = [e for e in plan.entries.values() if e[4] is not None]
