@@ -255,3 +255,28 @@ def test_bench_self_launches_its_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["dtype"] == "f16x3" and rec["value"] > 0
     assert rec["config"]["ranks_share_devices"] == (torch.cuda.device_count() < 2)
+
+
+def test_two_rank_bench_training_graph_equals_hooks_path():
+    """`python bench.py --gpus 2` (the inference leg, then the f16x3 training leg): nothing between the training steps (the per-step recordings of the tests above put
+    torch kernels between the eager SGD launch and the next replay, which is exactly what hid round 3's corruption -- the
+    memset node of the captured step, profiles/r04_graph_memset_node.txt).  The captured data-parallel step must end where the
+    eager hooks path ends: final losses of 14 steps equal to 1e-4 (a wrong run ended at hm_loss 99 ... inf against 93.72)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "CTDET_BENCH_BACKEND",
+                                                               "CTDET_TRAIN_GRAPH", "CTDET_TRAIN_CHECK")}
+    finals = {}
+    for mode in ("hooks", "1"):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                              "--no-cpu-baseline", "--no-f32", "--no-f16", "--no-roofline"],
+                             env=dict(base, CTDET_TRAIN_GRAPH=mode), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        rec = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][-1])["train"]
+        assert rec["n_gpus"] == 2 and rec["config"]["graph_state"] == ("captured" if mode == "1" else "eager"), rec["config"]
+        finals[mode] = rec["config"]["final_losses"]
+    for k, v in finals["hooks"].items():
+        assert abs(finals["1"][k] - v) <= 1e-4 * abs(v), finals
