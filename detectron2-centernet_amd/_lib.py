@@ -37,6 +37,7 @@ SIGNATURES = {
     "ctdet_preprocess": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp]),
     "ctdet_head_fused_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "ctdet_dla_base_fwd": (_i32, [_vp] * 14),
+    "ctdet_dla_base_x3_fwd": (_i32, [_vp] * 14),
     "ctdet_maxpool2x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_maxpool3x3s2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_maxpool3x3s2_ceil": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

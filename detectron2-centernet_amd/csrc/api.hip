@@ -133,7 +133,7 @@ extern "C" {
 const char* ctdet_last_error(void) { return g_err; }
 int32_t ctdet_set_tuning_flags(uint32_t flags) { g_tuning.store(flags, std::memory_order_relaxed); return 0; }
 uint32_t ctdet_get_tuning_flags(void) { return g_tuning.load(std::memory_order_relaxed); }
-int32_t ctdet_abi_version(void) { return 6; }
+int32_t ctdet_abi_version(void) { return 7; }
 int32_t ctdet_conv_cout_tile(int32_t cout) {
   if (cout <= 16) return 16;
   if (cout <= 32) return 32;
@@ -302,6 +302,24 @@ int32_t ctdet_dla_base_fwd(const ctdet_dla_base_desc* d, const void* images, con
   a.y = out; a.out_stride = d->out_stride;
   a.pool = pooled; a.pool_stride = d->pool_stride;
   return launch_dla_base(a, (hipStream_t)stream);
+}
+
+int32_t ctdet_dla_base_x3_fwd(const ctdet_dla_base_desc* d, const void* images, const void* w_stem, const float* scale_stem,
+                              const float* bias_stem, const void* w_l0, const float* scale_l0, const float* bias_l0,
+                              const void* w_l1, const float* scale_l1, const float* bias_l1, float* out, float* pooled,
+                              void* stream) {
+  CTDET_CHECK(d && images && w_stem && scale_stem && bias_stem && w_l0 && scale_l0 && bias_l0 && w_l1 && scale_l1 && bias_l1 &&
+              out, "dla_base(f16x3): null pointer");
+  BaseArgs a = {};
+  a.img = images; a.img_dtype = d->img_dtype; a.img_batch_stride = (long)d->img_batch_stride;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Hp = d->Hp; a.Wp = d->Wp;
+  for (int i = 0; i < 3; ++i) { a.mean[i] = d->mean[i]; a.stdv[i] = d->std[i]; }
+  a.w0 = w_stem; a.s0 = scale_stem; a.b0 = bias_stem;
+  a.w1 = w_l0; a.s1 = scale_l0; a.b1 = bias_l0;
+  a.w2 = w_l1; a.s2 = scale_l1; a.b2 = bias_l1;
+  a.y = out; a.out_stride = d->out_stride;
+  a.pool = pooled; a.pool_stride = d->pool_stride;
+  return launch_dla_base_x3(a, (hipStream_t)stream);
 }
 
 int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,

@@ -101,6 +101,7 @@ struct BaseArgs {
   int pool_stride;
 };
 int launch_dla_base(const BaseArgs& a, hipStream_t s);
+int launch_dla_base_x3(const BaseArgs& a, hipStream_t s);   // f16x3: w* = ctdet_pack_weights_x3 layout 0 images, y / pool f32
 
 // argument block of the batched decode (decode.hip)
 struct DecArgs {

@@ -131,8 +131,8 @@ __global__ void __launch_bounds__(256, 2) dla_base_fused_kernel(const BaseArgs a
   constexpr int FAST_N = 3 * INH * FAST_PER_ROW;                 // 825
   constexpr int FAST_ROUNDS = (FAST_N + 255) / 256;              // 4
   // (byte images, border tiles: the three channels of a pixel packed into one register -- that path waits for its loads)
-  constexpr int RAWC = BYTES ? 1 : 3;
-  unsigned raw[IN_ROUNDS * RAWC];
+  constexpr int raw1C = BYTES ? 1 : 3;
+  unsigned raw[IN_ROUNDS * raw1C];
   unsigned okmask = 0;
   bool raw_fast = false;
   auto tile_origin = [&](int tile, int& ox, int& oy, int& b) {
@@ -368,6 +368,352 @@ int launch_dla_base(const BaseArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((dla_base_fused_kernel<float>), dim3(blocks), dim3(256), 0, s, a, (int)tiles);
   else
     CTDET_CHECK(false, "dla_base: image dtype %d (want u8 or f32)", a.img_dtype);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// f16x3 form of the fused base (f32 tensors, every product as hi*hi + lo*hi + hi*lo on the f16 matrix pipe, f32 accumulate:
+// the arithmetic of conv_f32_win_kernel<..., SP>, which runs these three layers one by one in that mode -- 0.63 + 0.70 +
+// 0.48 ms at batch 64 x 512^2, each a 1-2 GB f32 stream, plus 0.2 ms of preprocessing and pooling).  Same tile and
+// receptive-field walk as the f16 kernel above (8x16 level1 outputs <- 17x33 level0 <- 19x35 stem <- 25x41 input pixels), one
+// tile per workgroup, two workgroups per CU:
+//   * the window is normalised in f32 with the reference's operation order ((x / 255 - mean) / std; byte images through a
+//     3 x 256 table built per workgroup in the stem planes' bytes, free until the stem phase) and stored split, 16 bytes per
+//     pixel = {hi[4], lo[4]} (channel 3 zero);
+//   * the stem's k order is the f16 kernel's (kernel row, 8 taps of which the eighth has zero weights, 4 channels): a K step is
+//     four consecutive taps of a row, lane group q takes tap 4 half + q, so every LDS address of the kernel is
+//     (per-run lane base) + (compile-time offset) -- no vector address arithmetic inside the K loops;
+//   * a fragment read ({hi[4], lo[4]} of one tap / 4-channel group) IS the B operand of both products of the generic scheme
+//     (conv_f32_win_kernel): wa = {w_lo, w_hi}, wb = {w_hi, 0} from the {w_hi[4], w_lo[4]} groups of ctdet_pack_weights_x3
+//     (layout 0, k = tap * channels + c, rows scaled by a power of two that the folded BatchNorm scale carries back);
+//   * stem and level0 outputs (f32 after scale / bias / ReLU, zero outside the map) are split once, when they are written to
+//     LDS: four planes of 4 channels, 16 bytes per pixel and plane, so the 16 pixel-lanes of a fragment read consecutive
+//     slots.  The level0 planes reuse the bytes of the input window (dead after the stem phase): 42.8 + 36.1 KB per workgroup;
+//   * a phase's weight groups are fetched from L2 one phase ahead of their use (all three sets do not fit in 256 registers).
+// HBM sees the image once (50 MB of bytes at batch 64) and the level1 map (+ its 2x2 max-pool) once (0.54 + 0.13 GB).
+// Measured alternatives (profiles/r04_base_x3_ablation.txt): persistent workgroups with the next window prefetched (no gain:
+// the time is in the three K-loop phases, not in the window stage), all weights resident in registers with the second operand
+// assembled next to its MFMA (spills; slower).
+// ------------------------------------------------------------------------------------------
+namespace {
+constexpr int X3_STP = (NST * 16 + 63) / 64 * 64, X3_L0P = (NL0 * 16 + 63) / 64 * 64;    // plane strides (bytes)
+constexpr int X3_NK0 = 14;                          // stem K steps: 7 kernel rows x 8 taps (the eighth zero) x 4 channels = 224
+static_assert((NIN + IN_PAD) * 16 <= 4 * X3_L0P, "the input window fits under the level0 planes");
+static_assert(3 * 256 * 4 <= 4 * X3_STP, "the byte table fits under the stem planes");
+static_assert(4 * X3_STP + 4 * X3_L0P <= 81920, "two workgroups per CU");
+
+__device__ __forceinline__ f16x8 split4(const f32x4 v) {
+  const f16x4 hi = __builtin_convertvector(v, f16x4);
+  f32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = v[j] - (float)hi[j];
+  const f16x4 lo = __builtin_convertvector(r, f16x4);
+  return __builtin_shufflevector(hi, lo, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ f32x4 bn_relu_f32(const f32x4 acc, const f32x4 sc, const f32x4 bi) {
+  f32x4 v = acc * sc;
+  v = v + bi;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+  return v;
+}
+// one phase's raw weight groups of a lane ({w_hi[4], w_lo[4]} each), fetched ahead of the phase that uses them
+template <int NKT>
+__device__ __forceinline__ void x3_fetch(const void* w, int row, int kpad, int q, f16x8 (&raw)[NKT]) {
+#if defined(CTDET_BASE_ABLATE) && (CTDET_BASE_ABLATE & 64)
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) raw[kt] = (f16x8){(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
+  return;
+#endif
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) raw[kt] = *(const f16x8*)((const char*)w + ((long)row * kpad + kt * 16 + q * 4) * 4);
+}
+// the two A operands of the generic f16x3 scheme from the packed groups: wa = {w_lo, w_hi}, wb = {w_hi, 0}
+template <int NKT>
+__device__ __forceinline__ void x3_operands(const f16x8 (&raw)[NKT], f16x8 (&wa)[NKT], f16x8 (&wb)[NKT]) {
+  const f16x4 z4 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    wa[kt] = __builtin_shufflevector(raw[kt], raw[kt], 4, 5, 6, 7, 0, 1, 2, 3);
+    wb[kt] = __builtin_shufflevector(__builtin_shufflevector(raw[kt], raw[kt], 0, 1, 2, 3), z4, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+}  // namespace
+
+// measurement builds only (tools/ablate_base.sh): CTDET_BASE_ABLATE == 1 drops the fragment reads of the K loops (one read per
+// run instead), == 2 drops their MFMAs; bits 4 / 8 / 16 / 32 / 64 skip the window conversion / the stem loop / the level0 loop /
+// the level1 phase / the weight fetches
+#ifndef CTDET_BASE_ABLATE
+#define CTDET_BASE_ABLATE 0
+#endif
+#if CTDET_BASE_ABLATE == 1
+#define X3_FRAG(ptr, off) (*(const f16x8*)(ptr))
+#else
+#define X3_FRAG(ptr, off) (*(const f16x8*)((ptr) + (off)))
+#endif
+__device__ __forceinline__ f32x4 x3_mma(const f16x8 w, const f16x8 h, f32x4 acc) {
+#if CTDET_BASE_ABLATE == 2
+  acc[0] += (float)h[0] * (float)w[0];
+  return acc;
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, h, acc, 0, 0, 0);
+#endif
+}
+
+template <typename TIn>
+__global__ void __launch_bounds__(256, 2) dla_base_x3_kernel(const BaseArgs a, int ntiles) {
+  __shared__ __attribute__((aligned(16))) char stb[4 * X3_STP];    // [plane][pixel]{hi[4], lo[4]} stem outputs
+  __shared__ __attribute__((aligned(16))) char l0b[4 * X3_L0P];    // the input window, then the level0 outputs
+  char* const inb = l0b;
+  constexpr bool BYTES = sizeof(TIn) == 1;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, q = lane >> 4;
+  const int H1 = a.Hp >> 1, W1 = a.Wp >> 1;
+  const int tiles_x = W1 / T1W, tiles_y = H1 / T1H;
+  // consecutive workgroups go to different XCDs: give each XCD a contiguous run of tiles (neighbours share window pixels in L2)
+  int tile = blockIdx.x;
+  if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
+  const int ox = (tile % tiles_x) * T1W;
+  const int oy = ((tile / tiles_x) % tiles_y) * T1H;
+  const int b = tile / (tiles_x * tiles_y);
+
+  f16x8 raw0[X3_NK0];
+  x3_fetch<X3_NK0>(a.w0, fr, X3_NK0 * 16, q, raw0);                // in flight during the window stage
+
+  // ---- input window: rows 2oy-5 .. 2oy+19, columns 2ox-5 .. 2ox+35 of the image; zero outside it (also inside the padded
+  // map: the reference pads the NORMALISED batch with zeros, centernet.py:193-200 + ImageList) ----
+  {
+    const TIn* img = (const TIn*)a.img + (long)b * a.img_batch_stride;
+    const long plane = (long)a.H * a.W;
+    const int iy0 = 2 * oy - 5, ix0 = 2 * ox - 5;
+    float* lut = (float*)stb;
+    constexpr int ROUNDS = (NIN + 255) / 256;
+    // tap column 7 (zero weights) of the window's last row reads the pixels behind it: finite values wanted
+    if (tid < IN_PAD) *(f16x8*)(inb + (NIN + tid) * 16) = split4((f32x4){0.f, 0.f, 0.f, 0.f});
+    if constexpr (BYTES) {
+      unsigned rawpx[ROUNDS];                                      // the three channels of a pixel, 0xffffffff = outside
+#pragma unroll
+      for (int c = 0; c < 3; ++c) lut[c * 256 + tid] = ((float)tid / 255.f - a.mean[c]) / a.stdv[c];
+#pragma unroll
+      for (int i = 0; i < ROUNDS; ++i) {
+        const int p = tid + 256 * i;
+        const int wy = p / INW, wx = p - wy * INW;
+        const int y = iy0 + wy, x = ix0 + wx;
+        rawpx[i] = 0xffffffffu;
+        if (p < NIN && y >= 0 && y < a.H && x >= 0 && x < a.W) {
+          const TIn* s = img + (long)y * a.W + x;
+          rawpx[i] = (unsigned)s[0] | ((unsigned)s[plane] << 8) | ((unsigned)s[2 * plane] << 16);
+        }
+      }
+      __syncthreads();
+      if (!(CTDET_BASE_ABLATE & 4)) {
+#pragma unroll
+      for (int i = 0; i < ROUNDS; ++i) {
+        const int p = tid + 256 * i;
+        if (p < NIN) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (rawpx[i] != 0xffffffffu) {
+            v[0] = lut[rawpx[i] & 255]; v[1] = lut[256 + ((rawpx[i] >> 8) & 255)]; v[2] = lut[512 + ((rawpx[i] >> 16) & 255)];
+          }
+          *(f16x8*)(inb + p * 16) = split4(v);
+        }
+      }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < ROUNDS; ++i) {
+        const int p = tid + 256 * i;
+        if (p < NIN) {
+          const int wy = p / INW, wx = p - wy * INW;
+          const int y = iy0 + wy, x = ix0 + wx;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
+            const TIn* s = img + (long)y * a.W + x;
+            v[0] = ((float)s[0] / 255.f - a.mean[0]) / a.stdv[0];
+            v[1] = ((float)s[plane] / 255.f - a.mean[1]) / a.stdv[1];
+            v[2] = ((float)s[2 * plane] / 255.f - a.mean[2]) / a.stdv[2];
+          }
+          *(f16x8*)(inb + p * 16) = split4(v);
+        }
+      }
+    }
+  }
+
+  f16x8 raw1[9];
+  x3_fetch<9>(a.w1, fr, 144, q, raw1);                             // level0's weights: in flight during the stem phase
+
+  // ---- stem: 7x7 on 4-channel pixels, 14 K steps (kernel row, half row of 4 taps).  A wave walks its share of the 42 runs of
+  // 16 pixels two at a time (two independent accumulator chains), a last odd run alone ----
+  {
+    f16x8 wa[X3_NK0], wb[X3_NK0];
+    x3_operands<X3_NK0>(raw0, wa, wb);
+    const f32x4 sc = *(const f32x4*)(a.s0 + 4 * q), bi = *(const f32x4*)(a.b0 + 4 * q);
+    __syncthreads();                                               // the window is complete (and the table no longer needed)
+    constexpr int RUNS = (NST + 15) / 16;                          // 42: waves 0, 1 take 11, waves 2, 3 take 10
+    const int r0 = wave * (RUNS / 4) + (wave < RUNS % 4 ? wave : RUNS % 4), nr = RUNS / 4 + (wave < RUNS % 4 ? 1 : 0);
+    auto run = [&](int t, auto pairc) {
+      constexpr int NU = decltype(pairc)::value;
+      int py[NU], px[NU], pp[NU];
+      const char* rp[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int p = (t + u) * 16 + fr;
+        pp[u] = p;
+        const int pc = p < NST ? p : NST - 1;
+        py[u] = pc / STW; px[u] = pc - py[u] * STW;
+        rp[u] = inb + (py[u] * INW + px[u] + q) * 16;
+      }
+      f32x4 acc[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < X3_NK0; ++kt) {
+        f16x8 h[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) h[u] = X3_FRAG(rp[u], ((kt >> 1) * INW + (kt & 1) * 4) * 16);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc[u] = x3_mma(wa[kt], h[u], acc[u]);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc[u] = x3_mma(wb[kt], h[u], acc[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (pp[u] < NST) {
+          const int sy = 2 * oy - 2 + py[u], sx = 2 * ox - 2 + px[u];
+          f32x4 v = bn_relu_f32(acc[u], sc, bi);
+          if (!(sy >= 0 && sy < a.Hp && sx >= 0 && sx < a.Wp)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          *(f16x8*)(stb + q * X3_STP + pp[u] * 16) = split4(v);
+        }
+      }
+    };
+    if (!(CTDET_BASE_ABLATE & 8)) {
+      int t = r0;
+      for (; t + 1 < r0 + nr; t += 2) run(t, std::integral_constant<int, 2>{});
+      if (t < r0 + nr) run(t, std::integral_constant<int, 1>{});
+    }
+  }
+
+  f16x8 raw2[9];
+  x3_fetch<9>(a.w2, fr, 144, q, raw2);                             // level1's first cout tile: in flight during level0
+  __syncthreads();                                                 // stem planes complete; the window is dead
+
+  // ---- level0: 3x3, 16 -> 16: a K step = one tap, lane group q reads plane q ----
+  {
+    f16x8 wa[9], wb[9];
+    x3_operands<9>(raw1, wa, wb);
+    const f32x4 sc = *(const f32x4*)(a.s1 + 4 * q), bi = *(const f32x4*)(a.b1 + 4 * q);
+    constexpr int RUNS = (NL0 + 15) / 16;                          // 36: 9 per wave
+    const int r0 = wave * (RUNS / 4) + (wave < RUNS % 4 ? wave : RUNS % 4), nr = RUNS / 4 + (wave < RUNS % 4 ? 1 : 0);
+    auto run = [&](int t, auto pairc) {
+      constexpr int NU = decltype(pairc)::value;
+      int py[NU], px[NU], pp[NU];
+      const char* rp[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int p = (t + u) * 16 + fr;
+        pp[u] = p;
+        const int pc = p < NL0 ? p : NL0 - 1;
+        py[u] = pc / L0W; px[u] = pc - py[u] * L0W;
+        rp[u] = stb + q * X3_STP + (py[u] * STW + px[u]) * 16;
+      }
+      f32x4 acc[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < 9; ++kt) {
+        f16x8 h[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) h[u] = X3_FRAG(rp[u], ((kt / 3) * STW + kt % 3) * 16);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc[u] = x3_mma(wa[kt], h[u], acc[u]);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc[u] = x3_mma(wb[kt], h[u], acc[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (pp[u] < NL0) {
+          const int ly = 2 * oy - 1 + py[u], lx = 2 * ox - 1 + px[u];
+          f32x4 v = bn_relu_f32(acc[u], sc, bi);
+          if (!(ly >= 0 && ly < a.Hp && lx >= 0 && lx < a.Wp)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          *(f16x8*)(l0b + q * X3_L0P + pp[u] * 16) = split4(v);
+        }
+      }
+    };
+    if (!(CTDET_BASE_ABLATE & 16)) {
+      int t = r0;
+      for (; t + 1 < r0 + nr; t += 2) run(t, std::integral_constant<int, 2>{});
+      if (t < r0 + nr) run(t, std::integral_constant<int, 1>{});
+    }
+  }
+  f16x8 raw3[9];
+  x3_fetch<9>(a.w2, 16 + fr, 144, q, raw3);                        // level1's second cout tile
+  __syncthreads();
+
+  // ---- level1: 3x3 stride 2, 16 -> 32: wave w owns tile rows 2w, 2w + 1; the two cout tiles one after the other ----
+  {
+    const char* rp = l0b + q * X3_L0P + (2 * (2 * wave) * L0W + 2 * fr) * 16;   // level0 row 2r of tile row r = 2 wave
+    float* yp = (float*)a.y + ((long)(b * H1 + oy + 2 * wave) * W1 + ox + fr) * a.out_stride + 4 * q;
+    auto tile_c = [&](const f16x8 (&raw)[9], int c) {
+      f16x8 wa[9], wb[9];
+      x3_operands<9>(raw, wa, wb);
+      const f32x4 sc = *(const f32x4*)(a.s2 + c * 16 + 4 * q), bi = *(const f32x4*)(a.b2 + c * 16 + 4 * q);
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kt = 0; kt < 9; ++kt) {
+        const f16x8 h0 = X3_FRAG(rp, ((kt / 3) * L0W + kt % 3) * 16);
+        const f16x8 h1 = X3_FRAG(rp, ((kt / 3 + 2) * L0W + kt % 3) * 16);
+        acc[0] = x3_mma(wa[kt], h0, acc[0]);
+        acc[1] = x3_mma(wa[kt], h1, acc[1]);
+        acc[0] = x3_mma(wb[kt], h0, acc[0]);
+        acc[1] = x3_mma(wb[kt], h1, acc[1]);
+      }
+      const f32x4 v0 = bn_relu_f32(acc[0], sc, bi), v1 = bn_relu_f32(acc[1], sc, bi);
+      *(f32x4*)(yp + c * 16) = v0;
+      *(f32x4*)(yp + (long)W1 * a.out_stride + c * 16) = v1;
+      if (a.pool) {
+        f32x4 m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = fmaxf(v0[j], v1[j]);
+          // the pixel column fr ^ 1: quad_perm [1,0,3,2]
+          const float n = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+          m[j] = fmaxf(v, n);
+        }
+        if (!(fr & 1))
+          *(f32x4*)((float*)a.pool + ((long)(b * (H1 >> 1) + (oy >> 1) + wave) * (W1 >> 1) + ((ox + fr) >> 1)) * a.pool_stride +
+                    c * 16 + 4 * q) = m;
+      }
+    };
+    if (!(CTDET_BASE_ABLATE & 32)) {
+      tile_c(raw2, 0);
+      tile_c(raw3, 1);
+    }
+  }
+}
+
+int launch_dla_base_x3(const BaseArgs& a, hipStream_t s) {
+  CTDET_CHECK(a.Hp % (2 * T1H) == 0 && a.Wp % (2 * T1W) == 0, "dla_base(f16x3): padded size %dx%d must be a multiple of %dx%d",
+              a.Hp, a.Wp, 2 * T1H, 2 * T1W);
+  CTDET_CHECK(a.H <= a.Hp && a.W <= a.Wp && a.H > 0 && a.W > 0, "dla_base(f16x3): image %dx%d larger than padded %dx%d", a.H,
+              a.W, a.Hp, a.Wp);
+  CTDET_CHECK(a.out_stride >= 32 && a.out_stride % 4 == 0 && (((size_t)a.y) & 15) == 0,
+              "dla_base(f16x3): output rows must be 16-byte aligned");
+  CTDET_CHECK(!a.pool || (a.pool_stride >= 32 && a.pool_stride % 4 == 0 && (((size_t)a.pool) & 15) == 0),
+              "dla_base(f16x3): pooled output rows must be 16-byte aligned");
+  CTDET_CHECK(((((size_t)a.w0) | ((size_t)a.w1) | ((size_t)a.w2) | ((size_t)a.s0) | ((size_t)a.b0) | ((size_t)a.s1) | ((size_t)a.b1) |
+                ((size_t)a.s2) | ((size_t)a.b2)) & 15) == 0, "dla_base(f16x3): operands must be 16-byte aligned");
+  const long tiles = (long)a.B * (a.Hp / (2 * T1H)) * (a.Wp / (2 * T1W));
+  if (tiles == 0) return 0;
+  CTDET_CHECK(tiles < (1L << 31), "dla_base(f16x3): too many tiles");
+  if (a.img_dtype == CTDET_U8)
+    hipLaunchKernelGGL((dla_base_x3_kernel<uint8_t>), dim3((unsigned)tiles), dim3(256), 0, s, a, (int)tiles);
+  else if (a.img_dtype == CTDET_F32)
+    hipLaunchKernelGGL((dla_base_x3_kernel<float>), dim3((unsigned)tiles), dim3(256), 0, s, a, (int)tiles);
+  else
+    CTDET_CHECK(false, "dla_base(f16x3): image dtype %d (want u8 or f32)", a.img_dtype);
   CTDET_LAUNCH_CHECK();
   return 0;
 }

@@ -211,30 +211,34 @@ class DLA(Backbone):
 
     def base_fusable(self, ctx, Hp, Wp):
         """the one-launch form of normalisation + base_layer + level0 + level1 (ops.dla_base_fused): DLA-34's 3->16->16->32
-        base, f16, BatchNorm in eval mode."""
-        return (ctx.compute == F16 and ops.dla_base_fused_ok(Hp, Wp) and len(self.level0) == 3 and len(self.level1) == 3
+        base, f16 or f16x3, BatchNorm in eval mode."""
+        if ctx.compute == ops.F16X3 and ops.RANGE_CHECK:      # the debug range check reads every contraction's output: layer by layer
+            return False
+        return (ctx.compute in (F16, ops.F16X3) and ops.dla_base_fused_ok(Hp, Wp) and len(self.level0) == 3 and len(self.level1) == 3
                 and self.channels[0] == 16 and self.channels[1] == 32 and not self.base_layer[1].training)
 
-    def _packed_base(self):
+    def _packed_base(self, x3=False):
         mods = [self.base_layer[0], self.base_layer[1], self.level0[0], self.level0[1], self.level1[0], self.level1[1]]
         tensors = []
         for conv, bn in zip(mods[0::2], mods[1::2]):
             tensors += [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
         ver = hipnn._versions(*tensors)
-        hit = self.__dict__.get("_ctdet_packed_base")
+        key = "_ctdet_packed_base_x3" if x3 else "_ctdet_packed_base"
+        hit = self.__dict__.get(key)
         if hit is None or hit[0] != ver:
             args = []
             for conv, bn in zip(mods[0::2], mods[1::2]):
                 args += [conv.weight, hipnn.fold_bn(bn)]
-            hit = (ver, ops.PackedDlaBase(*args))
-            self.__dict__["_ctdet_packed_base"] = hit
+            hit = (ver, (ops.PackedDlaBaseX3 if x3 else ops.PackedDlaBase)(*args))
+            self.__dict__[key] = hit
         return hit[1]
 
-    def base_level1(self, images, mean, std, Hp, Wp, out=None, pooled=None):
-        """images: [B,3,H,W] uint8/f32 device batch (not normalised) -> level1 output [B,Hp/2,Wp/2,32] f16 NHWC, computed by
-        the fused base kernel (normalisation, base_layer, level0, level1); level 0 is never materialised.  pooled: optional
-        [B,Hp/4,Wp/4,32] buffer for the 2x2 max-pool of the output (level2's down-sampled input)."""
-        return ops.dla_base_fused(images, mean, std, Hp, Wp, self._packed_base(), out=out, pooled=pooled)
+    def base_level1(self, images, mean, std, Hp, Wp, out=None, pooled=None, x3=False):
+        """images: [B,3,H,W] uint8/f32 device batch (not normalised) -> level1 output [B,Hp/2,Wp/2,32] NHWC (f16; f32 with
+        x3: f16x3 arithmetic), computed by the fused base kernel (normalisation, base_layer, level0, level1); level 0 is never
+        materialised.  pooled: optional [B,Hp/4,Wp/4,32] buffer for the 2x2 max-pool of the output (level2's down-sampled
+        input)."""
+        return ops.dla_base_fused(images, mean, std, Hp, Wp, self._packed_base(x3), out=out, pooled=pooled)
 
     def hip_forward_level1(self, x, ctx, pooled=None):
         """the six level outputs given level1's (level 0 is None); pooled: MaxPool2d(2) of x when already computed"""

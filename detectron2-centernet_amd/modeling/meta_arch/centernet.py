@@ -88,8 +88,8 @@ class _EvalEngine:
         xch = 4 if (model._ctx.dtype == torch.float32 and model.backbone_type == "dla34") else 8
         self.xpad = None if self.fused_base else torch.zeros(B, Hp + 2 * self.border, Wp + 2 * self.border, xch,
                                                              dtype=model._ctx.dtype, device=dev)
-        self.l1 = torch.empty(B, Hp // 2, Wp // 2, 32, dtype=torch.float16, device=dev) if self.fused_base else None
-        self.l1p = torch.empty(B, Hp // 4, Wp // 4, 32, dtype=torch.float16, device=dev) if self.fused_base else None
+        self.l1 = torch.empty(B, Hp // 2, Wp // 2, 32, dtype=model._ctx.dtype, device=dev) if self.fused_base else None
+        self.l1p = torch.empty(B, Hp // 4, Wp // 4, 32, dtype=model._ctx.dtype, device=dev) if self.fused_base else None
         self.graph = None
         self.Hp, self.Wp = Hp, Wp
         if self.fused_base:
@@ -138,7 +138,8 @@ class _EvalEngine:
 
     def _base(self, images):
         m = self.model
-        m.backbone.base.base_level1(images, m._mean_host, m._std_host, self.Hp, self.Wp, out=self.l1, pooled=self.l1p)
+        m.backbone.base.base_level1(images, m._mean_host, m._std_host, self.Hp, self.Wp, out=self.l1, pooled=self.l1p,
+                                    x3=m._ctx.compute == ops.F16X3)
 
     def _run(self):
         m = self.model

@@ -768,6 +768,25 @@ class PackedDlaBase:
         self.b0 = sb_stem[1].detach().float().contiguous()
 
 
+class PackedDlaBaseX3:
+    """operands of ctdet_dla_base_x3_fwd: the three layers as f16x3 PackedConvs (the split tap-major images of
+    ctdet_pack_weights_x3, the stem on 4-channel pixels) -- exactly what the layer-by-layer f16x3 path contracts with."""
+    x3 = True
+
+    def __init__(self, w_stem, sb_stem, w_l0, sb_l0, w_l1, sb_l1):
+        assert tuple(w_stem.shape) == (16, 3, 7, 7) and tuple(w_l0.shape) == (16, 16, 3, 3) and tuple(w_l1.shape) == (32, 16, 3, 3)
+        # stem operand: k = (r*8 + s)*4 + c -- 4-channel pixels, kernel rows padded to 8 taps (a K step = four consecutive
+        # taps of a row); packed as the [16, 224, 1, 1] weight of a 1x1 contraction
+        w4 = torch.zeros(16, 7, 8, 4, dtype=torch.float32, device=w_stem.device)
+        w4[:, :, :7, :3] = w_stem.detach().float().permute(0, 2, 3, 1)
+        self.p0 = PackedConv(w4.reshape(16, 224, 1, 1), sb_stem[0], sb_stem[1], compute=F16X3)
+        self.p1 = PackedConv(w_l0.detach().float().contiguous(), sb_l0[0], sb_l0[1], stride=1, pad=1, compute=F16X3)
+        self.p2 = PackedConv(w_l1.detach().float().contiguous(), sb_l1[0], sb_l1[1], stride=2, pad=1, compute=F16X3)
+        for p, kpad, rows in ((self.p0, 224, 16), (self.p1, 144, 16), (self.p2, 144, 32)):
+            assert p.korder == 0 and p.Kpad == kpad and p.w.shape[0] >= rows and p.w.shape[1] == kpad, (p.korder, p.Kpad, p.w.shape)
+            assert p.scale.numel() >= rows and p.bias.numel() >= rows
+
+
 BASE_FUSED = os.environ.get("CTDET_NO_FUSED_BASE", "0") != "1"
 
 
@@ -776,15 +795,18 @@ def dla_base_fused_ok(Hp, Wp):
 
 
 def dla_base_fused(images, mean, std, Hp, Wp, p, out=None, pooled=None):
-    """images [B,3,H,W] uint8/f32 on device -> level1 output of DLA (f16 NHWC [B,Hp/2,Wp/2,32]) in one launch:
-    normalisation, 7x7 stem, level0, level1 (stride 2), BatchNorm folded, ReLU after each.  pooled: optional f16
-    [B,Hp/4,Wp/4,>=32] buffer that receives MaxPool2d(2) of the output (what level2's Tree starts with)."""
+    """images [B,3,H,W] uint8/f32 on device -> level1 output of DLA (NHWC [B,Hp/2,Wp/2,32]; f16, or f32 when p is a
+    PackedDlaBaseX3: f16x3 arithmetic) in one launch: normalisation, 7x7 stem, level0, level1 (stride 2), BatchNorm folded,
+    ReLU after each.  pooled: optional [B,Hp/4,Wp/4,>=32] buffer of the output's dtype that receives MaxPool2d(2) of the
+    output (what level2's Tree starts with)."""
     _require_cuda(images, out, pooled)
     B, Cc, H, W = images.shape
     assert Cc == 3 and images.stride(3) == 1 and images.stride(2) == W and images.stride(1) == H * W
+    x3 = getattr(p, "x3", False)
+    odt = torch.float32 if x3 else torch.float16
     if out is None:
-        out = torch.empty(B, Hp // 2, Wp // 2, 32, dtype=torch.float16, device=images.device)
-    assert out.dtype == torch.float16 and tuple(out.shape[:3]) == (B, Hp // 2, Wp // 2) and out.shape[3] >= 32
+        out = torch.empty(B, Hp // 2, Wp // 2, 32, dtype=odt, device=images.device)
+    assert out.dtype == odt and tuple(out.shape[:3]) == (B, Hp // 2, Wp // 2) and out.shape[3] >= 32
     d = _lib.DlaBaseDesc()
     d.B, d.H, d.W, d.Hp, d.Wp, d.img_dtype = B, H, W, Hp, Wp, dt_of(images)
     d.img_batch_stride = images.stride(0)
@@ -792,18 +814,24 @@ def dla_base_fused(images, mean, std, Hp, Wp, p, out=None, pooled=None):
         d.mean[i], d.std[i] = float(mean[i]), float(std[i])
     d.out_stride = _nhwc_stride(out)
     if pooled is not None:
-        assert pooled.dtype == torch.float16 and tuple(pooled.shape[:3]) == (B, Hp // 4, Wp // 4) and pooled.shape[3] >= 32
+        assert pooled.dtype == odt and tuple(pooled.shape[:3]) == (B, Hp // 4, Wp // 4) and pooled.shape[3] >= 32
         d.pool_stride = _nhwc_stride(pooled)
     px = B * Hp * Wp
-    prof = _Prof(None, px, False, F16, name="dla_base_fused_kernel<u8|f32 -> 32ch,f16>",
+    prof = _Prof(None, px, False, F16X3 if x3 else F16,
+                 name="dla_base_x3_kernel<u8|f32 -> 32ch,f16x3>" if x3 else "dla_base_fused_kernel<u8|f32 -> 32ch,f16>",
                  flops=2.0 * (px * 16 * 147 + px * 16 * 144 + (px // 4) * 32 * 144))
     for _ in range(prof.reps()):
-        rc = _lib.lib().ctdet_dla_base_fwd(C.byref(d), _ptr(images), _ptr(p.w0), _ptr(p.s0), _ptr(p.b0), _ptr(p.p1.w),
-                                           _ptr(p.p1.scale), _ptr(p.p1.bias), _ptr(p.p2.w), _ptr(p.p2.scale),
-                                           _ptr(p.p2.bias), _ptr(out), _ptr(pooled), _stream())
+        if x3:
+            rc = _lib.lib().ctdet_dla_base_x3_fwd(C.byref(d), _ptr(images), _ptr(p.p0.w), _ptr(p.p0.scale), _ptr(p.p0.bias),
+                                                  _ptr(p.p1.w), _ptr(p.p1.scale), _ptr(p.p1.bias), _ptr(p.p2.w),
+                                                  _ptr(p.p2.scale), _ptr(p.p2.bias), _ptr(out), _ptr(pooled), _stream())
+        else:
+            rc = _lib.lib().ctdet_dla_base_fwd(C.byref(d), _ptr(images), _ptr(p.w0), _ptr(p.s0), _ptr(p.b0), _ptr(p.p1.w),
+                                               _ptr(p.p1.scale), _ptr(p.p1.bias), _ptr(p.p2.w), _ptr(p.p2.scale),
+                                               _ptr(p.p2.bias), _ptr(out), _ptr(pooled), _stream())
     _lib.check(rc, "ctdet_dla_base_fwd")
     if prof.on:
-        prof.bytes = images.numel() * images.element_size() + (px // 4) * 32 * 2
+        prof.bytes = images.numel() * images.element_size() + (px // 4) * 32 * out.element_size() * (1.25 if pooled is not None else 1.0)
         prof.info = f"M={px} 3->16->16->32 fused"
     prof.done()
     return out

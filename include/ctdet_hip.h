@@ -167,6 +167,16 @@ int32_t ctdet_dla_base_fwd(const ctdet_dla_base_desc* d, const void* images, con
                            const float* bias_stem, const void* w_l0, const float* scale_l0, const float* bias_l0,
                            const void* w_l1, const float* scale_l1, const float* bias_l1, void* out, void* pooled,
                            void* stream);
+/* The same three layers (dla.py:204-215 after centernet.py:193-200) in f16x3 arithmetic: f32 tensors, every product as
+ * hi*hi + lo*hi + hi*lo on the f16 matrix pipe with f32 accumulation -- what ctdet_conv2d computes for them one by one in
+ * CTDET_F16X3 mode.  w_*: the layout-0 images of ctdet_pack_weights_x3 (stem: [16][224], k = (r*8 + s)*4 + c with tap column
+ * s = 7 and channel c = 3 zero; level0 [16][144],
+ * level1 [32][144], 16-byte groups {w_hi[4], w_lo[4]}); scale_*: folded BatchNorm scale times the pack's row scale.
+ * out f32 [B,Hp/2,Wp/2,out_stride >= 32], pooled (may be NULL) f32 [B,Hp/4,Wp/4,pool_stride >= 32]. */
+int32_t ctdet_dla_base_x3_fwd(const ctdet_dla_base_desc* d, const void* images, const void* w_stem, const float* scale_stem,
+                              const float* bias_stem, const void* w_l0, const float* scale_l0, const float* bias_l0,
+                              const void* w_l1, const float* scale_l1, const float* bias_l1, float* out, float* pooled,
+                              void* stream);
 
 /* nn.MaxPool2d(2, stride=2) on NHWC (dla.py:128-129). */
 int32_t ctdet_maxpool2x2(const void* x, void* y, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,

@@ -297,6 +297,49 @@ def test_dla_base_fused(ops, dev, case):
     assert (t != y).float().mean().item() < 0.02
 
 
+@pytest.mark.parametrize("case", [("u8_ragged", torch.uint8, 2, 50, 70, 64, 96), ("u8_full", torch.uint8, 3, 64, 64, 64, 64),
+                                  ("f32", torch.float32, 1, 32, 64, 32, 64), ("u8_tall", torch.uint8, 1, 130, 40, 144, 64),
+                                  ("u8_interior", torch.uint8, 2, 128, 160, 128, 160),
+                                  ("u8_interior_ragged", torch.uint8, 1, 121, 150, 128, 160),
+                                  ("f32_interior", torch.float32, 1, 96, 128, 96, 128)])
+def test_dla_base_fused_f16x3(ops, dev, case):
+    """the f16x3 form of the fused base (f32 tensors, hi*hi + lo*hi + hi*lo on the f16 matrix pipe): against torch fp32 on the
+    same f32 weights (f32-grade: 2e-5 of the output range through three layers, tolerance written here) and against the
+    layer-by-layer f16x3 HIP path on the same packed operands (same split points, same products); pooled output == 2x2 max-pool"""
+    name, dt, B, H, W, Hp, Wp = case
+    g = torch.Generator().manual_seed(H + W + 1)
+    img = torch.randint(0, 256, (B, 3, H, W), generator=g).to(dt)
+    mean, std = [103.5 / 255, 116.3 / 255, 123.7 / 255], [0.225, 0.224, 0.229]
+    ws = [torch.randn(16, 3, 7, 7, generator=g) / 147 ** 0.5, torch.randn(16, 16, 3, 3, generator=g) / 12,
+          torch.randn(32, 16, 3, 3, generator=g) / 12]
+    sb = [(torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3) for c in (16, 16, 32)]
+    x = (img.float() / 255 - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    ref = F.pad(x, (0, Wp - W, 0, Hp - H)).double()
+    for w, (sc, bi), (st, pd) in zip(ws, sb, ((1, 3), (1, 1), (2, 1))):
+        ref = (F.conv2d(ref, w.double(), None, st, pd) * sc.double().view(1, -1, 1, 1) + bi.double().view(1, -1, 1, 1)).relu()
+    args = []
+    for w, (sc, bi) in zip(ws, sb):
+        args += [w.to(dev), (sc.to(dev), bi.to(dev))]
+    pb = ops.PackedDlaBaseX3(*args)
+    pooled = torch.empty(B, Hp // 4, Wp // 4, 32, dtype=torch.float32, device=dev)
+    y = ops.dla_base_fused(img.to(dev), mean, std, Hp, Wp, pb, pooled=pooled)
+    assert y.dtype == torch.float32
+    assert torch.equal(pooled, ops.maxpool2x2(y)), f"{name}: fused 2x2 max-pool"
+    assert torch.equal(y, ops.dla_base_fused(img.to(dev), mean, std, Hp, Wp, pb)), f"{name}: with / without the pooled output"
+    got = nchw(y.cpu()).double()
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), f"{name}: max err {err} vs torch fp64"
+    # the layer-by-layer f16x3 path on the same operands
+    t = ops.preprocess(img.to(dev), mean, std, Hp, Wp, out=torch.empty(B, Hp, Wp, 4, dtype=torch.float32, device=dev))
+    p0 = ops.PackedConv(ws[0].to(dev), sb[0][0].to(dev), sb[0][1].to(dev), stride=1, pad=3, compute=ops.F16X3, cin_pad=4)
+    t = ops.conv2d(t, p0, act=ops.ACT_RELU)
+    t = ops.conv2d(t, pb.p1, act=ops.ACT_RELU)
+    t = ops.conv2d(t, pb.p2, act=ops.ACT_RELU)
+    d = (t[..., :32] - y).abs().max().item()
+    assert d <= 1e-5 * max(1.0, ref.abs().max().item()), f"{name}: {d} vs the layer-by-layer path"
+
+
 def test_dla_base_fused_rejects_bad_shapes(ops, dev):
     g = torch.Generator().manual_seed(1)
     args = [torch.randn(16, 3, 7, 7, generator=g).to(dev), (torch.ones(16, device=dev), torch.zeros(16, device=dev)),

@@ -156,7 +156,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     l = _lib.lib()
-    assert l.ctdet_abi_version() == 6
+    assert l.ctdet_abi_version() == 7
     assert [l.ctdet_conv_cout_tile(c) for c in (4, 16, 28, 64, 80, 128, 768)] == [16, 16, 32, 64, 128, 128, 128]
     assert l.ctdet_decode_workspace_bytes(2, 128, 128, 80, 100) == 2 * l.ctdet_decode_workspace_bytes(1, 128, 128, 80, 100)
     # argument validation happens before any device work: a null descriptor is rejected with a message
