@@ -275,8 +275,9 @@ def test_two_rank_bench_training_graph_equals_hooks_path():
                               "--no-cpu-baseline", "--no-f32", "--no-f16", "--no-roofline"],
                              env=dict(base, CTDET_TRAIN_GRAPH=mode), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert out.returncode == 0, out.stderr.decode()[-2000:]
-        rec = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][-1])["train"]
-        assert rec["n_gpus"] == 2 and rec["config"]["graph_state"] == ("captured" if mode == "1" else "eager"), rec["config"]
+        line = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][-1])
+        rec = line["train"]
+        assert line["n_gpus"] == 2 and rec["config"]["graph_state"] == ("captured" if mode == "1" else "eager"), rec["config"]
         finals[mode] = rec["config"]["final_losses"]
     for k, v in finals["hooks"].items():
         assert abs(finals["1"][k] - v) <= 1e-4 * abs(v), finals
