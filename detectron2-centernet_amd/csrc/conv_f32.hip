@@ -748,7 +748,9 @@ __global__ void __launch_bounds__(256, 2) dcn_f32_window_kernel(const ConvArgs a
 // Same tile (8x16 pixels x 64 couts), window (18x26 pixels, 16-channel chunks of f32), ring (a stage = the three taps of a
 // kernel row) and barriers as dcn_f32_window_kernel.
 // ------------------------------------------------------------------------------------------
-template <int TP, int BC>
+// COLS: the instantiation that also writes the sampled columns (training forward); a template parameter so that the inference
+// kernel's register allocation does not carry the pointer and index (with it the <2,64> form spilled 14 registers: +8 % time)
+template <int TP, int BC, bool COLS = false>
 __global__ void __launch_bounds__(512 / TP, 2) dcn_split_window_kernel(const ConvArgs a) {
   constexpr int TH = 8, TW = 16, BP = 128, MG = 4;
   constexpr int NT = 512 / TP;                                  // TP = 2: 4 waves of 32 pixels, TP = 1: 8 waves of 16
@@ -903,7 +905,7 @@ __global__ void __launch_bounds__(512 / TP, 2) dcn_split_window_kernel(const Con
   // training: the sampled value of (pixel, tap t, channels chunk*16 + 4q..) is also the backward pass's `columns` entry --
   // stored from here (the cout tile 0 workgroup of the pixel tile) it costs a 16-byte store per blend and saves the separate
   // sampling pass over the layer (ctdet_dcn_cols) in the backward
-  float* const colp = (a.cols_out && n0 == 0) ? a.cols_out + q * 4 : nullptr;
+  float* const colp = (COLS && n0 == 0) ? a.cols_out + q * 4 : nullptr;
   auto blend = [&](const Raw& r, f16x8 (&b1)[TP], f16x8 (&b2)[TP], int t, int chunk) {
 #pragma unroll
     for (int p = 0; p < TP; ++p) {
@@ -911,9 +913,11 @@ __global__ void __launch_bounds__(512 / TP, 2) dcn_split_window_kernel(const Con
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         val[e] = r.w[p][0] * r.v[p][0][e] + r.w[p][1] * r.v[p][1][e] + r.w[p][2] * r.v[p][2][e] + r.w[p][3] * r.v[p][3][e];
-      if (colp) {
-        const long m = (long)(b * a.H + ty0 + prow) * a.W + tx0 + (TP == 2 ? 8 * p : 0) + pcol;
-        *(f32x4*)(colp + m * (9L * a.Cin) + t * a.Cin + chunk * 16) = val;
+      if constexpr (COLS) {
+        if (colp) {
+          const long m = (long)(b * a.H + ty0 + prow) * a.W + tx0 + (TP == 2 ? 8 * p : 0) + pcol;
+          *(f32x4*)(colp + m * (9L * a.Cin) + t * a.Cin + chunk * 16) = val;
+        }
       }
       split_b(val, b1[p], b2[p]);
     }
@@ -1310,9 +1314,11 @@ static int launch_conv_f32_t(const ConvArgs& a, bool deform, hipStream_t s) {
         // eight waves per CU with half the gathers per MFMA (CTDET_TUNE_DCN_SPLIT_4W: 64-cout tiles everywhere)
         if (a.Cout_pad % 128 == 0 && !(ctdet_tuning_flags() & CTDET_TUNE_DCN_SPLIT_4W)) {
           dim3 grid128(8 * ((nbx + 7) / 8) * (a.Cout_pad / 128));
-          hipLaunchKernelGGL((dcn_split_window_kernel<1, 128>), grid128, dim3(512), 0, s, a);
+          if (a.cols_out) hipLaunchKernelGGL((dcn_split_window_kernel<1, 128, true>), grid128, dim3(512), 0, s, a);
+          else hipLaunchKernelGGL((dcn_split_window_kernel<1, 128>), grid128, dim3(512), 0, s, a);
         } else {
-          hipLaunchKernelGGL((dcn_split_window_kernel<2, 64>), grid, dim3(256), 0, s, a);
+          if (a.cols_out) hipLaunchKernelGGL((dcn_split_window_kernel<2, 64, true>), grid, dim3(256), 0, s, a);
+          else hipLaunchKernelGGL((dcn_split_window_kernel<2, 64>), grid, dim3(256), 0, s, a);
         }
       }
       else
