@@ -751,10 +751,10 @@ __global__ void __launch_bounds__(256, 2) dcn_f32_window_kernel(const ConvArgs a
 // COLS: the instantiation that also writes the sampled columns (training forward); a template parameter so that the inference
 // kernel's register allocation does not carry the pointer and index (with it the <2,64> form spilled 14 registers: +8 % time)
 template <int TP, int BC, bool COLS = false>
-__global__ void __launch_bounds__(512 / TP, 2) dcn_split_window_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(512 / TP, (TP == 1 && BC == 64) ? 4 : 2) dcn_split_window_kernel(const ConvArgs a) {
   constexpr int TH = 8, TW = 16, BP = 128, MG = 4;
   constexpr int NT = 512 / TP;                                  // TP = 2: 4 waves of 32 pixels, TP = 1: 8 waves of 16
-  static_assert(BC * 4 == NT, "one weight piece per thread and tap");
+  static_assert(BC * 4 <= NT, "at most one weight piece per thread and tap (waves beyond BC / 16 fetch none)");
   constexpr int WR = TH + 2 + 2 * MG, WCOLS = TW + 2 + 2 * MG;  // 18 x 26 window pixels
   constexpr int NPIECE = WR * WCOLS * 4;                        // 1872 16-byte pieces
   constexpr int W_LD = (NPIECE + NT - 1) / NT;                  // DMA rounds; the last one ends with the window
@@ -762,7 +762,7 @@ __global__ void __launch_bounds__(512 / TP, 2) dcn_split_window_kernel(const Con
   constexpr int GEOW = 9 * BP * 16, GEOC = 9 * BP * 4;          // {w1 m, w2 m, w3 m, w4 m} and the window code per (tap, pixel)
   constexpr int TC = BC / 16;                                   // wave = 16 * TP pixels x all BC couts
   constexpr int WST = BC * 64, NST = 2, STG = 3 * WST;          // a stage = the three taps of a kernel row
-  static_assert(WINB + GEOW + GEOC + NST * STG <= (TP == 2 ? 81920 : 163840), "two workgroups (TP = 2) / one (TP = 1) per CU");
+  static_assert(WINB + GEOW + GEOC + NST * STG <= ((TP == 2 || BC == 64) ? 81920 : 163840), "two workgroups / one (128 couts) per CU");
   __shared__ __attribute__((aligned(16))) char smem[WINB + GEOW + GEOC + NST * STG];
   char* const win = smem;
   char* const geow = smem + WINB;
@@ -793,6 +793,7 @@ __global__ void __launch_bounds__(512 / TP, 2) dcn_split_window_kernel(const Con
     wptr = (const float*)a.w + (long)(n0 + cout_of<TC>(tt, r >> 2, r & 3)) * a.Kpad + gwk * 4;
   }
   auto issue_w = [&](int chunk, int tr, int st) {      // step (chunk, kernel row tr): 3 taps x 16 channels of every cout
+    if (BC * 4 < NT && wave >= BC / 16) return;        // (eight waves on a 64-cout tile: the first four carry the weights)
 #pragma unroll
     for (int ts = 0; ts < 3; ++ts)
       dma16(wptr + (tr * 3 + ts) * a.Cin + chunk * 16, ring + st * STG + ts * WST + wave * 1024);
@@ -1318,6 +1319,8 @@ static int launch_conv_f32_t(const ConvArgs& a, bool deform, hipStream_t s) {
           else hipLaunchKernelGGL((dcn_split_window_kernel<1, 128>), grid128, dim3(512), 0, s, a);
         } else {
           if (a.cols_out) hipLaunchKernelGGL((dcn_split_window_kernel<2, 64, true>), grid, dim3(256), 0, s, a);
+          else if (ctdet_tuning_flags() & CTDET_TUNE_DCN_SPLIT_8W64)
+            hipLaunchKernelGGL((dcn_split_window_kernel<1, 64>), grid, dim3(512), 0, s, a);
           else hipLaunchKernelGGL((dcn_split_window_kernel<2, 64>), grid, dim3(256), 0, s, a);
         }
       }
