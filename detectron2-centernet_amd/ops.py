@@ -672,10 +672,12 @@ def dcnv2(x, offset_mask, p, out=None, act=ACT_NONE, out_dtype=None, mask_is_pro
     assert tuple(offset_mask.shape[:3]) == tuple(out.shape[:3])
     p._wp_scaled = None          # a deformable conv's weights: no pair image will be needed
     d = p.desc(x, out, act, None)
-    prof = _Prof(p, d.B * d.Ho * d.Wo, True, d.out_dtype, x.shape)
     cols = None
     if want_cols and p.compute == F16X3 and _lib.lib().ctdet_dcnv2_cols_supported(C.byref(d), _ptr(x), _ptr(out)):
         cols = torch.empty(x.shape[0], x.shape[1], x.shape[2], 9 * p.Cin, dtype=torch.float32, device=x.device)
+    prof = _Prof(p, d.B * d.Ho * d.Wo, True, d.out_dtype, x.shape)     # (after the allocation: a 600 MB hipMalloc is not kernel time)
+    if prof.on and cols is not None:
+        prof.bytes += cols.numel() * 4
     for _ in range(prof.reps()):
         if cols is not None:
             rc = _lib.lib().ctdet_dcnv2_fwd_cols(C.byref(d), _ptr(x), _ptr(offset_mask), _nhwc_stride(offset_mask), int(mask_is_prob),
