@@ -71,6 +71,9 @@ int launch_bn_train_fwd_f32(const float*, int, const float*, int, float*, int, i
 int launch_bn_train_bwd_f32(const float*, int, const float*, int, const float*, int, const float*, const float*, const float*,
                             int, int, int, float*, int, float*, int, float*, float*, float, void*, hipStream_t);
 int launch_maxpool2x2_bwd_f32(const float*, int, const float*, int, float*, int, int, int, int, int, hipStream_t);
+int launch_maxpool3x3s2_bwd(const void*, int, const void*, int, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
+int launch_ese_dot(const void*, int, const void*, int, int, int, int, int, float*, hipStream_t);
+int launch_ese_bwd(const void*, int, const float*, const float*, void*, int, int, int, int, int, hipStream_t);
 int launch_dwconvT_bwd_f32(const float*, int, const float*, int, const float*, float*, int, float*, int, int, int, int, int,
                            hipStream_t);
 int launch_dcn_cols_f32(const float*, int, const float*, int, float*, int, int, int, int, int, hipStream_t);
@@ -539,6 +542,34 @@ int32_t ctdet_depth_to_space2(const void* src, int32_t src_stride, void* dst, in
   CTDET_CHECK(src && dst, "depth_to_space2: null pointer");
   CTDET_CHECK(dtype == CTDET_DT_F16 || dtype == CTDET_DT_F32, "depth_to_space2: bad dtype %d", dtype);
   return launch_depth_to_space2(src, src_stride, dst, dst_stride, B, H, W, C, Hs, Ws, dtype, (hipStream_t)stream);
+}
+
+int32_t ctdet_maxpool3x3s2_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, void* dx, int32_t dx_stride,
+                               int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ceil_nopad, void* stream) {
+  CTDET_CHECK(x && dz && dx, "maxpool3x3s2_bwd: null pointer");
+  int Ho, Wo, pad;
+  if (ceil_nopad) {
+    pad = 0;
+    Ho = (H - 3 + 1) / 2 + 1; Wo = (W - 3 + 1) / 2 + 1;
+    if ((Ho - 1) * 2 >= H) --Ho;
+    if ((Wo - 1) * 2 >= W) --Wo;
+  } else {
+    pad = 1;
+    Ho = (H - 1) / 2 + 1; Wo = (W - 1) / 2 + 1;
+  }
+  return launch_maxpool3x3s2_bwd(x, x_stride, dz, dz_stride, dx, dx_stride, dtype, B, H, W, C, pad, Ho, Wo, (hipStream_t)stream);
+}
+
+int32_t ctdet_ese_dot(const void* dy, int32_t dy_stride, const void* x, int32_t x_stride, int32_t dtype, int32_t B, int32_t HW,
+                      int32_t C, float* out, void* stream) {
+  CTDET_CHECK(dy && x && out, "ese_dot: null pointer");
+  return launch_ese_dot(dy, dy_stride, x, x_stride, dtype, B, HW, C, out, (hipStream_t)stream);
+}
+
+int32_t ctdet_ese_bwd(const void* dy, int32_t dy_stride, const float* gate, const float* pooled_grad, void* dx, int32_t dx_stride,
+                      int32_t dtype, int32_t B, int32_t HW, int32_t C, void* stream) {
+  CTDET_CHECK(dy && gate && pooled_grad && dx, "ese_bwd: null pointer");
+  return launch_ese_bwd(dy, dy_stride, gate, pooled_grad, dx, dx_stride, dtype, B, HW, C, (hipStream_t)stream);
 }
 
 int32_t ctdet_maxpool2x2_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, void* dx,

@@ -591,6 +591,142 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// VoVNet pieces of the training step (round 4; the forward kernels are the eval path's, pointwise.hip).
+// MaxPool2d(3, stride 2) backward, pad 1 (BasicStem) or pad 0 + ceil_mode (the VoVNet stage pooling, vovnet.py:291-292): windows
+// overlap, so the kernel GATHERS -- one thread per input element vector, which looks at the (up to four) windows that contain
+// it, re-derives each window's first maximum in (dy, dx) scan order (PyTorch's argmax rule: strict >) and takes that window's
+// gradient if the maximum is this element.  No atomics, deterministic.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool3x3s2_bwd_kernel(const T* __restrict__ x, int x_stride, const T* __restrict__ dz,
+                                                               int dz_stride, T* __restrict__ dx, int dx_stride, int B, int H, int W,
+                                                               int C, int pad, int Ho, int Wo) {
+  typedef typename VecT<T>::type V;
+  constexpr int N = VecT<T>::N;
+  const int CV = C / N;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * H * W * CV) return;
+  const int cv = (int)(idx % CV);
+  long t = idx / CV;
+  const int xi = (int)(t % W); t /= W;
+  const int yi = (int)(t % H);
+  const int b = (int)(t / H);
+  const V self = *(const V*)(x + ((long)(b * H + yi) * W + xi) * x_stride + cv * N);
+  float g[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) g[e] = 0.f;
+  // window (ho, wo) covers rows 2 ho - pad .. 2 ho - pad + 2
+  const int ho_lo = (yi + pad - 2 + 1) >> 1 > 0 ? (yi + pad - 2 + 1) >> 1 : 0, ho_hi = (yi + pad) >> 1 < Ho - 1 ? (yi + pad) >> 1 : Ho - 1;
+  const int wo_lo = (xi + pad - 2 + 1) >> 1 > 0 ? (xi + pad - 2 + 1) >> 1 : 0, wo_hi = (xi + pad) >> 1 < Wo - 1 ? (xi + pad) >> 1 : Wo - 1;
+  for (int ho = ho_lo; ho <= ho_hi; ++ho)
+    for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+      float m[N];
+      int arg[N];
+#pragma unroll
+      for (int e = 0; e < N; ++e) { m[e] = -INFINITY; arg[e] = -1; }
+      for (int dy = 0; dy < 3; ++dy) {
+        const int yy = 2 * ho - pad + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dxx = 0; dxx < 3; ++dxx) {
+          const int xx = 2 * wo - pad + dxx;
+          if (xx < 0 || xx >= W) continue;
+          const V v = *(const V*)(x + ((long)(b * H + yy) * W + xx) * x_stride + cv * N);
+#pragma unroll
+          for (int e = 0; e < N; ++e)
+            if ((float)v[e] > m[e] || arg[e] < 0) { m[e] = (float)v[e]; arg[e] = yy * W + xx; }
+        }
+      }
+      const V gz = *(const V*)(dz + ((long)(b * Ho + ho) * Wo + wo) * dz_stride + cv * N);
+#pragma unroll
+      for (int e = 0; e < N; ++e)
+        if (arg[e] == yi * W + xi) g[e] += (float)gz[e];
+    }
+  (void)self;
+  V o;
+#pragma unroll
+  for (int e = 0; e < N; ++e) o[e] = (T)g[e];
+  *(V*)(dx + ((long)(b * H + yi) * W + xi) * dx_stride + cv * N) = o;
+}
+
+template <typename T>
+static int launch_maxpool3x3s2_bwd_t(const void* x, int xs, const void* dz, int dzs, void* dx, int dxs, int B, int H, int W, int C,
+                                     int pad, int Ho, int Wo, hipStream_t s) {
+  constexpr int N = VecT<T>::N;
+  CTDET_CHECK(C % N == 0 && xs % N == 0 && dzs % N == 0 && dxs % N == 0, "maxpool3x3s2_bwd: channels / strides must be multiples of %d", N);
+  const long total = (long)B * H * W * (C / N);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL((maxpool3x3s2_bwd_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)x, xs, (const T*)dz,
+                     dzs, (T*)dx, dxs, B, H, W, C, pad, Ho, Wo);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+int launch_maxpool3x3s2_bwd(const void* x, int xs, const void* dz, int dzs, void* dx, int dxs, int dtype, int B, int H, int W, int C,
+                            int pad, int Ho, int Wo, hipStream_t s) {
+  if (dtype == CTDET_F16) return launch_maxpool3x3s2_bwd_t<f16>(x, xs, dz, dzs, dx, dxs, B, H, W, C, pad, Ho, Wo, s);
+  if (dtype == CTDET_F32) return launch_maxpool3x3s2_bwd_t<float>(x, xs, dz, dzs, dx, dxs, B, H, W, C, pad, Ho, Wo, s);
+  CTDET_CHECK(false, "maxpool3x3s2_bwd: bad dtype %d", dtype);
+  return 0;
+}
+
+// eSE attention backward (vovnet.py:200-213; forward: y = x * hsigmoid(s[b][c]) (+ identity), s = fc(mean over pixels of x)):
+//   ese_dot_kernel    r[b][c] = sum over the pixels of dy * x          (the gradient reaching hsigmoid(s), before its slope)
+//   ese_bwd_kernel    dx = dy * g[b][c] + gp[b][c]                      (g = hsigmoid(s); gp = d(mean) / HW, the pooled path)
+// The B x C numbers in between (hsigmoid's slope, the fc layer's three gradients) are a handful of tiny device-side torch ops.
+template <typename T>
+__global__ void __launch_bounds__(256) ese_dot_kernel(const T* __restrict__ dy, int dy_stride, const T* __restrict__ x, int x_stride,
+                                                      int HW, int C, float* __restrict__ out) {
+  __shared__ float red[256];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < C)
+    for (int p = pl; p < HW; p += 4) acc += (float)dy[((long)b * HW + p) * dy_stride + c] * (float)x[((long)b * HW + p) * x_stride + c];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (pl == 0 && c < C)
+    out[(long)b * C + c] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) ese_bwd_kernel(const T* __restrict__ dy, int dy_stride, const float* __restrict__ g,
+                                                      const float* __restrict__ gp, T* __restrict__ dx, int dx_stride, int B, int HW,
+                                                      int C) {
+  typedef typename VecT<T>::type V;
+  constexpr int N = VecT<T>::N;
+  const int CV = C / N;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * HW * CV) return;
+  const int cv = (int)(idx % CV);
+  const long m = idx / CV;
+  const int b = (int)(m / HW);
+  const V v = *(const V*)(dy + m * dy_stride + cv * N);
+  V r;
+#pragma unroll
+  for (int e = 0; e < N; ++e) r[e] = (T)((float)v[e] * g[(long)b * C + cv * N + e] + gp[(long)b * C + cv * N + e]);
+  *(V*)(dx + m * dx_stride + cv * N) = r;
+}
+int launch_ese_dot(const void* dy, int dys, const void* x, int xs, int dtype, int B, int HW, int C, float* out, hipStream_t s) {
+  if ((long)B * HW * C == 0) return 0;
+  const dim3 grid((C + 63) / 64, B);
+  if (dtype == CTDET_F16) hipLaunchKernelGGL((ese_dot_kernel<f16>), grid, dim3(256), 0, s, (const f16*)dy, dys, (const f16*)x, xs, HW, C, out);
+  else if (dtype == CTDET_F32) hipLaunchKernelGGL((ese_dot_kernel<float>), grid, dim3(256), 0, s, (const float*)dy, dys, (const float*)x, xs, HW, C, out);
+  else CTDET_CHECK(false, "ese_dot: bad dtype %d", dtype);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+int launch_ese_bwd(const void* dy, int dys, const float* g, const float* gp, void* dx, int dxs, int dtype, int B, int HW, int C,
+                   hipStream_t s) {
+  const int N = dtype == CTDET_F16 ? 8 : 4;
+  CTDET_CHECK(C % N == 0 && dys % N == 0 && dxs % N == 0, "ese_bwd: channels / strides must be multiples of %d", N);
+  const long total = (long)B * HW * (C / N);
+  if (total == 0) return 0;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == CTDET_F16) hipLaunchKernelGGL((ese_bwd_kernel<f16>), grid, dim3(256), 0, s, (const f16*)dy, dys, g, gp, (f16*)dx, dxs, B, HW, C);
+  else if (dtype == CTDET_F32) hipLaunchKernelGGL((ese_bwd_kernel<float>), grid, dim3(256), 0, s, (const float*)dy, dys, g, gp, (float*)dx, dxs, B, HW, C);
+  else CTDET_CHECK(false, "ese_bwd: bad dtype %d", dtype);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // MaxPool2d(2,2) backward: the gradient goes to the first maximum in (dy,dx) scan order (PyTorch's argmax rule)
 // ------------------------------------------------------------------------------------------------
 template <typename T>

@@ -13,8 +13,8 @@ import torch
 
 from .. import ops
 from ..layers import hipnn
-from ..ops_train import (BNActFn, ConvFn, ConvTransposeFn, DeformConvFn, DwConvTAddFn, FocalLossFn, FrozenConvFn, MaxPoolFn,
-                         RegL1Fn)
+from ..ops_train import (BNActFn, ConvFn, ConvTransposeFn, DeformConvFn, DwConvTAddFn, EseFn, FocalLossFn, FrozenConvFn,
+                         MaxPool3x3s2Fn, MaxPoolFn, RegL1Fn)
 
 
 _COUNTERS = []
@@ -184,15 +184,9 @@ class _ParamOfTorchOp(torch.autograd.Function):
 
 
 def _ese(m, x, identity):
-    """eSEModule (vovnet.py:200-213) in training: x * hsigmoid(fc(avgpool(x))) (+ identity of the later blocks of a stage).
-    B x C numbers through a C x C matrix: device-side torch ops with their own autograd (the eval path has fused kernels)"""
-    Cc = m.fc.weight.shape[0]
-    # (multiply + reduce instead of F.linear: no BLAS call, hence no BLAS workspace, inside a HIP-graph capture of the step)
-    pooled = x.float().mean(dim=(1, 2))
-    s = (pooled[:, None, :] * _ParamOfTorchOp.apply(m.fc.weight).view(1, Cc, Cc)).sum(dim=2) + _ParamOfTorchOp.apply(m.fc.bias)
-    s = torch.nn.functional.relu6(s + 3.0) / 6.0
-    y = x * s.to(x.dtype)[:, None, None, :]
-    return y + identity if identity is not None else y
+    """eSEModule (vovnet.py:200-213) in training: x * hsigmoid(fc(avgpool(x))) (+ identity of the later blocks of a stage) --
+    ops_train.EseFn: the passes over the map are HIP kernels in both directions"""
+    return EseFn.apply(x, m.fc.weight, m.fc.bias, identity)
 
 
 def vovnet_osa(m, x):
@@ -207,8 +201,7 @@ def vovnet_osa(m, x):
 
 def vovnet_features(backbone, x, ctx, want="stage4"):
     """stem + stages up to `want` (vovnet.py:397-407).  Frozen parts (MODEL.BACKBONE.FREEZE_AT, vovnet.py:384-395) run on the
-    inference kernels without a tape, the others as autograd nodes; the stage pooling MaxPool2d(3, 2, ceil_mode=True) of a
-    trainable stage is torch's (its backward is needed; the eval path has its own kernel)."""
+    inference kernels without a tape, the others as autograd nodes (stage pooling: ops_train.MaxPool3x3s2Fn)."""
     from ..modeling.backbone.vovnet import _run_seq
     frozen = lambda mod: not any(p.requires_grad for p in mod.parameters())
     if not frozen(backbone.stem):
@@ -223,7 +216,7 @@ def vovnet_features(backbone, x, ctx, want="stage4"):
         else:
             for m in stage.children():
                 if isinstance(m, torch.nn.MaxPool2d):
-                    x = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, ceil_mode=True).permute(0, 2, 3, 1).contiguous()
+                    x = MaxPool3x3s2Fn.apply(x, True)
                 else:
                     x = vovnet_osa(m, x)
         if name == want:

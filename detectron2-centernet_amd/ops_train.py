@@ -653,6 +653,73 @@ class MaxPoolFn(torch.autograd.Function):
         return maxpool2x2_bwd(x, dz.contiguous())
 
 
+def maxpool3x3s2_bwd(x, dz, ceil_nopad):
+    B, H, W, Cc = x.shape
+    dx = torch.empty(B, H, W, Cc, dtype=x.dtype, device=x.device)
+    rc = _lib.lib().ctdet_maxpool3x3s2_bwd(_ptr(x), _nhwc_stride(x), _ptr(dz), _nhwc_stride(dz), _ptr(dx), _nhwc_stride(dx),
+                                           dt_of(x), B, H, W, Cc, int(ceil_nopad), _stream())
+    _lib.check(rc, "ctdet_maxpool3x3s2_bwd")
+    return dx
+
+
+class MaxPool3x3s2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, ceil_mode=True) (VoVNet stage pooling, vovnet.py:291-292; ceil=True) or F.max_pool2d(x, 3, 2, 1)
+    (BasicStem; ceil=False) with its autograd, NHWC, both directions on HIP kernels"""
+
+    @staticmethod
+    def forward(ctx, x, ceil):
+        ctx.ceil = bool(ceil)
+        ctx.save_for_backward(x)
+        return ops.maxpool3x3s2_ceil(x) if ceil else ops.maxpool3x3s2(x)
+
+    @staticmethod
+    def backward(ctx, dz):
+        (x,) = ctx.saved_tensors
+        return maxpool3x3s2_bwd(x, dz.contiguous(), ctx.ceil), None
+
+
+class EseFn(torch.autograd.Function):
+    """eSEModule (vovnet.py:200-213): y = x * hsigmoid(fc(mean over pixels of x)) (+ identity).  The two passes over the map in
+    each direction are HIP kernels (ctdet_global_avgpool / ctdet_ese_scale forward, ctdet_ese_dot / ctdet_ese_bwd backward); the
+    B x C numbers in between -- the C x C fc layer, hsigmoid and its slope -- are device-side torch ops (multiply + reduce, no
+    BLAS call: the step is captured as a HIP graph).  The fc layer's gradients go straight into the optimizer's flat buffer."""
+
+    @staticmethod
+    def forward(ctx, x, fc_w, fc_b, identity):
+        Cc = fc_w.shape[0]
+        pooled = ops.global_avgpool(x)                                               # f32 [B, C]
+        w2 = fc_w.detach().view(Cc, Cc).float()
+        s = (pooled[:, None, :] * w2[None]).sum(dim=2) + fc_b.detach().float()
+        ctx.params = (fc_w, fc_b)
+        ctx.has_identity = identity is not None
+        ctx.save_for_backward(x, pooled, s, w2)
+        return ops.ese_scale(x, s, identity)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pooled, s, w2 = ctx.saved_tensors
+        fc_w, fc_b = ctx.params
+        dy = dy.contiguous()
+        B, H, W, Cc = x.shape
+        r = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+        rc = _lib.lib().ctdet_ese_dot(_ptr(dy), _nhwc_stride(dy), _ptr(x), _nhwc_stride(x), dt_of(x), B, H * W, Cc, _ptr(r), _stream())
+        _lib.check(rc, "ctdet_ese_dot")
+        gate = torch.clamp(s + 3.0, 0.0, 6.0) / 6.0
+        gs = r * ((s > -3.0) & (s < 3.0)).float() / 6.0                              # through relu6(s + 3) / 6
+        gw = (gs[:, :, None] * pooled[:, None, :]).sum(dim=0)                        # [C_out, C_in]
+        gb = gs.sum(dim=0)
+        gp = ((gs[:, :, None] * w2[None]).sum(dim=1) / float(H * W)).contiguous()    # d(mean) spread over the pixels
+        dx = torch.empty_like(x)
+        rc = _lib.lib().ctdet_ese_bwd(_ptr(dy), _nhwc_stride(dy), _ptr(gate.contiguous()), _ptr(gp), _ptr(dx), _nhwc_stride(dx),
+                                      dt_of(x), B, H * W, Cc, _stream())
+        _lib.check(rc, "ctdet_ese_bwd")
+        gw = (gw * PARAM_GRAD_MULT).view_as(fc_w)
+        gb = gb * PARAM_GRAD_MULT
+        gw = None if grad_into_slot(fc_w, gw) else gw
+        gb = None if grad_into_slot(fc_b, gb) else gb
+        return dx, gw, gb, (dy if ctx.has_identity else None)
+
+
 class DwConvTAddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, skip, f):

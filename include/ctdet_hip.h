@@ -354,6 +354,18 @@ int32_t ctdet_grad_scatter_oihw(const void* const* src, void* const* dst, const 
  * over dY (ops_train.conv_dgrad), dst the [B,H,W,C] gradient (C % 8 == 0). */
 int32_t ctdet_depth_to_space2(const void* src, int32_t src_stride, void* dst, int32_t dst_stride, int32_t B, int32_t H,
                               int32_t W, int32_t C, int32_t Hs, int32_t Ws, int32_t dtype, void* stream);
+/* Training pieces of the VoVNet backbone (ABI 7).  ctdet_maxpool3x3s2_bwd: autograd of F.max_pool2d(x, 3, 2, 1)
+ * (ceil_nopad = 0; resnet.py:341-345) / nn.MaxPool2d(3, 2, ceil_mode=True) (ceil_nopad = 1; vovnet.py:291-292): the gradient of a
+ * window goes to its first maximum in scan order (PyTorch's rule), gathered per input element (no atomics).
+ * eSE attention (vovnet.py:200-213), y = x * hsigmoid(s[b][c]) (+ identity): ctdet_ese_dot: out f32 [B][C] = sum over the pixels
+ * of dy * x (the gradient reaching hsigmoid(s) before its slope); ctdet_ese_bwd: dx = dy * gate[b][c] + pooled_grad[b][c]
+ * (gate = hsigmoid(s); pooled_grad = d(mean) / HW, the gradient that comes back through the fc layer and the average pool). */
+int32_t ctdet_maxpool3x3s2_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, void* dx, int32_t dx_stride,
+                               int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ceil_nopad, void* stream);
+int32_t ctdet_ese_dot(const void* dy, int32_t dy_stride, const void* x, int32_t x_stride, int32_t dtype, int32_t B, int32_t HW,
+                      int32_t C, float* out, void* stream);
+int32_t ctdet_ese_bwd(const void* dy, int32_t dy_stride, const float* gate, const float* pooled_grad, void* dx, int32_t dx_stride,
+                      int32_t dtype, int32_t B, int32_t HW, int32_t C, void* stream);
 int32_t ctdet_maxpool2x2_bwd(const void* x, int32_t x_stride, const void* dz, int32_t dz_stride, void* dx,
                              int32_t dx_stride, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 /* depthwise ConvTranspose2d backward: dx f16, dw f32 [2f][2f][C] (+=, zeroed by the caller); w as in the forward */

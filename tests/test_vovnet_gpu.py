@@ -75,6 +75,53 @@ def test_vovnet_pool_and_ese_kernels(dev, tdt):
     assert (nchw(out.float().cpu()) - (ref + idn)).abs().max() <= tol * (ref + idn).abs().max()
 
 
+@pytest.mark.parametrize("tdt", [torch.float16, torch.float32])
+def test_vovnet_pool_and_ese_backward(dev, tdt):
+    """the training-side nodes of the VoVNet pieces (round 4: both directions on HIP kernels): MaxPool2d(3, 2, ceil_mode=True)
+    and F.max_pool2d(x, 3, 2, 1) backward against torch's (ties included: the map is quantised so that windows hold equal
+    maxima and the first one in scan order must take the gradient), eSE forward + backward against torch autograd of
+    x * hsigmoid(fc(mean(x))) + identity, gradients of x, identity, fc.weight and fc.bias"""
+    from detectron2_centernet_amd import ops_train
+    g = torch.Generator().manual_seed(5)
+    for ceil in (True, False):
+        for H, W in ((17, 25), (16, 24), (5, 7), (3, 3)):
+            x = (torch.randn(2, 16, H, W, generator=g) * 2).round().div(2)      # many ties
+            xr = x.clone().requires_grad_(True)
+            ref = F.max_pool2d(xr, 3, 2, ceil_mode=True) if ceil else F.max_pool2d(xr, 3, 2, 1)
+            dz = torch.randn(ref.shape, generator=g).half().float()
+            ref.backward(dz)
+            xh = nhwc(x).to(tdt).to(dev).requires_grad_(True)
+            y = ops_train.MaxPool3x3s2Fn.apply(xh, ceil)
+            assert torch.equal(nchw(y.detach().float().cpu()), ref.detach()), (ceil, H, W)
+            y.backward(nhwc(dz).to(tdt).to(dev))
+            got = nchw(xh.grad.float().cpu())
+            assert torch.allclose(got, xr.grad, atol=2e-3 if tdt == torch.float16 else 1e-6), (ceil, H, W, (got - xr.grad).abs().max())
+    B, Cc, H, W = 3, 80, 9, 13
+    x = torch.randn(B, Cc, H, W, generator=g).half().float()
+    idn = torch.randn(B, Cc, H, W, generator=g).half().float()
+    fw = (torch.randn(Cc, Cc, 1, 1, generator=g) * 0.5)
+    fb = torch.randn(Cc, generator=g)
+    dy = torch.randn(B, Cc, H, W, generator=g).half().float()
+    for with_id in (False, True):
+        xr, ir, wr, br = (t.clone().requires_grad_(True) for t in (x, idn, fw, fb))
+        s = F.conv2d(xr.mean((2, 3), keepdim=True), wr, br)
+        ref = xr * (F.relu6(s + 3) / 6) + (ir if with_id else 0)
+        ref.backward(dy)
+        xh, ih = (nhwc(t).to(tdt).to(dev).requires_grad_(True) for t in (x, idn))
+        wh, bh = fw.to(dev).requires_grad_(True), fb.to(dev).requires_grad_(True)
+        mult = ops_train.PARAM_GRAD_MULT
+        y = ops_train.EseFn.apply(xh, wh, bh, ih if with_id else None)
+        tol = 3e-3 if tdt == torch.float16 else 2e-6
+        assert (nchw(y.detach().float().cpu()) - ref.detach()).abs().max() <= tol * ref.abs().max()
+        y.backward(nhwc(dy).to(tdt).to(dev))
+        assert (nchw(xh.grad.float().cpu()) - xr.grad).abs().max() <= tol * xr.grad.abs().max(), with_id
+        if with_id:
+            assert torch.equal(nchw(ih.grad.float().cpu()), dy)
+        gtol = 2e-2 if tdt == torch.float16 else 1e-5
+        assert (wh.grad.cpu() / mult - wr.grad).abs().max() <= gtol * wr.grad.abs().max()
+        assert (bh.grad.cpu() / mult - br.grad).abs().max() <= gtol * br.grad.abs().max()
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3", "f16"])
 def test_vovnet19_slim_centernet_eval_matches_oracle(tmp_path, dev, precision):
     import sys
