@@ -68,6 +68,7 @@ SIGNATURES = {
     "ctdet_grad_scatter_oihw": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ctdet_depth_to_space2": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_maxpool3x3s2_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ctdet_finite_flag": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "ctdet_ese_dot": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ctdet_ese_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ctdet_maxpool2x2_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -24,6 +24,7 @@ int launch_maxpool2x2(const void*, void*, int, int, int, int, int, int, int, hip
 int launch_maxpool3x3s2(const void*, void*, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_global_avgpool(const void*, int, int, int, int, int, float*, hipStream_t);
 int launch_ese_scale(const void*, int, const float*, const void*, int, void*, int, int, int, int, int, hipStream_t);
+int launch_finite_flag(const float*, long, int, int, int*, hipStream_t);
 int launch_pack_weights(const float*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_dwconvT_add(const void*, const float*, const void*, void*, int, int, int, int, int, int, int, int, int,
                        hipStream_t);
@@ -347,6 +348,11 @@ int32_t ctdet_global_avgpool(const void* x, int32_t dtype, int32_t B, int32_t HW
                              void* stream) {
   CTDET_CHECK(x && out, "global_avgpool: null pointer");
   return launch_global_avgpool(x, dtype, B, HW, C, stride, out, (hipStream_t)stream);
+}
+
+int32_t ctdet_finite_flag(const float* x, int64_t M, int32_t C, int32_t stride, int32_t* flag, void* stream) {
+  CTDET_CHECK(x && flag, "finite_flag: null pointer");
+  return launch_finite_flag(x, (long)M, C, stride, (int*)flag, (hipStream_t)stream);
 }
 
 int32_t ctdet_ese_scale(const void* x, int32_t x_stride, const float* s, const void* identity, int32_t identity_stride,

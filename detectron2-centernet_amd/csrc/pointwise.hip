@@ -388,6 +388,29 @@ __global__ void __launch_bounds__(256) ese_scale_kernel(const T* __restrict__ x,
   *(V*)(y + m * y_stride + cv * N) = r;
 }
 
+// Are all values of an [M][C] f32 map (pixel stride `stride`) finite?  *flag (set to 1 by the caller) becomes 0 otherwise.  The eval step's per-step guard on the size /
+// offset maps: torch's isfinite().all() reduces a 4 M element map through a semaphore buffer that it clears with
+// hipMemsetAsync -- a memset node in the captured step, which holds kernels only (engine/graph_nodes.py).
+__global__ void __launch_bounds__(256) finite_flag_kernel(const float* __restrict__ x, long M, int C, int stride,
+                                                          int* __restrict__ flag) {
+  const long n = M * C, step = (long)gridDim.x * 256;
+  bool bad = false;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += step) {
+    const long m = i / C;
+    const int c = (int)(i - m * C);
+    bad |= !(fabsf(x[m * stride + c]) <= 3.402823466e38f);      // NaN compares false
+  }
+  if (bad) *flag = 0;
+}
+int launch_finite_flag(const float* x, long M, int C, int stride, int* flag, hipStream_t s) {
+  if (M * C == 0) return 0;
+  CTDET_CHECK(C >= 1 && stride >= C, "finite_flag: bad channel count / pixel stride (%d, %d)", C, stride);
+  const long nb = (M * C + 255) / 256;
+  hipLaunchKernelGGL(finite_flag_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, s, x, M, C, stride, flag);
+  CTDET_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_global_avgpool(const void* x, int dtype, int B, int HW, int C, int stride, float* out, hipStream_t s) {
   if ((long)B * HW * C == 0) return 0;
   const dim3 grid((C + 63) / 64, B);

@@ -155,7 +155,7 @@ class _EvalEngine:
         # activation that left the f16 range on its way through an f16x3 (or f16) layer -- hi = f16(x) is inf beyond 65504 --
         # or any other blow-up of a diverged network ends up here as inf / NaN (the heat map would hide it: its epilogue
         # clamps NaN to the floor).  _post() folds the flag into the per-image counts the host reads back anyway.
-        self.finite = torch.isfinite(wh).all() & torch.isfinite(reg).all()
+        self.finite = ops.finite_flag(wh, reg).bool()      # (not torch.isfinite().all(): its reduction brings a memset node)
 
     def _post(self):
         """threshold / rescale / clip / compact into FRESH output tensors: runs after the captured part, outside the graph, so

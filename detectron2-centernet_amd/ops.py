@@ -920,6 +920,18 @@ def maxpool3x3s2_ceil(x, out=None):
     return out
 
 
+def finite_flag(*tensors):
+    """int32 [1] on the device: 1 if every value of the f32 NHWC maps (channel slices of wider buffers allowed) is finite, else
+    0 -- kernels only (no torch reduction: those clear their semaphores with a memset, which a captured step must not hold)"""
+    _require_cuda(*tensors)
+    flag = torch.ones(1, dtype=torch.int32, device=tensors[0].device)
+    for t in tensors:
+        assert t.dtype == torch.float32 and t.dim() == 4 and t.stride(3) == 1
+        B, H, W, Cc = t.shape
+        _lib.check(_lib.lib().ctdet_finite_flag(_ptr(t), B * H * W, Cc, _nhwc_stride(t), _ptr(flag), _stream()), "ctdet_finite_flag")
+    return flag
+
+
 def global_avgpool(x):
     """NHWC x -> f32 [B, C]: the mean over the pixels (nn.AdaptiveAvgPool2d(1) of the eSE module, vovnet.py:203)."""
     _require_cuda(x)

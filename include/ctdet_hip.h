@@ -196,6 +196,9 @@ int32_t ctdet_maxpool3x3s2_ceil(const void* x, void* y, int32_t dtype, int32_t B
  * OSA blocks of a stage (vovnet.py:268-271). */
 int32_t ctdet_global_avgpool(const void* x, int32_t dtype, int32_t B, int32_t HW, int32_t C, int32_t stride, float* out,
                              void* stream);
+/* *flag (int32 on the device, set to 1 by the caller) becomes 0 if any value of the f32 map x[M][C] (pixel stride `stride`
+ * elements) is inf or NaN: the per-step guard of the eval step on the size / offset maps (ABI 7). */
+int32_t ctdet_finite_flag(const float* x, int64_t M, int32_t C, int32_t stride, int32_t* flag, void* stream);
 int32_t ctdet_ese_scale(const void* x, int32_t x_stride, const float* s, const void* identity, int32_t identity_stride,
                         void* y, int32_t y_stride, int32_t dtype, int32_t B, int32_t HW, int32_t C, void* stream);
 
