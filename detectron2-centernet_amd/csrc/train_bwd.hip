@@ -1434,9 +1434,14 @@ int launch_bn_train_bwd_f32(const float* dz, int dz_stride, const float* z, int 
 #define WW_LD 40   // LDS row pitch in f16 elements (32 channels + 8 pad: 80 bytes, spreads the transposing reads over banks)
 // X3: f32 operands split on the way to LDS (hi and lo tiles of both operands: 95 KB, one workgroup per CU -- which is how
 // the kernel is launched anyway), three MFMAs per product
-template <bool X3>
-__global__ void __launch_bounds__(256, X3 ? 1 : 2) conv_wgrad_win_kernel(const WgradArgs a) {
+// NW waves per workgroup: 4 (f16: two workgroups per CU) or 8 (X3: the 95 KB of split tiles allow one workgroup per CU, so the
+// eight waves that keep a SIMD's two slots busy must come from that one workgroup: a wave then owns ONE tile row)
+template <bool X3, int NW = X3 ? 8 : 4>
+__global__ void __launch_bounds__(64 * NW, 2) conv_wgrad_win_kernel(const WgradArgs a) {
   constexpr int TH = 8, TW = 32, WC = TW + 2, NWIN = (TH + 2) * WC;   // 340 window pixels
+  constexpr int NTH = 64 * NW, PPR = 16 * NW;                         // threads; pixels a load round covers (4 pieces per pixel)
+  constexpr int NYP = TH * TW / PPR, NXP = (NWIN + PPR - 1) / PPR;    // dY / window pieces per thread (4 + 6, or 2 + 3)
+  constexpr int RPW = TH / NW;                                        // tile rows per wave (2 or 1)
   constexpr int NT = X3 ? 2 : 1, ES = X3 ? 4 : 2;
   constexpr int LOY = TH * TW * WW_LD, LOX = NWIN * WW_LD;
   __shared__ __attribute__((aligned(16))) f16 sm[NT * (LOY + LOX)];   // 47680 B per tile set; the first 36864 B hold the f32 sums at the end
@@ -1471,12 +1476,12 @@ __global__ void __launch_bounds__(256, X3 ? 1 : 2) conv_wgrad_win_kernel(const W
   const int g = tid & 3, pix = tid >> 2;
   const bool n_ok = n0 + g * 8 < a.Cout;
   const unsigned y_first = (unsigned)((((pix >> 5) * a.W + (pix & 31)) * a.dy_stride + n0 + g * 8) * ES);
-  const unsigned y_step = (unsigned)(2 * a.W * a.dy_stride * ES);      // 64 pixels of the tile = two rows further down
-  int woff[6];
+  const unsigned y_step = (unsigned)((PPR / TW) * a.W * a.dy_stride * ES);   // a load round further down the tile
+  int woff[NXP];
   unsigned wflags = 0;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int wpx = pix + 64 * i, wr = wpx / WC, wc = wpx - wr * WC;
+  for (int i = 0; i < NXP; ++i) {
+    const int wpx = pix + PPR * i, wr = wpx / WC, wc = wpx - wr * WC;
     woff[i] = wr * a.W + wc;
     const unsigned f = (wr == 0 ? 1u : 0u) | (wr == TH + 1 ? 2u : 0u) | (wc == 0 ? 4u : 0u) | (wc == WC - 1 ? 8u : 0u) |
                        (wpx >= NWIN ? 16u : 0u);
@@ -1484,7 +1489,7 @@ __global__ void __launch_bounds__(256, X3 ? 1 : 2) conv_wgrad_win_kernel(const W
   }
   const char* const xbase = (const char*)a.x + (size_t)(c0 + g * 8) * ES;
   const char* const ybase = (const char*)a.dy;
-  Piece<X3> yv[4], xv[6];
+  Piece<X3> yv[NYP], xv[NXP];
   unsigned okbits = 0;
   auto fetch = [&](int tile) {
     const int txi = tile % tiles_x, tq = tile / tiles_x, tyi = tq % tiles_y, b = tq / tiles_y;
@@ -1494,13 +1499,13 @@ __global__ void __launch_bounds__(256, X3 ? 1 : 2) conv_wgrad_win_kernel(const W
     const int tile_pix = (b * a.H + ty0 - 1) * a.W + tx0 - 1;
     const unsigned ytile = (unsigned)(((b * a.H + ty0) * a.W + tx0) * a.dy_stride * ES);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NYP; ++i) {
       const unsigned off = n_ok ? ytile + y_first + y_step * i : 0u;
       yv[i] = piece_load<X3>(ybase + off);
     }
     okbits = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NXP; ++i) {
       const bool ok = ((bad >> (5 * i)) & 31u) == 0u;
       const unsigned off = ok ? (unsigned)((tile_pix + woff[i]) * a.in_stride * ES) : 0u;
       xv[i] = piece_load<X3>(xbase + off);
@@ -1512,28 +1517,28 @@ __global__ void __launch_bounds__(256, X3 ? 1 : 2) conv_wgrad_win_kernel(const W
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();   // the previous tile's fragment reads are done
 #pragma unroll
-    for (int i = 0; i < 4; ++i) piece_store<X3>(sY + (pix + 64 * i) * WW_LD + g * 8, LOY, yv[i], n_ok);
+    for (int i = 0; i < NYP; ++i) piece_store<X3>(sY + (pix + PPR * i) * WW_LD + g * 8, LOY, yv[i], n_ok);
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-      if (pix + 64 * i < NWIN) piece_store<X3>(sX + (pix + 64 * i) * WW_LD + g * 8, LOX, xv[i], (okbits >> i) & 1u);
+    for (int i = 0; i < NXP; ++i)
+      if (pix + PPR * i < NWIN) piece_store<X3>(sX + (pix + PPR * i) * WW_LD + g * 8, LOX, xv[i], (okbits >> i) & 1u);
     __syncthreads();
     if (tile + 1 < t_end) fetch(tile + 1);
-    // dY fragments of this wave's two tile rows (K slabs of 32 pixels), both cout tiles: kept for all nine taps
-    Frag<X3> fy[2][2];
+    // dY fragments of this wave's tile rows (K slabs of 32 pixels), both cout tiles: kept for all nine taps
+    Frag<X3> fy[RPW][2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < RPW; ++h)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fy[h][i] = frag_read<X3>(sY + ((2 * wave + h) * TW + 8 * grp + q) * WW_LD + i * 16 + 4 * p, WW_LD, LOY);
-    // window rows 2*wave .. 2*wave+3: row v serves tap row v of tile row 0 and tap row v-1 of tile row 1
+      for (int i = 0; i < 2; ++i) fy[h][i] = frag_read<X3>(sY + ((RPW * wave + h) * TW + 8 * grp + q) * WW_LD + i * 16 + 4 * p, WW_LD, LOY);
+    // window rows RPW*wave .. RPW*wave + RPW + 1: row v serves tap row v - h of the wave's tile row h
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
+    for (int v = 0; v < RPW + 2; ++v)
 #pragma unroll
       for (int ts = 0; ts < 3; ++ts) {
         Frag<X3> fx[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fx[j] = frag_read<X3>(sX + ((2 * wave + v) * WC + ts + 8 * grp + q) * WW_LD + j * 16 + 4 * p, WW_LD, LOX);
+        for (int j = 0; j < 2; ++j) fx[j] = frag_read<X3>(sX + ((RPW * wave + v) * WC + ts + 8 * grp + q) * WW_LD + j * 16 + 4 * p, WW_LD, LOX);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < RPW; ++h) {
           const int tr = v - h;
           if (tr < 0 || tr > 2) continue;
 #pragma unroll
@@ -1543,13 +1548,13 @@ __global__ void __launch_bounds__(256, X3 ? 1 : 2) conv_wgrad_win_kernel(const W
         }
       }
   }
-  // The four waves hold partial sums of the same 32 x 32 x 9 block with the same lane -> element mapping.  f32 atomics to
+  // The waves hold partial sums of the same 32 x 32 x 9 block with the same lane -> element mapping.  f32 atomics to
   // L2 are what this kernel's fixed cost is made of, so the waves are summed through LDS first (wave 3 stores, 2 / 1 / 0
   // add their registers in turn -- no LDS atomics needed) and one atomic per element leaves the workgroup.
   float* const red = (float*)sm;    // [36 tiles][4 r][64 lanes]
   __syncthreads();
 #pragma unroll
-  for (int w = 3; w >= 0; --w) {
+  for (int w = NW - 1; w >= 0; --w) {
     if (wave == w) {
 #pragma unroll
       for (int t = 0; t < 9; ++t)
@@ -1560,13 +1565,13 @@ __global__ void __launch_bounds__(256, X3 ? 1 : 2) conv_wgrad_win_kernel(const W
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float* slot = red + (((t * 2 + i) * 2 + j) * 4 + r) * 64 + lane;
-              *slot = w == 3 ? acc[t][i][j][r] : *slot + acc[t][i][j][r];
+              *slot = w == NW - 1 ? acc[t][i][j][r] : *slot + acc[t][i][j][r];
             }
     }
     __syncthreads();
   }
   // D[row = cout][col = cin]: lane held rows 4*(lane>>4)+r, column lane&15; k = tap*Cin + c (tap-major dW)
-  for (int e = tid; e < 36 * 256; e += 256) {
+  for (int e = tid; e < 36 * 256; e += NTH) {
     const int tile = e >> 8, t = tile >> 2, i = (tile >> 1) & 1, j = tile & 1, r = (e >> 6) & 3, ln = e & 63;
     const int n = n0 + i * 16 + 4 * (ln >> 4) + r;
     if (n < a.Cout) wg_add(a, n, t * a.Cin + c0 + j * 16 + (ln & 15), red[e] * a.scale);
@@ -1784,7 +1789,7 @@ static int launch_conv_wgrad_t(const WgradArgs& a0, hipStream_t s) {
     if (split < 1) split = 1;
     if (split > ntiles) split = ntiles;
     a.msplit = split;
-    hipLaunchKernelGGL(conv_wgrad_win_kernel<X3>, dim3(gx * gy * split), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(conv_wgrad_win_kernel<X3>, dim3(gx * gy * split), dim3(X3 ? 512 : 256), 0, s, a);
     CTDET_LAUNCH_CHECK();
     return 0;
   }

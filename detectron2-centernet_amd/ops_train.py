@@ -144,7 +144,8 @@ def conv_wgrad(x, dy, Cout, R, S, stride, pad, dil=1, scale=None, into=None, com
     d.compute_dtype = dt_of(x) if comp is None or x.dtype == torch.float16 else comp
     assert dy.dtype == x.dtype
     sc = float(PARAM_GRAD_MULT if scale is None else scale)
-    with ops.prof_region(f"conv_wgrad<{R}x{S}>", flops=2.0 * B * Ho * Wo * Cout * R * S * Cin, nbytes=0.0):
+    with ops.prof_region(f"conv_wgrad<{R}x{S}>", flops=2.0 * B * Ho * Wo * Cout * R * S * Cin, nbytes=0.0,
+                         info=f"M={B * Ho * Wo} {Cin}->{Cout} k{R} s{stride}"):
         if into is not None:
             grad, taps, cin_k = into
             assert grad.dtype == torch.float32 and grad.is_contiguous() and grad.dim() == 4
