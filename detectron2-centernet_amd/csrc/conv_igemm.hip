@@ -1366,11 +1366,15 @@ int launch_halo_pair2(const ConvArgs& a, hipStream_t s) {
                   a.in_stride % 4 == 0 && (((size_t)a.x | (size_t)a.w) & 15) == 0,
               "conv(f16x3, cross-chunk pair weights): needs 3x3/s1/p1, Cin %% 32 == 0 and a map divisible by 8x32 or 16x16 (Cin=%d, %dx%d, Kpad=%d)",
               a.Cin, a.H, a.W, a.Kpad);
+  // a grid of 64-cout tiles that leaves CUs without a workgroup (the 512-channel level at batch 16: 16 pixel tiles x 8) runs on
+  // 32-cout tiles instead: twice the workgroups, each with half the MFMAs behind the same window traffic
+  const bool small_grid = (long)(a.M / 256) * (a.Cout_pad / 64) < ctdet_device_cu_count() && a.Cout_pad % 32 == 0 &&
+                          !(ctdet_tuning_flags() & CTDET_TUNE_NO_SMALL_GRID_TILES);
   if (a.W % 32 != 0) {                  // 16 x 16-pixel tiles
-    if (pick_bc(a.Cout) <= 32) return launch_halo_pair2_t<32, 4, 1, 16>(a, s);
+    if (pick_bc(a.Cout) <= 32 || small_grid) return launch_halo_pair2_t<32, 4, 1, 16>(a, s);
     return launch_halo_pair2_t<64, 4, 1, 16>(a, s);
   }
-  if (pick_bc(a.Cout) <= 32) return launch_halo_pair2_t<32, 4, 1>(a, s);
+  if (pick_bc(a.Cout) <= 32 || small_grid) return launch_halo_pair2_t<32, 4, 1>(a, s);
   if ((ctdet_tuning_flags() & CTDET_TUNE_PAIR2_128) && a.Cout_pad % 128 == 0) return launch_halo_pair2_t<128, 4, 1>(a, s);
   return launch_halo_pair2_t<64, 4, 1>(a, s);
 }
