@@ -9,7 +9,10 @@
  *
  * Device layout: activations NHWC ("pixel rows" of `*_stride` elements), f16 (throughput mode) or
  * f32 (exact mode); conv weights pre-packed with ctdet-side layout (see ctdet_conv_desc).
- * All launches go to the stream passed in; nothing synchronises; all functions are graph-capturable.
+ * All launches go to the stream passed in; nothing synchronises; all functions are graph-capturable, and since ABI 7 every
+ * launch is a KERNEL: no hipMemsetAsync / hipMemcpyAsync is issued on the caller's stream (a captured step holds kernel nodes
+ * only -- a memset node of a replayed training step was seen to run out of order; ctdet_decode_status, which copies a status
+ * word to the host and is not part of a step, is the exception).
  */
 #ifndef CTDET_HIP_H
 #define CTDET_HIP_H
