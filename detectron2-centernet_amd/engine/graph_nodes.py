@@ -36,3 +36,20 @@ def node_types(raw_graph):
         name = _NAMES.get(t.value, str(t.value))
         out[name] = out.get(name, 0) + 1
     return out
+
+
+def inspect(graph, what):
+    """node types of a torch.cuda.CUDAGraph captured with keep_graph=True, with the warning about anything that is not a kernel;
+    a failure of the inspection itself (an API that is not there) is logged and does not touch the capture: returns None"""
+    import logging
+    log = logging.getLogger(__name__)
+    try:
+        nodes = node_types(graph.raw_cuda_graph())
+    except Exception as e:   # noqa: BLE001 -- the look at the graph is a check, not a step of the capture
+        log.warning("could not list the nodes of the captured %s: %r", what, e)
+        return None
+    other = {k: v for k, v in nodes.items() if k not in ("kernel", "empty")}
+    if other:
+        log.warning("the captured %s holds non-kernel nodes %s: replace the hipMemsetAsync / contiguous copy_ / large torch "
+                    "reduction behind them by kernels", what, other)
+    return nodes

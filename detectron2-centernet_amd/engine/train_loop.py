@@ -202,12 +202,7 @@ class SimpleTrainer:
         # memset / memcpy node, and a replay launched on an idle stream ran such a node out of order with the kernel after it
         # (the data-parallel step, whose SGD launch is eager: round 3's "CTDET_TRAIN_GRAPH=ddp gives inf hm_loss"; engine/
         # graph_nodes.py).  Anything else found here is reported, loudly, once per capture.
-        g["nodes"] = graph_nodes.node_types(graph.raw_cuda_graph())
-        other = {k: v for k, v in g["nodes"].items() if k not in ("kernel", "empty")}
-        if other:
-            import logging
-            logging.getLogger(__name__).warning("the captured training step holds non-kernel nodes %s: replace the "
-                                                "hipMemsetAsync / contiguous copy_ behind them by kernels", other)
+        g["nodes"] = graph_nodes.inspect(graph, "training step") or {}
         graph.instantiate()
         g["graph"], g["inputs"] = graph, inputs
         g["losses"] = {k: v.detach() for k, v in loss_dict.items()}

@@ -111,11 +111,7 @@ class _EvalEngine:
                 # kernels only, like the training step (engine/graph_nodes.py: a memset / memcpy node of a replay launched on
                 # an idle stream was seen to run out of order with the kernel after it)
                 from ...engine import graph_nodes
-                self.graph_nodes = graph_nodes.node_types(g.raw_cuda_graph())
-                other = {k: v for k, v in self.graph_nodes.items() if k not in ("kernel", "empty")}
-                if other:
-                    import logging
-                    logging.getLogger(__name__).warning("the captured eval step holds non-kernel nodes %s", other)
+                self.graph_nodes = graph_nodes.inspect(g, "eval step") or {}
                 g.instantiate()
             finally:
                 if gc_was_on:

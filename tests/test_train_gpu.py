@@ -721,7 +721,7 @@ def test_captured_step_survives_eval_and_other_shapes(tmp_path, dev):
         if mode == "graph":
             assert tr.graph_state == "captured"
             for g in (g for g in tr._graphs.values() if g["graph"] is not None):   # kernels only (engine/graph_nodes.py)
-                assert set(g["nodes"]) <= {"kernel", "empty"}, g["nodes"]
+                assert g["nodes"].get("kernel", 0) > 0 and set(g["nodes"]) <= {"kernel", "empty"}, g["nodes"]
         assert all(math.isfinite(h) for h in hist), hist
         res[mode] = (hist, (tr.optimizer.flat_param - p0).norm().item())
     (he, de), (hg, dg) = res["eager"], res["graph"]
