@@ -221,8 +221,8 @@ class SideLane:
     def join(self):
         if self.active:
             torch.cuda.current_stream().wait_stream(self.stream)
-            self.keep.clear()
             self.active = False
+        self.keep.clear()
 
 
 SIDE = SideLane()
@@ -276,8 +276,8 @@ def wgrad_to_param(p, x, dy, Cout_k, R, S, stride, pad, taps, cin_k, scale=None,
         xin = make_x() if make_x is not None else x
         return conv_wgrad(xin, dy, Cout_k, R, S, stride, pad, comp=comp), xin
     dw, xin = SIDE.run(work, x, dy, *keep)
-    if make_x is not None:
-        SIDE.keep.append((xin,))
+    if make_x is not None and SIDE.enabled:    # (with the side stream off nothing outlives the call: round 4 found the eager
+        SIDE.keep.append((xin,))               # step holding every DCNv2 layer's columns here, 5 GB per step)
     PENDING.append((slot, dw, taps, cin_k))
     grad_done(p)
     return True
