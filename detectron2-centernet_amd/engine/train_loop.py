@@ -10,6 +10,9 @@ from . import graph_nodes, train_step
 from .reducer import BucketedReducer
 
 
+MAX_TRAIN_GRAPHS = int(os.environ.get("CTDET_MAX_TRAIN_GRAPHS", "4"))
+
+
 class SimpleTrainer:
     """model(data) -> loss dict; sum; zero_grad; backward (bucketed all-reduce overlapped); SGD step; LR schedule.
 
@@ -80,10 +83,24 @@ class SimpleTrainer:
         g = self._graphs.get(key)
         if g is None:
             g = self._graphs[key] = {"calls": 0, "graph": None}
+        else:
+            self._graphs[key] = self._graphs.pop(key)          # most recently used last
         g["calls"] += 1
         if g["graph"] is None and g["calls"] <= 2 or g.get("failed"):
             return self._finish_step(self.model.train_batch_tensor(images, boxes, classes, counts))
         if g["graph"] is None:
+            # a captured step owns a private memory pool the size of the step's working set (gigabytes): multi-scale training
+            # (MIN_SIZE_TRAIN with six sizes, ragged aspect ratios) would pile them up.  At most MAX_TRAIN_GRAPHS stay; the
+            # least recently used one is destroyed here, outside any capture, and its shape goes back to eager steps until
+            # it has been seen twice again.  Entries of shapes that never reached a capture are only counters.
+            live = [k for k, e in self._graphs.items() if e["graph"] is not None]
+            while len(live) >= MAX_TRAIN_GRAPHS:
+                old = self._graphs.pop(live.pop(0))
+                old["graph"] = old["inputs"] = old["losses"] = None
+                del old
+            if len(self._graphs) > 64:                          # counters of shapes seen once or twice
+                for k in [k for k, e in self._graphs.items() if e["graph"] is None and k != key][:len(self._graphs) - 64]:
+                    del self._graphs[k]
             self._capture(g, images, boxes, classes, counts, with_step=not multi)
             if g.get("failed"):
                 return self._finish_step(self.model.train_batch_tensor(images, boxes, classes, counts))

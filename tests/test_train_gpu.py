@@ -690,6 +690,29 @@ def test_pack_plan_refreshes_weights_after_each_update(T, dev):
         ops.PACK_PLAN, ot.ARENA = prev_plan, prev_arena
 
 
+def test_captured_training_graphs_are_bounded(tmp_path, dev, monkeypatch):
+    """multi-scale training (the reference's MIN_SIZE_TRAIN has six sizes) meets a new batch shape every few steps, and every
+    captured step owns a private pool of the step's working set: at most MAX_TRAIN_GRAPHS stay alive, least recently used
+    first out; an evicted shape steps eagerly until it is captured again; losses stay finite throughout"""
+    from test_model_gpu import make_model
+    from detectron2_centernet_amd.engine import train_loop
+    from detectron2_centernet_amd.engine.bench_train import synthetic_batch
+    monkeypatch.setattr(train_loop, "MAX_TRAIN_GRAPHS", 2)
+    model, cfg = make_model(tmp_path, "f16x3", seed=8, calibrated=False)
+    cfg.SOLVER.IMS_PER_BATCH = 2
+    tr = train_loop.SimpleTrainer(model, None, cfg)
+    shapes = [synthetic_batch(2, s, i, dev) for i, s in enumerate((96, 128, 160))]
+    for batch in shapes + [shapes[0]]:
+        for _ in range(4):                                       # eager, eager, capture + replay, replay
+            losses = tr.run_step_tensors(*batch)
+            assert all(math.isfinite(float(v)) for v in losses.values())
+        live = [g for g in tr._graphs.values() if g["graph"] is not None]
+        assert 1 <= len(live) <= 2, len(live)
+    assert tr.graph_state == "captured"
+    key0 = tuple((tuple(t.shape), t.dtype) for t in shapes[0])
+    assert tr._graphs[key0]["graph"] is not None                 # the first shape was evicted by the third and captured again
+
+
 @pytest.mark.parametrize("precision", ["f16", "f16x3"])
 def test_eager_steps_do_not_accumulate_device_memory(tmp_path, dev, precision, monkeypatch):
     """an eager training step (CTDET_TRAIN_GRAPH=0, and the hooks path of data-parallel runs) must leave nothing behind on the

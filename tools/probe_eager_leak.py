@@ -12,11 +12,12 @@ from detectron2_centernet_amd.engine.bench_train import synthetic_batch  # noqa:
 from detectron2_centernet_amd.engine.train_loop import SimpleTrainer  # noqa: E402
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
+config = sys.argv[2] if len(sys.argv) > 2 else "dla34"
 dev = torch.device("cuda:0")
-model, cfg = bench.build_model(prec, dev, calibrate=False)
+model, cfg = bench.build_model(prec, dev, calibrate=False, config=config)
 model.train()
 tr = SimpleTrainer(model, None, cfg)
-batch = synthetic_batch(16, 512, 0, dev)
+batch = synthetic_batch(16 if config == "dla34" else 4, 512, 0, dev)
 for i in range(12):
     tr.run_step_tensors(*batch)
     torch.cuda.synchronize()
