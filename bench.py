@@ -536,7 +536,9 @@ def infer_record(precision, state, images, steps, warmup, dist, backend, device,
     assert len(out) == B
     rec = {"value": world * B * steps / elapsed, "unit": "images/s", "ms_per_step": 1000.0 * elapsed / steps, "steps": steps,
            "warmup": warmup, "dtype": precision, "note": MODE_NOTES[precision],
-           "detections_per_image": sum(len(o["instances"]) for o in out) / max(1, len(out))}
+           "detections_per_image": sum(len(o["instances"]) for o in out) / max(1, len(out)),
+           # node types of the captured eval step (kernels only: no memset / memcpy node; engine/graph_nodes.py)
+           "graph_nodes": next((e.graph_nodes for e in model._engines.values() if e.B == B and e.graph is not None), None)}
     if with_roofline:
         rec["roofline"] = roofline_record(roofline_pass(model, images, passes=2 if headline else 1), PEAKS[precision],
                                           with_traffic=headline)
@@ -643,7 +645,8 @@ def main():
                                    f"{rec['detections_per_image']:.0f} detections per image post-processed",
                        "precision": MODE_NOTES[args.precision],
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"replicas x{world}",
-                       "ranks_share_devices": backend != "nccl" and world > 1},
+                       "ranks_share_devices": backend != "nccl" and world > 1,
+                       "graph_nodes": rec.get("graph_nodes")},
         }
         if "roofline" in rec:
             result["roofline"] = rec["roofline"]

@@ -134,5 +134,7 @@ def _record(model, args, B, world, elapsed, losses, trainer, comm_rec):
         "config": {"workload": f"{'DLA-34' if model.backbone_type == 'dla34' else 'ResNet'} CenterNet train step (targets+fwd+loss+bwd+allreduce+SGD), {B}x3x{args.size}x"
                                f"{args.size} per GPU, 80 classes, " + _MODE[model._ctx.compute][1],
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "final_losses": losses, "graph_state": trainer.graph_state, "allreduce": comm_rec},
+                   "final_losses": losses, "graph_state": trainer.graph_state,
+                   "graph_nodes": next((g.get("nodes") for g in trainer._graphs.values() if g["graph"] is not None), None),
+                   "allreduce": comm_rec},
     }
