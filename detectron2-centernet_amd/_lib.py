@@ -104,6 +104,8 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        if os.environ.get("CTDET_TUNE_FLAGS"):      # kernel-selection bits for a whole process (A/B runs of bench.py's ranks)
+            l.ctdet_set_tuning_flags(int(os.environ["CTDET_TUNE_FLAGS"], 0))
     return _lib
 
 
@@ -143,6 +145,7 @@ class HeadDesc(C.Structure):
 TUNE_NO_HALO, TUNE_NO_WIN, TUNE_DCN_MIXED, TUNE_NO_WGRAD_WINDOW, TUNE_NO_COL2IM_WINDOW, TUNE_NO_F32_DCN_WINDOW, TUNE_DCN_WINDOW_V1, TUNE_NO_SMALL_GRID_TILES = 1, 2, 4, 8, 16, 32, 64, 128
 TUNE_DCN_SPLIT_4W = 256
 TUNE_NO_HALO_TAP2 = 512
+TUNE_PAIR2_128, TUNE_DCN_SPLIT_8W64, TUNE_TARGETS_MEMSET = 1024, 2048, 4096
 
 
 class tuning:

@@ -131,6 +131,8 @@ enum {
   CTDET_TUNE_DCN_SPLIT_4W = 256,     // f16x3 DCNv2 window kernel: 64-cout tiles (four 32-pixel waves) also for the 128- and 256-cout layers
   CTDET_TUNE_PAIR2_128 = 1024,       // f16x3 3x3 halo pair kernel: 128-cout tiles, one workgroup per CU (512 registers per wave)
   CTDET_TUNE_DCN_SPLIT_8W64 = 2048,  // f16x3 DCNv2 window kernel, 64-cout layers: eight 16-pixel waves per workgroup, four waves per SIMD
+  CTDET_TUNE_TARGETS_MEMSET = 4096,   // gaussian targets: clear the heat map with hipMemsetAsync (round 3's form: a memset NODE in a captured step;
+                                      // kept to reproduce profiles/r04_graph_memset_node.txt and to test the node check)
   CTDET_TUNE_DCN_WINDOW_V1 = 64,     // 64-cout f16 DCNv2: the per-tap-barrier window kernel instead of the row-step one
 };
 unsigned ctdet_tuning_flags();

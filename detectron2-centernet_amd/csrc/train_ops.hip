@@ -131,6 +131,10 @@ int launch_gaussian_targets(const float* boxes, const int64_t* classes, const in
   if (B == 0) return 0;
   CTDET_CHECK(((uintptr_t)hm & 15) == 0, "gaussian_targets: hm must be 16-byte aligned");
   const long n = (long)B * H * W * C;
+  if (ctdet_tuning_flags() & CTDET_TUNE_TARGETS_MEMSET) {
+    const hipError_t e = hipMemsetAsync(hm, 0, (size_t)n * sizeof(float), s);
+    CTDET_CHECK(e == hipSuccess, "gaussian_targets: memset failed: %s", hipGetErrorString(e));
+  } else
   hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)std::min<long>((n / 4 + 255) / 256 + 1, 2048)), dim3(256), 0, s, hm, n);
   CTDET_LAUNCH_CHECK();
   hipLaunchKernelGGL(gaussian_targets_kernel, dim3(128, B), dim3(256), 0, s, boxes, classes, counts, Nmax, H, W, C, hm,

@@ -690,6 +690,35 @@ def test_pack_plan_refreshes_weights_after_each_update(T, dev):
         ops.PACK_PLAN, ot.ARENA = prev_plan, prev_arena
 
 
+def test_memset_node_in_a_captured_step_is_reported(tmp_path, dev, caplog):
+    """the node check of the trainer sees what it is there for: with the round-3 form of the target clear (hipMemsetAsync,
+    _lib.TUNE_TARGETS_MEMSET) the captured step holds exactly one memset node and the trainer says so; without the switch the
+    step is kernels only.  (The corruption that node caused is stochastic and needs two processes: profiles/r04_graph_memset_node.txt,
+    tools/repro_memset_node.sh.)"""
+    import logging
+    from test_model_gpu import make_model
+    from detectron2_centernet_amd import _lib
+    from detectron2_centernet_amd.engine.bench_train import synthetic_batch
+    from detectron2_centernet_amd.engine.train_loop import SimpleTrainer
+    seen = {}
+    for flag in (_lib.TUNE_TARGETS_MEMSET, 0):
+        model, cfg = make_model(tmp_path, "f16x3", seed=12, calibrated=False)
+        cfg.SOLVER.IMS_PER_BATCH = 2
+        tr = SimpleTrainer(model, None, cfg)
+        batch = synthetic_batch(2, 128, 0, dev)
+        caplog.clear()
+        with caplog.at_level(logging.WARNING), _lib.tuning(flag):
+            for _ in range(3):
+                tr.run_step_tensors(*batch)
+        assert tr.graph_state == "captured"
+        seen[flag] = (next(g["nodes"] for g in tr._graphs.values() if g["graph"] is not None),
+                      [r.getMessage() for r in caplog.records if "non-kernel" in r.getMessage()])
+    nodes, warned = seen[_lib.TUNE_TARGETS_MEMSET]
+    assert nodes.get("memset") == 1 and len(warned) == 1 and "memset" in warned[0], (nodes, warned)
+    nodes, warned = seen[0]
+    assert set(nodes) <= {"kernel", "empty"} and not warned, (nodes, warned)
+
+
 def test_captured_training_graphs_are_bounded(tmp_path, dev, monkeypatch):
     """multi-scale training (the reference's MIN_SIZE_TRAIN has six sizes) meets a new batch shape every few steps, and every
     captured step owns a private pool of the step's working set: at most MAX_TRAIN_GRAPHS stay alive, least recently used
