@@ -33,14 +33,22 @@ def run_train_bench(model, cfg, args, B, rank, world, device, dist):
     cfg.SOLVER.IMS_PER_BATCH = B * world
     trainer = SimpleTrainer(model, None, cfg)
     images, boxes, classes, counts = synthetic_batch(B, args.size, rank, device)
-    for _ in range(args.warmup):
-        trainer.run_step_tensors(images, boxes, classes, counts)
+    import contextlib
+    import os
+    # CTDET_BENCH_STREAM=1 (measurement only): the steps run on a stream of their own instead of the default (null) stream
+    side = torch.cuda.Stream() if os.environ.get("CTDET_BENCH_STREAM") == "1" else None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream())
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        for _ in range(args.warmup):
+            trainer.run_step_tensors(images, boxes, classes, counts)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.run_step_tensors(images, boxes, classes, counts)
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        for _ in range(args.steps):
+            trainer.run_step_tensors(images, boxes, classes, counts)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
